@@ -1,0 +1,505 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+CPU restatement, in plain fp32 PyTorch ops, of the reference algorithms on the
+FedFR per-client training hot path.  Written from the semantics listed in
+SURVEY.md App. B; every function cites the reference file:line it follows.
+Pinned against the imported reference by tests/golden/*.npz
+(tools/make_golden.py), checked in tests/test_oracle_golden.py.
+
+Everything is *functional*: a network is just an ordered ``dict`` of tensors with
+the reference's state_dict key names, so the same code drives parity checks,
+golden generation and the timed CPU baseline.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# network description  (reference: backbones/iresnet.py:182-204 factories)
+# --------------------------------------------------------------------------------------
+IRESNET_LAYERS = {
+    "iresnet18": (2, 2, 2, 2),
+    "iresnet34": (3, 4, 6, 3),
+    "iresnet50": (3, 4, 14, 3),
+    "iresnet100": (3, 13, 30, 3),
+    "iresnet200": (6, 26, 60, 6),
+}
+STAGE_PLANES = (64, 128, 256, 512)
+BN_EPS = 1e-5          # iresnet.py:37,39,42,77,95,98,123
+BN_MOMENTUM = 0.1      # torch default, used everywhere in the reference
+
+
+def _bn_keys(prefix: str, c: int) -> List[Tuple[str, Tuple[int, ...], str]]:
+    return [
+        (prefix + ".weight", (c,), "bn_w"),
+        (prefix + ".bias", (c,), "bn_b"),
+        (prefix + ".running_mean", (c,), "bn_rm"),
+        (prefix + ".running_var", (c,), "bn_rv"),
+        (prefix + ".num_batches_tracked", (), "bn_nbt"),
+    ]
+
+
+def iresnet_spec(layers: Sequence[int], num_features: int = 512,
+                 in_hw: int = 112) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Ordered (key, shape, kind) list == reference ``state_dict()`` order.
+
+    Mirrors module registration order in IResNet.__init__ (iresnet.py:76-98) and
+    IBasicBlock.__init__ (iresnet.py:37-43).
+    """
+    spec: List[Tuple[str, Tuple[int, ...], str]] = []
+    spec.append(("conv1.weight", (64, 3, 3, 3), "conv"))
+    spec += _bn_keys("bn1", 64)
+    spec.append(("prelu.weight", (64,), "prelu"))
+    inpl = 64
+    for si, (planes, nblk) in enumerate(zip(STAGE_PLANES, layers)):
+        for bi in range(nblk):
+            p = "layer%d.%d" % (si + 1, bi)
+            cin = inpl if bi == 0 else planes
+            spec += _bn_keys(p + ".bn1", cin)
+            spec.append((p + ".conv1.weight", (planes, cin, 3, 3), "conv"))
+            spec += _bn_keys(p + ".bn2", planes)
+            spec.append((p + ".prelu.weight", (planes,), "prelu"))
+            spec.append((p + ".conv2.weight", (planes, planes, 3, 3), "conv"))
+            spec += _bn_keys(p + ".bn3", planes)
+            if bi == 0:  # stride 2 in every stage => always a downsample (iresnet.py:120-125)
+                spec.append((p + ".downsample.0.weight", (planes, cin, 1, 1), "conv"))
+                spec += _bn_keys(p + ".downsample.1", planes)
+        inpl = planes
+    spec += _bn_keys("bn2", 512)
+    fc_in = 512 * (in_hw // 16) ** 2
+    spec.append(("fc.weight", (num_features, fc_in), "fc_w"))
+    spec.append(("fc.bias", (num_features,), "fc_b"))
+    spec += _bn_keys("features", num_features)
+    return spec
+
+
+# --------------------------------------------------------------------------------------
+# closed-form (RNG-free) tensors shared by the golden generator and the tests
+# --------------------------------------------------------------------------------------
+def closed_form(shape: Sequence[int], a: float, b: float, scale: float = 1.0,
+                offset: float = 0.0) -> torch.Tensor:
+    """``offset + scale * sin(a*i + b)`` over the flattened index, computed in fp64."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    i = torch.arange(n, dtype=torch.float64)
+    v = offset + scale * torch.sin(a * i + b)
+    return v.to(torch.float32).reshape(tuple(shape))
+
+
+def closed_form_state_dict(layers: Sequence[int], num_features: int = 512,
+                           in_hw: int = 112, tag: float = 0.0) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic, well-conditioned iresnet state (no RNG; ``tag`` decorrelates variants)."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for idx, (key, shape, kind) in enumerate(iresnet_spec(layers, num_features, in_hw)):
+        a = 0.37 + 0.011 * (idx % 89) + 0.0007 * tag
+        b = 0.13 * idx + tag
+        if kind == "conv":
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = closed_form(shape, a, b, scale=math.sqrt(2.0 / fan_in) * 1.5)
+        elif kind == "fc_w":
+            t = closed_form(shape, a, b, scale=1.0 / math.sqrt(shape[1]))
+        elif kind == "fc_b":
+            t = closed_form(shape, a, b, scale=0.05)
+        elif kind == "bn_w":
+            if key == "features.weight":  # frozen at 1 (iresnet.py:99-100)
+                t = torch.ones(shape)
+            else:
+                t = closed_form(shape, a, b, scale=0.25, offset=1.0)
+        elif kind == "bn_b":
+            t = closed_form(shape, a, b, scale=0.1)
+        elif kind == "bn_rm":
+            t = closed_form(shape, a, b, scale=0.05)
+        elif kind == "bn_rv":
+            t = closed_form(shape, a, b, scale=0.2, offset=1.0)
+        elif kind == "bn_nbt":
+            t = torch.tensor(3 + (idx % 5), dtype=torch.int64)
+        elif kind == "prelu":
+            t = closed_form(shape, a, b, scale=0.1, offset=0.25)
+        else:  # pragma: no cover
+            raise AssertionError(kind)
+        sd[key] = t
+    return sd
+
+
+def closed_form_images(batch: int, hw: int = 112, tag: float = 0.0) -> torch.Tensor:
+    """Synthetic faces in [-1, 1] (reference normalisation dataset.py:81-86)."""
+    return closed_form((batch, 3, hw, hw), 0.0173 + 0.001 * tag, 0.5 + tag, scale=1.0)
+
+
+def closed_form_labels(batch: int, num_classes: int, tag: int = 0) -> torch.Tensor:
+    i = torch.arange(batch, dtype=torch.int64)
+    return (i * 7919 + 13 * tag + 5) % num_classes
+
+
+# --------------------------------------------------------------------------------------
+# backbone  (reference: backbones/iresnet.py:46-57 block, :158-172 forward)
+# --------------------------------------------------------------------------------------
+def _bn(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """nn.BatchNorm{1,2}d semantics: biased batch var for normalisation, unbiased for the
+    running update, momentum 0.1, num_batches_tracked += 1 in training."""
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if training:
+        sd[prefix + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"],
+                        training, BN_MOMENTUM, BN_EPS)
+
+
+def ibasic_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: int,
+                 training: bool) -> torch.Tensor:
+    """iresnet.py:46-57: BN→conv3x3(s1)→BN→PReLU→conv3x3(stride)→BN, (+1x1 conv+BN shortcut), add."""
+    out = _bn(sd, p + ".bn1", x, training)
+    out = F.conv2d(out, sd[p + ".conv1.weight"], None, 1, 1)
+    out = _bn(sd, p + ".bn2", out, training)
+    out = F.prelu(out, sd[p + ".prelu.weight"])
+    out = F.conv2d(out, sd[p + ".conv2.weight"], None, stride, 1)
+    out = _bn(sd, p + ".bn3", out, training)
+    if (p + ".downsample.0.weight") in sd:
+        idn = F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0)
+        idn = _bn(sd, p + ".downsample.1", idn, training)
+    else:
+        idn = x
+    return out + idn
+
+
+def iresnet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, layers: Sequence[int],
+                    training: bool = True, return_taps: bool = False):
+    """iresnet.py:158-172 with fp16=False (CPU path) and dropout p=0 (client.py:142)."""
+    taps = {}
+    h = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
+    h = _bn(sd, "bn1", h, training)
+    h = F.prelu(h, sd["prelu.weight"])
+    taps["stem"] = h
+    for si, nblk in enumerate(layers):
+        for bi in range(nblk):
+            h = ibasic_block(sd, "layer%d.%d" % (si + 1, bi), h, 2 if bi == 0 else 1, training)
+        taps["layer%d" % (si + 1)] = h
+    h = _bn(sd, "bn2", h, training)
+    h = torch.flatten(h, 1)
+    h = F.linear(h, sd["fc.weight"], sd["fc.bias"])
+    h = _bn(sd, "features", h, training)
+    return (h, taps) if return_taps else h
+
+
+def trainable_keys(sd: Dict[str, torch.Tensor]) -> List[str]:
+    """Keys ``model.parameters()`` yields with requires_grad (features.weight is frozen, iresnet.py:100)."""
+    out = []
+    for k, v in sd.items():
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            continue
+        if k == "features.weight":
+            continue
+        out.append(k)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# heads and losses
+# --------------------------------------------------------------------------------------
+def fc_module_forward(x: torch.Tensor, fc: torch.Tensor, normalize_feat: bool = True) -> torch.Tensor:
+    """client.py:69-74: cosine logits, F.normalize p=2 dim=1 eps=1e-12 on both sides."""
+    w = F.normalize(fc)
+    return (F.normalize(x) if normalize_feat else x) @ w.t()
+
+
+def cosface(cosine: torch.Tensor, label: torch.Tensor, s: float, m: float) -> torch.Tensor:
+    """losses.py:23-29: subtract m at the target column of rows with label != -1, then scale by s."""
+    rows = torch.nonzero(label != -1).flatten()
+    shift = torch.zeros_like(cosine)
+    shift[rows, label[rows]] = m
+    return (cosine - shift) * s
+
+
+def arcface(cosine: torch.Tensor, label: torch.Tensor, s: float, m: float) -> torch.Tensor:
+    """losses.py:38-45: theta = acos(c) (unclamped); theta += m at target; cos(theta) * s."""
+    rows = torch.nonzero(label != -1).flatten()
+    theta = torch.acos(cosine)
+    add = torch.zeros_like(cosine)
+    add[rows, label[rows]] = m
+    return torch.cos(theta + add) * s
+
+
+MARGINS = {"CosFace": cosface, "ArcFace": arcface}
+
+
+def bce_module_forward(x: torch.Tensor, labels: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor,
+                       weight: torch.Tensor, bias: torch.Tensor, m: float = 0.4, r: float = 30.0,
+                       t: int = 3) -> Tuple[torch.Tensor, torch.Tensor]:
+    """client.py:45-58 with converter_layer == 1 (config.py:31)."""
+    feat = F.linear(x, conv_w, conv_b)
+    cos = F.normalize(feat) @ F.normalize(weight).t()
+    n_class = weight.shape[0]
+    gt = torch.zeros(x.shape[0], n_class, dtype=torch.bool)
+    inr = labels < n_class                        # labels >= n_class => all-negative row (client.py:48-52)
+    gt[torch.nonzero(inr).flatten(), labels[inr]] = True
+    g = 2.0 * ((cos + 1.0) / 2.0).pow(t) - 1.0
+    z = torch.where(gt, r * (g - m), r * (g + m)) + bias.unsqueeze(0)
+    return z, gt
+
+
+def bce_loss(z: torch.Tensor, gt: torch.Tensor, r: float = 30.0, lambda_: float = 0.7) -> torch.Tensor:
+    """losses.py:11-15, reduction 'sum_mean'."""
+    pos = (lambda_ / r) * torch.log(1 + torch.exp(-z) + 1e-8)
+    neg = ((1 - lambda_) / r) * torch.log(1 + torch.exp(z) + 1e-8)
+    return torch.where(gt, pos, neg).sum(dim=1).mean()
+
+
+def contrastive_loss(feats: torch.Tensor, global_feats: torch.Tensor, last_feats: torch.Tensor,
+                     temperature: float = 0.5) -> torch.Tensor:
+    """client.py:372-375: 2-way CE over cosine-sim(feats, global)/T vs cosine-sim(feats, last)/T."""
+    pos = F.cosine_similarity(feats, global_feats, dim=1) / temperature
+    neg = F.cosine_similarity(feats, last_feats, dim=1) / temperature
+    return F.cross_entropy(torch.stack([pos, neg], dim=1), torch.zeros(len(feats), dtype=torch.long))
+
+
+# --------------------------------------------------------------------------------------
+# optimiser  (torch.optim.SGD semantics; client.py:335,527-529; config.py:8-9)
+# --------------------------------------------------------------------------------------
+def sgd_step(params: List[torch.Tensor], grads: List[Optional[torch.Tensor]],
+             bufs: List[Optional[torch.Tensor]], lr: float, momentum: float = 0.9,
+             weight_decay: float = 5e-4) -> None:
+    """g += wd*p ; buf = g (first step) | mu*buf + g ; p -= lr*buf.  In place; bufs list is filled."""
+    with torch.no_grad():
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if g is None:
+                continue
+            d = g + weight_decay * p
+            if bufs[i] is None:
+                bufs[i] = d.clone()
+            else:
+                bufs[i].mul_(momentum).add_(d)
+            p.sub_(lr * bufs[i])
+
+
+def lr_step_func(epoch: int, steps=(6, 14)) -> float:
+    """config.py:22-25."""
+    if epoch < -1:
+        return ((epoch + 1) / (4 + 1)) ** 2
+    return 0.1 ** len([m for m in steps if m - 1 <= epoch])
+
+
+# --------------------------------------------------------------------------------------
+# federated aggregation (server.py:25-46)
+# --------------------------------------------------------------------------------------
+def fedpavg(models: List[Dict[str, torch.Tensor]], weights: Sequence[float]) -> "OrderedDict[str, torch.Tensor]":
+    """server.py:25-34: w_i = n_i / sum(n) as Python floats; ascending-client accumulation from 0."""
+    tot = sum(weights)
+    ws = [w / tot for w in weights]
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name in models[0]:
+        acc = 0
+        for w, m in zip(ws, models):
+            acc = acc + w * m[name]
+        out[name] = acc
+    return out
+
+
+def fedavg_on_fc(pretrain_fc: torch.Tensor, models: List[torch.Tensor], weights: Sequence[float],
+                 p: float) -> torch.Tensor:
+    """server.py:36-46."""
+    tot = sum(weights)
+    ws = [w / tot for w in weights]
+    acc = models[0].clone() * ws[0]
+    for i in range(1, len(models)):
+        acc = acc + models[i] * ws[i]
+    return acc if p == 1 else (1 - p) * pretrain_fc + p * acc
+
+
+# --------------------------------------------------------------------------------------
+# one client local-training run  (client.py:511-571 ``Client.train``)
+# --------------------------------------------------------------------------------------
+def client_train(sd: Dict[str, torch.Tensor], fc: torch.Tensor, batches, layers: Sequence[int],
+                 loss_name: str = "CosFace", s: float = 30.0, m: float = 0.4, lr: float = 0.1,
+                 momentum: float = 0.9, weight_decay: float = 5e-4):
+    """state_dict in -> N x (zero_grad, fwd, margin, CE, bwd, SGD step) -> state_dict out.
+
+    ``batches`` is an iterable of (imgs, labels).  Fresh optimiser (momentum reset, F8).
+    Returns (per-step losses, sd, fc); sd/fc are updated in place.
+    """
+    keys = trainable_keys(sd)
+    params = [sd[k] for k in keys] + [fc]
+    bufs: List[Optional[torch.Tensor]] = [None] * len(params)
+    margin = MARGINS[loss_name]
+    losses = []
+    for imgs, labels in batches:
+        if len(imgs) == 1:                       # client.py:538-540
+            imgs, labels = torch.cat([imgs, imgs]), torch.cat([labels, labels])
+        for p in params:
+            p.requires_grad_(True)
+            p.grad = None
+        feats = iresnet_forward(sd, imgs, layers, training=True)
+        logits = margin(fc_module_forward(feats, fc), labels, s, m)
+        loss = F.cross_entropy(logits, labels)
+        loss.backward()
+        grads = [p.grad for p in params]
+        for p in params:
+            p.requires_grad_(False)
+        sgd_step(params, grads, bufs, lr, momentum, weight_decay)
+        losses.append(float(loss.detach()))
+    return losses, sd, fc
+
+
+def train_step_grads(sd: Dict[str, torch.Tensor], fc: torch.Tensor, imgs: torch.Tensor,
+                     labels: torch.Tensor, layers: Sequence[int], loss_name: str = "CosFace",
+                     s: float = 30.0, m: float = 0.4):
+    """One fwd+bwd; returns (feats, cosine, loss, {key: grad}, fc_grad).  BN buffers in sd are updated."""
+    keys = trainable_keys(sd)
+    ps = [sd[k].requires_grad_(True) for k in keys]
+    fc.requires_grad_(True)
+    for p in ps + [fc]:
+        p.grad = None
+    feats = iresnet_forward(sd, imgs, layers, training=True)
+    cosine = fc_module_forward(feats, fc)
+    logits = MARGINS[loss_name](cosine.clone(), labels, s, m)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: sd[k].grad.detach().clone() for k in keys}
+    fcg = fc.grad.detach().clone()
+    for p in ps + [fc]:
+        p.requires_grad_(False)
+        p.grad = None
+    return feats.detach(), cosine.detach(), float(loss.detach()), grads, fcg
+
+
+# --------------------------------------------------------------------------------------
+# PartialFC  (partial_fc.py:19-176) — functional restatement, collectives via callables
+# --------------------------------------------------------------------------------------
+class SingleRankComm:
+    """world_size == 1 stand-in for the six torch.distributed call sites (partial_fc.py:122-173)."""
+    world_size = 1
+    rank = 0
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        return t.clone()
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def reduce_scatter_sum(self, t: torch.Tensor) -> torch.Tensor:
+        return t.clone()
+
+
+class DistComm:
+    """gloo/RCCL-backed comm with the same four verbs (gloo lacks reduce_scatter: all_reduce + chunk)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world_size = dist.get_world_size()
+        self.rank = dist.get_rank()
+
+    def all_gather(self, t):
+        outs = [torch.zeros_like(t) for _ in range(self.world_size)]
+        self.dist.all_gather(outs, t.contiguous())
+        return torch.cat(outs, dim=0)
+
+    def all_reduce_max(self, t):
+        t = t.clone()
+        self.dist.all_reduce(t, self.dist.ReduceOp.MAX)
+        return t
+
+    def all_reduce_sum(self, t):
+        t = t.clone()
+        self.dist.all_reduce(t, self.dist.ReduceOp.SUM)
+        return t
+
+    def reduce_scatter_sum(self, t):
+        t = t.clone()
+        self.dist.all_reduce(t, self.dist.ReduceOp.SUM)
+        return t.chunk(self.world_size, dim=0)[self.rank].clone()
+
+
+def pfc_shard(num_classes: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """partial_fc.py:34-35 → (num_local, class_start)."""
+    num_local = num_classes // world_size + int(rank < num_classes % world_size)
+    class_start = num_classes // world_size * rank + min(rank, num_classes % world_size)
+    return num_local, class_start
+
+
+def pfc_sample(total_label: torch.Tensor, num_local: int, class_start: int, num_sample: int,
+               sample_rate: float, perm: Optional[torch.Tensor] = None):
+    """partial_fc.py:89-106.  ``perm`` = the uniform draw (torch.rand(num_local)); injected so
+    parity does not depend on RNG streams.  Returns (remapped label, index or None)."""
+    lab = total_label.clone()
+    pos_mask = (class_start <= lab) & (lab < class_start + num_local)
+    lab[~pos_mask] = -1
+    lab[pos_mask] -= class_start
+    if int(sample_rate) == 1:
+        return lab, None
+    positive = torch.unique(lab[pos_mask], sorted=True)
+    if num_sample - positive.numel() >= 0:
+        pr = perm.clone()
+        pr[positive] = 2.0
+        index = torch.topk(pr, k=num_sample)[1].sort()[0]
+    else:
+        index = positive
+    lab[pos_mask] = torch.searchsorted(index, lab[pos_mask])
+    return lab, index
+
+
+def pfc_forward_backward(label: torch.Tensor, features: torch.Tensor, weight: torch.Tensor,
+                         weight_mom: torch.Tensor, comm, batch_size: int, num_classes: int,
+                         sample_rate: float, margin_name: str, s: float, m: float,
+                         perm: Optional[torch.Tensor] = None):
+    """partial_fc.py:118-176.  Returns dict with x_grad, loss_v, index, total_label,
+    sub_weight, sub_weight_grad (grad wrt the *un-normalised* sampled rows)."""
+    W, rank = comm.world_size, comm.rank
+    num_local, class_start = pfc_shard(num_classes, W, rank)
+    num_sample = int(sample_rate * num_local)
+    total_label = comm.all_gather(label)                               # C1 :122
+    total_label, index = pfc_sample(total_label, num_local, class_start, num_sample, sample_rate, perm)
+    sub_weight = (weight if index is None else weight[index]).clone().requires_grad_(True)
+    norm_weight = F.normalize(sub_weight)                              # :127
+    total_features = comm.all_gather(features.detach()).requires_grad_(True)   # C2 :134
+    logits = F.linear(total_features, norm_weight)                     # :110
+    logits = MARGINS[margin_name](logits, total_label, s, m)           # :138
+    with torch.no_grad():
+        mx = comm.all_reduce_max(logits.max(dim=1, keepdim=True)[0])   # C3 :142
+        ex = torch.exp(logits - mx)
+        sm = comm.all_reduce_sum(ex.sum(dim=1, keepdim=True))          # C4 :147
+        prob = ex / sm
+        rows = torch.nonzero(total_label != -1).flatten()
+        loss = torch.zeros(prob.shape[0], 1)
+        loss[rows] = prob[rows].gather(1, total_label[rows, None])
+        loss = comm.all_reduce_sum(loss)                               # C5 :161
+        loss_v = -loss.clamp_min(1e-30).log().mean()
+        grad = prob.clone()
+        grad[rows, total_label[rows]] -= 1.0
+        grad = grad / (batch_size * W)
+    logits.backward(grad)
+    x_grad = comm.reduce_scatter_sum(total_features.grad) * W          # C6 :173-174
+    return {
+        "x_grad": x_grad, "loss_v": loss_v, "index": index, "total_label": total_label,
+        "sub_weight": sub_weight.detach(), "sub_weight_grad": sub_weight.grad.detach(),
+        "num_local": num_local, "class_start": class_start,
+    }
+
+
+def pfc_sgd_update(weight: torch.Tensor, weight_mom: torch.Tensor, index: Optional[torch.Tensor],
+                   sub_weight_grad: torch.Tensor, lr: float, momentum: float = 0.9,
+                   weight_decay: float = 5e-4) -> None:
+    """Caller protocol (upstream convention): opt.step() on sub_weight with the aliased
+    momentum rows (partial_fc.py:124-126, buffer already exists => buf = mu*buf + g), then
+    ``update()`` scatters rows back (partial_fc.py:113-116)."""
+    with torch.no_grad():
+        if index is None:
+            sw, sm = weight, weight_mom
+        else:
+            sw, sm = weight[index], weight_mom[index]
+        d = sub_weight_grad + weight_decay * sw
+        sm = momentum * sm + d
+        sw = sw - lr * sm
+        if index is None:
+            weight.copy_(sw)
+            weight_mom.copy_(sm)
+        else:
+            weight[index] = sw
+            weight_mom[index] = sm

@@ -1,0 +1,214 @@
+"""Pin the CPU restatement (oracle/ref_cpu.py) to golden vectors captured from the imported
+reference by tools/make_golden.py.  CPU only; no reference import at test time."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import ref_cpu as R
+
+torch.set_num_threads(8)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach() if isinstance(a, torch.Tensor) else T(a)
+    b = T(b)
+    torch.testing.assert_close(a.to(b.dtype), b, rtol=rtol, atol=atol)
+
+
+def test_spec_counts():
+    # r50 475 keys, r100 925 keys (771 float + 154 int64)
+    s50 = R.iresnet_spec(R.IRESNET_LAYERS["iresnet50"])
+    s100 = R.iresnet_spec(R.IRESNET_LAYERS["iresnet100"])
+    assert len(s50) == 475 and len(s100) == 925
+    assert sum(1 for _, _, k in s100 if k == "bn_nbt") == 154
+    n_par = sum(int(np.prod(s)) for k, s, kind in s100 if kind in ("conv", "bn_w", "bn_b", "prelu", "fc_w", "fc_b"))
+    assert n_par == 65156160
+    n_par = sum(int(np.prod(s)) for k, s, kind in s50 if kind in ("conv", "bn_w", "bn_b", "prelu", "fc_w", "fc_b"))
+    assert n_par == 43590848
+
+
+@pytest.mark.parametrize("arch,batch,fname", [("iresnet50", 4, "r50_b4"), ("iresnet100", 2, "r100_b2")])
+def test_backbone_matches_reference(arch, batch, fname):
+    g = load_golden(fname)
+    layers = R.IRESNET_LAYERS[arch]
+    C = int(g["num_classes"])
+    sd = R.closed_form_state_dict(layers)
+    x = R.closed_form_images(batch)
+    lab = R.closed_form_labels(batch, C)
+    with torch.no_grad():
+        fe = R.iresnet_forward({k: v.clone() for k, v in sd.items()}, x, layers, training=False)
+    close(fe, g["feat_eval"], 1e-4, 1e-5)
+    fc = R.closed_form((C, 512), 0.41, 0.3, 0.01)
+    feats, cosine, loss, grads, fcg = R.train_step_grads(sd, fc, x, lab, layers, "CosFace", 30.0, 0.4)
+    close(feats, g["feat_train"], 1e-4, 1e-5)
+    close(cosine, g["cosine"], 1e-4, 1e-6)
+    assert abs(loss - float(g["loss"])) < 1e-5
+    names = [str(n) for n in g["grad_names"]]
+    assert names == R.trainable_keys(sd)
+    norms = np.array([float(grads[k].norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("g_") and k[2:] in grads:
+            close(grads[k[2:]], g[k], 2e-3, 1e-6)
+    close(grads["layer3.1.conv1.weight"][:4, :16], g["g_layer3.1.conv1.weight_slice"], 2e-3, 1e-6)
+    close(grads["fc.weight"][:4, :2048], g["g_fc.weight_slice"], 2e-3, 1e-7)
+    close(fcg[:8], g["g_fc_head_rows"], 1e-4, 1e-7)
+    for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer4.2.bn3", "bn2", "features"):
+        close(sd[k + ".running_mean"], g["rm_" + k], 1e-4, 1e-6)
+        close(sd[k + ".running_var"], g["rv_" + k], 1e-4, 1e-6)
+        assert int(sd[k + ".num_batches_tracked"]) == int(g["nbt_" + k])
+
+
+def test_heads_match_reference():
+    g = load_golden("heads")
+    B, C = int(g["B"]), int(g["C"])
+    x = R.closed_form((B, 512), 0.113, 0.2, 1.0)
+    w = R.closed_form((C, 512), 0.071, 1.1, 0.01)
+    lab, lab_m1 = T(g["labels"]), T(g["labels_m1"])
+    for nm, fn, s, m in (("cos", R.cosface, 30.0, 0.4), ("arc", R.arcface, 30.0, 0.4),
+                         ("cos64", R.cosface, 64.0, 0.4), ("arc64", R.arcface, 64.0, 0.5)):
+        xx = x.clone().requires_grad_(True)
+        ww = w.clone().requires_grad_(True)
+        cosine = R.fc_module_forward(xx, ww)
+        logits = fn(cosine.clone(), lab, s, m)
+        loss = F.cross_entropy(logits, lab)
+        loss.backward()
+        close(cosine, g[nm + "_cosine"])
+        close(logits, g[nm + "_logits"], 1e-5, 1e-5)
+        close(loss, g[nm + "_loss"])
+        close(xx.grad, g[nm + "_dx"], 1e-4, 1e-7)
+        close(ww.grad, g[nm + "_dw"], 1e-4, 1e-6)
+        close(fn(R.fc_module_forward(x, w), lab_m1, s, m), g[nm + "_logits_m1"], 1e-5, 1e-5)
+    close(R.fc_module_forward(x, w, normalize_feat=False), g["nonorm_cosine"])
+
+
+def test_bce_matches_reference():
+    g = load_golden("bce")
+    B, C = int(g["B"]), int(g["C"])
+    x = R.closed_form((B, 512), 0.113, 0.2, 1.0).requires_grad_(True)
+    weight = R.closed_form((C, 512), 0.071, 1.1, 0.05).requires_grad_(True)
+    bias = R.closed_form((C,), 0.5, 0.1, 0.1).requires_grad_(True)
+    cw = (torch.eye(512) + R.closed_form((512, 512), 0.013, 0.7, 0.01)).requires_grad_(True)
+    cb = R.closed_form((512,), 0.3, 0.2, 0.01).requires_grad_(True)
+    z, gt = R.bce_module_forward(x, T(g["labels"]), cw, cb, weight, bias)
+    loss = R.bce_loss(z, gt)
+    loss.backward()
+    close(z, g["z"], 1e-4, 1e-5)
+    assert bool((gt == T(g["gt"])).all())
+    close(loss, g["loss"])
+    close(x.grad, g["dx"], 1e-4, 1e-7)
+    close(weight.grad, g["d_weight"], 1e-4, 1e-6)
+    close(bias.grad, g["d_bias"], 1e-4, 1e-7)
+    close(cw.grad[:8, :64], g["d_conv_w_slice"], 1e-4, 1e-7)
+    close(cb.grad, g["d_conv_b"], 1e-4, 1e-7)
+
+
+def test_sgd_matches_reference():
+    g = load_golden("sgd")
+    ps = [R.closed_form(s, 0.2 + 0.1 * i, 0.3 * i, 0.5) for i, s in enumerate([(7, 5), (33,), (4, 3, 3, 3)])]
+    bufs = [None] * 3
+    for step in range(3):
+        grads = [R.closed_form(tuple(p.shape), 0.15 + 0.05 * i + 0.01 * step, 0.7 * step, 0.3)
+                 for i, p in enumerate(ps)]
+        R.sgd_step(ps, grads, bufs, 0.1, 0.9, 5e-4)
+        for i in range(3):
+            close(ps[i], g["p%d_s%d" % (i, step)], 1e-6, 1e-7)
+            close(bufs[i], g["m%d_s%d" % (i, step)], 1e-6, 1e-7)
+
+
+def test_fedavg_matches_reference():
+    g = load_golden("fedavg")
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sizes = [int(v) for v in g["sizes"]]
+    models = []
+    for i in range(3):
+        sd = R.closed_form_state_dict(layers, tag=float(i + 1))
+        models.append({k: v for k, v in sd.items() if not k.startswith("fc.weight")})
+    agg = R.fedpavg(models, sizes)
+    for k in g.files:
+        if k.startswith("agg_") and k[4:] in agg:
+            a, b = agg[k[4:]], T(g[k])
+            assert a.dtype == b.dtype, k          # F9: int64 nbt becomes float32
+            assert torch.equal(a, b), k           # same op order => bit exact
+    tot = sum(float(v.double().sum()) for v in agg.values())
+    assert tot == float(g["agg_checksum"])
+    fcs = [R.closed_form((60, 512), 0.1 + 0.01 * i, 0.2 * i, 0.02) for i in range(3)]
+    pre = R.closed_form((60, 512), 0.31, 0.5, 0.02)
+    assert torch.equal(R.fedavg_on_fc(pre, fcs, sizes, 1), T(g["fc_p1"]))
+    assert torch.equal(R.fedavg_on_fc(pre, fcs, sizes, 0.5), T(g["fc_p05"]))
+
+
+def _pfc_inputs(B, C, rank, st, num_local):
+    feats = F.normalize(R.closed_form((B, 512), 0.113 + 0.01 * rank + 0.001 * st, 0.2 + st, 1.0))
+    lab = (R.closed_form_labels(B, C, tag=st + 3 * rank) * 31 + rank) % C
+    perm = R.closed_form((num_local,), 0.77 + 0.1 * st, 0.3 + rank, 0.5, 0.5)
+    return feats, lab, perm
+
+
+def _pfc_check(g, comm, rank, world):
+    B, C, rate = int(g["B"]), int(g["C"]), float(g["rate"])
+    s, m, steps, mn = float(g["s"]), float(g["m"]), int(g["steps"]), str(g["margin"])
+    num_local, _ = R.pfc_shard(C, world, rank)
+    weight = R.closed_form((num_local, 512), 0.071 + 0.003 * rank, 1.1, 0.01)
+    mom = torch.zeros_like(weight)
+    for st in range(steps):
+        feats, lab, perm = _pfc_inputs(B, C, rank, st, num_local)
+        r = R.pfc_forward_backward(lab, feats, weight, mom, comm, B, C, rate, mn, s, m, perm)
+        pre = "r%d_s%d_" % (rank, st)
+        close(r["x_grad"], g[pre + "x_grad"], 1e-4, 1e-6)
+        close(r["loss_v"], g[pre + "loss_v"], 1e-5, 1e-6)
+        if (pre + "index") in g.files:
+            assert torch.equal(r["index"], T(g[pre + "index"]))
+        swg = r["sub_weight_grad"]
+        close(swg[:: max(1, swg.shape[0] // 48)][:48], g[pre + "sub_weight_grad_rows"], 1e-4, 1e-6)
+        close(swg.norm(dim=1), g[pre + "sub_weight_grad_rownorm"], 1e-4, 1e-6)
+        R.pfc_sgd_update(weight, mom, r["index"], swg, 0.1, 0.9, 5e-4)
+        close(weight[:: max(1, num_local // 64)][:64], g[pre + "weight_rows"], 1e-5, 1e-7)
+        close(mom[:: max(1, num_local // 64)][:64], g[pre + "mom_rows"], 1e-4, 1e-6)
+        assert abs(float(weight.double().sum()) - float(g[pre + "weight_sum"])) < 1e-3
+        assert abs(float(mom.double().sum()) - float(g[pre + "mom_sum"])) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["pfc_w1_arc_r01", "pfc_w1_cos_r1", "pfc_w1_cos_r03"])
+def test_partial_fc_w1_matches_reference(name):
+    _pfc_check(load_golden(name), R.SingleRankComm(), 0, 1)
+
+
+def _pfc_w2_worker(rank, port):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        _pfc_check(load_golden("pfc_w2"), R.DistComm(), rank, 2)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_partial_fc_w2_gloo_matches_reference():
+    import torch.multiprocessing as mp
+    mp.spawn(_pfc_w2_worker, args=(29633,), nprocs=2, join=True)
+
+
+def test_client_loop_matches_reference():
+    g = load_golden("client_r18")
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    B, C, steps = int(g["B"]), int(g["C"]), int(g["steps"])
+    sd = R.closed_form_state_dict(layers, tag=2.0)
+    fc = R.closed_form((C, 512), 0.41, 0.3, 0.01)
+    batches = [(R.closed_form_images(B, tag=float(st)), R.closed_form_labels(B, C, tag=st)) for st in range(steps)]
+    losses, sd, fc = R.client_train(sd, fc, batches, layers, "CosFace", 30.0, 0.4, 0.1, 0.9, 5e-4)
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=2e-4)
+    for k in g.files:
+        if k.startswith("sd_") and k[3:] in sd:
+            close(sd[k[3:]], g[k], 2e-3, 2e-5)
+    close(sd["fc.weight"][:4, :2048], g["sd_fc.weight_slice"], 2e-3, 2e-5)
+    close(fc, g["head_fc"], 2e-3, 2e-5)

@@ -1,0 +1,461 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by driving the IMPORTED reference (/root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).
+Inputs/weights are closed-form (oracle.ref_cpu.closed_form*), so fixtures hold only
+outputs + the few generator parameters.  Re-run:  python tools/make_golden.py
+
+What is captured (reference symbol → fixture):
+  backbones.iresnet.IBasicBlock           → block.npz
+  backbones.iresnet50 / iresnet100        → r50_b4.npz / r100_b2.npz  (train fwd+bwd, eval fwd)
+  client.FC_module, losses.CosFace/ArcFace, F.cross_entropy → heads.npz
+  client.BCE_module, losses.BCE_loss      → bce.npz
+  torch.optim.SGD (momentum .9, wd 5e-4)  → sgd.npz
+  server.FedPavg / FedAvg_on_FC           → fedavg.npz
+  partial_fc.PartialFC (W=1, and W=2 over gloo) → pfc_w1_*.npz / pfc_w2.npz
+  a 3-step Client.train-equivalent loop on iresnet18 → client_r18.npz
+"""
+import os
+import sys
+import types
+import contextlib
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+torch.set_num_threads(8)
+
+
+# ---- stubs for absent third-party modules -------------------------------
+class _ED(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+_m = types.ModuleType("easydict")
+_m.EasyDict = _ED
+sys.modules["easydict"] = _m
+for _n in ("mxnet", "cv2", "prettytable", "torchvision", "torchvision.transforms"):
+    sys.modules[_n] = types.ModuleType(_n)
+sys.modules["mxnet"].ndarray = types.ModuleType("nd")
+sys.modules["mxnet.ndarray"] = sys.modules["mxnet"].ndarray
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+sys.modules["prettytable"].PrettyTable = object
+
+import warnings
+warnings.filterwarnings("ignore")
+import backbones          # noqa: E402  (reference)
+import losses             # noqa: E402
+import client             # noqa: E402
+import server             # noqa: E402
+
+from oracle import ref_cpu as R   # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print("wrote %-22s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def load_closed_form(model, layers, tag=0.0):
+    sd = R.closed_form_state_dict(layers, tag=tag)
+    ref_keys = list(model.state_dict().keys())
+    assert ref_keys == list(sd.keys()), "spec order differs from reference state_dict order"
+    model.load_state_dict(sd)
+    return sd
+
+
+# ---- 1. IBasicBlock -------------------------------------------------------------------------
+def gen_block():
+    from backbones.iresnet import IBasicBlock, conv1x1
+    out = {}
+    for name, cin, cout, stride, hw in (("s1", 64, 64, 1, 14), ("s2", 64, 128, 2, 16)):
+        ds = None
+        if stride != 1 or cin != cout:
+            ds = torch.nn.Sequential(conv1x1(cin, cout, stride), torch.nn.BatchNorm2d(cout, eps=1e-5))
+        blk = IBasicBlock(cin, cout, stride, ds)
+        blk.train()
+        sd = blk.state_dict()
+        for i, (k, v) in enumerate(sd.items()):
+            if v.dtype == torch.int64:
+                sd[k] = torch.tensor(2)
+            elif k.endswith("running_var"):
+                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.2, 1.0)
+            elif k.endswith(".weight") and v.dim() == 1 and "prelu" not in k:
+                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.25, 1.0)
+            elif "prelu" in k:
+                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.1, 0.25)
+            elif v.dim() == 4:
+                fan = v.shape[1] * v.shape[2] * v.shape[3]
+                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, (2.0 / fan) ** 0.5 * 1.5)
+            else:
+                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.1)
+        blk.load_state_dict(sd)
+        x = R.closed_form((3, cin, hw, hw), 0.0211, 0.4, 1.0).requires_grad_(True)
+        y = blk(x)
+        gy = R.closed_form(tuple(y.shape), 0.0137, 0.9, 1.0)
+        y.backward(gy)
+        out[name + "_y"] = y
+        out[name + "_dx"] = x.grad
+        for k, p in blk.named_parameters():
+            g = p.grad
+            out[name + "_g_" + k] = g if g.numel() <= 4096 else g.flatten()[:: max(1, g.numel() // 2048)][:2048]
+            out[name + "_gn_" + k] = g.norm()
+        for k, b in blk.named_buffers():
+            out[name + "_b_" + k] = b
+    save("block", **out)
+
+
+# ---- 2. full backbones ------------------------------------------------------------------------
+def gen_backbone(arch, layers, batch, fname, num_classes=1000):
+    model = getattr(backbones, arch)(False, dropout=0, fp16=False)
+    load_closed_form(model, layers)
+    fcm = client.FC_module(512, num_classes, "/tmp")
+    fcm.fc.data = R.closed_form((num_classes, 512), 0.41, 0.3, 0.01)
+    x = R.closed_form_images(batch)
+    lab = R.closed_form_labels(batch, num_classes)
+    out = {"batch": batch, "num_classes": num_classes}
+    # eval-mode forward first (does not touch buffers)
+    model.eval()
+    with torch.no_grad():
+        out["feat_eval"] = model(x)
+    model.train()
+    feats = model(x)
+    cosine = fcm(feats)
+    logits = losses.CosFace(s=30, m=0.4)(cosine.clone(), lab)
+    loss = F.cross_entropy(logits, lab)
+    loss.backward()
+    out["feat_train"] = feats
+    out["cosine"] = cosine
+    out["loss"] = loss
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(p.grad.norm()))
+        if p.grad.numel() <= 512 and (k.startswith(("bn1", "prelu", "layer1.0", "layer4.2", "bn2", "fc.bias",
+                                                     "features", "layer3.5")) or "downsample.1" in k):
+            out["g_" + k] = p.grad
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, dtype=np.float64)
+    out["g_conv1.weight"] = model.conv1.weight.grad
+    out["g_fc_head_norm"] = fcm.fc.grad.norm()
+    out["g_fc_head_rows"] = fcm.fc.grad[:8]
+    g = model.layer3[1].conv1.weight.grad
+    out["g_layer3.1.conv1.weight_slice"] = g[:4, :16]
+    g = model.fc.weight.grad
+    out["g_fc.weight_slice"] = g[:4, :2048]
+    for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer4.2.bn3", "bn2", "features"):
+        mod = dict(model.named_modules())[k]
+        out["rm_" + k] = mod.running_mean
+        out["rv_" + k] = mod.running_var
+        out["nbt_" + k] = mod.num_batches_tracked
+    save(fname, **out)
+
+
+# ---- 3. heads ---------------------------------------------------------------------------------------
+def gen_heads():
+    B, C = 16, 40
+    x = R.closed_form((B, 512), 0.113, 0.2, 1.0)
+    w = R.closed_form((C, 512), 0.071, 1.1, 0.01)
+    lab = R.closed_form_labels(B, C)
+    lab_m1 = lab.clone()
+    lab_m1[[1, 5, 11]] = -1      # PartialFC convention rows (losses.py:24,39)
+    out = {"B": B, "C": C, "labels": lab, "labels_m1": lab_m1}
+    fcm = client.FC_module(512, C, "/tmp")
+    fcm.fc.data = w.clone()
+    for nm, cls, s, m in (("cos", losses.CosFace, 30.0, 0.4), ("arc", losses.ArcFace, 30.0, 0.4),
+                          ("cos64", losses.CosFace, 64.0, 0.4), ("arc64", losses.ArcFace, 64.0, 0.5)):
+        xx = x.clone().requires_grad_(True)
+        fcm.fc.grad = None
+        cosine = fcm(xx)
+        logits = cls(s=s, m=m)(cosine.clone(), lab)
+        loss = F.cross_entropy(logits, lab)
+        loss.backward()
+        out[nm + "_cosine"] = cosine
+        out[nm + "_logits"] = logits
+        out[nm + "_loss"] = loss
+        out[nm + "_dx"] = xx.grad
+        out[nm + "_dw"] = fcm.fc.grad.clone()
+        with torch.no_grad():
+            out[nm + "_logits_m1"] = cls(s=s, m=m)(fcm(x).clone(), lab_m1)
+    with torch.no_grad():
+        out["nonorm_cosine"] = fcm(x, normalize_feat=False)
+    save("heads", **out)
+
+
+def gen_bce():
+    B, C = 12, 10
+    x = R.closed_form((B, 512), 0.113, 0.2, 1.0).requires_grad_(True)
+    mod = client.BCE_module(512, C, 1)
+    mod.weight.data = R.closed_form((C, 512), 0.071, 1.1, 0.05)
+    mod.bias.data = R.closed_form((C,), 0.5, 0.1, 0.1)
+    cw = torch.eye(512) + R.closed_form((512, 512), 0.013, 0.7, 0.01)
+    mod.converter[0].weight.data = cw
+    mod.converter[0].bias.data = R.closed_form((512,), 0.3, 0.2, 0.01)
+    lab = torch.tensor([0, 3, 9, 12, 5, 5, 25, 1, 2, 7, 10, 4])   # >= C => all-negative rows
+    z, gt = mod(x, lab)
+    loss = losses.BCE_loss()(z.clone(), gt)
+    loss.backward()
+    save("bce", B=B, C=C, labels=lab, z=z, gt=gt, loss=loss, dx=x.grad,
+         d_weight=mod.weight.grad, d_bias=mod.bias.grad,
+         d_conv_w_slice=mod.converter[0].weight.grad[:8, :64], d_conv_b=mod.converter[0].bias.grad,
+         conv_w_norm=mod.converter[0].weight.grad.norm())
+
+
+# ---- 4. SGD ------------------------------------------------------------------------------------------
+def gen_sgd():
+    ps = [torch.nn.Parameter(R.closed_form(s, 0.2 + 0.1 * i, 0.3 * i, 0.5)) for i, s in
+          enumerate([(7, 5), (33,), (4, 3, 3, 3)])]
+    opt = torch.optim.SGD(ps, lr=0.1, momentum=0.9, weight_decay=5e-4)
+    out = {}
+    for step in range(3):
+        for i, p in enumerate(ps):
+            p.grad = R.closed_form(tuple(p.shape), 0.15 + 0.05 * i + 0.01 * step, 0.7 * step, 0.3)
+        opt.step()
+        for i, p in enumerate(ps):
+            out["p%d_s%d" % (i, step)] = p.detach().clone()
+            out["m%d_s%d" % (i, step)] = opt.state[p]["momentum_buffer"].clone()
+    save("sgd", **out)
+
+
+# ---- 5. FedAvg ------------------------------------------------------------------------------------------
+def gen_fedavg():
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sizes = [1200, 800, 3100]
+    models = []
+    for i in range(3):
+        sd = R.closed_form_state_dict(layers, tag=float(i + 1))
+        small = {k: v for k, v in sd.items() if not k.startswith("fc.weight")}   # keep fixture small
+        models.append(small)
+    agg = server.FedPavg(models, sizes)
+    out = {"sizes": np.array(sizes)}
+    for k in ("conv1.weight", "bn1.running_var", "bn1.num_batches_tracked", "layer2.0.downsample.0.weight",
+              "layer4.1.prelu.weight", "fc.bias", "features.running_mean", "layer3.1.bn2.num_batches_tracked"):
+        out["agg_" + k] = agg[k]
+    out["agg_dtype_nbt"] = np.array(str(agg["bn1.num_batches_tracked"].dtype))
+    tot = 0.0
+    for k, v in agg.items():
+        tot += float(v.double().sum())
+    out["agg_checksum"] = tot
+    fcs = [R.closed_form((60, 512), 0.1 + 0.01 * i, 0.2 * i, 0.02) for i in range(3)]
+    pre = R.closed_form((60, 512), 0.31, 0.5, 0.02)
+    out["fc_p1"] = server.FedAvg_on_FC(pre, fcs, sizes, 1)
+    out["fc_p05"] = server.FedAvg_on_FC(pre, fcs, sizes, 0.5)
+    save("fedavg", **out)
+
+
+# ---- 6. PartialFC ----------------------------------------------------------------------------------------
+class _FakeStream:
+    def __init__(self, *a, **k):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+
+@contextlib.contextmanager
+def _cpu_cuda_shims():
+    import torch._dynamo  # noqa: F401  (App. C: import before patching torch.device)
+    real_device = torch.device
+    saved = (torch.cuda.Stream, torch.cuda.current_stream, torch.cuda.stream, torch.Tensor.cuda)
+
+    class _DevMeta(type):
+        def __instancecheck__(cls, inst):
+            return isinstance(inst, real_device)
+
+    class _Dev(metaclass=_DevMeta):
+        def __new__(cls, *a, **k):
+            if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+                return real_device("cpu")
+            return real_device(*a, **k)
+
+    torch.device = _Dev
+    torch.cuda.Stream = _FakeStream
+    torch.cuda.current_stream = lambda *a, **k: _FakeStream()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.device = real_device
+        torch.cuda.Stream, torch.cuda.current_stream, torch.cuda.stream, torch.Tensor.cuda = saved
+
+
+def _pfc_run(rank, world, B, C, rate, margin_name, s, m, steps, seed_base, q=None):
+    import torch.distributed as dist
+    import partial_fc
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = "29611"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        def _rs(out, lst, *a, **k):   # gloo lacks reduce_scatter
+            t = torch.cat([x.detach() for x in lst], dim=0)
+            dist.all_reduce(t)
+            out.data.copy_(t.chunk(world, dim=0)[rank])
+        dist.reduce_scatter = _rs
+    else:
+        # world_size 1: make the six dist calls identities
+        dist.all_gather = lambda outs, t, *a, **k: [o.copy_(t) for o in outs][:0]
+        dist.all_reduce = lambda t, *a, **k: None
+
+        def _rs1(out, lst, *a, **k):
+            out.data.copy_(lst[0].detach())
+        dist.reduce_scatter = _rs1
+    margin = getattr(losses, margin_name)(s=s, m=m)
+    with _cpu_cuda_shims():
+        pfc = partial_fc.PartialFC(rank=rank, local_rank=0, world_size=world, batch_size=B, resume=False,
+                                   margin_softmax=margin, num_classes=C, sample_rate=rate,
+                                   embedding_size=512, prefix="/tmp")
+        num_local, class_start = R.pfc_shard(C, world, rank)
+        pfc.weight = R.closed_form((num_local, 512), 0.071 + 0.003 * rank, 1.1, 0.01)
+        pfc.weight_mom = torch.zeros_like(pfc.weight)
+        if int(rate) == 1:
+            pfc.sub_weight = torch.nn.Parameter(pfc.weight)
+            pfc.sub_weight_mom = pfc.weight_mom
+        dummy = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([{"params": [dummy]}, {"params": [pfc.sub_weight]}], lr=0.1, momentum=0.9,
+                              weight_decay=5e-4)
+        res = {}
+        real_rand = torch.rand
+        for st in range(steps):
+            # upstream callers hand PartialFC L2-normalised embeddings (ArcFace's acos is unclamped)
+            feats = F.normalize(R.closed_form((B, 512), 0.113 + 0.01 * rank + 0.001 * st, 0.2 + st, 1.0))
+            lab = (R.closed_form_labels(B, C, tag=st + 3 * rank) * 31 + rank) % C
+            perm = R.closed_form((num_local,), 0.77 + 0.1 * st, 0.3 + rank, 0.5, 0.5)
+            opt.zero_grad()                                # caller protocol: fresh grads every step
+            torch.rand = lambda *a, **k: perm.clone()      # inject the draw (partial_fc.py:97)
+            x_grad, loss_v = pfc.forward_backward(lab, feats, opt)
+            torch.rand = real_rand
+            sw_grad = pfc.sub_weight.grad.clone()
+            opt.step()
+            pfc.update()
+            pre = "r%d_s%d_" % (rank, st)
+            res[pre + "x_grad"] = x_grad.detach().clone()
+            res[pre + "loss_v"] = loss_v.detach().clone()
+            res[pre + "sub_weight_grad_rows"] = sw_grad[:: max(1, sw_grad.shape[0] // 48)][:48].clone()
+            res[pre + "sub_weight_grad_rownorm"] = sw_grad.norm(dim=1)
+            if pfc.index is not None:
+                res[pre + "index"] = pfc.index.clone()
+            res[pre + "weight_rows"] = pfc.weight[:: max(1, num_local // 64)][:64].clone()
+            res[pre + "mom_rows"] = pfc.weight_mom[:: max(1, num_local // 64)][:64].clone()
+            res[pre + "weight_sum"] = pfc.weight.double().sum()
+            res[pre + "mom_sum"] = pfc.weight_mom.double().sum()
+    if world > 1:
+        q.put({k: v.numpy() for k, v in res.items()})
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
+
+
+def gen_pfc():
+    import torch.multiprocessing as mp
+    # subprocess per config so the dist monkey-patches do not leak
+    cfgs = [("pfc_w1_arc_r01", 1, 8, 2000, 0.1, "ArcFace", 30.0, 0.4, 2),
+            ("pfc_w1_cos_r1", 1, 8, 300, 1.0, "CosFace", 30.0, 0.4, 2),
+            ("pfc_w1_cos_r03", 1, 8, 1000, 0.3, "CosFace", 64.0, 0.4, 2)]
+    ctx = mp.get_context("spawn")
+    for name, W, B, C, rate, mn, s, m, steps in cfgs:
+        q = ctx.Queue()
+        p = ctx.Process(target=_pfc_single_entry, args=(q, B, C, rate, mn, s, m, steps))
+        p.start()
+        res = q.get()
+        p.join()
+        save(name, B=B, C=C, rate=rate, s=s, m=m, steps=steps, margin=np.array(mn), **res)
+    # W = 2 over gloo, uneven shards (1001 classes → 501/500)
+    q = ctx.Queue()
+    B, C, rate, mn, s, m, steps = 8, 1001, 0.2, "CosFace", 30.0, 0.4, 2
+    procs = [ctx.Process(target=_pfc_run, args=(r, 2, B, C, rate, mn, s, m, steps, 0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        res.update(q.get())
+    for p in procs:
+        p.join()
+    save("pfc_w2", B=B, C=C, rate=rate, s=s, m=m, steps=steps, margin=np.array(mn), **res)
+
+
+def _pfc_single_entry(q, B, C, rate, mn, s, m, steps):
+    res = _pfc_run(0, 1, B, C, rate, mn, s, m, steps, 0)
+    q.put({k: v.numpy() for k, v in res.items()})
+
+
+# ---- 7. client loop on iresnet18 ------------------------------------------------------------------------------
+def gen_client():
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    C, B, steps = 20, 4, 3
+    model = backbones.iresnet18(False, dropout=0, fp16=False)
+    load_closed_form(model, layers, tag=2.0)
+    fcm = client.FC_module(512, C, "/tmp")
+    fcm.fc.data = R.closed_form((C, 512), 0.41, 0.3, 0.01)
+    model.train()
+    fcm.train()
+    seq = torch.nn.Sequential(model, fcm)
+    opt = torch.optim.SGD(params=seq.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    margin = losses.CosFace(s=30, m=0.4)
+    out = {"B": B, "C": C, "steps": steps}
+    ls = []
+    for st in range(steps):
+        imgs = R.closed_form_images(B, tag=float(st))
+        lab = R.closed_form_labels(B, C, tag=st)
+        opt.zero_grad()
+        logits = seq(imgs)
+        logits = margin(logits, lab)
+        loss = F.cross_entropy(logits, lab)
+        loss.backward()
+        opt.step()
+        ls.append(float(loss))
+    out["losses"] = np.array(ls, dtype=np.float64)
+    sd = model.state_dict()
+    for k in ("conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var",
+              "bn1.num_batches_tracked", "prelu.weight", "layer2.0.downsample.0.weight",
+              "layer4.1.bn3.running_var", "fc.bias", "features.bias", "features.running_mean"):
+        out["sd_" + k] = sd[k]
+    out["sd_fc.weight_slice"] = sd["fc.weight"][:4, :2048]
+    out["sd_layer3.1.conv2.weight_slice"] = sd["layer3.1.conv2.weight"][:4, :32]
+    out["head_fc"] = fcm.fc.data
+    tot = 0.0
+    for k, v in sd.items():
+        tot += float(v.double().abs().sum())
+    out["sd_abs_checksum"] = tot
+    save("client_r18", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client"]
+    if "block" in which:
+        gen_block()
+    if "r50" in which:
+        gen_backbone("iresnet50", R.IRESNET_LAYERS["iresnet50"], 4, "r50_b4")
+    if "r100" in which:
+        gen_backbone("iresnet100", R.IRESNET_LAYERS["iresnet100"], 2, "r100_b2")
+    if "heads" in which:
+        gen_heads()
+    if "bce" in which:
+        gen_bce()
+    if "sgd" in which:
+        gen_sgd()
+    if "fedavg" in which:
+        gen_fedavg()
+    if "pfc" in which:
+        gen_pfc()
+    if "client" in which:
+        gen_client()

@@ -1,0 +1,127 @@
+"""ctypes binding of libfedfr_hip.so (C ABI: include/fedfr_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError carrying
+``fedfr_last_error_string()`` is raised.  Device memory is owned by torch tensors; raw
+``data_ptr()`` values and the current HIP stream handle are passed through.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfedfr_hip.so")
+
+_lib: Optional[C.CDLL] = None
+
+vp, i32, i64, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_ulonglong, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/fedfr_hip.h declares (tests/test_abi.py checks).
+SIGNATURES = {
+    "fedfr_version": (i32, []),
+    "fedfr_last_error_string": (C.c_char_p, []),
+    "fedfr_set_option": (i32, [C.c_char_p, i32]),
+    "fedfr_net_create": (vp, [C.POINTER(i32), i32, i32, i32]),
+    "fedfr_net_destroy": (None, [vp]),
+    "fedfr_net_query": (i32, [vp, i32, C.POINTER(i64)]),
+    "fedfr_net_tensor_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),
+                                    C.POINTER(i32), C.POINTER(i32)]),
+    "fedfr_net_prepare_weights": (i32, [vp, vp, vp, i32, vp]),
+    "fedfr_net_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "fedfr_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "fedfr_conv2d_stat_rows": (i32, [i32, i32, i32]),
+    "fedfr_conv2d_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fedfr_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fedfr_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "fedfr_conv2d_wgrad": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
+    "fedfr_weight_shadows": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "fedfr_gemm_nt": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "fedfr_gemm_tn": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "fedfr_stem_stat_rows": (i32, [i32, i32]),
+    "fedfr_stem_fwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "fedfr_stem_wgrad_ws_bytes": (sz, [i32, i32]),
+    "fedfr_stem_wgrad": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "fedfr_bn_finalize": (i32, [vp, i32, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]),
+    "fedfr_bn_apply_stat_rows": (i32, [i32, i32]),
+    "fedfr_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "fedfr_bn_bwd_rows": (i32, [i32, i32]),
+    "fedfr_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "fedfr_normalize_rows": (i32, [vp, vp, vp, i32, i32, f32, vp]),
+    "fedfr_normalize_rows_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "fedfr_sgemm": (i32, [vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i32, f32, f32, vp, vp]),
+    "fedfr_margin_rowmax": (i32, [vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp]),
+    "fedfr_exp_rowsum": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "fedfr_softmax_grad": (i32, [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp]),
+    "fedfr_nll_mean": (i32, [vp, i32, f32, vp, vp]),
+    "fedfr_bce": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
+    "fedfr_colsum_f32": (i32, [vp, i32, i32, vp, vp]),
+    "fedfr_sum_scale": (i32, [vp, i32, f32, vp, vp]),
+    "fedfr_sgd_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, i32, vp]),
+    "fedfr_fedavg_axpy": (i32, [vp, vp, f32, sz, i32, vp]),
+    "fedfr_fedavg_i64": (i32, [vp, vp, f32, i32, i32, vp, vp]),
+    "fedfr_pfc_rand": (i32, [vp, i32, u64, u64, vp]),
+    "fedfr_pfc_localize": (i32, [vp, i32, i64, i32, vp, vp]),
+    "fedfr_pfc_topk": (i32, [vp, i32, i32, vp, vp, vp]),
+    "fedfr_pfc_positive": (i32, [vp, i32, vp, vp, vp]),
+    "fedfr_pfc_remap": (i32, [vp, i32, vp, i32, vp]),
+    "fedfr_rows_gather": (i32, [vp, vp, vp, i32, i32, vp]),
+    "fedfr_rows_scatter": (i32, [vp, vp, vp, i32, i32, vp]),
+}
+
+# query keys (include/fedfr_hip.h)
+Q_PARAM_COUNT, Q_TRAINABLE_COUNT, Q_BUFFER_COUNT, Q_NBT_COUNT, Q_SHADOW_COUNT, Q_ACT_BYTES, Q_WS_BYTES, \
+    Q_NUM_TENSORS, Q_FC_IN = range(9)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "fedfr_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C fedfr_amd/csrc`.  There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    return lib().fedfr_last_error_string().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError("fedfr_hip %s failed (rc=%d): %s" % (what, rc, last_error()))
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning entry point and raise on failure."""
+    check(getattr(lib(), name)(*args), name)
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def require_gpu_tensor(t: torch.Tensor, dtype=None, name: str = "tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("fedfr_amd: %s must live on an MI355X device (got %s); no CPU fallback exists" % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("fedfr_amd: %s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("fedfr_amd: %s must be contiguous" % name)
+    return t

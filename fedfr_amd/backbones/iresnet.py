@@ -1,0 +1,473 @@
+"""IResNet on MI355X — drop-in for the reference's ``backbones/iresnet.py``.
+
+Same factories and constructor signature (reference iresnet.py:60-63, :182-204), same module tree
+and therefore the same ``state_dict`` keys, same ``forward(x[B,3,112,112]) -> [B,512]``.
+What differs is underneath:
+
+* every parameter / buffer is a *view* into one flat fp32 tensor (conv weights are stored KRSC, i.e.
+  they are channels_last OIHW tensors), so SGD, FedAvg and the bf16 weight shadows are single flat
+  kernels / collectives;
+* forward and backward are one call each into libfedfr_hip.so (``fedfr_net_forward`` /
+  ``fedfr_net_backward``): NHWC bf16 activations, MFMA implicit-GEMM convolutions, fused BN
+  statistics, fp32 master weights.  There is no PyTorch fallback: without the library (or on a CPU
+  tensor) ``forward`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import _C
+
+__all__ = ["iresnet18", "iresnet34", "iresnet50", "iresnet100", "iresnet200", "IResNet", "IBasicBlock"]
+
+KIND_CONV, KIND_BNW, KIND_BNB, KIND_PRELU, KIND_FCW, KIND_FCB, KIND_RM, KIND_RV, KIND_NBT = range(9)
+
+
+# ---------------------------------------------------------------------------------------------
+# holder modules: they only carry Parameters/buffers under the reference's attribute names
+# ---------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("fedfr_amd: sub-modules are parameter holders; call the IResNet itself "
+                           "(the whole network runs as fused HIP kernels)")
+
+
+class Conv2d(_Holder):
+    def __init__(self, cin, cout, k, stride):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = cin, cout, (k, k), (stride, stride)
+
+
+class BatchNorm2d(_Holder):     # class name contains 'BatchNorm' (reference freeze_BN, iresnet.py:142)
+    def __init__(self, c):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, 1e-5, 0.1
+
+
+class BatchNorm1d(BatchNorm2d):
+    pass
+
+
+class PReLU(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.num_parameters = c
+
+
+class Linear(_Holder):
+    def __init__(self, i, o):
+        super().__init__()
+        self.in_features, self.out_features = i, o
+
+
+class Downsample(nn.Sequential):
+    pass
+
+
+class IBasicBlock(_Holder):
+    """Holder with the reference's attribute names (iresnet.py:37-43)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.bn1 = BatchNorm2d(inplanes)
+        self.conv1 = Conv2d(inplanes, planes, 3, 1)
+        self.bn2 = BatchNorm2d(planes)
+        self.prelu = PReLU(planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride)
+        self.bn3 = BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _Plan:
+    """One C-side plan (batch-size specific) + its activation arena and workspace."""
+
+    def __init__(self, layers, batch, in_hw, nfeat, device):
+        l = _C.lib()
+        arr = (C.c_int * 4)(*layers)
+        self.handle = l.fedfr_net_create(arr, batch, in_hw, nfeat)
+        if not self.handle:
+            raise RuntimeError("fedfr_net_create failed: " + _C.last_error())
+        self.batch = batch
+        self.act = torch.empty(self.query(_C.Q_ACT_BYTES), dtype=torch.uint8, device=device)
+        self.ws = torch.empty(self.query(_C.Q_WS_BYTES), dtype=torch.uint8, device=device)
+
+    def query(self, what) -> int:
+        q = C.c_longlong()
+        _C.call("fedfr_net_query", self.handle, what, C.byref(q))
+        return q.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _C.lib().fedfr_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _tensor_table(layers, in_hw, nfeat):
+    """state_dict layout from the C plan (batch-independent part)."""
+    l = _C.lib()
+    arr = (C.c_int * 4)(*layers)
+    h = l.fedfr_net_create(arr, 8, in_hw, nfeat)
+    if not h:
+        raise RuntimeError("fedfr_net_create failed: " + _C.last_error())
+    try:
+        q = C.c_longlong()
+        counts = {}
+        for key in (_C.Q_PARAM_COUNT, _C.Q_TRAINABLE_COUNT, _C.Q_BUFFER_COUNT, _C.Q_NBT_COUNT, _C.Q_SHADOW_COUNT,
+                    _C.Q_NUM_TENSORS, _C.Q_FC_IN):
+            _C.call("fedfr_net_query", h, key, C.byref(q))
+            counts[key] = q.value
+        table = []
+        name = C.create_string_buffer(128)
+        kind, region, ndim = C.c_int(), C.c_int(), C.c_int()
+        off = C.c_longlong()
+        shape = (C.c_int * 4)()
+        for i in range(counts[_C.Q_NUM_TENSORS]):
+            _C.call("fedfr_net_tensor_info", h, i, name, 128, C.byref(kind), C.byref(region), C.byref(off), C.byref(ndim), shape)
+            table.append((name.value.decode(), kind.value, region.value, off.value, tuple(shape[: ndim.value])))
+        return counts, table
+    finally:
+        l.fedfr_net_destroy(h)
+
+
+class _IResNetFn(torch.autograd.Function):
+    """autograd bridge: forward = fedfr_net_forward, backward = fedfr_net_backward (hand-written adjoint)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, net):
+        feats = net._run_forward(x, training=True)
+        ctx.net = net
+        ctx.x = x
+        ctx.plan = net._plan(x.shape[0])
+        ctx.gen = net._fwd_generation
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        net = ctx.net
+        if ctx.gen != net._fwd_generation:
+            raise RuntimeError("fedfr_amd: backward() after a newer forward() on the same IResNet — saved "
+                               "activations live in a per-module arena and were overwritten")
+        net._run_backward(ctx.plan, ctx.x, dfeats.contiguous())
+        return None, None, None
+
+
+class IResNet(nn.Module):
+    fc_scale = 7 * 7
+
+    def __init__(self, block, layers, dropout=0, num_features=512, zero_init_residual=False, groups=1,
+                 width_per_group=64, replace_stride_with_dilation=None, fp16=False):
+        super().__init__()
+        if groups != 1 or width_per_group != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")       # iresnet.py:33-34
+        if replace_stride_with_dilation is not None and any(replace_stride_with_dilation):
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")          # iresnet.py:35-36
+        self.fp16 = fp16          # accepted for signature parity; this backend always stores bf16 / accumulates fp32
+        self.layers_cfg = tuple(int(v) for v in layers)
+        self.num_features = num_features
+        self.in_hw = 112
+        self.dropout_p = float(dropout)
+        counts, table = _tensor_table(self.layers_cfg, self.in_hw, num_features)
+        self._counts, self._table = counts, table
+        # flat storage (CPU until .to(device), like any nn.Module)
+        self._flat_params = torch.zeros(counts[_C.Q_PARAM_COUNT], dtype=torch.float32)
+        self._flat_bufs = torch.zeros(counts[_C.Q_BUFFER_COUNT], dtype=torch.float32)
+        self._flat_nbt = torch.zeros(counts[_C.Q_NBT_COUNT], dtype=torch.int64)
+        self._flat_grads: Optional[torch.Tensor] = None
+        self._shadow: Optional[torch.Tensor] = None
+        self._plans: Dict[int, _Plan] = {}
+        self._shadow_dirty = True
+        self._grads_live = False
+        self._fwd_generation = 0
+        self._anchor = torch.zeros(1, requires_grad=True)     # keeps the autograd graph connected
+        # module tree with the reference's names (iresnet.py:76-98)
+        self.conv1 = Conv2d(3, 64, 3, 1)
+        self.bn1 = BatchNorm2d(64)
+        self.prelu = PReLU(64)
+        inpl = 64
+        for si, (planes, nblk) in enumerate(zip((64, 128, 256, 512), self.layers_cfg)):
+            blocks = []
+            for bi in range(nblk):
+                cin = inpl if bi == 0 else planes
+                ds = Downsample(Conv2d(cin, planes, 1, 2), BatchNorm2d(planes)) if bi == 0 else None
+                blocks.append(IBasicBlock(cin, planes, 2 if bi == 0 else 1, ds))
+            setattr(self, "layer%d" % (si + 1), nn.Sequential(*blocks))
+            inpl = planes
+        self.bn2 = BatchNorm2d(512)
+        self.dropout = nn.Dropout(p=dropout, inplace=True)
+        self.fc = Linear(512 * self.fc_scale, num_features)
+        self.features = BatchNorm1d(num_features)
+        self._bind(create=True)
+        self._init_weights(zero_init_residual)
+
+    # ------------------------------------------------------------------ storage plumbing
+    def _views(self):
+        """yield (owner module, attr, view tensor, is_param, kind) for every state_dict entry."""
+        mods = dict(self.named_modules())
+        for name, kind, region, off, shape in self._table:
+            mod_name, attr = name.rsplit(".", 1)
+            owner = mods[mod_name]
+            if region == 0:
+                if kind == KIND_CONV:
+                    o, i, r, _ = shape
+                    v = self._flat_params[off: off + o * i * r * r].view(o, r, r, i).permute(0, 3, 1, 2)
+                else:
+                    n = 1
+                    for s in shape:
+                        n *= s
+                    v = self._flat_params[off: off + n].view(shape)
+                yield owner, attr, v, True, kind, name
+            elif region == 1:
+                yield owner, attr, self._flat_bufs[off: off + shape[0]], False, kind, name
+            else:
+                yield owner, attr, self._flat_nbt[off], False, kind, name
+
+    def _bind(self, create=False):
+        for owner, attr, v, is_param, kind, name in self._views():
+            if is_param:
+                if create:
+                    owner.register_parameter(attr, nn.Parameter(v, requires_grad=(name != "features.weight")))
+                else:
+                    getattr(owner, attr).data = v
+            else:
+                if create:
+                    owner.register_buffer(attr, v)
+                else:
+                    owner._buffers[attr] = v
+        self._grad_views = None
+
+    def _init_weights(self, zero_init_residual):
+        """Reference init (iresnet.py:97-112): conv N(0, .1); BN 1/0; fc = nn.Linear default; PReLU .25."""
+        with torch.no_grad():
+            for owner, attr, v, is_param, kind, name in self._views():
+                if kind == KIND_CONV:
+                    v.normal_(0, 0.1)
+                elif kind == KIND_BNW or kind == KIND_RV:
+                    v.fill_(1.0)
+                elif kind == KIND_PRELU:
+                    v.fill_(0.25)
+                elif kind == KIND_FCW or kind == KIND_FCB:
+                    bound = 1.0 / (512 * self.fc_scale) ** 0.5
+                    v.uniform_(-bound, bound)
+                elif kind in (KIND_BNB, KIND_RM):
+                    v.zero_()
+            if zero_init_residual:
+                for m in self.modules():
+                    if isinstance(m, IBasicBlock):
+                        m.bn2.weight.zero_()          # bn2, as the reference does (iresnet.py:109-112)
+
+    def _apply(self, fn, recurse=True):
+        new = fn(self._flat_params)
+        if new.dtype != torch.float32:
+            raise RuntimeError("fedfr_amd.IResNet keeps fp32 master weights (bf16 compute copies are internal); "
+                               "dtype conversion to %s is not supported" % new.dtype)
+        self._flat_params = new
+        self._flat_bufs = fn(self._flat_bufs)
+        self._flat_nbt = fn(self._flat_nbt) if not self._flat_nbt.is_floating_point() else self._flat_nbt
+        if self._flat_nbt.device != self._flat_params.device:
+            self._flat_nbt = self._flat_nbt.to(self._flat_params.device)
+        self._anchor = torch.zeros(1, device=self._flat_params.device, requires_grad=True)
+        self._flat_grads = None
+        self._shadow = None
+        self._plans = {}
+        self._shadow_dirty = True
+        self._grads_live = False
+        self._bind(create=False)
+        return self
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_plans"] = {}
+        st["_shadow"] = None
+        st["_flat_grads"] = None
+        st["_grad_views"] = None
+        st["_shadow_dirty"] = True
+        st["_grads_live"] = False
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._bind(create=False)
+        return new
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._shadow_dirty = True
+        return out
+
+    def mark_weights_dirty(self):
+        """Call after modifying parameters in place outside of this package's optimiser while in eval mode."""
+        self._shadow_dirty = True
+
+    # reference API (iresnet.py:140-156).  Per-module eval() of BN is not supported by the fused kernels:
+    # only the affine-freeze part is honoured.
+    def freeze_BN(self, test_mode=True, fix_affine=False):
+        if test_mode:
+            raise NotImplementedError("fedfr_amd: BN layers follow the model-wide train/eval flag; "
+                                      "freeze_BN(test_mode=True) (BN in eval inside a training net) is not supported")
+        if fix_affine:
+            for m in self.modules():
+                if m.__class__.__name__.find("BatchNorm") != -1:
+                    for p in m.parameters():
+                        p.requires_grad = False
+
+    def unfreeze_BN(self, test_mode=False, affine=True):
+        if test_mode:
+            raise NotImplementedError("fedfr_amd: unfreeze_BN(test_mode=True) is not supported")
+        if affine:
+            for n, m in self.named_modules():
+                if m.__class__.__name__.find("BatchNorm") != -1:
+                    for pn, p in m.named_parameters():
+                        p.requires_grad = True
+
+    # ------------------------------------------------------------------ device side
+    @property
+    def device(self):
+        return self._flat_params.device
+
+    def _plan(self, batch) -> _Plan:
+        p = self._plans.get(batch)
+        if p is None:
+            if len(self._plans) >= 2:       # arenas are GBs: keep at most two batch sizes alive
+                self._plans.pop(next(iter(self._plans)))
+            p = _Plan(self.layers_cfg, batch, self.in_hw, self.num_features, self.device)
+            self._plans[batch] = p
+        return p
+
+    def _ensure_device_state(self):
+        if not self._flat_params.is_cuda:
+            raise RuntimeError("fedfr_amd.IResNet runs only on an MI355X device: move the module with .to('cuda') "
+                               "(there is no CPU / PyTorch fallback path)")
+        if self._shadow is None:
+            self._shadow = torch.empty(self._counts[_C.Q_SHADOW_COUNT], dtype=torch.bfloat16, device=self.device)
+            self._shadow_dirty = True
+        if self._flat_grads is None:
+            self._flat_grads = torch.zeros(self._counts[_C.Q_PARAM_COUNT], dtype=torch.float32, device=self.device)
+            self._grad_views = None
+
+    def refresh_shadows(self, fwd_shadow_too=True):
+        self._ensure_device_state()
+        plan = next(iter(self._plans.values())) if self._plans else self._plan(8)
+        _C.call("fedfr_net_prepare_weights", plan.handle, self._flat_params.data_ptr(), self._shadow.data_ptr(),
+                1 if fwd_shadow_too else 0, _C.stream())
+        self._shadow_dirty = False
+
+    def _check_input(self, x):
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.in_hw or x.shape[3] != self.in_hw:
+            raise RuntimeError("fedfr_amd.IResNet expects [B,3,%d,%d] input, got %s" % (self.in_hw, self.in_hw, tuple(x.shape)))
+        _C.require_gpu_tensor(x, torch.float32, "input batch")
+        if x.device != self.device:
+            raise RuntimeError("input on %s but model on %s" % (x.device, self.device))
+
+    def _run_forward(self, x, training: bool):
+        self._ensure_device_state()
+        plan = self._plan(x.shape[0])
+        if training or self._shadow_dirty:
+            self.refresh_shadows(True)
+        feats = torch.empty(x.shape[0], self.num_features, dtype=torch.float32, device=self.device)
+        _C.call("fedfr_net_forward", plan.handle, x.data_ptr(), self._flat_params.data_ptr(), self._flat_bufs.data_ptr(),
+                self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1 if training else 0,
+                _C.stream())
+        if training:
+            self._flat_nbt += 1
+        self._fwd_generation += 1
+        return feats
+
+    def _grad_view_list(self):
+        if self._grad_views is None:
+            mods = dict(self.named_modules())
+            views = []
+            tc = self._counts[_C.Q_TRAINABLE_COUNT]
+            for name, kind, region, off, shape in self._table:
+                if region != 0 or off >= tc:
+                    continue
+                mod_name, attr = name.rsplit(".", 1)
+                p = getattr(mods[mod_name], attr)
+                if kind == KIND_CONV:
+                    o, i, r, _ = shape
+                    g = self._flat_grads[off: off + o * i * r * r].view(o, r, r, i).permute(0, 3, 1, 2)
+                else:
+                    n = 1
+                    for s in shape:
+                        n *= s
+                    g = self._flat_grads[off: off + n].view(shape)
+                views.append((p, g))
+            self._grad_views = views
+        return self._grad_views
+
+    def _run_backward(self, plan, x, dfeats):
+        """Writes parameter gradients into the flat grad buffer and exposes them as ``p.grad`` views
+        (accumulating if the caller did not zero them — torch.optim semantics)."""
+        views = self._grad_view_list()
+        accumulate = self._grads_live and any(p.grad is not None for p, _ in views[:1])
+        target = self._flat_grads
+        if accumulate:
+            target = torch.empty_like(self._flat_grads)
+        _C.call("fedfr_net_backward", plan.handle, x.data_ptr(), dfeats.data_ptr(), self._flat_params.data_ptr(),
+                self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), target.data_ptr(), _C.stream())
+        if accumulate:
+            self._flat_grads.add_(target)
+        for p, g in views:
+            if p.requires_grad:
+                p.grad = g
+        self._grads_live = True
+
+    def forward(self, x):
+        self._check_input(x)
+        x = x.contiguous()
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("fedfr_amd: dropout>0 is outside the accelerated hot path "
+                                      "(the FL configs use dropout=0, reference client.py:142)")
+        if self.training and torch.is_grad_enabled():
+            if self._anchor.device != x.device:
+                self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            return _IResNetFn.apply(x, self._anchor, self)
+        return self._run_forward(x, training=self.training)
+
+    # flat accessors used by the fused trainer / FedAvg
+    def flat_state(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        return self._flat_params, self._flat_bufs, self._flat_nbt
+
+    def trainable_count(self) -> int:
+        return self._counts[_C.Q_TRAINABLE_COUNT]
+
+
+def _iresnet(arch, block, layers, pretrained, progress, **kwargs):
+    model = IResNet(block, layers, **kwargs)
+    if pretrained:
+        raise ValueError()          # reference iresnet.py:176-178
+    return model
+
+
+def iresnet18(pretrained=False, progress=True, **kwargs):
+    return _iresnet("iresnet18", IBasicBlock, [2, 2, 2, 2], pretrained, progress, **kwargs)
+
+
+def iresnet34(pretrained=False, progress=True, **kwargs):
+    return _iresnet("iresnet34", IBasicBlock, [3, 4, 6, 3], pretrained, progress, **kwargs)
+
+
+def iresnet50(pretrained=False, progress=True, **kwargs):
+    return _iresnet("iresnet50", IBasicBlock, [3, 4, 14, 3], pretrained, progress, **kwargs)
+
+
+def iresnet100(pretrained=False, progress=True, **kwargs):
+    return _iresnet("iresnet100", IBasicBlock, [3, 13, 30, 3], pretrained, progress, **kwargs)
+
+
+def iresnet200(pretrained=False, progress=True, **kwargs):
+    return _iresnet("iresnet200", IBasicBlock, [6, 26, 60, 6], pretrained, progress, **kwargs)

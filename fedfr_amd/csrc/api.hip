@@ -1,0 +1,283 @@
+// C-ABI exports (include/fedfr_hip.h): thin argument-checking wrappers over the internal launchers.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/fedfr_hip.h"
+#include "common.h"
+#include "ew.h"
+#include "gemm.h"
+#include "head.h"
+#include "net.h"
+#include "optim.h"
+
+static thread_local char g_err[512] = "";
+extern int g_tn_use_tr;
+
+void fedfr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+int fedfr_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fedfr_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return FEDFR_ERR_HIP;
+  }
+  return FEDFR_OK;
+}
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define BF(p) reinterpret_cast<const bf16_t*>(p)
+#define BFM(p) reinterpret_cast<bf16_t*>(p)
+
+extern "C" {
+
+int fedfr_version(void) { return 100; }
+const char* fedfr_last_error_string(void) { return g_err; }
+int fedfr_set_option(const char* name, int value) {
+  if (name && !strcmp(name, "tn_use_tr")) {
+    g_tn_use_tr = value ? 1 : 0;
+    return FEDFR_OK;
+  }
+  fedfr_set_error("set_option: unknown option '%s'", name ? name : "(null)");
+  return FEDFR_ERR_ARG;
+}
+
+// ---- net -------------------------------------------------------------------------------------------
+fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_features) {
+  if (!layers4) {
+    fedfr_set_error("net_create: layers is null");
+    return nullptr;
+  }
+  return net_create(layers4, batch, in_hw, num_features);
+}
+void fedfr_net_destroy(fedfr_net_t* net) { delete net; }
+int fedfr_net_query(const fedfr_net_t* n, int what, long long* out) {
+  FEDFR_REQUIRE(n && out, "net_query: null");
+  switch (what) {
+    case FEDFR_Q_PARAM_COUNT: *out = n->param_count; break;
+    case FEDFR_Q_TRAINABLE_COUNT: *out = n->trainable_count; break;
+    case FEDFR_Q_BUFFER_COUNT: *out = n->buffer_count; break;
+    case FEDFR_Q_NBT_COUNT: *out = n->nbt_count; break;
+    case FEDFR_Q_SHADOW_COUNT: *out = n->shadow_count; break;
+    case FEDFR_Q_ACT_BYTES: *out = n->act_bytes; break;
+    case FEDFR_Q_WS_BYTES: *out = (long long)n->ws_bytes; break;
+    case FEDFR_Q_NUM_TENSORS: *out = (long long)n->tensors.size(); break;
+    case FEDFR_Q_FC_IN: *out = n->fc_in; break;
+    default: fedfr_set_error("net_query: unknown key %d", what); return FEDFR_ERR_ARG;
+  }
+  return FEDFR_OK;
+}
+int fedfr_net_tensor_info(const fedfr_net_t* n, int i, char* name, int name_cap, int* kind, int* region, long long* offset,
+                          int* ndim, int* shape4) {
+  FEDFR_REQUIRE(n && i >= 0 && i < (int)n->tensors.size() && name && name_cap > 0 && kind && region && offset && ndim && shape4,
+                "net_tensor_info: bad args");
+  const NetTensor& t = n->tensors[i];
+  snprintf(name, name_cap, "%s", t.name.c_str());
+  *kind = t.kind; *region = t.region; *offset = t.offset; *ndim = t.ndim;
+  for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+  return FEDFR_OK;
+}
+int fedfr_net_prepare_weights(const fedfr_net_t* n, const float* params, uint16_t* shadow, int fwd_shadow_too, void* stream) {
+  return net_prepare_weights(n, params, BFM(shadow), fwd_shadow_too, ST(stream));
+}
+int fedfr_net_forward(const fedfr_net_t* n, const float* x, const float* params, float* bufs, const uint16_t* shadow, void* act,
+                      void* ws, float* feats, int training, void* stream) {
+  return net_forward(n, x, params, bufs, BF(shadow), (unsigned char*)act, (unsigned char*)ws, feats, training, ST(stream));
+}
+int fedfr_net_backward(const fedfr_net_t* n, const float* x, const float* dfeats, const float* params, const uint16_t* shadow,
+                       void* act, void* ws, float* grads, void* stream) {
+  return net_backward(n, x, dfeats, params, BF(shadow), (unsigned char*)act, (unsigned char*)ws, grads, ST(stream));
+}
+
+// ---- single convolutions ---------------------------------------------------------------------------------
+static int conv_args_ok(int batch, int hin, int cin, int cout, int ksize, int stride) {
+  FEDFR_REQUIRE(batch > 0 && hin > 0 && (cin % 64) == 0 && (cout % 64) == 0 && (ksize == 1 || ksize == 3) &&
+                    (stride == 1 || stride == 2) && hin % stride == 0,
+                "conv2d: unsupported geometry batch=%d hin=%d cin=%d cout=%d k=%d s=%d", batch, hin, cin, cout, ksize, stride);
+  return FEDFR_OK;
+}
+int fedfr_conv2d_stat_rows(int batch, int hout, int cout) { return gemm_nt_stat_rows(batch * hout * hout, cout); }
+int fedfr_conv2d_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* stats, int batch, int hin, int cin, int cout,
+                     int ksize, int stride, void* stream) {
+  FEDFR_TRY(conv_args_ok(batch, hin, cin, cout, ksize, stride));
+  FEDFR_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
+  const int hout = hin / stride;
+  GemmNT p{};
+  p.A = BF(x); p.B = BF(w); p.M = batch * hout * hout; p.N = cout; p.K = ksize * ksize * cin;
+  p.mode = 1; p.H = hin; p.W = hin; p.C = cin; p.Ho = hout; p.Wo = hout; p.S = ksize; p.stride = stride;
+  p.pad = ksize == 3 ? 1 : 0; p.up = 1; p.Cb = BFM(y); p.ldc = cout; p.stats = stats;
+  return gemm_nt_launch(p, 1, ST(stream));
+}
+int fedfr_conv2d_dgrad(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int batch, int hin, int cin, int cout, int ksize,
+                       int stride, void* stream) {
+  FEDFR_TRY(conv_args_ok(batch, hin, cin, cout, ksize, stride));
+  FEDFR_REQUIRE(dy && wd && dx, "conv2d_dgrad: null tensor");
+  const int hout = hin / stride;
+  GemmNT p{};
+  p.A = BF(dy); p.B = BF(wd); p.N = cin; p.K = ksize * ksize * cout; p.Cb = BFM(dx); p.ldc = cin;
+  if (ksize == 1) {   // compact result at the OUTPUT resolution: dx[m_out][cin]
+    p.mode = 0; p.M = batch * hout * hout; p.lda = cout;
+  } else {
+    p.mode = 1; p.M = batch * hin * hin; p.H = hout; p.W = hout; p.C = cout; p.Ho = hin; p.Wo = hin; p.S = 3;
+    p.stride = 1; p.pad = 1; p.up = stride;
+  }
+  return gemm_nt_launch(p, 1, ST(stream));
+}
+size_t fedfr_conv2d_wgrad_ws_bytes(int batch, int hin, int cin, int cout, int ksize, int stride) {
+  const int hout = hin / (stride > 0 ? stride : 1);
+  const int NJ = ksize * ksize * cin;
+  return (size_t)gemm_tn_pick_splits(batch * hout * hout, cout, NJ, cin) * cout * NJ * sizeof(float);
+}
+int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* ws, size_t ws_bytes, int batch, int hin, int cin,
+                       int cout, int ksize, int stride, void* stream) {
+  FEDFR_TRY(conv_args_ok(batch, hin, cin, cout, ksize, stride));
+  FEDFR_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  const int hout = hin / stride;
+  GemmTN p{};
+  p.P = BF(dy); p.Q = BF(x); p.Kp = batch * hout * hout; p.NI = cout; p.NJ = ksize * ksize * cin;
+  p.mode = 1; p.H = hin; p.W = hin; p.C = cin; p.Ho = hout; p.Wo = hout; p.S = ksize; p.stride = stride;
+  p.pad = ksize == 3 ? 1 : 0; p.ldp = cout; p.use_tr = g_tn_use_tr;
+  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C);
+  if (splits == 1) {
+    p.out = dw;
+    return gemm_tn_launch(p, 1, ST(stream));
+  }
+  if (!ws || ws_bytes < (size_t)splits * p.NI * p.NJ * sizeof(float)) {
+    fedfr_set_error("conv2d_wgrad: workspace too small (%zu bytes)", ws_bytes);
+    return FEDFR_ERR_WORKSPACE;
+  }
+  p.out = (float*)ws;
+  FEDFR_TRY(gemm_tn_launch(p, splits, ST(stream)));
+  return ew_reduce_slabs(dw, (const float*)ws, splits, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream));
+}
+int fedfr_weight_shadows(const float* w, uint16_t* wb, uint16_t* wdb, int cout, int ksize, int cin, void* stream) {
+  FEDFR_REQUIRE(w, "weight_shadows: null");
+  if (wb) FEDFR_TRY(ew_cast_f32_bf16(w, BFM(wb), (size_t)cout * ksize * ksize * cin, ST(stream)));
+  if (wdb) FEDFR_TRY(ew_weight_dgrad_shadow(w, BFM(wdb), cout, ksize, ksize, cin, ST(stream)));
+  return FEDFR_OK;
+}
+int fedfr_gemm_nt(const uint16_t* A, const uint16_t* B, float* C, void* ws, size_t ws_bytes, int M, int N, int K, void* stream) {
+  FEDFR_REQUIRE(A && B && C, "gemm_nt: null");
+  GemmNT p{};
+  p.A = BF(A); p.B = BF(B); p.M = M; p.N = N; p.K = K; p.mode = 0; p.lda = K;
+  const int splits = gemm_nt_pick_splits(M, N, K);
+  if (splits == 1) {
+    p.Cf = C;
+    return gemm_nt_launch(p, 1, ST(stream));
+  }
+  if (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float)) {
+    fedfr_set_error("gemm_nt: workspace too small: need %zu bytes", (size_t)splits * M * N * sizeof(float));
+    return FEDFR_ERR_WORKSPACE;
+  }
+  p.Cf = (float*)ws;
+  FEDFR_TRY(gemm_nt_launch(p, splits, ST(stream)));
+  return ew_reduce_slabs(C, (const float*)ws, splits, (size_t)M * N, nullptr, 0, ST(stream));
+}
+int fedfr_gemm_tn(const uint16_t* P, const uint16_t* Q, float* C, int Kp, int NI, int NJ, void* stream) {
+  GemmTN p{};
+  p.P = BF(P); p.Q = BF(Q); p.Kp = Kp; p.NI = NI; p.NJ = NJ; p.mode = 0; p.ldp = NI; p.ldq = NJ; p.out = C; p.use_tr = g_tn_use_tr;
+  return gemm_tn_launch(p, 1, ST(stream));
+}
+int fedfr_stem_stat_rows(int batch, int hw) { return ew_stem_stat_rows(batch, hw, hw); }
+int fedfr_stem_fwd(const float* x, const float* w, uint16_t* y, float* stats, int batch, int hw, void* stream) {
+  return ew_stem_fwd(x, w, BFM(y), stats, batch, hw, hw, ST(stream));
+}
+size_t fedfr_stem_wgrad_ws_bytes(int batch, int hw) { return (size_t)ew_stem_wgrad_blocks(batch, hw, hw) * 2048 * sizeof(float); }
+int fedfr_stem_wgrad(const float* x, const uint16_t* dy, float* dw, void* ws, int batch, int hw, void* stream) {
+  return ew_stem_wgrad(x, BF(dy), dw, (float*)ws, batch, hw, hw, ST(stream));
+}
+
+// ---- BN ----------------------------------------------------------------------------------------------------
+int fedfr_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta, float* rm,
+                      float* rv, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd,
+                      float* tmp, void* stream) {
+  return ew_bn_finalize(partials, P, C, count, gamma, beta, rm, rv, momentum, eps, scale, shift, save_mean, save_rstd, tmp, ST(stream));
+}
+int fedfr_bn_apply_stat_rows(int M, int C) { return ew_bn_apply_grid(M, C); }
+int fedfr_bn_apply(const uint16_t* x1, const float* sc1, const float* sh1, const float* alpha, const uint16_t* x2, const float* sc2,
+                   const float* sh2, uint16_t* y, int M, int C, int nchw_hw, float* stats, void* stream) {
+  BnApply a{};
+  a.x1 = BF(x1); a.sc1 = sc1; a.sh1 = sh1; a.alpha = alpha; a.x2 = BF(x2); a.sc2 = sc2; a.sh2 = sh2; a.y = BFM(y);
+  a.M = M; a.C = C; a.nchw_hw = nchw_hw; a.stats = stats;
+  return ew_bn_apply(a, ST(stream));
+}
+int fedfr_bn_bwd_rows(int M, int C) { return ew_bn_bwd_grid(M, C); }
+int fedfr_bn_bwd(const uint16_t* dy, const uint16_t* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 const float* alpha, int M, int C, float* partials, float* coef, float* dgamma, float* dbeta, float* dalpha,
+                 const uint16_t* add, const uint16_t* add_up, int H, uint16_t* dx, void* stream) {
+  BnBwd p{};
+  p.dy = BF(dy); p.x = BF(x); p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha; p.M = M; p.C = C;
+  p.partials = partials; p.coef = coef; p.add = BF(add); p.add_up = BF(add_up); p.H = H; p.W = H; p.dx = BFM(dx);
+  FEDFR_TRY(ew_bn_bwd_reduce(p, ST(stream)));
+  FEDFR_TRY(ew_bn_bwd_finalize(partials, ew_bn_bwd_grid(M, C), C, (double)M, gamma, rstd, dgamma, dbeta, dalpha, coef, ST(stream)));
+  return ew_bn_bwd_apply(p, ST(stream));
+}
+
+// ---- head ------------------------------------------------------------------------------------------------------
+int fedfr_normalize_rows(const float* x, float* xn, float* inv, int R, int D, float eps, void* stream) {
+  return head_normalize_rows(x, xn, inv, R, D, eps, ST(stream));
+}
+int fedfr_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn, float* dx, int R, int D, float beta, void* stream) {
+  return head_normalize_rows_bwd(xn, inv, dxn, dx, R, D, beta, ST(stream));
+}
+int fedfr_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk,
+                long long sbn, int ldc, float alpha, float beta, const float* bias, void* stream) {
+  return head_sgemm(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, ST(stream));
+}
+int fedfr_margin_rowmax(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arc, float* row_max,
+                        float* dmul, void* stream) {
+  return head_margin_rowmax(z, label, R, C, ldz, s, m, arc, row_max, dmul, ST(stream));
+}
+int fedfr_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float* row_sum, void* stream) {
+  return head_exp_rowsum(z, R, C, ldz, row_max, row_sum, ST(stream));
+}
+int fedfr_softmax_grad(float* z, const long long* label, int R, int C, int ldz, const float* row_sum, const float* dmul, float s,
+                       float inv_batch, float* prob_t, void* stream) {
+  return head_softmax_grad(z, label, R, C, ldz, row_sum, dmul, s, inv_batch, prob_t, ST(stream));
+}
+int fedfr_nll_mean(const float* prob_t, int R, float floor_, float* loss, void* stream) {
+  return head_nll_mean(prob_t, R, floor_, loss, ST(stream));
+}
+int fedfr_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t, float lam,
+              float loss_scale, float* z_out, float* dcos, float* dz, float* row_loss, void* stream) {
+  return head_bce(cosv, label, bias, B, C, m, r, t, lam, loss_scale, z_out, dcos, dz, row_loss, ST(stream));
+}
+int fedfr_colsum_f32(const float* x, int R, int C, float* out, void* stream) { return head_colsum_f32(x, R, C, out, ST(stream)); }
+int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream) { return head_sum_scale(x, n, scale, out, ST(stream)); }
+
+// ---- optimiser / aggregation / PartialFC ------------------------------------------------------------------------
+int fedfr_sgd_step(float* params, const float* grads, float* buf, uint16_t* shadow, size_t n, float lr, float momentum,
+                   float weight_decay, int first_step, void* stream) {
+  return optim_sgd(params, grads, buf, BFM(shadow), n, lr, momentum, weight_decay, first_step, ST(stream));
+}
+int fedfr_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, void* stream) {
+  return optim_fedavg_axpy(dst, src, w, n, accumulate, ST(stream));
+}
+int fedfr_fedavg_i64(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc, void* stream) {
+  return optim_fedavg_i64(acc, src, w, n, accumulate, out_trunc, ST(stream));
+}
+int fedfr_pfc_rand(float* perm, int n, unsigned long long seed, unsigned long long step, void* stream) {
+  return optim_pfc_rand(perm, n, seed, step, ST(stream));
+}
+int fedfr_pfc_localize(long long* label, int n, long long class_start, int num_local, float* perm, void* stream) {
+  return optim_pfc_localize(label, n, class_start, num_local, perm, ST(stream));
+}
+int fedfr_pfc_topk(const float* perm, int n, int k, long long* index, int* npos_out, void* stream) {
+  return optim_pfc_topk(perm, n, k, index, npos_out, ST(stream));
+}
+int fedfr_pfc_positive(const float* perm, int n, long long* index, int* count, void* stream) {
+  return optim_pfc_positive(perm, n, index, count, ST(stream));
+}
+int fedfr_pfc_remap(long long* label, int n, const long long* index, int k, void* stream) {
+  return optim_pfc_remap(label, n, index, k, ST(stream));
+}
+int fedfr_rows_gather(float* dst, const float* src, const long long* index, int k, int D, void* stream) {
+  return optim_rows(dst, src, index, k, D, 0, ST(stream));
+}
+int fedfr_rows_scatter(float* dst, const float* src, const long long* index, int k, int D, void* stream) {
+  return optim_rows(dst, src, index, k, D, 1, ST(stream));
+}
+
+}  // extern "C"

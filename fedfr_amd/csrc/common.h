@@ -1,0 +1,100 @@
+// fedfr_amd — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// wave = 64 lanes; MFMA 16x16x32 bf16; LDS 160 KiB/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef unsigned short bf16_t;   // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define FEDFR_OK 0
+#define FEDFR_ERR_ARG (-1)
+#define FEDFR_ERR_HIP (-2)
+#define FEDFR_ERR_WORKSPACE (-3)
+#define FEDFR_ERR_UNSUPPORTED (-4)
+
+// ---- error plumbing (never throw across the C ABI) ---------------------------------
+void fedfr_set_error(const char* fmt, ...);
+int fedfr_check_launch(const char* what);
+
+#define FEDFR_REQUIRE(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      fedfr_set_error(__VA_ARGS__);              \
+      return FEDFR_ERR_ARG;                      \
+    }                                            \
+  } while (0)
+
+#define FEDFR_LAUNCH_CHECK(what)                 \
+  do {                                           \
+    int _rc = fedfr_check_launch(what);          \
+    if (_rc != FEDFR_OK) return _rc;             \
+  } while (0)
+
+#define FEDFR_TRY(expr)                          \
+  do {                                           \
+    int _rc = (expr);                            \
+    if (_rc != FEDFR_OK) return _rc;             \
+  } while (0)
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t u) {
+  return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) {      // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __builtin_bit_cast(float, v.x << 16); f[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+  f[2] = __builtin_bit_cast(float, v.y << 16); f[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+  f[4] = __builtin_bit_cast(float, v.z << 16); f[5] = __builtin_bit_cast(float, v.z & 0xffff0000u);
+  f[6] = __builtin_bit_cast(float, v.w << 16); f[7] = __builtin_bit_cast(float, v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]);
+  v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+  return v;
+}
+
+// ---- wave / block reductions (64-lane wavefront) -----------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// exact n / d for n*d < 2^40 via one 64-bit multiply: magic = ceil(2^40 / d)
+struct FastDiv {
+  unsigned long long magic;
+  unsigned d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = ((1ull << 40) + d - 1) / d;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  return (unsigned)(((unsigned long long)n * f.magic) >> 40);
+}
+
+__host__ __device__ static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

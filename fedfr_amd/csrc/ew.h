@@ -1,0 +1,77 @@
+// HBM-bound elementwise / column-reduction kernels: train-mode BatchNorm (stats finalize, apply,
+// backward), PReLU, residual add, layout conversions, split-K slab reduction, stem conv.
+// All activations are NHWC bf16 viewed as [M = N*H*W][C]; per-channel parameters are fp32.
+#pragma once
+#include "common.h"
+
+// ---- forward BN -------------------------------------------------------------------------------------
+// partials: [P][2][C] (sum, sumsq).  tmp must hold 64*2*C floats when P > 1024 (two-stage reduce).
+int ew_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* scale, float* shift, float* save_mean, float* save_rstd, float* tmp, hipStream_t st);
+// eval mode: scale/shift from running stats
+int ew_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* scale, float* shift, hipStream_t st);
+
+struct BnApply {
+  const bf16_t* x1; const float* sc1; const float* sh1; const float* alpha;   // y = prelu?(x1*sc1+sh1)
+  const bf16_t* x2; const float* sc2; const float* sh2;                       // + (x2*sc2+sh2)  (sc2 null => + x2)
+  bf16_t* y;
+  int M, C;
+  int nchw_hw;        // >0: write y as [img][C][hw] (flatten order of the reference fc), hw = nchw_hw
+  float* stats;       // [grid][2][C] partial (sum, sumsq) of y, or null
+};
+int ew_bn_apply_grid(int M, int C);          // number of partial rows the kernel writes
+int ew_bn_apply(const BnApply& p, hipStream_t st);
+
+// ---- backward BN (+PReLU) --------------------------------------------------------------------------
+struct BnBwd {
+  const bf16_t* dy;       // grad wrt (prelu?)(bn(x))
+  const bf16_t* x;        // BN input (conv output)
+  const float* mean; const float* rstd; const float* gamma; const float* beta;
+  const float* alpha;     // non-null => PReLU after the BN
+  int M, C;
+  float* partials;        // [grid][3][C]
+  // apply stage
+  const float* coef;      // [3][C]: a = gamma*rstd, b = mean(dz), c = mean(dz*xhat)
+  const bf16_t* add;      // optional same-shape addend (identity-path gradient)
+  const bf16_t* add_up;   // optional compact [img][H/2][W/2][C] addend placed at even (h, w)
+  int H, W;               // needed for add_up
+  bf16_t* dx;
+};
+int ew_bn_bwd_grid(int M, int C);
+int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st);
+int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* rstd,
+                       float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st);
+int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st);
+
+// ---- BatchNorm1d on fp32 [B][C] (the `features` layer) ------------------------------------------------
+int ew_bn1d_fwd(const float* x, float* y, int B, int C, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, float momentum, float eps, int training,
+                float* save_mean, float* save_rstd, hipStream_t st);
+// dx = bn1d backward; also dbeta (bias grad), and colsum(dx) -> fc bias grad
+int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const float* gamma,
+                const float* save_mean, const float* save_rstd, float* dbeta, float* dx_colsum,
+                bf16_t* dx_bf16, bf16_t* dx_bf16_t, int ldt, hipStream_t st);
+
+// ---- split-K slab reductions ---------------------------------------------------------------------------
+int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n,
+                    hipStream_t st);
+int ew_reduce_slabs_bf16(bf16_t* dst, const float* slabs, int nsplit, size_t n, hipStream_t st);
+
+// ---- conversions -----------------------------------------------------------------------------------------------
+int ew_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
+// KRSC fp32 [Cout][R][S][Cin] -> dgrad shadow bf16 [Cin][R][S][Cout] with (r,s) flipped
+int ew_weight_dgrad_shadow(const float* w, bf16_t* dst, int Cout, int R, int S, int Cin, hipStream_t st);
+// fp32 [B][C][HW] -> bf16 [B][HW][C]
+int ew_nchw_f32_to_nhwc_bf16(const float* src, bf16_t* dst, int B, int C, int HW, hipStream_t st);
+// bf16 [R][Ccols] -> bf16 [Ccols][R]
+int ew_transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int Ccols, hipStream_t st);
+
+// ---- stem: conv3x3(3->64, s1, p1) on fp32 NCHW input ----------------------------------------------------------
+// w: KRSC fp32 [64][3][3][3]; y: NHWC bf16 [B][H][W][64]; stats partials [stem_stat_rows][2][64]
+int ew_stem_stat_rows(int B, int H, int W);
+int ew_stem_fwd(const float* x, const float* w, bf16_t* y, float* stats, int B, int H, int W, hipStream_t st);
+// dw (KRSC fp32 [64][3][3][3]) = sum over pixels; tmp holds stem_wgrad_blocks*64*32 floats
+int ew_stem_wgrad_blocks(int B, int H, int W);
+int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st);

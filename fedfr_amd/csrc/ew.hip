@@ -1,0 +1,844 @@
+// HBM-bound kernels (see ew.h).  Mapping used throughout for [M][C] bf16 tensors: one thread owns 8
+// consecutive channels (16-byte vector load/store), C/8 threads cover a row, 256/(C/8) rows per pass,
+// blocks stride over row slabs; per-channel partials are reduced through LDS and written as one row per
+// block (deterministic, no atomics), then finalised in fp64 by a tiny second kernel.
+#include "ew.h"
+
+#define EW_THREADS 256
+
+static inline int rows_per_pass(int C) { return EW_THREADS / (C >> 3); }
+static int slab_rows(int M, int C, int max_blocks) {
+  const int rpp = rows_per_pass(C);
+  long long rows = (long long)rpp * 8;
+  const long long need = (M + max_blocks - 1) / max_blocks;
+  if (rows < need) rows = need;
+  rows = (rows + rpp - 1) / rpp * rpp;
+  return (int)rows;
+}
+static int check_mc(int M, int C, const char* who) {
+  if (M <= 0 || C <= 0 || (C & 7) || (C >> 3) > EW_THREADS) {
+    fedfr_set_error("%s: unsupported shape M=%d C=%d (need C%%8==0, C<=2048)", who, M, C);
+    return FEDFR_ERR_ARG;
+  }
+  return FEDFR_OK;
+}
+
+// =====================================================================================================
+// forward BN finalize
+// =====================================================================================================
+// stage A: [P][W] -> [S][W] partial sums (W = ncols), block = 32 cols x 32 row-groups
+__global__ __launch_bounds__(1024) void colsum_stage_kernel(const float* __restrict__ in, int P, int W,
+                                                           float* __restrict__ out, int S) {
+  __shared__ double red[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  const int slice = blockIdx.y;
+  double s = 0.0;
+  if (col < W)
+    for (int row = slice + S * rg; row < P; row += S * 32) s += (double)in[(size_t)row * W + col];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && col < W) {
+    double t = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) t += red[i][cl];
+    out[(size_t)slice * W + col] = (float)t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int P, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps,
+                                                          float* scale, float* shift, float* save_mean, float* save_rstd) {
+  __shared__ double rs[32][33], rq[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int row = rg; row < P; row += 32) {
+      s += (double)part[(size_t)row * 2 * C + c];
+      q += (double)part[(size_t)row * 2 * C + C + c];
+    }
+  rs[rg][cl] = s;
+  rq[rg][cl] = q;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    double ts = 0.0, tq = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      ts += rs[i][cl];
+      tq += rq[i][cl];
+    }
+    const double mean = ts / count;
+    double var = tq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = (float)((double)g * rstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)b - mean * (double)g * rstd);
+    save_mean[c] = (float)mean;
+    save_rstd[c] = (float)rstd;
+    if (running_mean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  }
+}
+
+int ew_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                   float* save_mean, float* save_rstd, float* tmp, hipStream_t st) {
+  FEDFR_REQUIRE(partials && P > 0 && C > 0 && scale && shift && save_mean && save_rstd, "bn_finalize: bad args");
+  const float* src = partials;
+  if (P > 1024) {
+    FEDFR_REQUIRE(tmp != nullptr, "bn_finalize: P=%d needs a tmp buffer", P);
+    const int S = 64, W = 2 * C;
+    hipLaunchKernelGGL(colsum_stage_kernel, dim3(ceil_div(W, 32), S), dim3(1024), 0, st, partials, P, W, tmp, S);
+    FEDFR_LAUNCH_CHECK("colsum_stage");
+    src = tmp;
+    P = S;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, src, P, C, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
+  FEDFR_LAUNCH_CHECK("bn_finalize");
+  return FEDFR_OK;
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * rstd;
+  shift[c] = b - rm[c] * g * rstd;
+}
+int ew_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                      float* scale, float* shift, hipStream_t st) {
+  FEDFR_REQUIRE(C > 0 && rm && rv && scale && shift, "bn_eval_coeffs: bad args");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, gamma, beta, rm, rv, eps, scale, shift);
+  FEDFR_LAUNCH_CHECK("bn_eval_coeffs");
+  return FEDFR_OK;
+}
+
+// =====================================================================================================
+// forward BN apply (+PReLU) (+second normalised/identity input) (+stats of the result)
+// =====================================================================================================
+__device__ __forceinline__ void load8f(const float* p, int c0, float* v, float dflt) {
+  if (p) {
+    const float4 a = *reinterpret_cast<const float4*>(p + c0), b = *reinterpret_cast<const float4*>(p + c0 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = dflt;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int slab) {
+  extern __shared__ float red[];   // [rpp][2C] when stats
+  const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
+  const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const bool active = rl < rpp;
+  const int c0 = cl * 8;
+  float sc1[8], sh1[8], al[8], sc2[8], sh2[8];
+  load8f(p.sc1, c0, sc1, 1.f);
+  load8f(p.sh1, c0, sh1, 0.f);
+  load8f(p.alpha, c0, al, 1.f);
+  load8f(p.sc2, c0, sc2, 1.f);
+  load8f(p.sh2, c0, sh2, 0.f);
+  const bool has_alpha = p.alpha != nullptr;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  const int mbeg = blockIdx.x * slab;
+  const int mend = min(p.M, mbeg + slab);
+  if (active) {
+    for (int m = mbeg + rl; m < mend; m += rpp) {
+      const size_t off = (size_t)m * p.C + c0;
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.x1 + off), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = f[j] * sc1[j] + sh1[j];
+        if (has_alpha) v = v > 0.f ? v : al[j] * v;
+        f[j] = v;
+      }
+      if (p.x2) {
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.x2 + off), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j] * sc2[j] + sh2[j];
+      }
+      const uint4 o = pack8(f);
+      if (p.stats) {
+        float r[8];
+        unpack8(o, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s[j] += r[j];
+          q[j] += r[j] * r[j];
+        }
+      }
+      if (p.nchw_hw > 0) {
+        const int img = m / p.nchw_hw, hw = m - img * p.nchw_hw;
+        const bf16_t* ob = reinterpret_cast<const bf16_t*>(&o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p.y[((size_t)img * p.C + c0 + j) * p.nchw_hw + hw] = ob[j];
+      } else {
+        *reinterpret_cast<uint4*>(p.y + off) = o;
+      }
+    }
+  }
+  if (p.stats) {
+    const int W = 2 * p.C;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[rl * W + c0 + j] = s[j];
+        red[rl * W + p.C + c0 + j] = q[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < W; i += EW_THREADS) {
+      float t = 0.f;
+      for (int r = 0; r < rpp; ++r) t += red[r * W + i];
+      p.stats[(size_t)blockIdx.x * W + i] = t;
+    }
+  }
+}
+
+int ew_bn_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 1024)); }
+
+int ew_bn_apply(const BnApply& p, hipStream_t st) {
+  FEDFR_TRY(check_mc(p.M, p.C, "bn_apply"));
+  FEDFR_REQUIRE(p.x1 && p.y, "bn_apply: null tensor");
+  const int slab = slab_rows(p.M, p.C, 1024);
+  const int grid = ceil_div(p.M, slab);
+  const size_t lds = p.stats ? (size_t)rows_per_pass(p.C) * 2 * p.C * sizeof(float) : 0;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+  FEDFR_LAUNCH_CHECK("bn_apply");
+  return FEDFR_OK;
+}
+
+// =====================================================================================================
+// backward BN (+PReLU)
+// =====================================================================================================
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(BnBwd p, int slab) {
+  extern __shared__ float red[];   // [rpp][3C]
+  const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
+  const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const bool active = rl < rpp;
+  const int c0 = cl * 8;
+  float mean[8], rstd[8], ga[8], be[8], al[8];
+  load8f(p.mean, c0, mean, 0.f);
+  load8f(p.rstd, c0, rstd, 1.f);
+  load8f(p.gamma, c0, ga, 1.f);
+  load8f(p.beta, c0, be, 0.f);
+  load8f(p.alpha, c0, al, 1.f);
+  const bool has_alpha = p.alpha != nullptr;
+  float s1[8], s2[8], s3[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
+  const int mbeg = blockIdx.x * slab, mend = min(p.M, mbeg + slab);
+  if (active) {
+    for (int m = mbeg + rl; m < mend; m += rpp) {
+      const size_t off = (size_t)m * p.C + c0;
+      float dy[8], x[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.dy + off), dy);
+      unpack8(*reinterpret_cast<const uint4*>(p.x + off), x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (x[j] - mean[j]) * rstd[j];
+        float dz = dy[j];
+        if (has_alpha) {
+          const float z = ga[j] * xh + be[j];
+          if (z <= 0.f) {
+            s3[j] += dy[j] * z;
+            dz = dy[j] * al[j];
+          }
+        }
+        s1[j] += dz;
+        s2[j] += dz * xh;
+      }
+    }
+  }
+  const int W = 3 * p.C;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[rl * W + c0 + j] = s1[j];
+      red[rl * W + p.C + c0 + j] = s2[j];
+      red[rl * W + 2 * p.C + c0 + j] = s3[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < W; i += EW_THREADS) {
+    float t = 0.f;
+    for (int r = 0; r < rpp; ++r) t += red[r * W + i];
+    p.partials[(size_t)blockIdx.x * W + i] = t;
+  }
+}
+
+int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 512)); }
+
+int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st) {
+  FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_reduce"));
+  FEDFR_REQUIRE(p.dy && p.x && p.mean && p.rstd && p.partials, "bn_bwd_reduce: null tensor");
+  const int slab = slab_rows(p.M, p.C, 512);
+  const int grid = ceil_div(p.M, slab);
+  const size_t lds = (size_t)rows_per_pass(p.C) * 3 * p.C * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+  FEDFR_LAUNCH_CHECK("bn_bwd_reduce");
+  return FEDFR_OK;
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int P, int C, double count,
+                                                              const float* gamma, const float* rstd, float* dgamma,
+                                                              float* dbeta, float* dalpha, float* coef) {
+  __shared__ double r1[32][33], r2[32][33], r3[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0, b = 0.0, d = 0.0;
+  if (c < C)
+    for (int row = rg; row < P; row += 32) {
+      const float* pr = part + (size_t)row * 3 * C;
+      a += (double)pr[c];
+      b += (double)pr[C + c];
+      d += (double)pr[2 * C + c];
+    }
+  r1[rg][cl] = a;
+  r2[rg][cl] = b;
+  r3[rg][cl] = d;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      t1 += r1[i][cl];
+      t2 += r2[i][cl];
+      t3 += r3[i][cl];
+    }
+    if (dgamma) dgamma[c] = (float)t2;
+    if (dbeta) dbeta[c] = (float)t1;
+    if (dalpha) dalpha[c] = (float)t3;
+    const float g = gamma ? gamma[c] : 1.f;
+    coef[c] = g * rstd[c];
+    coef[C + c] = (float)(t1 / count);
+    coef[2 * C + c] = (float)(t2 / count);
+  }
+}
+
+int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* rstd,
+                       float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st) {
+  FEDFR_REQUIRE(partials && P > 0 && C > 0 && rstd && coef, "bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partials, P, C, count, gamma, rstd,
+                     dgamma, dbeta, dalpha, coef);
+  FEDFR_LAUNCH_CHECK("bn_bwd_finalize");
+  return FEDFR_OK;
+}
+
+struct BnBwdDiv {
+  FastDiv dHW, dW;
+};
+
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab) {
+  const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
+  const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  if (rl >= rpp) return;
+  const int c0 = cl * 8;
+  float mean[8], rstd[8], ga[8], be[8], al[8], ca[8], cb[8], cc[8];
+  load8f(p.mean, c0, mean, 0.f);
+  load8f(p.rstd, c0, rstd, 1.f);
+  load8f(p.gamma, c0, ga, 1.f);
+  load8f(p.beta, c0, be, 0.f);
+  load8f(p.alpha, c0, al, 1.f);
+  load8f(p.coef, c0, ca, 1.f);
+  load8f(p.coef + p.C, c0, cb, 0.f);
+  load8f(p.coef + 2 * p.C, c0, cc, 0.f);
+  const bool has_alpha = p.alpha != nullptr;
+  const int mbeg = blockIdx.x * slab, mend = min(p.M, mbeg + slab);
+  for (int m = mbeg + rl; m < mend; m += rpp) {
+    const size_t off = (size_t)m * p.C + c0;
+    float dy[8], x[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(p.dy + off), dy);
+    unpack8(*reinterpret_cast<const uint4*>(p.x + off), x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (x[j] - mean[j]) * rstd[j];
+      float dz = dy[j];
+      if (has_alpha) {
+        const float z = ga[j] * xh + be[j];
+        if (z <= 0.f) dz = dy[j] * al[j];
+      }
+      o[j] = ca[j] * (dz - cb[j] - xh * cc[j]);
+    }
+    if (p.add) {
+      float a[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.add + off), a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += a[j];
+    }
+    if (p.add_up) {
+      const unsigned img = fdiv((unsigned)m, dv.dHW);
+      const unsigned rem = (unsigned)m - img * dv.dHW.d;
+      const unsigned h = fdiv(rem, dv.dW), w = rem - h * dv.dW.d;
+      if (((h | w) & 1u) == 0u) {
+        const size_t uoff = (((size_t)img * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.C + c0;
+        float a[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.add_up + uoff), a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += a[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(p.dx + off) = pack8(o);
+  }
+}
+
+int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
+  FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_apply"));
+  FEDFR_REQUIRE(p.dy && p.x && p.mean && p.rstd && p.coef && p.dx, "bn_bwd_apply: null tensor");
+  BnBwdDiv dv;
+  dv.dHW = make_fastdiv(1);
+  dv.dW = make_fastdiv(1);
+  if (p.add_up) {
+    FEDFR_REQUIRE(p.H > 0 && p.W > 0 && !(p.H & 1) && !(p.W & 1) && p.M % (p.H * p.W) == 0, "bn_bwd_apply: add_up needs even H, W");
+    dv.dHW = make_fastdiv((unsigned)(p.H * p.W));
+    dv.dW = make_fastdiv((unsigned)p.W);
+  }
+  const int slab = slab_rows(p.M, p.C, 2048);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(p.M, slab)), dim3(EW_THREADS), 0, st, p, dv, slab);
+  FEDFR_LAUNCH_CHECK("bn_bwd_apply");
+  return FEDFR_OK;
+}
+
+// =====================================================================================================
+// BatchNorm1d on fp32 [B][C]
+// =====================================================================================================
+__global__ void bn1d_fwd_kernel(const float* x, float* y, int B, int C, const float* gamma, const float* beta,
+                                float* rm, float* rv, float momentum, float eps, int training, float* save_mean,
+                                float* save_rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, rstd;
+  if (training) {
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += (double)x[(size_t)b * C + c];
+    const double mu = s / B;
+    double v = 0.0;
+    for (int b = 0; b < B; ++b) {
+      const double d = (double)x[(size_t)b * C + c] - mu;
+      v += d * d;
+    }
+    const double var = v / B;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const double unb = B > 1 ? v / (B - 1) : var;
+    rm[c] = (float)((1.0 - momentum) * (double)rm[c] + momentum * mu);
+    rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unb);
+  } else {
+    mean = rm[c];
+    rstd = 1.f / sqrtf(rv[c] + eps);
+  }
+  if (save_mean) {
+    save_mean[c] = mean;
+    save_rstd[c] = rstd;
+  }
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  for (int b = 0; b < B; ++b) y[(size_t)b * C + c] = (x[(size_t)b * C + c] - mean) * rstd * g + bt;
+}
+
+int ew_bn1d_fwd(const float* x, float* y, int B, int C, const float* gamma, const float* beta, float* rm, float* rv,
+                float momentum, float eps, int training, float* save_mean, float* save_rstd, hipStream_t st) {
+  FEDFR_REQUIRE(x && y && B > 0 && C > 0 && rm && rv, "bn1d_fwd: bad args");
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, x, y, B, C, gamma, beta, rm, rv, momentum, eps,
+                     training, save_mean, save_rstd);
+  FEDFR_LAUNCH_CHECK("bn1d_fwd");
+  return FEDFR_OK;
+}
+
+__global__ void bn1d_bwd_kernel(const float* dy, const float* x, float* dx, int B, int C, const float* gamma,
+                                const float* mean, const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb,
+                                bf16_t* dxbt, int ldt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float d = dy[(size_t)b * C + c];
+    s1 += d;
+    s2 += (double)d * (double)((x[(size_t)b * C + c] - mu) * rs);
+  }
+  const float m1 = (float)(s1 / B), m2 = (float)(s2 / B);
+  if (dbeta) dbeta[c] = (float)s1;
+  double cs = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float xh = (x[(size_t)b * C + c] - mu) * rs;
+    const float v = g * rs * (dy[(size_t)b * C + c] - m1 - xh * m2);
+    dx[(size_t)b * C + c] = v;
+    cs += v;
+    if (dxb) dxb[(size_t)b * C + c] = f2bf(v);
+    if (dxbt) dxbt[(size_t)c * ldt + b] = f2bf(v);
+  }
+  if (dx_colsum) dx_colsum[c] = (float)cs;
+}
+
+int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const float* gamma, const float* mean,
+                const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb, bf16_t* dxbt, int ldt, hipStream_t st) {
+  FEDFR_REQUIRE(dy && x && dx && B > 0 && C > 0 && mean && rstd, "bn1d_bwd: bad args");
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, dy, x, dx, B, C, gamma, mean, rstd, dbeta,
+                     dx_colsum, dxb, dxbt, ldt);
+  FEDFR_LAUNCH_CHECK("bn1d_bwd");
+  return FEDFR_OK;
+}
+
+// =====================================================================================================
+// split-K slab reductions, casts, transposes
+// =====================================================================================================
+__global__ void reduce_slabs_kernel(float* dst, const float* slabs, int nsplit, size_t n4, const float* bias, int bias_n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(slabs)[i];
+    for (int s = 1; s < nsplit; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(slabs + (size_t)s * n4 * 4)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias) {
+      const int c = (int)((i * 4) % (size_t)bias_n);
+      a.x += bias[c]; a.y += bias[c + 1]; a.z += bias[c + 2]; a.w += bias[c + 3];
+    }
+    reinterpret_cast<float4*>(dst)[i] = a;
+  }
+}
+int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n, hipStream_t st) {
+  FEDFR_REQUIRE(dst && slabs && nsplit > 0 && n > 0 && (n & 3) == 0, "reduce_slabs: bad args (n%%4)");
+  if (bias) FEDFR_REQUIRE((bias_n & 3) == 0 && bias_n > 0, "reduce_slabs: bias_n%%4");
+  const size_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n);
+  FEDFR_LAUNCH_CHECK("reduce_slabs");
+  return FEDFR_OK;
+}
+
+__global__ void reduce_slabs_bf16_kernel(bf16_t* dst, const float* slabs, int nsplit, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(slabs)[i];
+    for (int s = 1; s < nsplit; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(slabs + (size_t)s * n4 * 4)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    uint2 o;
+    o.x = pack_bf2(a.x, a.y);
+    o.y = pack_bf2(a.z, a.w);
+    reinterpret_cast<uint2*>(dst)[i] = o;
+  }
+}
+int ew_reduce_slabs_bf16(bf16_t* dst, const float* slabs, int nsplit, size_t n, hipStream_t st) {
+  FEDFR_REQUIRE(dst && slabs && nsplit > 0 && n > 0 && (n & 3) == 0, "reduce_slabs_bf16: bad args (n%%4)");
+  const size_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3(grid), dim3(256), 0, st, dst, slabs, nsplit, n4);
+  FEDFR_LAUNCH_CHECK("reduce_slabs_bf16");
+  return FEDFR_OK;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* src, bf16_t* dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n8 = n / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    uint4 o;
+    o.x = pack_bf2(a.x, a.y); o.y = pack_bf2(a.z, a.w); o.z = pack_bf2(b.x, b.y); o.w = pack_bf2(b.z, b.w);
+    reinterpret_cast<uint4*>(dst)[i] = o;
+  }
+  for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = f2bf(src[i]);
+}
+int ew_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
+  FEDFR_REQUIRE(src && dst && n > 0, "cast_f32_bf16: bad args");
+  FEDFR_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "cast_f32_bf16: 16-byte alignment");
+  const size_t work = n / 8 + 1;
+  const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, st, src, dst, n);
+  FEDFR_LAUNCH_CHECK("cast_f32_bf16");
+  return FEDFR_OK;
+}
+
+// [Cout][RS][Cin] fp32 -> [Cin][RS(flipped)][Cout] bf16, 64x64 LDS-tiled transpose
+__global__ __launch_bounds__(256) void weight_dgrad_shadow_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst,
+                                                                  int Cout, int RS, int Cin) {
+  __shared__ float tile[64][65];
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 4) + 16 * i, col = (t & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(w + ((size_t)(co0 + row) * RS + tap) * Cin + ci0 + col);
+    tile[row][col] = v.x; tile[row][col + 1] = v.y; tile[row][col + 2] = v.z; tile[row][col + 3] = v.w;
+  }
+  __syncthreads();
+  const int tapf = RS - 1 - tap;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = (t >> 3) + 32 * i, co8 = (t & 7) * 8;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = tile[co8 + j][ci];
+    *reinterpret_cast<uint4*>(dst + ((size_t)(ci0 + ci) * RS + tapf) * Cout + co0 + co8) = pack8(f);
+  }
+}
+int ew_weight_dgrad_shadow(const float* w, bf16_t* dst, int Cout, int R, int S, int Cin, hipStream_t st) {
+  FEDFR_REQUIRE(w && dst && (Cout & 63) == 0 && (Cin & 63) == 0 && R > 0 && S > 0, "weight_dgrad_shadow: need Cout,Cin %%64==0");
+  hipLaunchKernelGGL(weight_dgrad_shadow_kernel, dim3(Cout / 64, Cin / 64, R * S), dim3(256), 0, st, w, dst, Cout, R * S, Cin);
+  FEDFR_LAUNCH_CHECK("weight_dgrad_shadow");
+  return FEDFR_OK;
+}
+
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* src, bf16_t* dst, int B, int C, int HW) {
+  const size_t n = (size_t)B * C * HW;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const int hw = (int)(r % HW), b = (int)(r / HW);
+    dst[i] = f2bf(src[((size_t)b * C + c) * HW + hw]);
+  }
+}
+int ew_nchw_f32_to_nhwc_bf16(const float* src, bf16_t* dst, int B, int C, int HW, hipStream_t st) {
+  FEDFR_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0, "nchw_f32_to_nhwc_bf16: bad args");
+  const size_t n = (size_t)B * C * HW;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(grid), dim3(256), 0, st, src, dst, B, C, HW);
+  FEDFR_LAUNCH_CHECK("nchw_f32_to_nhwc_bf16");
+  return FEDFR_OK;
+}
+
+__global__ void transpose_bf16_kernel(const bf16_t* src, bf16_t* dst, int R, int C) {
+  const size_t n = (size_t)R * C;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i % R), c = (int)(i / R);
+    dst[i] = src[(size_t)r * C + c];
+  }
+}
+int ew_transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st) {
+  FEDFR_REQUIRE(src && dst && R > 0 && C > 0, "transpose_bf16: bad args");
+  const size_t n = (size_t)R * C;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(grid), dim3(256), 0, st, src, dst, R, C);
+  FEDFR_LAUNCH_CHECK("transpose_bf16");
+  return FEDFR_OK;
+}
+
+// =====================================================================================================
+// stem conv 3 -> 64, 3x3 s1 p1, fp32 NCHW input, one 16x16x32 MFMA per 16 pixels x 16 channels (K = 27 -> 32)
+// =====================================================================================================
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       bf16_t* __restrict__ y, float* __restrict__ stats, int B, int H,
+                                                       int W) {
+  __shared__ __attribute__((aligned(16))) unsigned char sC[256 * 144];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int M = B * H * W;
+  // weight fragments (A operand: row n = ni*16 + l15, k = 8*lg + j); KRSC index = n*27 + k
+  bf16x8_t wf[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    s16x8_t v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lg + j;
+      v[j] = (short)f2bf(k < 27 ? w[(ni * 16 + l15) * 27 + k] : 0.f);
+    }
+    wf[ni] = __builtin_bit_cast(bf16x8_t, v);
+  }
+  const int mblk = blockIdx.x * 256 + wave * 64;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = mblk + mi * 16 + l15;
+    s16x8_t v;
+    const bool okm = m < M;
+    const int mm = okm ? m : 0;
+    const int img = mm / (H * W), rem = mm - img * H * W;
+    const int h = rem / W, wq = rem - h * W;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lg + j;
+      const int tap = k / 3, ci = k - tap * 3;
+      const int r = tap / 3, s = tap - r * 3;
+      const int hp = h + r - 1, wp = wq + s - 1;
+      float f = 0.f;
+      if (okm && k < 27 && (unsigned)hp < (unsigned)H && (unsigned)wp < (unsigned)W)
+        f = x[(((size_t)img * 3 + ci) * H + hp) * W + wp];
+      v[j] = (short)f2bf(f);
+    }
+    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+      acc[ni][mi] = MFMA16(wf[ni], xf, z4);
+    }
+  }
+  // D: n = ni*16 + lg*4 + reg ; m(local) = wave*64 + mi*16 + l15
+  float ssum[4][4], ssq[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      bf16_t hh[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        hh[q] = f2bf(acc[ni][mi][q]);
+        const float v = bf2f(hh[q]);
+        ssum[ni][q] += v;
+        ssq[ni][q] += v * v;
+      }
+      uint2 pk;
+      pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
+      pk.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
+      *reinterpret_cast<uint2*>(sC + (wave * 64 + mi * 16 + l15) * 144 + (ni * 16 + lg * 4) * 2) = pk;
+    }
+  if (stats) {
+    float* prow = stats + (size_t)(blockIdx.x * 4 + wave) * 128;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = ssum[ni][q], b = ssq[ni][q];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        if (l15 == 0) {
+          prow[ni * 16 + lg * 4 + q] = a;
+          prow[64 + ni * 16 + lg * 4 + q] = b;
+        }
+      }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 256 * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    const int m = blockIdx.x * 256 + row;
+    if (m < M) *reinterpret_cast<uint4*>(y + (size_t)m * 64 + c * 8) = *reinterpret_cast<const uint4*>(sC + row * 144 + c * 16);
+  }
+}
+
+int ew_stem_stat_rows(int B, int H, int W) { return ceil_div((long long)B * H * W, 256) * 4; }
+
+int ew_stem_fwd(const float* x, const float* w, bf16_t* y, float* stats, int B, int H, int W, hipStream_t st) {
+  FEDFR_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "stem_fwd: bad args");
+  const int M = B * H * W;
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, x, w, y, stats, B, H, W);
+  FEDFR_LAUNCH_CHECK("stem_fwd");
+  return FEDFR_OK;
+}
+
+// stem wgrad: dw[co][k] = sum_m dy[m][co] * col[m][k]; VALU, LDS-staged (5.5 GFLOP at B=128: not worth MFMA staging)
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                         float* __restrict__ tmp, int B, int H, int W, int px_per_block) {
+  __shared__ float sdy[64][64];
+  __shared__ __attribute__((aligned(16))) float scol[64][32];
+  const int tid = threadIdx.x;
+  const int co = tid & 63, kq = tid >> 6;
+  const int M = B * H * W;
+  const int mbeg = blockIdx.x * px_per_block, mend = min(M, mbeg + px_per_block);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int mc = mbeg; mc < mend; mc += 64) {
+    // dy tile: 64 px x 64 co bf16 = 512 chunks of 16 B
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      const int px = idx >> 3, c8 = (idx & 7) * 8;
+      const int m = mc + px;
+      float f[8];
+      if (m < mend) {
+        unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)m * 64 + c8), f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sdy[px][c8 + j] = f[j];
+    }
+    {
+      const int px = tid & 63;
+      const int m = mc + px;
+      const bool okm = m < mend;
+      const int mm = okm ? m : 0;
+      const int img = mm / (H * W), rem = mm - img * H * W;
+      const int h = rem / W, wq = rem - h * W;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int k = (tid >> 6) + 4 * jj;
+        const int tap = k / 3, ci = k - tap * 3;
+        const int r = tap / 3, s = tap - r * 3;
+        const int hp = h + r - 1, wp = wq + s - 1;
+        float f = 0.f;
+        if (okm && k < 27 && (unsigned)hp < (unsigned)H && (unsigned)wp < (unsigned)W)
+          f = x[(((size_t)img * 3 + ci) * H + hp) * W + wp];
+        scol[px][k] = f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int px = 0; px < 64; ++px) {
+      const float d = sdy[px][co];
+      const float4 c0 = *reinterpret_cast<const float4*>(&scol[px][kq * 8]);
+      const float4 c1 = *reinterpret_cast<const float4*>(&scol[px][kq * 8 + 4]);
+      acc[0] += d * c0.x; acc[1] += d * c0.y; acc[2] += d * c0.z; acc[3] += d * c0.w;
+      acc[4] += d * c1.x; acc[5] += d * c1.y; acc[6] += d * c1.z; acc[7] += d * c1.w;
+    }
+    __syncthreads();
+  }
+  float* o = tmp + (size_t)blockIdx.x * 2048 + co * 32 + kq * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ tmp, int nblk, float* __restrict__ dw) {
+  __shared__ double red[8][32];
+  const int co = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
+  double s = 0.0;
+  for (int b = g; b < nblk; b += 8) s += (double)tmp[(size_t)b * 2048 + co * 32 + k];
+  red[g][k] = s;
+  __syncthreads();
+  if (g == 0 && k < 27) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][k];
+    dw[co * 27 + k] = (float)t;
+  }
+}
+
+static int stem_px_per_block(int M) {
+  int ppb = ceil_div(M, 1024);
+  ppb = (ppb + 63) / 64 * 64;
+  if (ppb < 64) ppb = 64;
+  return ppb;
+}
+int ew_stem_wgrad_blocks(int B, int H, int W) {
+  const int M = B * H * W;
+  return ceil_div(M, stem_px_per_block(M));
+}
+int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st) {
+  FEDFR_REQUIRE(x && dy && dw && tmp && B > 0 && H > 0 && W > 0, "stem_wgrad: bad args");
+  const int M = B * H * W;
+  const int ppb = stem_px_per_block(M);
+  const int nblk = ceil_div(M, ppb);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dy, tmp, B, H, W, ppb);
+  FEDFR_LAUNCH_CHECK("stem_wgrad");
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, tmp, nblk, dw);
+  FEDFR_LAUNCH_CHECK("stem_wgrad_reduce");
+  return FEDFR_OK;
+}

@@ -1,0 +1,50 @@
+// Descriptors + launchers for the two MFMA workhorse kernels (bf16 in, fp32 accumulate).
+//
+//  gemm_nt : C[m][n] = sum_k A(m,k) * B[n][k]      A = plain row-major or conv gather (NHWC)
+//            used for conv fwd, conv dgrad (flipped/transposed weight shadow), fc fwd.
+//  gemm_tn : C[i][j] = sum_p P[p][i] * Q(p,j)      both operands reduction-major in memory
+//            (LDS transpose reads, ds_read_b64_tr_b16); used for conv wgrad, fc dgrad/wgrad.
+#pragma once
+#include "common.h"
+
+struct GemmNT {
+  const bf16_t* A;
+  const bf16_t* B;        // [N][K], K contiguous
+  int M, N, K;
+  int mode;               // 0 plain A[M][lda]; 1 conv gather
+  int H, W, C;            // gather source tensor [img][H][W][C]
+  int Ho, Wo;             // row m -> (img, ho, wo)
+  int S;                  // filter width (tap = r*S + s)
+  int stride, pad, up;    // pos = ho*stride + r - pad; up==2: pos must be even, then pos/2
+  int lda;
+  int cpt;                // 64-wide k-chunks per tap (C/64)
+  bf16_t* Cb;             // bf16 out [M][ldc] (or null)
+  int ldc;
+  float* Cf;              // fp32 split-K slabs [splits][M][N] (or null)
+  float* stats;           // [gridM*WM][2][N] per-column partial (sum, sumsq) of the bf16-rounded output
+  int ksteps_total, ksteps_per_split;
+  int nbn;                // number of N tiles (for the 1-D XCD-swizzled grid)
+};
+
+struct GemmTN {
+  const bf16_t* P;        // [Kp][ldp]  (dy side)
+  const bf16_t* Q;        // plain [Kp][ldq] or conv gather source NHWC
+  int Kp, NI, NJ;
+  int mode;               // 0 plain; 1 conv gather (row p -> (img,ho,wo) of the dy tensor)
+  int H, W, C, Ho, Wo, S, stride, pad;
+  FastDiv dHoWo, dWo;
+  int ldp, ldq;
+  float* out;             // [splits][NI][NJ]
+  int ksteps_total, ksteps_per_split;
+  int nbj;                // number of j tiles
+  int use_tr;             // 1: ds_read_b64_tr_b16 fragments; 0: scalar LDS gathers (validation fallback)
+};
+
+// rows of partial stats the NT kernel writes for a given M (needed to size / finalize)
+int gemm_nt_stat_rows(int M, int N);
+// number of splits / workspace helpers
+int gemm_nt_pick_splits(int M, int N, int K);
+int gemm_nt_launch(GemmNT p, int splits, hipStream_t st);
+int gemm_tn_launch(GemmTN p, int splits, hipStream_t st);
+int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C_or_0);
+void gemm_tn_tiles(int NI, int NJ, int C_or_0, int* TI, int* TJ);

@@ -1,0 +1,532 @@
+// MFMA implicit-GEMM kernels for gfx950 (see gemm.h).  256 threads = 4 waves, 16x16x32 bf16 MFMA,
+// BK = 64, register-staged double-buffered LDS tiles with XOR-swizzled 16-byte chunks
+// (conflict-free ds_read_b128 / ds_read_b64_tr_b16), one barrier per K-step, XCD-aware 1-D grid.
+#include "gemm.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = id & 7, loc = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+}
+
+// =====================================================================================================
+// NT kernel
+// =====================================================================================================
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+  constexpr int AI = BM / 32, BI = BN / 32;             // 16-B chunks per thread per tile
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;   // 16x16 fragments per wave
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = lid % p.nbn, bm = lid / p.nbn;
+  const int split = blockIdx.y;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int kt0 = split * p.ksteps_per_split;
+  const int kt1 = min(kt0 + p.ksteps_per_split, p.ksteps_total);
+
+  const int ch = tid & 7, rbase = tid >> 3;
+  int a_hb[AI], a_wb[AI], a_pix[AI];
+  bool a_ok[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + rbase + 32 * i;
+    a_ok[i] = m < p.M;
+    if (p.mode == 1) {
+      const int mm = a_ok[i] ? m : 0;
+      const int hw = p.Ho * p.Wo;
+      const int img = mm / hw, rem = mm - img * hw;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      a_hb[i] = ho * p.stride - p.pad;
+      a_wb[i] = wo * p.stride - p.pad;
+      a_pix[i] = img * p.H * p.W;
+    } else {
+      a_hb[i] = a_wb[i] = 0;
+      a_pix[i] = m;
+    }
+  }
+  // tap state for k-step kt: (r, s, cc)
+  int tap = kt0 / p.cpt, cc = kt0 - tap * p.cpt;
+  int r = tap / p.S, s = tap - r * p.S;
+
+  uint4 ra[AI], rb[BI];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      uint4 v = zero4;
+      if (p.mode == 1) {
+        int hp = a_hb[i] + r, wp = a_wb[i] + s;
+        bool ok = a_ok[i];
+        if (p.up == 2) {
+          ok = ok && (((hp | wp) & 1) == 0);
+          hp >>= 1;
+          wp >>= 1;
+        }
+        ok = ok && (unsigned)hp < (unsigned)p.H && (unsigned)wp < (unsigned)p.W;
+        if (ok) {
+          const size_t off = (size_t)(a_pix[i] + hp * p.W + wp) * p.C + cc * 64 + ch * 8;
+          v = *reinterpret_cast<const uint4*>(p.A + off);
+        }
+      } else {
+        const int k = kt * 64 + ch * 8;
+        if (a_ok[i] && k < p.K) v = *reinterpret_cast<const uint4*>(p.A + (size_t)a_pix[i] * p.lda + k);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int n = n0 + rbase + 32 * i;
+      const int k = kt * 64 + ch * 8;
+      uint4 v = zero4;
+      if (n < p.N && k < p.K) v = *reinterpret_cast<const uint4*>(p.B + (size_t)n * p.K + k);
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = rbase + 32 * i;
+      *reinterpret_cast<uint4*>(sA + buf * A_BYTES + row * 128 + ((ch ^ (row & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int row = rbase + 32 * i;
+      *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 128 + ((ch ^ (row & 7)) << 4)) = rb[i];
+    }
+  };
+  auto advance = [&]() {
+    if (++cc == p.cpt) {
+      cc = 0;
+      if (++s == p.S) {
+        s = 0;
+        ++r;
+      }
+    }
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (kt0 < kt1) {
+    load_tiles(kt0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int l15 = lane & 15, lg = lane >> 4;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) {
+      advance();
+      load_tiles(kt + 1);
+    }
+    const unsigned char* cA = sA + buf * A_BYTES;
+    const unsigned char* cB = sB + buf * B_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + lg;
+      bf16x8_t fb[TN], fa[TM];
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int row = wn * (BN / WN) + ni * 16 + l15;
+        fb[ni] = *reinterpret_cast<const bf16x8_t*>(cB + row * 128 + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row = wm * (BM / WM) + mi * 16 + l15;
+        fa[mi] = *reinterpret_cast<const bf16x8_t*>(cA + row * 128 + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = MFMA16(fb[ni], fa[mi], acc[ni][mi]);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[ni][mi][reg]: n = wn*(BN/WN)+ni*16+lg*4+reg ; m = wm*(BM/WM)+mi*16+l15 ----
+  if (p.Cf) {
+    float* slab = p.Cf + (size_t)split * p.M * p.N;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * (BM / WM) + mi * 16 + l15;
+        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4;
+        if (m < p.M && n < p.N) *reinterpret_cast<float4*>(slab + (size_t)m * p.N + n) =
+            make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+      }
+    return;
+  }
+  constexpr int CST = BN * 2 + 16;   // staged C row stride in bytes
+  unsigned char* sC = smem;          // all waves are past the last barrier of the K loop
+  float ssum[TN][4], ssq[TN][4];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int ml = wm * (BM / WM) + mi * 16 + l15;
+      const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
+      bf16_t h[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h[q] = f2bf(acc[ni][mi][q]);
+        const float v = bf2f(h[q]);
+        ssum[ni][q] += v;
+        ssq[ni][q] += v * v;
+      }
+      uint2 pk;
+      pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+      pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+      *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
+    }
+  if (p.stats) {
+    float* prow = p.stats + (size_t)(bm * WM + wm) * 2 * p.N;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = ssum[ni][q], b = ssq[ni][q];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
+        if (l15 == 0 && n < p.N) {
+          prow[n] = a;
+          prow[p.N + n] = b;
+        }
+      }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;   // 16-B chunks per staged row
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    const int m = m0 + row, n = n0 + c * 8;
+    if (m < p.M && n < p.N)
+      *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_nt(const GemmNT& p0, int splits, hipStream_t st) {
+  GemmNT p = p0;
+  const int nbm = ceil_div(p.M, BM);
+  p.nbn = ceil_div(p.N, BN);
+  p.ksteps_per_split = ceil_div(p.ksteps_total, splits);
+  const int real_splits = ceil_div(p.ksteps_total, p.ksteps_per_split);
+  FEDFR_REQUIRE(real_splits == splits, "gemm_nt: splits=%d leaves an empty split (ksteps=%d)", splits, p.ksteps_total);
+  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(nbm * p.nbn, splits, 1);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, p);
+  FEDFR_LAUNCH_CHECK("gemm_nt");
+  return FEDFR_OK;
+}
+
+static inline int nt_bm(int M, int N) {
+  // 128-row tiles unless that leaves fewer than ~1.5 tiles per CU (256 CUs)
+  const int bn = (N <= 64) ? 64 : 128;
+  const long long tiles128 = (long long)ceil_div(M, 128) * ceil_div(N, bn);
+  return (tiles128 >= 384) ? 128 : 64;
+}
+
+int gemm_nt_pick_splits(int M, int N, int K) {
+  const int BM = nt_bm(M, N);
+  const int bn = (N <= 64) ? 64 : 128;
+  const int tiles = ceil_div(M, BM) * ceil_div(N, bn);
+  const int ksteps = ceil_div(K, 64);
+  int splits = ceil_div(512, tiles);
+  if (splits > ksteps / 4) splits = ksteps / 4;
+  if (splits < 1) splits = 1;
+  const int per = ceil_div(ksteps, splits);
+  return ceil_div(ksteps, per);
+}
+
+int gemm_nt_stat_rows(int M, int N) {
+  // must mirror the tile choice in gemm_nt_launch: rows = ceil(M/BM) * WM
+  const int BM = nt_bm(M, N);
+  const int WM = (BM == 128) ? 2 : ((N <= 64) ? 2 : 1);
+  return ceil_div(M, BM) * WM;
+}
+
+int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
+  FEDFR_REQUIRE(p.A && p.B && p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: null/empty operand");
+  FEDFR_REQUIRE((p.K & 7) == 0, "gemm_nt: K=%d must be a multiple of 8", p.K);
+  FEDFR_REQUIRE((p.Cb != nullptr) != (p.Cf != nullptr), "gemm_nt: exactly one of bf16 / fp32-slab outputs");
+  if (p.Cb) FEDFR_REQUIRE((p.N & 7) == 0 && (p.ldc & 7) == 0 && splits == 1, "gemm_nt: bf16 output needs N%%8==0, ldc%%8==0, splits==1");
+  if (p.Cf) FEDFR_REQUIRE((p.N & 3) == 0, "gemm_nt: fp32 output needs N%%4==0");
+  if (p.mode == 1) {
+    FEDFR_REQUIRE((p.C & 63) == 0, "gemm_nt: gather needs C%%64==0 (C=%d)", p.C);
+    p.cpt = p.C / 64;
+    FEDFR_REQUIRE(p.K % p.C == 0 && p.S > 0 && (p.K / p.C) % p.S == 0, "gemm_nt: K must be taps*C");
+    FEDFR_REQUIRE(p.up == 1 || p.up == 2, "gemm_nt: up must be 1 or 2");
+  } else {
+    FEDFR_REQUIRE((p.lda & 7) == 0, "gemm_nt: lda%%8");
+    p.cpt = 1 << 30;
+    p.S = 1;
+  }
+  p.ksteps_total = ceil_div(p.K, 64);
+  const int BM = nt_bm(p.M, p.N);
+  if (BM == 128) {
+    if (p.N <= 64) return launch_nt<128, 64, 2, 2>(p, splits, st);
+    return launch_nt<128, 128, 2, 2>(p, splits, st);
+  }
+  if (p.N <= 64) return launch_nt<64, 64, 2, 2>(p, splits, st);
+  return launch_nt<64, 128, 1, 4>(p, splits, st);
+}
+
+// =====================================================================================================
+// TN kernel
+// =====================================================================================================
+template <int RB>   // tile row bytes (128 or 256): chunk swizzle that makes tr-reads and b128 writes conflict-free
+__device__ __forceinline__ int tn_swz(int row) {
+  if (RB == 256) return ((row & 3) << 1) | (((row >> 3) & 1) << 3);
+  return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+}
+
+template <int RB, bool USE_TR>
+__device__ __forceinline__ bf16x8_t tn_frag(const unsigned char* tile, int ks, int colblk, int lane) {
+  // returns this lane's 8 reduction-consecutive elements (pixels ks*32 + 8*(lane>>4) + j) of column colblk + (lane&15)
+  const int g = lane >> 4, li = lane & 15;
+  if (USE_TR) {
+    const int q = li >> 2, pp = li & 3;
+    const int col = colblk + 4 * pp;
+    const int c = col >> 3, half = (col >> 2) & 1;
+    const int r0 = ks * 32 + 8 * g + q, r1 = r0 + 4;
+    const unsigned char* a0 = tile + r0 * RB + ((c ^ tn_swz<RB>(r0)) << 4) + half * 8;
+    const unsigned char* a1 = tile + r1 * RB + ((c ^ tn_swz<RB>(r1)) << 4) + half * 8;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    const int col = colblk + li;
+    const int c = col >> 3, e = col & 7;
+    s16x8_t v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int rr = ks * 32 + 8 * g + j;
+      v[j] = *reinterpret_cast<const short*>(tile + rr * RB + ((c ^ tn_swz<RB>(rr)) << 4) + e * 2);
+    }
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+template <int TI, int TJ, bool USE_TR>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+  constexpr int WI = 2, WJ = 2;
+  constexpr int RBP = TI * 2, RBQ = TJ * 2;             // tile row bytes
+  constexpr int CPRP = TI / 8, CPRQ = TJ / 8;           // chunks per row
+  constexpr int RSP = 256 / CPRP, RSQ = 256 / CPRQ;     // rows covered per pass
+  constexpr int PI = 64 / RSP, QI = 64 / RSQ;           // chunks per thread
+  constexpr int FI = TI / WI / 16, FJ = TJ / WJ / 16;
+  constexpr int P_BYTES = 64 * RBP, Q_BYTES = 64 * RBQ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sP = smem;
+  unsigned char* sQ = smem + 2 * P_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bj = lid % p.nbj, bi = lid / p.nbj;
+  const int split = blockIdx.y;
+  const int i0 = bi * TI, j0 = bj * TJ;
+  const int kt0 = split * p.ksteps_per_split;
+  const int kt1 = min(kt0 + p.ksteps_per_split, p.ksteps_total);
+
+  int r = 0, s = 0, cj0 = j0;
+  if (p.mode == 1) {
+    const int tap = j0 / p.C;
+    cj0 = j0 - tap * p.C;
+    r = tap / p.S;
+    s = tap - r * p.S;
+  }
+  const int pc = tid % CPRP, prow = tid / CPRP;
+  const int qc = tid % CPRQ, qrow = tid / CPRQ;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  uint4 rp[PI], rq[QI];
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+      const int m = kt * 64 + prow + RSP * i;
+      const int col = i0 + pc * 8;
+      uint4 v = zero4;
+      if (m < p.Kp && col < p.NI) v = *reinterpret_cast<const uint4*>(p.P + (size_t)m * p.ldp + col);
+      rp[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+      const int m = kt * 64 + qrow + RSQ * i;
+      uint4 v = zero4;
+      if (m < p.Kp) {
+        if (p.mode == 1) {
+          const unsigned img = fdiv((unsigned)m, p.dHoWo);
+          const unsigned rem = (unsigned)m - img * p.dHoWo.d;
+          const unsigned ho = fdiv(rem, p.dWo);
+          const unsigned wo = rem - ho * p.dWo.d;
+          const int hp = (int)ho * p.stride + r - p.pad, wp = (int)wo * p.stride + s - p.pad;
+          if ((unsigned)hp < (unsigned)p.H && (unsigned)wp < (unsigned)p.W)
+            v = *reinterpret_cast<const uint4*>(p.Q + ((size_t)(img * p.H + hp) * p.W + wp) * p.C + cj0 + qc * 8);
+        } else {
+          const int col = j0 + qc * 8;
+          if (col < p.NJ) v = *reinterpret_cast<const uint4*>(p.Q + (size_t)m * p.ldq + col);
+        }
+      }
+      rq[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+      const int row = prow + RSP * i;
+      *reinterpret_cast<uint4*>(sP + buf * P_BYTES + row * RBP + ((pc ^ tn_swz<RBP>(row)) << 4)) = rp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+      const int row = qrow + RSQ * i;
+      *reinterpret_cast<uint4*>(sQ + buf * Q_BYTES + row * RBQ + ((qc ^ tn_swz<RBQ>(row)) << 4)) = rq[i];
+    }
+  };
+
+  f32x4_t acc[FJ][FI];
+#pragma unroll
+  for (int a = 0; a < FJ; ++a)
+#pragma unroll
+    for (int b = 0; b < FI; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (kt0 < kt1) {
+    load_tiles(kt0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) load_tiles(kt + 1);
+    const unsigned char* cP = sP + buf * P_BYTES;
+    const unsigned char* cQ = sQ + buf * Q_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fq[FJ], fp[FI];
+#pragma unroll
+      for (int tj = 0; tj < FJ; ++tj) fq[tj] = tn_frag<RBQ, USE_TR>(cQ, ks, wj * (TJ / WJ) + tj * 16, lane);
+#pragma unroll
+      for (int ti = 0; ti < FI; ++ti) fp[ti] = tn_frag<RBP, USE_TR>(cP, ks, wi * (TI / WI) + ti * 16, lane);
+#pragma unroll
+      for (int tj = 0; tj < FJ; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < FI; ++ti) acc[tj][ti] = MFMA16(fq[tj], fp[ti], acc[tj][ti]);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+  // D[row = j][col = i]: j = j0 + wj*(TJ/WJ) + tj*16 + (lane>>4)*4 + reg ; i = i0 + wi*(TI/WI) + ti*16 + (lane&15)
+  float* slab = p.out + (size_t)split * p.NI * p.NJ;
+#pragma unroll
+  for (int tj = 0; tj < FJ; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < FI; ++ti) {
+      const int i = i0 + wi * (TI / WI) + ti * 16 + (lane & 15);
+      const int j = j0 + wj * (TJ / WJ) + tj * 16 + (lane >> 4) * 4;
+      if (i < p.NI && j < p.NJ) *reinterpret_cast<float4*>(slab + (size_t)i * p.NJ + j) =
+          make_float4(acc[tj][ti][0], acc[tj][ti][1], acc[tj][ti][2], acc[tj][ti][3]);
+    }
+}
+
+void gemm_tn_tiles(int NI, int NJ, int C, int* TI, int* TJ) {
+  *TI = (NI <= 64) ? 64 : 128;
+  const int w = C > 0 ? C : NJ;
+  *TJ = (w <= 64 || (w % 128) != 0) ? 64 : 128;
+}
+
+int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C) {
+  int TI, TJ;
+  gemm_tn_tiles(NI, NJ, C, &TI, &TJ);
+  const int tiles = ceil_div(NI, TI) * ceil_div(NJ, TJ);
+  const int ksteps = ceil_div(Kp, 64);
+  int splits = ceil_div(768, tiles);
+  if (splits > ksteps) splits = ksteps;
+  // keep >= 4 k-steps per split so the slab write does not dominate
+  while (splits > 1 && ksteps / splits < 4) --splits;
+  if (splits < 1) splits = 1;
+  // no empty trailing split
+  const int per = ceil_div(ksteps, splits);
+  return ceil_div(ksteps, per);
+}
+
+template <int TI, int TJ, bool USE_TR>
+static int launch_tn(GemmTN p, int splits, hipStream_t st) {
+  const int nbi = ceil_div(p.NI, TI);
+  p.nbj = ceil_div(p.NJ, TJ);
+  p.ksteps_total = ceil_div(p.Kp, 64);
+  p.ksteps_per_split = ceil_div(p.ksteps_total, splits);
+  FEDFR_REQUIRE(ceil_div(p.ksteps_total, p.ksteps_per_split) == splits, "gemm_tn: splits=%d leaves an empty split", splits);
+  const size_t lds = 2 * (size_t)64 * (TI + TJ) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<TI, TJ, USE_TR>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(nbi * p.nbj, splits, 1);
+  hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, USE_TR>), grid, dim3(256), lds, st, p);
+  FEDFR_LAUNCH_CHECK("gemm_tn");
+  return FEDFR_OK;
+}
+
+int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
+  FEDFR_REQUIRE(p.P && p.Q && p.out && p.Kp > 0 && p.NI > 0 && p.NJ > 0, "gemm_tn: null/empty operand");
+  FEDFR_REQUIRE((p.NI & 7) == 0 && (p.NJ & 7) == 0 && (p.ldp & 7) == 0, "gemm_tn: NI, NJ, ldp must be multiples of 8");
+  int TI, TJ;
+  if (p.mode == 1) {
+    FEDFR_REQUIRE((p.C & 63) == 0 && p.NJ % p.C == 0, "gemm_tn: gather needs C%%64==0 and NJ=taps*C");
+    p.dHoWo = make_fastdiv((unsigned)(p.Ho * p.Wo));
+    p.dWo = make_fastdiv((unsigned)p.Wo);
+    FEDFR_REQUIRE((long long)p.Kp * (long long)(p.Ho * p.Wo) < (1ll << 40), "gemm_tn: fastdiv range");
+    gemm_tn_tiles(p.NI, p.NJ, p.C, &TI, &TJ);
+  } else {
+    FEDFR_REQUIRE((p.ldq & 7) == 0, "gemm_tn: ldq%%8");
+    gemm_tn_tiles(p.NI, p.NJ, 0, &TI, &TJ);
+  }
+#define TN_CASE(a, b)                                                \
+  if (TI == a && TJ == b) {                                          \
+    if (p.use_tr) return launch_tn<a, b, true>(p, splits, st);       \
+    return launch_tn<a, b, false>(p, splits, st);                    \
+  }
+  TN_CASE(128, 128)
+  TN_CASE(128, 64)
+  TN_CASE(64, 128)
+  TN_CASE(64, 64)
+#undef TN_CASE
+  fedfr_set_error("gemm_tn: no tile for TI=%d TJ=%d", TI, TJ);
+  return FEDFR_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,19 @@
+// fp32 head kernels (see head.hip).
+#pragma once
+#include "common.h"
+
+int head_normalize_rows(const float* x, float* xn, float* inv, int R, int D, float eps, hipStream_t st);
+int head_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn, float* dx, int R, int D, float beta,
+                            hipStream_t st);
+int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak,
+               long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, hipStream_t st);
+int head_margin_rowmax(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arc, float* row_max,
+                       float* dmul, hipStream_t st);
+int head_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float* row_sum, hipStream_t st);
+int head_softmax_grad(float* z, const long long* label, int R, int C, int ldz, const float* row_sum, const float* dmul, float s,
+                      float inv_batch, float* prob_t, hipStream_t st);
+int head_nll_mean(const float* prob_t, int R, float floor_, float* loss, hipStream_t st);
+int head_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t, float lam,
+             float loss_scale, float* zout, float* dcos, float* dz, float* row_loss, hipStream_t st);
+int head_colsum_f32(const float* x, int R, int C, float* out, hipStream_t st);
+int head_sum_scale(const float* x, int n, float scale, float* out, hipStream_t st);

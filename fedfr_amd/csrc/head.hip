@@ -1,0 +1,365 @@
+// fp32 head kernels: row L2-normalisation (fwd/bwd), strided fp32 GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 FMA
+// chain), CosFace/ArcFace margin + (optionally distributed) softmax-CE with hand-written gradient
+// (reference: client.py:69-74, losses.py:17-45, partial_fc.py:130-176), BCE personalised head elementwise part
+// (client.py:45-58, losses.py:4-15).  The head stays fp32: s=30..64 amplifies cosine error.
+#include "head.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// normalisation: one wave per row
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ xn,
+                                                             float* __restrict__ inv, int R, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* xr = x + (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i] * xr[i];
+  s = wave_sum(s);
+  const float iv = 1.f / fmaxf(sqrtf(s), eps);
+  if (lane == 0 && inv) inv[row] = iv;
+  if (xn)
+    for (int i = lane; i < D; i += 64) xn[(size_t)row * D + i] = xr[i] * iv;
+}
+int head_normalize_rows(const float* x, float* xn, float* inv, int R, int D, float eps, hipStream_t st) {
+  FEDFR_REQUIRE(x && R > 0 && D > 0, "normalize_rows: bad args");
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, x, xn, inv, R, D, eps);
+  FEDFR_LAUNCH_CHECK("normalize_rows");
+  return FEDFR_OK;
+}
+
+// dx = inv * (dxn - xn * <xn, dxn>)     (F.normalize backward; the eps clamp branch has zero measure)
+__global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ inv,
+                                                                 const float* __restrict__ dxn, float* __restrict__ dx,
+                                                                 int R, int D, float beta) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const size_t o = (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xn[o + i] * dxn[o + i];
+  s = wave_sum(s);
+  const float iv = inv[row];
+  for (int i = lane; i < D; i += 64) {
+    const float v = iv * (dxn[o + i] - xn[o + i] * s);
+    dx[o + i] = beta != 0.f ? beta * dx[o + i] + v : v;
+  }
+}
+int head_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn, float* dx, int R, int D, float beta,
+                            hipStream_t st) {
+  FEDFR_REQUIRE(xn && inv && dxn && dx && R > 0 && D > 0, "normalize_rows_bwd: bad args");
+  hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, xn, inv, dxn, dx, R, D, beta);
+  FEDFR_LAUNCH_CHECK("normalize_rows_bwd");
+  return FEDFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// strided fp32 GEMM  C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ beta*C)
+// block tile 64x64, 4 waves (2x2) of 32x32, BK = 16, v_mfma_f32_16x16x4_f32
+// ---------------------------------------------------------------------------------------------------------
+struct SgemmP {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  long long sam, sak, sbk, sbn;
+  int ldc;
+  float alpha, beta;
+  const float* bias;
+};
+
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
+  constexpr int BM = 64, BN = 64, BK = 16, LD = 80;   // k-major LDS rows; LD%32==16 + column XOR (k>>1)<<1: reads and writes conflict-free
+  __shared__ float sA[2][BK][LD], sB[2][BK][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  float ra[4], rb[4];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int m, k;
+      if (p.sak == 1) { k = e & 15; m = e >> 4; } else { m = e & 63; k = e >> 6; }
+      const int gm = m0 + m, gk = k0 + k;
+      ra[i] = (gm < p.M && gk < p.K) ? p.A[(long long)gm * p.sam + (long long)gk * p.sak] : 0.f;
+      int n, kb;
+      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 15; n = e >> 4; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      rb[i] = (gn < p.N && gkb < p.K) ? p.B[(long long)gkb * p.sbk + (long long)gn * p.sbn] : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int m, k;
+      if (p.sak == 1) { k = e & 15; m = e >> 4; } else { m = e & 63; k = e >> 6; }
+      sA[buf][k][m ^ ((k >> 1) << 1)] = ra[i];
+      int n, kb;
+      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 15; n = e >> 4; }
+      sB[buf][kb][n ^ ((kb >> 1) << 1)] = rb[i];
+    }
+  };
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nk = ceil_div(p.K, BK);
+  load(0);
+  store(0);
+  __syncthreads();
+  const int l15 = lane & 15, lg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load((kt + 1) * BK);
+#pragma unroll
+    for (int k4 = 0; k4 < BK; k4 += 4) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = k4 + lg, sw = (kk >> 1) << 1;
+        fa[i] = sA[buf][kk][(wm * 32 + i * 16 + l15) ^ sw];
+        fb[i] = sB[buf][kk][(wn * 32 + i * 16 + l15) ^ sw];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store(buf ^ 1);
+    __syncthreads();
+  }
+  // D[row = m][col = n]: m = wm*32 + i*16 + lg*4 + reg, n = wn*32 + j*16 + l15
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 32 + i * 16 + lg * 4 + q, n = n0 + wn * 32 + j * 16 + l15;
+        if (m < p.M && n < p.N) {
+          float v = p.alpha * acc[i][j][q];
+          if (p.bias) v += p.bias[n];
+          float* c = p.C + (size_t)m * p.ldc + n;
+          if (p.beta != 0.f) v += p.beta * *c;
+          *c = v;
+        }
+      }
+}
+
+int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak,
+               long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, hipStream_t st) {
+  FEDFR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "sgemm: bad args");
+  SgemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias};
+  hipLaunchKernelGGL(sgemm_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  FEDFR_LAUNCH_CHECK("sgemm");
+  return FEDFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// margin + softmax CE in three steps so the row max / row sum can be all-reduced between them (PartialFC
+// C3/C4/C5, partial_fc.py:142-161).  One 256-thread block per row.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+
+// step 1: logits = margin(cos) * s in place; row_max; dmul[row] = d logit_target / d cos_target
+__global__ __launch_bounds__(256) void margin_rowmax_kernel(float* __restrict__ z, const long long* __restrict__ label, int C,
+                                                            int ldz, float s, float m, int arc, float* __restrict__ row_max,
+                                                            float* __restrict__ dmul) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  float* zr = z + (size_t)row * ldz;
+  const long long y = label[row];
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float x = zr[c], v;
+    if (arc) {
+      float th = acosf(x);                     // unclamped, as losses.py:42
+      if (c == y) {
+        const float st = sinf(th);
+        if (dmul) dmul[row] = s * sinf(th + m) / st;
+        th += m;
+      }
+      v = cosf(th) * s;
+    } else {
+      if (c == y) {
+        x -= m;
+        if (dmul) dmul[row] = s;
+      }
+      v = x * s;
+    }
+    zr[c] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max(mx, sh);
+  if (threadIdx.x == 0) {
+    row_max[row] = mx;
+    if (dmul && (y < 0 || y >= C)) dmul[row] = s;
+  }
+}
+
+// step 2: z = exp(z - max) in place; row_sum
+__global__ __launch_bounds__(256) void exp_rowsum_kernel(float* __restrict__ z, int C, int ldz, const float* __restrict__ row_max,
+                                                         float* __restrict__ row_sum) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  float* zr = z + (size_t)row * ldz;
+  const float mx = row_max[row];
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float e = expf(zr[c] - mx);
+    zr[c] = e;
+    sum += e;
+  }
+  sum = block_sum(sum, sh);
+  if (threadIdx.x == 0) row_sum[row] = sum;
+}
+
+// step 3: p = z / sum; prob_t[row] = p[label] (0 when label == -1); grad wrt cos in place:
+//   g[c] = (p[c] - [c == y]) * inv_batch * (c == y ? dmul[row] : s)
+__global__ __launch_bounds__(256) void softmax_grad_kernel(float* __restrict__ z, const long long* __restrict__ label, int C, int ldz,
+                                                           const float* __restrict__ row_sum, const float* __restrict__ dmul,
+                                                           float s, float inv_batch, float* __restrict__ prob_t) {
+  const int row = blockIdx.x;
+  float* zr = z + (size_t)row * ldz;
+  const float inv = 1.f / row_sum[row];
+  const long long y = label[row];
+  if (threadIdx.x == 0 && (y < 0 || y >= C)) prob_t[row] = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float pr = zr[c] * inv;
+    float g = pr;
+    float mul = s;
+    if (c == y) {
+      prob_t[row] = pr;
+      g -= 1.f;
+      mul = dmul[row];
+    }
+    zr[c] = g * inv_batch * mul;
+  }
+}
+
+// loss = -mean_r log(max(prob_t[r], floor))   (floor = 1e-30 for PartialFC, 0 for F.cross_entropy)
+__global__ __launch_bounds__(256) void nll_mean_kernel(const float* __restrict__ prob_t, int R, float floor_, float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) s += -logf(fmaxf(prob_t[r], floor_));
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *loss = s / R;
+}
+
+int head_margin_rowmax(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arc, float* row_max,
+                       float* dmul, hipStream_t st) {
+  FEDFR_REQUIRE(z && label && row_max && R > 0 && C > 0 && ldz >= C, "margin_rowmax: bad args");
+  hipLaunchKernelGGL(margin_rowmax_kernel, dim3(R), dim3(256), 0, st, z, label, C, ldz, s, m, arc, row_max, dmul);
+  FEDFR_LAUNCH_CHECK("margin_rowmax");
+  return FEDFR_OK;
+}
+int head_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float* row_sum, hipStream_t st) {
+  FEDFR_REQUIRE(z && row_max && row_sum && R > 0 && C > 0, "exp_rowsum: bad args");
+  hipLaunchKernelGGL(exp_rowsum_kernel, dim3(R), dim3(256), 0, st, z, C, ldz, row_max, row_sum);
+  FEDFR_LAUNCH_CHECK("exp_rowsum");
+  return FEDFR_OK;
+}
+int head_softmax_grad(float* z, const long long* label, int R, int C, int ldz, const float* row_sum, const float* dmul, float s,
+                      float inv_batch, float* prob_t, hipStream_t st) {
+  FEDFR_REQUIRE(z && label && row_sum && dmul && prob_t && R > 0 && C > 0, "softmax_grad: bad args");
+  hipLaunchKernelGGL(softmax_grad_kernel, dim3(R), dim3(256), 0, st, z, label, C, ldz, row_sum, dmul, s, inv_batch, prob_t);
+  FEDFR_LAUNCH_CHECK("softmax_grad");
+  return FEDFR_OK;
+}
+int head_nll_mean(const float* prob_t, int R, float floor_, float* loss, hipStream_t st) {
+  FEDFR_REQUIRE(prob_t && loss && R > 0, "nll_mean: bad args");
+  hipLaunchKernelGGL(nll_mean_kernel, dim3(1), dim3(256), 0, st, prob_t, R, floor_, loss);
+  FEDFR_LAUNCH_CHECK("nll_mean");
+  return FEDFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BCE personalised head, elementwise part.  cos [B][C] in; z (logits) out; dcos = dL/dcos; per-row loss sums.
+//   g(x) = 2((x+1)/2)^t - 1 ; z = r*(g -/+ m) + bias ; loss_e = pos ? (lam/r) log(1+e^-z+1e-8) : ((1-lam)/r) log(1+e^z+1e-8)
+//   L = loss_scale * mean_b sum_c loss_e
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ cosv, const long long* __restrict__ label,
+                                                  const float* __restrict__ bias, int C, float m, float r, float t, float lam,
+                                                  float loss_scale, float inv_batch, float* __restrict__ zout,
+                                                  float* __restrict__ dcos, float* __restrict__ dz, float* __restrict__ row_loss) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  const long long y = label[row];
+  float ls = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const size_t i = (size_t)row * C + c;
+    const float x = cosv[i];
+    const float hb = (x + 1.f) * 0.5f;
+    const float pw1 = powf(hb, t - 1.f);
+    const float g = 2.f * pw1 * hb - 1.f;
+    const bool pos = (c == y);
+    const float z = r * (pos ? g - m : g + m) + bias[c];
+    if (zout) zout[i] = z;
+    float le, dldz;
+    if (pos) {
+      const float e = expf(-z);
+      le = (lam / r) * logf(1.f + e + 1e-8f);
+      dldz = (lam / r) * (-e) / (1.f + e + 1e-8f);
+    } else {
+      const float e = expf(z);
+      le = ((1.f - lam) / r) * logf(1.f + e + 1e-8f);
+      dldz = ((1.f - lam) / r) * e / (1.f + e + 1e-8f);
+    }
+    ls += le;
+    const float gz = dldz * inv_batch * loss_scale;
+    if (dz) dz[i] = gz;
+    if (dcos) dcos[i] = gz * r * t * pw1;      // dz/dcos = r * g'(x) = r * t * ((x+1)/2)^(t-1)
+  }
+  ls = block_sum(ls, sh);
+  if (threadIdx.x == 0) row_loss[row] = ls;
+}
+int head_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t, float lam,
+             float loss_scale, float* zout, float* dcos, float* dz, float* row_loss, hipStream_t st) {
+  FEDFR_REQUIRE(cosv && label && bias && row_loss && B > 0 && C > 0, "bce: bad args");
+  hipLaunchKernelGGL(bce_kernel, dim3(B), dim3(256), 0, st, cosv, label, bias, C, m, r, t, lam, loss_scale, 1.f / B, zout, dcos,
+                     dz, row_loss);
+  FEDFR_LAUNCH_CHECK("bce");
+  return FEDFR_OK;
+}
+
+// out[c] = sum_r x[r][c]  (fp32, small R)   and   *out = scale * sum_i x[i]
+__global__ void colsum_f32_kernel(const float* __restrict__ x, int R, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < R; ++r) s += (double)x[(size_t)r * C + c];
+  out[c] = (float)s;
+}
+int head_colsum_f32(const float* x, int R, int C, float* out, hipStream_t st) {
+  FEDFR_REQUIRE(x && out && R > 0 && C > 0, "colsum_f32: bad args");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, x, R, C, out);
+  FEDFR_LAUNCH_CHECK("colsum_f32");
+  return FEDFR_OK;
+}
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *out = s * scale;
+}
+int head_sum_scale(const float* x, int n, float scale, float* out, hipStream_t st) {
+  FEDFR_REQUIRE(x && out && n > 0, "sum_scale: bad args");
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, x, n, scale, out);
+  FEDFR_LAUNCH_CHECK("sum_scale");
+  return FEDFR_OK;
+}

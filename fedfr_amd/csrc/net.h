@@ -1,0 +1,70 @@
+// Host-side plan for an iresnet (reference: backbones/iresnet.py:60-172).  The plan owns NO device memory:
+// it only computes offsets into caller-provided flat buffers and sequences kernel launches on the
+// caller's stream.  Buffers (all allocated by the host framework, e.g. torch tensors):
+//   params  fp32  [param_count]      trainable region first (state_dict order), then frozen features.weight
+//                                    conv weights are KRSC ([Cout][kh][kw][Cin]) == channels_last OIHW views
+//   grads   fp32  [trainable_count]  same layout as the trainable region
+//   bufs    fp32  [buffer_count]     BN running_mean / running_var
+//   shadow  bf16  [shadow_count]     [0, trainable_count): bf16 mirror of params; then dgrad-layout conv copies
+//   act     bytes [act_bytes]        saved activations (NHWC bf16) + per-BN saved (scale, shift, mean, rstd)
+//   ws      bytes [ws_bytes]         gradient ping-pong buffers, split-K slabs, reduction partials
+#pragma once
+#include <string>
+#include <vector>
+#include "common.h"
+
+struct NetTensor {          // one state_dict entry
+  std::string name;
+  int kind;                 // 0 conv(KRSC) 1 bn_w 2 bn_b 3 prelu 4 fc_w 5 fc_b 6 running_mean 7 running_var 8 num_batches_tracked
+  int region;               // 0 params, 1 bufs, 2 nbt (index = offset)
+  long long offset;         // element offset inside the region
+  int shape[4];             // reference (OIHW / 1-D / 2-D) shape, unused dims = 0
+  int ndim;
+};
+
+struct ConvD {
+  int Cin, Cout, R, stride, Hin, Hout;
+  long long w_off;          // params / grads / fwd shadow offset
+  long long wd_off;         // dgrad shadow offset (absolute in shadow buffer)
+};
+struct BnD {
+  int C;
+  long long g_off, b_off;   // params
+  long long rm_off, rv_off; // bufs
+  long long save_off;       // float offset in the act "bnsave" region: scale, shift, mean, rstd (4*C floats)
+};
+struct BlockD {
+  int Cin, Cout, Hin, Hout, stride;
+  bool has_ds;
+  BnD bn1, bn2, bn3, bnds;
+  ConvD conv1, conv2, ds;
+  long long alpha_off;
+  long long x_off, a1_off, c1_off, a2_off, c2_off, d_off, out_off;   // bf16 element offsets in act
+};
+
+struct FedfrNet {
+  int layers[4];
+  int B, Bp, HW, F;                     // batch, batch padded to 8, input side, feature dim
+  std::vector<NetTensor> tensors;
+  std::vector<BlockD> blocks;
+  ConvD stem;
+  BnD stem_bn, bn2, feat_bn;
+  long long stem_alpha_off;
+  long long fc_w_off, fc_b_off;
+  long long c0_off, a0_off, t_off;      // stem conv out, stem act, flattened bn2 output [B][C*hw] (bf16, NCHW order)
+  long long yfc_off, feat_save_off;     // float offsets (act float region): fc output [B][F]; features mean/rstd
+  long long param_count, trainable_count, buffer_count, nbt_count, shadow_count;
+  long long act_bf16_count, act_float_off_bytes, act_bytes;
+  // workspace layout (byte offsets)
+  size_t ws_bytes;
+  size_t ws_g[2], ws_t[6], ws_part, ws_slab, ws_small, ws_fc;
+  size_t g_elems, part_floats, slab_floats;
+  int final_hw, final_C, fc_in;
+};
+
+FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features);
+int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st);
+int net_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, const bf16_t* shadow,
+                unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st);
+int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
+                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st);

@@ -1,0 +1,395 @@
+// iresnet plan + forward/backward sequencing (host code only; see net.h).
+// Reference behaviour: backbones/iresnet.py:46-57 (IBasicBlock.forward), :158-172 (IResNet.forward);
+// backward is the hand-derived adjoint of that graph (checked against autograd of the CPU oracle).
+#include "net.h"
+#include <algorithm>
+#include <cstdio>
+#include "ew.h"
+#include "gemm.h"
+
+static const int kPlanes[4] = {64, 128, 256, 512};
+static const float kBnEps = 1e-5f, kBnMomentum = 0.1f;
+int g_tn_use_tr = 1;   // option "tn_use_tr": 0 selects the scalar-LDS fallback fragments (validation)
+
+namespace {
+struct Builder {
+  FedfrNet* n;
+  long long poff = 0, boff = 0, nbt = 0, saveoff = 0;
+  std::vector<NetTensor> frozen;
+  long long add_param(const std::string& name, int kind, std::initializer_list<int> shape) {
+    NetTensor t;
+    t.name = name; t.kind = kind; t.region = 0; t.offset = poff; t.ndim = (int)shape.size();
+    long long numel = 1; int i = 0;
+    for (int s : shape) { t.shape[i++] = s; numel *= s; }
+    for (; i < 4; ++i) t.shape[i] = 0;
+    n->tensors.push_back(t);
+    const long long o = poff;
+    poff += (numel + 3) / 4 * 4;
+    return o;
+  }
+  BnD add_bn(const std::string& p, int C, bool frozen_weight = false) {
+    BnD b;
+    b.C = C;
+    if (frozen_weight) {
+      // features.weight: requires_grad False (iresnet.py:99-100) -> lives after the trainable region
+      NetTensor t; t.name = p + ".weight"; t.kind = 1; t.region = 0; t.offset = -1; t.ndim = 1;
+      t.shape[0] = C; t.shape[1] = t.shape[2] = t.shape[3] = 0;
+      n->tensors.push_back(t);
+      b.g_off = -1;
+    } else {
+      b.g_off = add_param(p + ".weight", 1, {C});
+    }
+    b.b_off = add_param(p + ".bias", 2, {C});
+    NetTensor t; t.ndim = 1; t.shape[0] = C; t.shape[1] = t.shape[2] = t.shape[3] = 0; t.region = 1;
+    t.name = p + ".running_mean"; t.kind = 6; t.offset = boff; b.rm_off = boff; boff += C; n->tensors.push_back(t);
+    t.name = p + ".running_var"; t.kind = 7; t.offset = boff; b.rv_off = boff; boff += C; n->tensors.push_back(t);
+    t.name = p + ".num_batches_tracked"; t.kind = 8; t.region = 2; t.offset = nbt++; t.ndim = 0; t.shape[0] = 0; n->tensors.push_back(t);
+    b.save_off = saveoff;
+    saveoff += 4 * (long long)C;
+    return b;
+  }
+  ConvD add_conv(const std::string& name, int Cin, int Cout, int R, int stride, int Hin) {
+    ConvD c;
+    c.Cin = Cin; c.Cout = Cout; c.R = R; c.stride = stride; c.Hin = Hin; c.Hout = Hin / stride;
+    c.w_off = add_param(name + ".weight", 0, {Cout, Cin, R, R});
+    c.wd_off = -1;
+    return c;
+  }
+};
+}  // namespace
+
+FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features) {
+  if (batch <= 0 || in_hw <= 0 || (in_hw % 16) != 0 || num_features <= 0 || (num_features % 64) != 0) {
+    fedfr_set_error("net_create: need batch>0, in_hw%%16==0, num_features%%64==0 (got %d, %d, %d)", batch, in_hw, num_features);
+    return nullptr;
+  }
+  for (int i = 0; i < 4; ++i)
+    if (layers[i] <= 0) { fedfr_set_error("net_create: layers[%d]=%d", i, layers[i]); return nullptr; }
+  FedfrNet* n = new FedfrNet();
+  for (int i = 0; i < 4; ++i) n->layers[i] = layers[i];
+  n->B = batch; n->Bp = (batch + 7) / 8 * 8; n->HW = in_hw; n->F = num_features;
+  Builder b; b.n = n;
+  // ---- tensors in reference state_dict order (iresnet.py:76-98, :37-43) ----
+  n->stem = b.add_conv("conv1", 3, 64, 3, 1, in_hw);
+  n->stem_bn = b.add_bn("bn1", 64);
+  n->stem_alpha_off = b.add_param("prelu.weight", 3, {64});
+  int inpl = 64, H = in_hw;
+  for (int s = 0; s < 4; ++s) {
+    for (int i = 0; i < layers[s]; ++i) {
+      char pfx[64];
+      snprintf(pfx, sizeof pfx, "layer%d.%d", s + 1, i);
+      const std::string p(pfx);
+      BlockD k;
+      k.Cin = (i == 0) ? inpl : kPlanes[s]; k.Cout = kPlanes[s];
+      k.stride = (i == 0) ? 2 : 1; k.Hin = H; k.Hout = H / k.stride; k.has_ds = (i == 0);
+      k.bn1 = b.add_bn(p + ".bn1", k.Cin);
+      k.conv1 = b.add_conv(p + ".conv1", k.Cin, k.Cout, 3, 1, k.Hin);
+      k.bn2 = b.add_bn(p + ".bn2", k.Cout);
+      k.alpha_off = b.add_param(p + ".prelu.weight", 3, {k.Cout});
+      k.conv2 = b.add_conv(p + ".conv2", k.Cout, k.Cout, 3, k.stride, k.Hin);
+      k.bn3 = b.add_bn(p + ".bn3", k.Cout);
+      if (k.has_ds) {
+        k.ds = b.add_conv(p + ".downsample.0", k.Cin, k.Cout, 1, k.stride, k.Hin);
+        k.bnds = b.add_bn(p + ".downsample.1", k.Cout);
+      }
+      n->blocks.push_back(k);
+      H = k.Hout;
+    }
+    inpl = kPlanes[s];
+  }
+  n->bn2 = b.add_bn("bn2", 512);
+  n->final_hw = H; n->final_C = 512; n->fc_in = 512 * H * H;
+  n->fc_w_off = b.add_param("fc.weight", 4, {num_features, n->fc_in});
+  n->fc_b_off = b.add_param("fc.bias", 5, {num_features});
+  n->feat_bn = b.add_bn("features", num_features, /*frozen_weight=*/true);
+  n->trainable_count = b.poff;
+  for (auto& t : n->tensors)
+    if (t.region == 0 && t.offset < 0) { t.offset = b.poff; n->feat_bn.g_off = b.poff; b.poff += (t.shape[0] + 3) / 4 * 4; }
+  n->param_count = b.poff;
+  n->buffer_count = b.boff;
+  n->nbt_count = b.nbt;
+  // ---- shadow: bf16 mirror of the trainable region, then dgrad-layout copies of every block conv ----
+  long long soff = (n->trainable_count + 7) / 8 * 8;
+  for (auto& k : n->blocks) {
+    k.conv1.wd_off = soff; soff += (long long)k.conv1.Cin * 9 * k.conv1.Cout;
+    k.conv2.wd_off = soff; soff += (long long)k.conv2.Cin * 9 * k.conv2.Cout;
+    if (k.has_ds) { k.ds.wd_off = soff; soff += (long long)k.ds.Cin * k.ds.Cout; }
+  }
+  n->shadow_count = soff;
+  // ---- activation arena (bf16 elements) ----
+  const long long Bq = batch;
+  long long aoff = 0;
+  auto take = [&](long long elems) { const long long o = aoff; aoff += (elems + 7) / 8 * 8; return o; };
+  const long long M0 = Bq * in_hw * in_hw;
+  n->c0_off = take(M0 * 64);
+  n->a0_off = take(M0 * 64);
+  long long prev = n->a0_off;
+  long long gmax = M0 * 64;
+  for (auto& k : n->blocks) {
+    const long long Mi = Bq * k.Hin * k.Hin, Mo = Bq * k.Hout * k.Hout;
+    k.x_off = prev;
+    k.a1_off = take(Mi * k.Cin);
+    k.c1_off = take(Mi * k.Cout);
+    k.a2_off = take(Mi * k.Cout);
+    k.c2_off = take(Mo * k.Cout);
+    k.d_off = k.has_ds ? take(Mo * k.Cout) : -1;
+    k.out_off = take(Mo * k.Cout);
+    prev = k.out_off;
+    gmax = std::max(gmax, std::max(Mi * k.Cin, Mi * k.Cout));
+  }
+  n->t_off = take(Bq * n->fc_in);
+  n->act_bf16_count = aoff;
+  n->act_float_off_bytes = (long long)align_up((size_t)aoff * 2, 256);
+  long long foff = b.saveoff;                 // bnsave floats first
+  n->yfc_off = foff; foff += Bq * num_features;
+  n->feat_save_off = foff; foff += 2 * (long long)num_features;
+  n->act_bytes = n->act_float_off_bytes + (long long)align_up((size_t)foff * 4, 256);
+  // ---- workspace ----
+  n->g_elems = (size_t)gmax;
+  long long part = (long long)ew_stem_stat_rows(batch, in_hw, in_hw) * 128;
+  long long slab = (long long)ew_stem_wgrad_blocks(batch, in_hw, in_hw) * 2048;
+  auto upd_part = [&](long long M, int C) {
+    part = std::max(part, (long long)ew_bn_apply_grid((int)M, C) * 2 * C);
+    part = std::max(part, (long long)ew_bn_bwd_grid((int)M, C) * 3 * C);
+  };
+  auto upd_conv = [&](const ConvD& c) {
+    const long long Mo = Bq * c.Hout * c.Hout;
+    part = std::max(part, (long long)gemm_nt_stat_rows((int)Mo, c.Cout) * 2 * c.Cout);
+    const int NJ = c.R * c.R * c.Cin;
+    slab = std::max(slab, (long long)gemm_tn_pick_splits((int)Mo, c.Cout, NJ, c.Cin) * c.Cout * NJ);
+  };
+  upd_part(M0, 64);
+  for (auto& k : n->blocks) {
+    const long long Mi = Bq * k.Hin * k.Hin, Mo = Bq * k.Hout * k.Hout;
+    upd_part(Mi, k.Cin); upd_part(Mi, k.Cout); upd_part(Mo, k.Cout);
+    upd_conv(k.conv1); upd_conv(k.conv2);
+    if (k.has_ds) upd_conv(k.ds);
+  }
+  upd_part(Bq * H * H, 512);
+  slab = std::max(slab, (long long)gemm_nt_pick_splits(batch, num_features, n->fc_in) * Bq * num_features);
+  n->part_floats = (size_t)part;
+  n->slab_floats = (size_t)slab;
+  size_t w = 0;
+  auto wtake = [&](size_t bytes) { const size_t o = w; w += align_up(bytes, 256); return o; };
+  for (int i = 0; i < 2; ++i) n->ws_g[i] = wtake(n->g_elems * 2);
+  for (int i = 0; i < 6; ++i) n->ws_t[i] = wtake(n->g_elems * 2);
+  n->ws_part = wtake(n->part_floats * 4);
+  n->ws_slab = wtake(n->slab_floats * 4);
+  // small: coef[3*512] | finalize tmp [64*2*512] | dyfc f32 [B*F] | dyb bf16 [B*F] | dybt bf16 [F*Bp]
+  n->ws_small = wtake((size_t)(3 * 512 + 64 * 2 * 512) * 4 + (size_t)Bq * num_features * 4 + (size_t)Bq * num_features * 2 +
+                      (size_t)num_features * n->Bp * 2 + 1024);
+  n->ws_fc = wtake((size_t)n->Bp * n->fc_in * 4);
+  n->ws_bytes = w;
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct Ctx {
+  const FedfrNet* n;
+  const float* params; float* bufs; const bf16_t* shadow; bf16_t* actb; float* actf; unsigned char* ws; float* grads;
+  hipStream_t st;
+  float* part() const { return reinterpret_cast<float*>(ws + n->ws_part); }
+  float* slab() const { return reinterpret_cast<float*>(ws + n->ws_slab); }
+  float* coef() const { return reinterpret_cast<float*>(ws + n->ws_small); }
+  float* ftmp() const { return coef() + 3 * 512; }
+  float* dyfc() const { return ftmp() + 64 * 2 * 512; }
+  bf16_t* dyb() const { return reinterpret_cast<bf16_t*>(dyfc() + (size_t)n->B * n->F); }
+  bf16_t* dybt() const { return dyb() + (size_t)n->B * n->F; }
+  bf16_t* g(int i) const { return reinterpret_cast<bf16_t*>(ws + n->ws_g[i]); }
+  bf16_t* t(int i) const { return reinterpret_cast<bf16_t*>(ws + n->ws_t[i]); }
+  float* save(const BnD& b, int which) const { return actf + b.save_off + (long long)which * b.C; }   // 0 scale 1 shift 2 mean 3 rstd
+  const float* gamma(const BnD& b) const { return params + b.g_off; }
+  const float* beta(const BnD& b) const { return params + b.b_off; }
+};
+
+static int conv_fwd(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* out, bool stats) {
+  GemmNT p{};
+  p.A = in; p.B = c.shadow + cv.w_off;
+  p.M = c.n->B * cv.Hout * cv.Hout; p.N = cv.Cout; p.K = cv.R * cv.R * cv.Cin;
+  p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = cv.R;
+  p.stride = cv.stride; p.pad = (cv.R == 3) ? 1 : 0; p.up = 1;
+  p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = stats ? c.part() : nullptr;
+  return gemm_nt_launch(p, 1, c.st);
+}
+// dx (at the conv's INPUT resolution) = conv_transpose(dy)
+static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* dx) {
+  GemmNT p{};
+  p.B = c.shadow + cv.wd_off; p.A = dy;
+  p.N = cv.Cin; p.K = cv.R * cv.R * cv.Cout;
+  p.Cb = dx; p.ldc = cv.Cin; p.Cf = nullptr; p.stats = nullptr;
+  if (cv.R == 1) {          // 1x1 stride-s: plain GEMM at the OUTPUT resolution (compact result; caller up-samples)
+    p.mode = 0; p.M = c.n->B * cv.Hout * cv.Hout; p.lda = cv.Cout;
+  } else {
+    p.mode = 1; p.M = c.n->B * cv.Hin * cv.Hin;
+    p.H = cv.Hout; p.W = cv.Hout; p.C = cv.Cout; p.Ho = cv.Hin; p.Wo = cv.Hin; p.S = 3;
+    p.stride = 1; p.pad = 1; p.up = cv.stride;
+  }
+  return gemm_nt_launch(p, 1, c.st);
+}
+static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy) {
+  GemmTN p{};
+  p.P = dy; p.Q = in;
+  p.Kp = c.n->B * cv.Hout * cv.Hout; p.NI = cv.Cout; p.NJ = cv.R * cv.R * cv.Cin;
+  p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = cv.R;
+  p.stride = cv.stride; p.pad = (cv.R == 3) ? 1 : 0;
+  p.ldp = cv.Cout; p.ldq = 0; p.use_tr = g_tn_use_tr;
+  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C);
+  float* dst = c.grads + cv.w_off;
+  if (splits == 1) {
+    p.out = dst;
+    return gemm_tn_launch(p, 1, c.st);
+  }
+  p.out = c.slab();
+  FEDFR_TRY(gemm_tn_launch(p, splits, c.st));
+  return ew_reduce_slabs(dst, c.slab(), splits, (size_t)p.NI * p.NJ, nullptr, 0, c.st);
+}
+static int bn_coeffs(const Ctx& c, const BnD& b, int P, double count, bool training) {
+  if (training)
+    return ew_bn_finalize(c.part(), P, b.C, count, c.gamma(b), c.beta(b), c.bufs + b.rm_off, c.bufs + b.rv_off, kBnMomentum,
+                          kBnEps, c.save(b, 0), c.save(b, 1), c.save(b, 2), c.save(b, 3), c.ftmp(), c.st);
+  return ew_bn_eval_coeffs(b.C, c.gamma(b), c.beta(b), c.bufs + b.rm_off, c.bufs + b.rv_off, kBnEps, c.save(b, 0), c.save(b, 1), c.st);
+}
+static int apply(const Ctx& c, const bf16_t* x1, const BnD& b1, const float* alpha, const bf16_t* x2, const BnD* b2, bf16_t* y,
+                 int M, bool stats, int nchw_hw = 0) {
+  BnApply a{};
+  a.x1 = x1; a.sc1 = c.save(b1, 0); a.sh1 = c.save(b1, 1); a.alpha = alpha;
+  a.x2 = x2; a.sc2 = b2 ? c.save(*b2, 0) : nullptr; a.sh2 = b2 ? c.save(*b2, 1) : nullptr;
+  a.y = y; a.M = M; a.C = b1.C; a.nchw_hw = nchw_hw; a.stats = stats ? c.part() : nullptr;
+  return ew_bn_apply(a, c.st);
+}
+
+int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st) {
+  FEDFR_REQUIRE(n && params && shadow, "prepare_weights: null");
+  if (fwd_shadow_too) FEDFR_TRY(ew_cast_f32_bf16(params, shadow, (size_t)n->trainable_count, st));
+  for (const auto& k : n->blocks) {
+    FEDFR_TRY(ew_weight_dgrad_shadow(params + k.conv1.w_off, shadow + k.conv1.wd_off, k.conv1.Cout, 3, 3, k.conv1.Cin, st));
+    FEDFR_TRY(ew_weight_dgrad_shadow(params + k.conv2.w_off, shadow + k.conv2.wd_off, k.conv2.Cout, 3, 3, k.conv2.Cin, st));
+    if (k.has_ds) FEDFR_TRY(ew_weight_dgrad_shadow(params + k.ds.w_off, shadow + k.ds.wd_off, k.ds.Cout, 1, 1, k.ds.Cin, st));
+  }
+  return FEDFR_OK;
+}
+
+int net_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, const bf16_t* shadow,
+                unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st) {
+  FEDFR_REQUIRE(n && x && params && bufs && shadow && act && ws && feats, "net_forward: null buffer");
+  Ctx c{n, params, bufs, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, nullptr, st};
+  const bool tr = training != 0;
+  const int B = n->B, HW = n->HW;
+  const int M0 = B * HW * HW;
+  bf16_t* A = c.actb;
+  // stem: conv -> BN -> PReLU   (iresnet.py:160-162)
+  FEDFR_TRY(ew_stem_fwd(x, params + n->stem.w_off, A + n->c0_off, tr ? c.part() : nullptr, B, HW, HW, st));
+  FEDFR_TRY(bn_coeffs(c, n->stem_bn, ew_stem_stat_rows(B, HW, HW), (double)M0, tr));
+  FEDFR_TRY(apply(c, A + n->c0_off, n->stem_bn, params + n->stem_alpha_off, nullptr, nullptr, A + n->a0_off, M0, tr));
+  int Pprev = ew_bn_apply_grid(M0, 64);
+  for (const auto& k : n->blocks) {
+    const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
+    // bn1(x)
+    FEDFR_TRY(bn_coeffs(c, k.bn1, Pprev, (double)Mi, tr));
+    FEDFR_TRY(apply(c, A + k.x_off, k.bn1, nullptr, nullptr, nullptr, A + k.a1_off, Mi, false));
+    // conv1 -> bn2 -> prelu
+    FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, tr));
+    FEDFR_TRY(bn_coeffs(c, k.bn2, gemm_nt_stat_rows(Mi, k.Cout), (double)Mi, tr));
+    FEDFR_TRY(apply(c, A + k.c1_off, k.bn2, params + k.alpha_off, nullptr, nullptr, A + k.a2_off, Mi, false));
+    // conv2(stride) -> bn3
+    FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, tr));
+    FEDFR_TRY(bn_coeffs(c, k.bn3, gemm_nt_stat_rows(Mo, k.Cout), (double)Mo, tr));
+    if (k.has_ds) {
+      FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, tr));
+      FEDFR_TRY(bn_coeffs(c, k.bnds, gemm_nt_stat_rows(Mo, k.Cout), (double)Mo, tr));
+      FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.d_off, &k.bnds, A + k.out_off, Mo, tr));
+    } else {
+      FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.x_off, nullptr, A + k.out_off, Mo, tr));
+    }
+    Pprev = ew_bn_apply_grid(Mo, k.Cout);
+  }
+  // bn2 -> flatten (NCHW order) -> fc -> features   (iresnet.py:167-171)
+  const BlockD& last = n->blocks.back();
+  const int hw = n->final_hw * n->final_hw, Mf = B * hw;
+  FEDFR_TRY(bn_coeffs(c, n->bn2, Pprev, (double)Mf, tr));
+  FEDFR_TRY(apply(c, A + last.out_off, n->bn2, nullptr, nullptr, nullptr, A + n->t_off, Mf, false, hw));
+  {
+    GemmNT p{};
+    p.A = A + n->t_off; p.B = shadow + n->fc_w_off; p.M = B; p.N = n->F; p.K = n->fc_in; p.mode = 0; p.lda = n->fc_in;
+    p.Cb = nullptr; p.Cf = c.slab(); p.stats = nullptr;
+    const int splits = gemm_nt_pick_splits(B, n->F, n->fc_in);
+    FEDFR_TRY(gemm_nt_launch(p, splits, st));
+    FEDFR_TRY(ew_reduce_slabs(c.actf + n->yfc_off, c.slab(), splits, (size_t)B * n->F, params + n->fc_b_off, n->F, st));
+  }
+  FEDFR_TRY(ew_bn1d_fwd(c.actf + n->yfc_off, feats, B, n->F, params + n->feat_bn.g_off, params + n->feat_bn.b_off,
+                        bufs + n->feat_bn.rm_off, bufs + n->feat_bn.rv_off, kBnMomentum, kBnEps, tr ? 1 : 0,
+                        c.actf + n->feat_save_off, c.actf + n->feat_save_off + n->F, st));
+  return FEDFR_OK;
+}
+
+static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
+                  const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off) {
+  BnBwd p{};
+  p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.beta = c.beta(b); p.alpha = alpha;
+  p.M = M; p.C = b.C; p.partials = c.part(); p.coef = c.coef(); p.add = add; p.add_up = add_up; p.H = H; p.W = H; p.dx = dx;
+  FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));
+  FEDFR_TRY(ew_bn_bwd_finalize(c.part(), ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 3), c.grads + b.g_off,
+                               c.grads + b.b_off, alpha ? c.grads + alpha_off : nullptr, c.coef(), c.st));
+  return ew_bn_bwd_apply(p, c.st);
+}
+
+int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
+                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st) {
+  FEDFR_REQUIRE(n && x && dfeats && params && shadow && act && ws && grads, "net_backward: null buffer");
+  Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
+  const int B = n->B, F = n->F, HW = n->HW;
+  bf16_t* A = c.actb;
+  // ---- features (BN1d) backward; fc.bias grad = colsum(d y_fc) ----
+  if (hipMemsetAsync(c.dybt(), 0, (size_t)F * n->Bp * 2, st) != hipSuccess) {
+    fedfr_set_error("net_backward: hipMemsetAsync failed");
+    return FEDFR_ERR_HIP;
+  }
+  FEDFR_TRY(ew_bn1d_bwd(dfeats, c.actf + n->yfc_off, c.dyfc(), B, F, params + n->feat_bn.g_off, c.actf + n->feat_save_off,
+                        c.actf + n->feat_save_off + F, grads + n->feat_bn.b_off, grads + n->fc_b_off, c.dyb(), c.dybt(), n->Bp, st));
+  float* dxfc = reinterpret_cast<float*>(ws + n->ws_fc);
+  {  // fc.weight grad [F][fc_in] = dY^T X   (both operands batch-major -> TN kernel)
+    GemmTN p{};
+    p.P = c.dyb(); p.Q = A + n->t_off; p.Kp = B; p.NI = F; p.NJ = n->fc_in; p.mode = 0; p.ldp = F; p.ldq = n->fc_in;
+    p.out = grads + n->fc_w_off; p.use_tr = g_tn_use_tr;
+    FEDFR_TRY(gemm_tn_launch(p, 1, st));
+  }
+  {  // dX [Bp][fc_in] = dY W   (reduction over F: P = dY^T [F][Bp], Q = W [F][fc_in])
+    GemmTN p{};
+    p.P = c.dybt(); p.Q = shadow + n->fc_w_off; p.Kp = F; p.NI = n->Bp; p.NJ = n->fc_in; p.mode = 0; p.ldp = n->Bp; p.ldq = n->fc_in;
+    p.out = dxfc; p.use_tr = g_tn_use_tr;
+    FEDFR_TRY(gemm_tn_launch(p, 1, st));
+  }
+  const BlockD& last = n->blocks.back();
+  const int hw = n->final_hw * n->final_hw, Mf = B * hw;
+  FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dxfc, c.g(0), B, n->final_C, hw, st));
+  FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0));
+  int cur = 1;
+  for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
+    const BlockD& k = n->blocks[bi];
+    const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
+    const bf16_t* g = c.g(cur);
+    bf16_t* gin = c.g(cur ^ 1);
+    // out = bn3(c2) + identity
+    FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, c.t(0), 0));
+    FEDFR_TRY(conv_wgrad(c, k.conv2, A + k.a2_off, c.t(0)));
+    FEDFR_TRY(conv_dgrad(c, k.conv2, c.t(0), c.t(1)));
+    // a2 = prelu(bn2(c1))
+    FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, c.t(1), A + k.c1_off, Mi, nullptr, nullptr, 0, c.t(2), k.alpha_off));
+    FEDFR_TRY(conv_wgrad(c, k.conv1, A + k.a1_off, c.t(2)));
+    FEDFR_TRY(conv_dgrad(c, k.conv1, c.t(2), c.t(3)));
+    // a1 = bn1(x); identity path
+    if (k.has_ds) {
+      FEDFR_TRY(bn_bwd(c, k.bnds, nullptr, g, A + k.d_off, Mo, nullptr, nullptr, 0, c.t(4), 0));
+      FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, c.t(4)));
+      FEDFR_TRY(conv_dgrad(c, k.ds, c.t(4), c.t(5)));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, nullptr, c.t(5), k.Hin, gin, 0));
+    } else {
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, g, nullptr, 0, gin, 0));
+    }
+    cur ^= 1;
+  }
+  // ---- stem: a0 = prelu(bn1(conv1(x))) ----
+  const int M0 = B * HW * HW;
+  FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, c.t(0), n->stem_alpha_off));
+  return ew_stem_wgrad(x, c.t(0), grads + n->stem.w_off, c.slab(), B, HW, HW, st);
+}

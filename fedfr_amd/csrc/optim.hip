@@ -1,0 +1,298 @@
+// HBM-bound flat-buffer kernels: fused momentum-SGD (+bf16 weight shadow), FedAvg scale/accumulate,
+// PartialFC sampling (counter-based RNG, radix top-k select, ordered compaction), row gather/scatter.
+// Reference semantics: torch.optim.SGD as used in client.py:335,527-529; server.py:25-46; partial_fc.py:89-116.
+#include "optim.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// SGD: g += wd*p ; buf = first ? g : mu*buf + g ; p -= lr*buf ; optional bf16 shadow of the new p.
+// Op order / fusion mirrors torch's vectorised CPU kernels (alpha-adds are fmadd, mul_ then add_ are two roundings).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgd_one(float p, float g, float& buf, float lr, float mu, float wd, int first) {
+  const float d = fmaf(wd, p, g);                                  // grad.add(param, alpha=wd)   (fmadd in torch)
+  const float b = first ? d : __fadd_rn(__fmul_rn(buf, mu), d);    // buf.mul_(mu).add_(d)        (two roundings)
+  buf = b;
+  return fmaf(-lr, b, p);                                          // param.add_(buf, alpha=-lr)  (fmadd in torch)
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  bf16_t* __restrict__ shadow, size_t n, float lr, float mu, float wd, int first) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
+    pv.x = sgd_one(pv.x, gv.x, bv.x, lr, mu, wd, first);
+    pv.y = sgd_one(pv.y, gv.y, bv.y, lr, mu, wd, first);
+    pv.z = sgd_one(pv.z, gv.z, bv.z, lr, mu, wd, first);
+    pv.w = sgd_one(pv.w, gv.w, bv.w, lr, mu, wd, first);
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(buf)[i] = bv;
+    if (shadow) {
+      uint2 o;
+      o.x = pack_bf2(pv.x, pv.y);
+      o.y = pack_bf2(pv.z, pv.w);
+      reinterpret_cast<uint2*>(shadow)[i] = o;
+    }
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float b = first ? 0.f : buf[i];
+    const float v = sgd_one(p[i], g[i], b, lr, mu, wd, first);
+    p[i] = v;
+    buf[i] = b;
+    if (shadow) shadow[i] = f2bf(v);
+  }
+}
+
+int optim_sgd(float* p, const float* g, float* buf, bf16_t* shadow, size_t n, float lr, float mu, float wd, int first,
+              hipStream_t st) {
+  FEDFR_REQUIRE(p && g && buf && n > 0, "sgd: bad args");
+  FEDFR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd: buffers must be 16-byte aligned");
+  const size_t work = n / 4 + 1;
+  const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first);
+  FEDFR_LAUNCH_CHECK("sgd");
+  return FEDFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FedAvg: dst = (accumulate ? dst : 0) + w * src, fp32, explicit op order (server.py:27-33: tmp += w_i * m_i)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fedavg_axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, float w,
+                                                          size_t n, int accumulate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 s = reinterpret_cast<const float4*>(src)[i];
+    float4 d = accumulate ? reinterpret_cast<float4*>(dst)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    d.x = __fadd_rn(d.x, __fmul_rn(w, s.x));
+    d.y = __fadd_rn(d.y, __fmul_rn(w, s.y));
+    d.z = __fadd_rn(d.z, __fmul_rn(w, s.z));
+    d.w = __fadd_rn(d.w, __fmul_rn(w, s.w));
+    reinterpret_cast<float4*>(dst)[i] = d;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = accumulate ? dst[i] : 0.f;
+    dst[i] = __fadd_rn(d, __fmul_rn(w, src[i]));
+  }
+}
+int optim_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, hipStream_t st) {
+  FEDFR_REQUIRE(dst && src && n > 0, "fedavg_axpy: bad args");
+  FEDFR_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0, "fedavg_axpy: buffers must be 16-byte aligned");
+  const size_t work = n / 4 + 1;
+  const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+  hipLaunchKernelGGL(fedavg_axpy_kernel, dim3(grid), dim3(256), 0, st, dst, src, w, n, accumulate);
+  FEDFR_LAUNCH_CHECK("fedavg_axpy");
+  return FEDFR_OK;
+}
+
+// int64 counters (num_batches_tracked): acc_f32 (+)= w * float(src) ; optional final truncation back to int64
+__global__ void fedavg_i64_kernel(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = accumulate ? acc[i] : 0.f;
+  const float v = __fadd_rn(d, __fmul_rn(w, (float)src[i]));
+  acc[i] = v;
+  if (out_trunc) out_trunc[i] = (long long)v;
+}
+int optim_fedavg_i64(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc, hipStream_t st) {
+  FEDFR_REQUIRE(acc && src && n > 0, "fedavg_i64: bad args");
+  hipLaunchKernelGGL(fedavg_i64_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, acc, src, w, n, accumulate, out_trunc);
+  FEDFR_LAUNCH_CHECK("fedavg_i64");
+  return FEDFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PartialFC sampling
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash_u32(unsigned long long x) {   // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (unsigned)(x >> 32);
+}
+__global__ void pfc_rand_kernel(float* perm, int n, unsigned long long seed, unsigned long long step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) perm[i] = (float)(hash_u32(seed * 0x100000001B3ull + step * 0x9E3779B1ull + (unsigned long long)i * 0xD6E8FEB86659FD93ull) >> 8) * (1.0f / 16777216.0f);
+}
+int optim_pfc_rand(float* perm, int n, unsigned long long seed, unsigned long long step, hipStream_t st) {
+  FEDFR_REQUIRE(perm && n > 0, "pfc_rand: bad args");
+  hipLaunchKernelGGL(pfc_rand_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, perm, n, seed, step);
+  FEDFR_LAUNCH_CHECK("pfc_rand");
+  return FEDFR_OK;
+}
+
+// labels -> local ids (or -1); perm[local] = 2.0 for positives (partial_fc.py:91-98)
+__global__ void pfc_localize_kernel(long long* label, int n, long long class_start, int num_local, float* perm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long l = label[i] - class_start;
+  if (l >= 0 && l < num_local) {
+    label[i] = l;
+    if (perm) perm[l] = 2.0f;
+  } else {
+    label[i] = -1;
+  }
+}
+int optim_pfc_localize(long long* label, int n, long long class_start, int num_local, float* perm, hipStream_t st) {
+  FEDFR_REQUIRE(label && n > 0 && num_local > 0, "pfc_localize: bad args");
+  hipLaunchKernelGGL(pfc_localize_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, label, n, class_start, num_local, perm);
+  FEDFR_LAUNCH_CHECK("pfc_localize");
+  return FEDFR_OK;
+}
+
+// Top-k of non-negative floats as an index set in ascending index order == sort(topk(perm,k).indices).
+// One 1024-thread block: 3-pass radix select (11+11+10 bits) for the k-th largest value, then ordered compaction.
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* sh, int& total) {
+  // sh: 17 ints.  returns exclusive prefix of v over the block; total = block sum
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) sh[w] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int t = sh[i];
+      sh[i] = run;
+      run += t;
+    }
+    sh[16] = run;
+  }
+  __syncthreads();
+  const int res = sh[w] + x - v;
+  total = sh[16];
+  __syncthreads();
+  return res;
+}
+
+__global__ __launch_bounds__(1024) void pfc_topk_kernel(const float* __restrict__ perm, int n, int k, long long* __restrict__ index,
+                                                        int* __restrict__ npos_out) {
+  __shared__ int hist[2048];
+  __shared__ int sh[17];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_k;
+  const unsigned* bits = reinterpret_cast<const unsigned*>(perm);
+  const int tid = threadIdx.x;
+  unsigned prefix = 0;     // selected high bits so far
+  int kk = k;              // how many still to take from the current candidate set
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  unsigned mask_hi = 0;    // mask of bits already fixed
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << widths[pass];
+    for (int i = tid; i < nb; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned b = bits[i];
+      if ((b & mask_hi) == prefix) atomicAdd(&hist[(b >> shifts[pass]) & (nb - 1)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int above = 0, bin = nb - 1;
+      for (; bin > 0; --bin) {
+        if (above + hist[bin] >= kk) break;
+        above += hist[bin];
+      }
+      s_prefix = prefix | ((unsigned)bin << shifts[pass]);
+      s_k = kk - above;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    kk = s_k;
+    mask_hi |= (unsigned)(nb - 1) << shifts[pass];
+    __syncthreads();
+  }
+  // prefix == bit pattern T of the k-th largest value; take all > T and the first kk of == T (index order)
+  const unsigned T = prefix;
+  int base = 0, eq_taken = 0, npos = 0;
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + tid;
+    const unsigned b = i < n ? bits[i] : 0u;
+    const int gt = (i < n && b > T) ? 1 : 0;
+    const int eq = (i < n && b == T) ? 1 : 0;
+    int tot_eq, tot_sel;
+    const int eq_rank = block_excl_scan_1024(eq, sh, tot_eq);
+    const int sel = gt | (eq && (eq_taken + eq_rank) < kk ? 1 : 0);
+    const int pos = block_excl_scan_1024(sel, sh, tot_sel);
+    if (sel) index[base + pos] = i;
+    if (i < n && b == 0x40000000u) ++npos;     // 2.0f marks a positive class
+    base += tot_sel;
+    eq_taken += tot_eq;
+  }
+  if (npos_out) {
+    int tot;
+    (void)block_excl_scan_1024(npos, sh, tot);
+    if (tid == 0) *npos_out = tot;
+  }
+}
+int optim_pfc_topk(const float* perm, int n, int k, long long* index, int* npos_out, hipStream_t st) {
+  FEDFR_REQUIRE(perm && index && n > 0 && k > 0 && k <= n, "pfc_topk: bad args (k=%d n=%d)", k, n);
+  hipLaunchKernelGGL(pfc_topk_kernel, dim3(1), dim3(1024), 0, st, perm, n, k, index, npos_out);
+  FEDFR_LAUNCH_CHECK("pfc_topk");
+  return FEDFR_OK;
+}
+
+// positives only (num_sample < #positives branch, partial_fc.py:101-102): ordered compaction of perm == 2.0
+__global__ __launch_bounds__(1024) void pfc_positive_kernel(const float* __restrict__ perm, int n, long long* __restrict__ index,
+                                                            int* __restrict__ count) {
+  __shared__ int sh[17];
+  int base = 0;
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    const int sel = (i < n && perm[i] == 2.0f) ? 1 : 0;
+    int tot;
+    const int pos = block_excl_scan_1024(sel, sh, tot);
+    if (sel) index[base + pos] = i;
+    base += tot;
+  }
+  if (threadIdx.x == 0) *count = base;
+}
+int optim_pfc_positive(const float* perm, int n, long long* index, int* count, hipStream_t st) {
+  FEDFR_REQUIRE(perm && index && count && n > 0, "pfc_positive: bad args");
+  hipLaunchKernelGGL(pfc_positive_kernel, dim3(1), dim3(1024), 0, st, perm, n, index, count);
+  FEDFR_LAUNCH_CHECK("pfc_positive");
+  return FEDFR_OK;
+}
+
+// label[i] = searchsorted(index, label[i]) for label != -1 (partial_fc.py:104)
+__global__ void pfc_remap_kernel(long long* label, int n, const long long* __restrict__ index, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long l = label[i];
+  if (l < 0) return;
+  int lo = 0, hi = k;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (index[mid] < l) lo = mid + 1; else hi = mid;
+  }
+  label[i] = lo;
+}
+int optim_pfc_remap(long long* label, int n, const long long* index, int k, hipStream_t st) {
+  FEDFR_REQUIRE(label && index && n > 0 && k > 0, "pfc_remap: bad args");
+  hipLaunchKernelGGL(pfc_remap_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, label, n, index, k);
+  FEDFR_LAUNCH_CHECK("pfc_remap");
+  return FEDFR_OK;
+}
+
+// row gather / scatter (fp32 rows of D floats, D % 4 == 0), one wave per row
+__global__ __launch_bounds__(256) void rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                   const long long* __restrict__ index, int k, int D, int scatter) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= k) return;
+  const long long r = index[row];
+  const float4* s = reinterpret_cast<const float4*>(src + (scatter ? (size_t)row : (size_t)r) * D);
+  float4* d = reinterpret_cast<float4*>(dst + (scatter ? (size_t)r : (size_t)row) * D);
+  for (int i = lane; i < D / 4; i += 64) d[i] = s[i];
+}
+int optim_rows(float* dst, const float* src, const long long* index, int k, int D, int scatter, hipStream_t st) {
+  FEDFR_REQUIRE(dst && src && index && k > 0 && D > 0 && (D & 3) == 0, "rows gather/scatter: bad args");
+  hipLaunchKernelGGL(rows_kernel, dim3(ceil_div(k, 4)), dim3(256), 0, st, dst, src, index, k, D, scatter);
+  FEDFR_LAUNCH_CHECK("rows");
+  return FEDFR_OK;
+}

@@ -1,0 +1,153 @@
+/* fedfr_hip.h — C ABI of libfedfr_hip.so: the MI355X (gfx950) implementation of FedFR's per-client
+ * training hot path.  The reference (jackie840129/FedFR) is pure Python/PyTorch and has no FFI; the
+ * entry points below are what its Python modules bind through ctypes.  Each
+ * group cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FEDFR_ERR_* otherwise; fedfr_last_error_string()
+ *     describes the most recent failure on the calling thread.  Nothing throws, nothing exits.
+ *   - all pointers are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr()); the library
+ *     allocates no device memory and retains no pointer after return.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it.
+ *   - activations are NHWC bf16 (raw uint16 bits); conv weights are KRSC ([Cout][kh][kw][Cin]) which is
+ *     exactly a torch channels_last OIHW tensor; parameters / grads / optimizer state are fp32.
+ */
+#ifndef FEDFR_HIP_H
+#define FEDFR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEDFR_OK 0
+#define FEDFR_ERR_ARG (-1)
+#define FEDFR_ERR_HIP (-2)
+#define FEDFR_ERR_WORKSPACE (-3)
+#define FEDFR_ERR_UNSUPPORTED (-4)
+
+int fedfr_version(void);
+const char* fedfr_last_error_string(void);
+/* options: "tn_use_tr" (1 = ds_read_b64_tr_b16 wgrad fragments [default], 0 = scalar LDS fallback) */
+int fedfr_set_option(const char* name, int value);
+
+/* ------------------------------------------------------------------------------------------------
+ * iresnet plan — replaces IResNet.__init__/_make_layer/forward (backbones/iresnet.py:60-172) and,
+ * through the hand-written adjoint, autograd's backward of it.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct FedfrNet fedfr_net_t;
+fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_features);
+void fedfr_net_destroy(fedfr_net_t* net);
+enum {
+  FEDFR_Q_PARAM_COUNT = 0,      /* fp32 elements: trainable region + frozen features.weight */
+  FEDFR_Q_TRAINABLE_COUNT = 1,
+  FEDFR_Q_BUFFER_COUNT = 2,     /* fp32 BN running stats */
+  FEDFR_Q_NBT_COUNT = 3,        /* int64 num_batches_tracked scalars */
+  FEDFR_Q_SHADOW_COUNT = 4,     /* bf16 elements */
+  FEDFR_Q_ACT_BYTES = 5,
+  FEDFR_Q_WS_BYTES = 6,
+  FEDFR_Q_NUM_TENSORS = 7,
+  FEDFR_Q_FC_IN = 8
+};
+int fedfr_net_query(const fedfr_net_t* net, int what, long long* out);
+/* state_dict entry i (reference key order).  kind: 0 conv 1 bn.weight 2 bn.bias 3 prelu 4 fc.weight
+ * 5 fc.bias 6 running_mean 7 running_var 8 num_batches_tracked; region: 0 params 1 bufs 2 nbt. */
+int fedfr_net_tensor_info(const fedfr_net_t* net, int i, char* name, int name_cap, int* kind, int* region,
+                          long long* offset, int* ndim, int* shape4);
+/* refresh the bf16 weight shadows from fp32 params (after load_state_dict / an external optimizer step);
+ * fwd_shadow_too = 0 when fedfr_sgd_step already wrote the mirror region. */
+int fedfr_net_prepare_weights(const fedfr_net_t* net, const float* params, uint16_t* shadow, int fwd_shadow_too,
+                              void* stream);
+/* x: fp32 NCHW [B][3][hw][hw] in [-1,1]; feats: fp32 [B][num_features] */
+int fedfr_net_forward(const fedfr_net_t* net, const float* x, const float* params, float* bufs,
+                      const uint16_t* shadow, void* act, void* ws, float* feats, int training, void* stream);
+/* grads (fp32 [trainable_count]) are assigned, not accumulated */
+int fedfr_net_backward(const fedfr_net_t* net, const float* x, const float* dfeats, const float* params,
+                       const uint16_t* shadow, void* act, void* ws, float* grads, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * single convolutions — replace nn.Conv2d fwd / dgrad / wgrad at the call sites iresnet.py:38,41,76,121
+ * (implicit GEMM on v_mfma_f32_16x16x32_bf16).  w: bf16 KRSC; wd: bf16 dgrad shadow [Cin][kh'][kw'][Cout].
+ * stats (optional): [fedfr_conv2d_stat_rows][2][Cout] fp32 partial (sum, sumsq) of the bf16 output.
+ * ------------------------------------------------------------------------------------------------ */
+int fedfr_conv2d_stat_rows(int batch, int hout, int cout);
+int fedfr_conv2d_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* stats, int batch, int hin, int cin,
+                     int cout, int ksize, int stride, void* stream);
+int fedfr_conv2d_dgrad(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int batch, int hin, int cin, int cout,
+                       int ksize, int stride, void* stream);
+size_t fedfr_conv2d_wgrad_ws_bytes(int batch, int hin, int cin, int cout, int ksize, int stride);
+int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* ws, size_t ws_bytes, int batch, int hin,
+                       int cin, int cout, int ksize, int stride, void* stream);
+int fedfr_weight_shadows(const float* w_krsc, uint16_t* w_bf16, uint16_t* wd_bf16, int cout, int ksize, int cin,
+                         void* stream);
+/* plain GEMMs on the same kernels: C[m][n] = sum_k A[m][k] B[n][k] (fp32 out) and C[i][j] = sum_p P[p][i] Q[p][j] */
+int fedfr_gemm_nt(const uint16_t* A, const uint16_t* B, float* C, void* ws, size_t ws_bytes, int M, int N, int K,
+                  void* stream);
+int fedfr_gemm_tn(const uint16_t* P, const uint16_t* Q, float* C, int Kp, int NI, int NJ, void* stream);
+/* stem conv 3->64 (iresnet.py:76) on fp32 NCHW input */
+int fedfr_stem_stat_rows(int batch, int hw);
+int fedfr_stem_fwd(const float* x, const float* w_krsc, uint16_t* y, float* stats, int batch, int hw, void* stream);
+size_t fedfr_stem_wgrad_ws_bytes(int batch, int hw);
+int fedfr_stem_wgrad(const float* x, const uint16_t* dy, float* dw, void* ws, int batch, int hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (train) + PReLU + residual — replace nn.BatchNorm2d / nn.PReLU / `out += identity`
+ * (iresnet.py:37-56).  Tensors are [M][C] bf16 views of NHWC activations.
+ * ------------------------------------------------------------------------------------------------ */
+int fedfr_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                      float* save_mean, float* save_rstd, float* tmp, void* stream);
+int fedfr_bn_apply_stat_rows(int M, int C);
+int fedfr_bn_apply(const uint16_t* x1, const float* sc1, const float* sh1, const float* alpha, const uint16_t* x2,
+                   const float* sc2, const float* sh2, uint16_t* y, int M, int C, int nchw_hw, float* stats,
+                   void* stream);
+/* backward: partials [fedfr_bn_bwd_rows][3][C]; coef [3][C]; grads assigned */
+int fedfr_bn_bwd_rows(int M, int C);
+int fedfr_bn_bwd(const uint16_t* dy, const uint16_t* x, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, const float* alpha, int M, int C, float* partials, float* coef, float* dgamma,
+                 float* dbeta, float* dalpha, const uint16_t* add, const uint16_t* add_up, int H, uint16_t* dx,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 head — replaces FC_module.forward (client.py:69-74), CosFace/ArcFace (losses.py:17-45),
+ * F.cross_entropy (client.py:545) and PartialFC's softmax/grad (partial_fc.py:138-166), BCE_module /
+ * BCE_loss elementwise parts (client.py:45-58, losses.py:4-15).
+ * ------------------------------------------------------------------------------------------------ */
+int fedfr_normalize_rows(const float* x, float* xn, float* inv_norm, int R, int D, float eps, void* stream);
+int fedfr_normalize_rows_bwd(const float* xn, const float* inv_norm, const float* dxn, float* dx, int R, int D,
+                             float beta, void* stream);
+/* C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+bias[n]) (+beta*C); exact fp32 FMA chain */
+int fedfr_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak,
+                long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, void* stream);
+int fedfr_margin_rowmax(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arcface,
+                        float* row_max, float* dmul, void* stream);
+int fedfr_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float* row_sum, void* stream);
+int fedfr_softmax_grad(float* z, const long long* label, int R, int C, int ldz, const float* row_sum,
+                       const float* dmul, float s, float inv_batch, float* prob_t, void* stream);
+int fedfr_nll_mean(const float* prob_t, int R, float floor_, float* loss, void* stream);
+int fedfr_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
+              float lam, float loss_scale, float* z_out, float* dcos, float* dz, float* row_loss, void* stream);
+int fedfr_colsum_f32(const float* x, int R, int C, float* out, void* stream);
+int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * optimiser / aggregation / PartialFC sampling — replace torch.optim.SGD.step (client.py:396,550),
+ * FedPavg / FedAvg_on_FC (server.py:25-46), PartialFC.sample / update (partial_fc.py:89-116).
+ * ------------------------------------------------------------------------------------------------ */
+int fedfr_sgd_step(float* params, const float* grads, float* momentum_buf, uint16_t* bf16_shadow, size_t n, float lr,
+                   float momentum, float weight_decay, int first_step, void* stream);
+int fedfr_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, void* stream);
+int fedfr_fedavg_i64(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc,
+                     void* stream);
+int fedfr_pfc_rand(float* perm, int n, unsigned long long seed, unsigned long long step, void* stream);
+int fedfr_pfc_localize(long long* label, int n, long long class_start, int num_local, float* perm, void* stream);
+int fedfr_pfc_topk(const float* perm, int n, int k, long long* index, int* npos_out, void* stream);
+int fedfr_pfc_positive(const float* perm, int n, long long* index, int* count, void* stream);
+int fedfr_pfc_remap(long long* label, int n, const long long* index, int k, void* stream);
+int fedfr_rows_gather(float* dst, const float* src, const long long* index, int k, int D, void* stream);
+int fedfr_rows_scatter(float* dst, const float* src, const long long* index, int k, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEDFR_HIP_H */

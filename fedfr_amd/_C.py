@@ -24,11 +24,14 @@ SIGNATURES = {
     "fedfr_version": (i32, []),
     "fedfr_last_error_string": (C.c_char_p, []),
     "fedfr_set_option": (i32, [C.c_char_p, i32]),
+    "fedfr_profile_enable": (i32, [i32]),
+    "fedfr_profile_read": (i32, [i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
     "fedfr_net_create": (vp, [C.POINTER(i32), i32, i32, i32]),
     "fedfr_net_destroy": (None, [vp]),
     "fedfr_net_query": (i32, [vp, i32, C.POINTER(i64)]),
     "fedfr_net_tensor_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),
                                     C.POINTER(i32), C.POINTER(i32)]),
+    "fedfr_net_act_info": (i32, [vp, i32, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
     "fedfr_net_prepare_weights": (i32, [vp, vp, vp, i32, vp]),
     "fedfr_net_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "fedfr_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -55,8 +58,10 @@ SIGNATURES = {
     "fedfr_margin_rowmax": (i32, [vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp]),
     "fedfr_exp_rowsum": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "fedfr_softmax_grad": (i32, [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp]),
+    "fedfr_margin_bwd": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
     "fedfr_nll_mean": (i32, [vp, i32, f32, vp, vp]),
-    "fedfr_bce": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
+    "fedfr_bce_logits": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp]),
+    "fedfr_bce_loss": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp]),
     "fedfr_colsum_f32": (i32, [vp, i32, i32, vp, vp]),
     "fedfr_sum_scale": (i32, [vp, i32, f32, vp, vp]),
     "fedfr_sgd_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, i32, vp]),

@@ -1,0 +1,3 @@
+"""Reference-compatible ``backbones`` namespace (reference backbones/__init__.py:1): the FL code looks
+models up with ``eval("backbones.{}".format(args.network))`` (client.py:133, server.py:83)."""
+from .iresnet import iresnet18, iresnet34, iresnet50, iresnet100, iresnet200, IResNet, IBasicBlock  # noqa: F401

@@ -1,0 +1,382 @@
+"""Client side of the federated loop on MI355X — mirrors the reference's ``client.py`` surface:
+``FC_module``, ``BCE_module``, ``Sequential_model``, ``Branch_model`` (client.py:25-113) and ``Client`` with
+``train`` / ``get_model`` / ``get_data_size`` / ``get_train_loss`` (client.py:116-157, :511-582).
+
+The hot loop (reference client.py:536-551: zero_grad → fwd → margin → CE → bwd → SGD step) runs through
+``FusedTrainer``: one ``fedfr_net_forward``, the fp32 head kernels, one ``fedfr_net_backward`` and the flat
+``fedfr_sgd_step`` — no per-layer Python, no PyTorch autograd on the hot path.
+"""
+from __future__ import annotations
+
+import logging
+from collections import OrderedDict
+from typing import Iterable, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _C, backbones, losses, ops
+from .config import config as cfg
+
+f32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# heads
+# ------------------------------------------------------------------------------------------------
+class FC_module(nn.Module):
+    """Dense cosine classifier (reference client.py:63-83)."""
+
+    def __init__(self, hidden, n_class, output_dir):
+        super().__init__()
+        self.fc = nn.Parameter(torch.normal(0, 0.01, (n_class, hidden)))
+        self.output_dir = output_dir
+        self.n_class = n_class
+
+    def forward(self, x, normalize_feat=True):
+        return ops.cosine_linear(x, self.fc, normalize_feat)
+
+    def update_from_tensor(self, fc):
+        self.fc.data = fc.clone()
+
+    def update_with_pretrain(self, pretrain_fc):
+        self.fc = nn.Parameter(torch.cat([self.fc.data, pretrain_fc.to(self.fc.device)], dim=0))
+
+    def remove_pretrain(self):
+        self.fc.data = self.fc.data[0:self.n_class]
+
+    def get_pretrain_fc(self):
+        return self.fc.data[self.n_class:]
+
+
+class _BceLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cosine, labels, bias, m, r, t):
+        cosine = ops._chk(cosine.detach(), "cosine")
+        labels = ops._chk(labels, "labels", torch.int64)
+        B, C = cosine.shape
+        z = torch.empty_like(cosine)
+        gt = torch.empty(B, C, dtype=torch.bool, device=cosine.device)
+        dzdcos = torch.empty_like(cosine)
+        _C.call("fedfr_bce_logits", cosine.data_ptr(), labels.data_ptr(), bias.detach().data_ptr(), B, C, m, r, float(t),
+                z.data_ptr(), gt.data_ptr(), dzdcos.data_ptr(), _C.stream())
+        ctx.save_for_backward(dzdcos)
+        ctx.mark_non_differentiable(gt)
+        return z, gt
+
+    @staticmethod
+    def backward(ctx, dz, _dgt):
+        (dzdcos,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        return dz * dzdcos, None, ops.colsum(dz), None, None, None
+
+
+class _BceLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, gt, r, lam):
+        z = ops._chk(z.detach(), "bce logits")
+        gt = ops._chk(gt, "gts", torch.bool)
+        B, C = z.shape
+        dz = torch.empty_like(z)
+        row_loss = torch.empty(B, dtype=f32, device=z.device)
+        _C.call("fedfr_bce_loss", z.data_ptr(), gt.data_ptr(), None, B, C, r, lam, 1.0, dz.data_ptr(), None, row_loss.data_ptr(),
+                _C.stream())
+        loss = torch.empty((), dtype=f32, device=z.device)
+        _C.call("fedfr_sum_scale", row_loss.data_ptr(), B, 1.0 / B, loss.data_ptr(), _C.stream())
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        (dz,) = ctx.saved_tensors
+        return dz * dl, None, None, None
+
+
+def bce_loss_from_logits(z, gt, r, lam):
+    return _BceLossFn.apply(z, gt, float(r), float(lam))
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b in exact fp32 (the 512x512 'converter' of the personalised head, client.py:29-33)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = ops._chk(x.detach(), "x"), ops._chk(w.detach(), "w")
+        ctx.save_for_backward(x, w)
+        return ops.sgemm(x, w, trans_b=True, bias=b.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = ops._chk(dy, "dy")
+        return ops.sgemm(dy, w), ops.sgemm(dy, x, trans_a=True), ops.colsum(dy)
+
+
+class _Converter(nn.Module):
+    def __init__(self, hidden):
+        super().__init__()
+        self.weight = nn.Parameter(torch.eye(hidden))
+        self.bias = nn.Parameter(torch.zeros(hidden))
+
+    def forward(self, x):
+        return _LinearFn.apply(x, self.weight, self.bias)
+
+
+class BCE_module(nn.Module):
+    """Personalised transform head (reference client.py:25-60), converter_layer == 1 only (config.py:31)."""
+
+    def __init__(self, hidden, n_class, converter_layer=1, m=0.4, r=30.0, t=3):
+        super().__init__()
+        if converter_layer != 1:
+            raise NotImplementedError("fedfr_amd: BottleBlock converter (converter_layer != 1) is out of scope (SURVEY §2.1)")
+        self.converter = nn.Sequential(_Converter(hidden))      # keeps the reference key 'converter.0.weight'
+        self.weight = nn.Parameter(torch.normal(0, 0.01, (n_class, hidden)))
+        self.bias = nn.Parameter(torch.zeros(n_class))
+        self.n_class, self.hidden, self.m, self.r, self.t = n_class, hidden, m, r, t
+
+    def forward(self, x, labels):
+        feat = self.converter(x)
+        cosine = ops.cosine_linear(feat, self.weight)
+        z, gt = _BceLogitsFn.apply(cosine, labels, self.bias, float(self.m), float(self.r), self.t)
+        return z, gt
+
+    def initialize(self, fc):
+        self.weight.data = fc.clone()
+
+
+class Branch_model(nn.Module):
+    """reference client.py:85-100."""
+
+    def __init__(self, backbone, fc_module, bce_module):
+        super().__init__()
+        self.backbone, self.fc_module, self.bce_module = backbone, fc_module, bce_module
+
+    def forward(self, imgs, labels, contrastive=False, detach=False):
+        feature = self.backbone(imgs)
+        cosface_logits = self.fc_module(feature)
+        bce_logits, bce_gts = self.bce_module(feature.detach() if detach else feature, labels)
+        if contrastive:
+            return cosface_logits, bce_logits, bce_gts, feature
+        return cosface_logits, bce_logits, bce_gts
+
+
+class Sequential_model(nn.Module):
+    """reference client.py:102-113."""
+
+    def __init__(self, backbone, fc_module):
+        super().__init__()
+        self.backbone, self.fc_module = backbone, fc_module
+
+    def forward(self, imgs, contrastive=False):
+        feature = self.backbone(imgs)
+        logits = self.fc_module(feature)
+        return (logits, feature) if contrastive else logits
+
+
+# ------------------------------------------------------------------------------------------------
+# fused train step
+# ------------------------------------------------------------------------------------------------
+class FusedTrainer:
+    """One optimiser lifetime (= one FL round for one client: the reference re-creates SGD every round, F8).
+
+    step(imgs, labels) == the body of the reference hot loop (client.py:537-550) for the Sequential model:
+    zero_grad; logits = fc(backbone(imgs)); logits = margin(logits, labels); loss = CE; backward; SGD step.
+    """
+
+    def __init__(self, backbone: "backbones.IResNet", fc: torch.Tensor, loss_name: str = "CosFace", s: float = 30.0,
+                 m: float = 0.4, lr: float = 0.1, momentum: float = 0.9, weight_decay: float = 5e-4):
+        if loss_name not in ("CosFace", "ArcFace"):
+            raise ValueError("loss must be CosFace or ArcFace")
+        self.bb = backbone
+        self.fc = _C.require_gpu_tensor(fc, f32, "fc weight")
+        self.arc = loss_name == "ArcFace"
+        self.s, self.m, self.lr, self.mu, self.wd = float(s), float(m), float(lr), float(momentum), float(weight_decay)
+        bb = backbone
+        bb._ensure_device_state()
+        bb.train()
+        self.n_train = bb.trainable_count()
+        self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
+        self.fc_mom = torch.empty_like(self.fc)
+        self.fc_grad = torch.empty_like(self.fc)
+        self.first = True
+        bb.refresh_shadows(True)
+
+    def set_lr(self, lr: float):
+        self.lr = float(lr)
+
+    def forward_backward(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        bb = self.bb
+        bb._check_input(imgs)
+        labels = _C.require_gpu_tensor(labels, torch.int64, "labels")
+        B = imgs.shape[0]
+        plan = bb._plan(B)
+        st = _C.stream()
+        feats = torch.empty(B, bb.num_features, dtype=f32, device=bb.device)
+        _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1, st)
+        bb._flat_nbt += 1
+        bb._fwd_generation += 1
+        # head: cosine logits -> margin -> softmax CE, gradient wrt cosine written in place
+        fn, finv = ops.normalize_rows(feats)
+        wn, winv = ops.normalize_rows(self.fc)
+        cos = ops.sgemm(fn, wn, trans_b=True)
+        prob_t, g = ops.softmax_ce_grad(cos, labels, self.s, self.m, self.arc, 1.0 / B)
+        loss = ops.nll_mean(prob_t, 0.0)
+        dfn = ops.sgemm(g, wn)
+        dwn = ops.sgemm(g, fn, trans_a=True)
+        dfeats = ops.normalize_rows_bwd(fn, finv, dfn)
+        _C.call("fedfr_normalize_rows_bwd", wn.data_ptr(), winv.data_ptr(), dwn.data_ptr(), self.fc_grad.data_ptr(),
+                wn.shape[0], wn.shape[1], 0.0, st)
+        _C.call("fedfr_net_backward", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st)
+        return loss
+
+    def optimizer_step(self):
+        bb = self.bb
+        st = _C.stream()
+        first = 1 if self.first else 0
+        _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, first, st)
+        _C.call("fedfr_sgd_step", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
+                self.lr, self.mu, self.wd, first, st)
+        bb.refresh_shadows(False)       # dgrad-layout copies; the bf16 mirror was written by the SGD kernel
+        self.first = False
+
+    def step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        loss = self.forward_backward(imgs, labels)
+        self.optimizer_step()
+        return loss
+
+
+# ------------------------------------------------------------------------------------------------
+# Client
+# ------------------------------------------------------------------------------------------------
+class AverageMeter:
+    """reference utils/utils_logging.py:6-27."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+class Client(object):
+    """Local trainer of one FL participant (reference client.py:116-157, :511-582).
+
+    ``data`` must expose ``train_class_sizes``, ``train_dataset_sizes`` and ``train_loaders`` (indexable by
+    cid; each loader iterates ``(imgs[B,3,112,112] fp32 in [-1,1], labels int64)`` and has ``.dataset.ID_base``),
+    exactly what ``All_Client_Dataset`` provides in the reference (dataset.py:73-142).
+    """
+
+    def __init__(self, cid, args, data, device: Optional[torch.device] = None):
+        self.cid = cid
+        self.args = args
+        self.num_classes = data.train_class_sizes[self.cid]
+        self.local_epoch = args.local_epoch
+        self.dataset_size = data.train_dataset_sizes[self.cid]
+        self.train_loader = data.train_loaders[self.cid]
+        ds = getattr(self.train_loader, "dataset", None)
+        self.ID_base = getattr(ds, "ID_base", 0)
+        self.target_ID = list(range(self.ID_base, self.ID_base + self.num_classes))
+        self.loss_name = args.loss
+        self.margin_softmax = getattr(losses, args.loss)(s=30, m=0.4)          # client.py:133
+        if getattr(self.args, "BCE_local", False):
+            self.bce_module = BCE_module(512, self.num_classes, cfg.converter_layer)
+            self.bce_loss = losses.BCE_loss()
+        self.rank = 0
+        self.local_rank = 0
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.dropout = 0.4 if cfg.dataset == "webface" else 0
+        self.backbone_state_dict = None
+        self.fc_module = FC_module(512, self.num_classes, getattr(args, "output_dir", "."))
+        self.logger = logging.getLogger("FL_face.client")
+        self._backbone = None
+        self.loss_meter = AverageMeter()
+        self.sync_every = getattr(args, "loss_sync_every", 1)      # reference syncs (loss.item()) every step
+
+    def _get_backbone(self):
+        if self._backbone is None:
+            self._backbone = getattr(backbones, self.args.network)(False, dropout=self.dropout, fp16=cfg.fp16).to(self.device)
+        return self._backbone
+
+    def train(self, start_epoch=0, callback_verification=None):
+        """reference client.py:511-571."""
+        backbone = self._get_backbone()
+        backbone.load_state_dict(self.backbone_state_dict)
+        backbone.train()
+        self.fc_module.to(self.device)
+        self.fc_module.train()
+        trainer = FusedTrainer(backbone, self.fc_module.fc.data, self.loss_name, 30.0, 0.4,
+                               lr=cfg.lr_func(start_epoch) * cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+        loss_meter = AverageMeter()
+        pending = []
+        for epoch in range(start_epoch, start_epoch + self.local_epoch):
+            for step, (imgs, labels) in enumerate(self.train_loader):
+                if len(imgs) == 1:                                              # client.py:538-540
+                    imgs = torch.cat([imgs, imgs], dim=0)
+                    labels = torch.cat([labels, labels])
+                imgs = imgs.to(self.device, non_blocking=True).contiguous()
+                labels = labels.to(self.device, non_blocking=True)
+                pending.append(trainer.step(imgs, labels))
+                if len(pending) >= self.sync_every:
+                    for l in pending:
+                        loss_meter.update(l.item(), 1)
+                    pending = []
+        for l in pending:
+            loss_meter.update(l.item(), 1)
+        self.loss_meter = loss_meter
+        self.backbone_state_dict = flat_state_dict(backbone)
+        self.fc_module.cpu()
+
+    def get_train_loss(self):
+        return self.loss_meter.avg
+
+    def get_model(self):
+        return self.backbone_state_dict
+
+    def get_global_fc(self):
+        return self.fc_module.get_pretrain_fc()
+
+    def get_data_size(self):
+        return self.dataset_size
+
+
+class FlatStateDict(OrderedDict):
+    """state_dict whose tensors are views of three flat tensors (kept as ``.flat``) so that FedPavg can run as
+    three fused kernels instead of a Python loop over 925 keys (reference server.py:25-34)."""
+    flat: Tuple[torch.Tensor, torch.Tensor, torch.Tensor] = None
+    table = None
+    layers = None
+
+
+def flat_state_dict(backbone, clone=True) -> FlatStateDict:
+    """Snapshot of a backbone's state as a FlatStateDict (device tensors; keys == reference state_dict keys)."""
+    p, b, n = backbone.flat_state()
+    if clone:
+        p, b, n = p.clone(), b.clone(), n.clone()
+    sd = FlatStateDict()
+    sd.flat = (p, b, n)
+    sd.table = backbone._table
+    sd.layers = backbone.layers_cfg
+    for name, kind, region, off, shape in backbone._table:
+        if region == 0:
+            if kind == backbones.iresnet.KIND_CONV:
+                o, i, r, _ = shape
+                sd[name] = p[off: off + o * i * r * r].view(o, r, r, i).permute(0, 3, 1, 2)
+            else:
+                num = 1
+                for s_ in shape:
+                    num *= s_
+                sd[name] = p[off: off + num].view(shape)
+        elif region == 1:
+            sd[name] = b[off: off + shape[0]]
+        else:
+            sd[name] = n[off]
+    return sd

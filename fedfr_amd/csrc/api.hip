@@ -44,6 +44,17 @@ int fedfr_set_option(const char* name, int value) {
   return FEDFR_ERR_ARG;
 }
 
+int fedfr_profile_enable(int on) {
+  gemm_profile_enable(on);
+  return FEDFR_OK;
+}
+int fedfr_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
+  FEDFR_REQUIRE(total_ms && launches && flops, "profile_read: null");
+  const int rc = gemm_profile_read(slot, total_ms, launches, flops);
+  FEDFR_REQUIRE(rc == 0, "profile_read: slot %d failed (%d) — synchronise the stream first", slot, rc);
+  return FEDFR_OK;
+}
+
 // ---- net -------------------------------------------------------------------------------------------
 fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_features) {
   if (!layers4) {
@@ -77,6 +88,29 @@ int fedfr_net_tensor_info(const fedfr_net_t* n, int i, char* name, int name_cap,
   snprintf(name, name_cap, "%s", t.name.c_str());
   *kind = t.kind; *region = t.region; *offset = t.offset; *ndim = t.ndim;
   for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+  return FEDFR_OK;
+}
+int fedfr_net_act_info(const fedfr_net_t* n, int block, int which, long long* offset, int* rows, int* channels) {
+  FEDFR_REQUIRE(n && offset && rows && channels, "net_act_info: null");
+  const int B = n->B;
+  if (block < 0) {          // which: 0 stem conv out (c0), 1 stem activation (a0), 2 flattened bn2 output t [B][fc_in]
+    FEDFR_REQUIRE(which >= 0 && which <= 2, "net_act_info: bad stem selector");
+    if (which == 2) { *offset = n->t_off; *rows = B; *channels = n->fc_in; return FEDFR_OK; }
+    *offset = which == 0 ? n->c0_off : n->a0_off; *rows = B * n->HW * n->HW; *channels = 64;
+    return FEDFR_OK;
+  }
+  FEDFR_REQUIRE(block < (int)n->blocks.size() && which >= 0 && which <= 6, "net_act_info: bad selector");
+  const BlockD& k = n->blocks[block];
+  const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
+  switch (which) {           // 0 x, 1 a1, 2 c1, 3 a2, 4 c2, 5 d, 6 out
+    case 0: *offset = k.x_off; *rows = Mi; *channels = k.Cin; break;
+    case 1: *offset = k.a1_off; *rows = Mi; *channels = k.Cin; break;
+    case 2: *offset = k.c1_off; *rows = Mi; *channels = k.Cout; break;
+    case 3: *offset = k.a2_off; *rows = Mi; *channels = k.Cout; break;
+    case 4: *offset = k.c2_off; *rows = Mo; *channels = k.Cout; break;
+    case 5: *offset = k.d_off; *rows = Mo; *channels = k.Cout; break;
+    default: *offset = k.out_off; *rows = Mo; *channels = k.Cout; break;
+  }
   return FEDFR_OK;
 }
 int fedfr_net_prepare_weights(const fedfr_net_t* n, const float* params, uint16_t* shadow, int fwd_shadow_too, void* stream) {
@@ -237,12 +271,19 @@ int fedfr_softmax_grad(float* z, const long long* label, int R, int C, int ldz, 
                        float inv_batch, float* prob_t, void* stream) {
   return head_softmax_grad(z, label, R, C, ldz, row_sum, dmul, s, inv_batch, prob_t, ST(stream));
 }
+int fedfr_margin_bwd(const float* dlogits, const long long* label, const float* dmul, float s, int R, int C, float* dcos, void* stream) {
+  return head_margin_bwd(dlogits, label, dmul, s, R, C, dcos, ST(stream));
+}
 int fedfr_nll_mean(const float* prob_t, int R, float floor_, float* loss, void* stream) {
   return head_nll_mean(prob_t, R, floor_, loss, ST(stream));
 }
-int fedfr_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t, float lam,
-              float loss_scale, float* z_out, float* dcos, float* dz, float* row_loss, void* stream) {
-  return head_bce(cosv, label, bias, B, C, m, r, t, lam, loss_scale, z_out, dcos, dz, row_loss, ST(stream));
+int fedfr_bce_logits(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
+                     float* z, unsigned char* gt, float* dzdcos, void* stream) {
+  return head_bce_logits(cosv, label, bias, B, C, m, r, t, z, gt, dzdcos, ST(stream));
+}
+int fedfr_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam, float loss_scale,
+                   float* dz, float* dcos, float* row_loss, void* stream) {
+  return head_bce_loss(z, gt, dzdcos, B, C, r, lam, loss_scale, dz, dcos, row_loss, ST(stream));
 }
 int fedfr_colsum_f32(const float* x, int R, int C, float* out, void* stream) { return head_colsum_f32(x, R, C, out, ST(stream)); }
 int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream) { return head_sum_scale(x, n, scale, out, ST(stream)); }

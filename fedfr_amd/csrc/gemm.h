@@ -48,3 +48,7 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st);
 int gemm_tn_launch(GemmTN p, int splits, hipStream_t st);
 int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C_or_0);
 void gemm_tn_tiles(int NI, int NJ, int C_or_0, int* TI, int* TJ);
+
+// optional HIP-event timing of every NT/TN launch (slots: see gemm.hip)
+void gemm_profile_enable(int on);
+int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops);

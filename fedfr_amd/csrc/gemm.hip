@@ -3,7 +3,65 @@
 // (conflict-free ds_read_b128 / ds_read_b64_tr_b16), one barrier per K-step, XCD-aware 1-D grid.
 #include "gemm.h"
 
+#include <vector>
+
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------
+// slots: 0..3 = gemm_nt <128,128> <128,64> <64,128> <64,64>; 4..7 = gemm_tn <128,128> <128,64> <64,128> <64,64>
+namespace {
+struct ProfSlot {
+  std::vector<hipEvent_t> ev;   // start/stop pairs
+  double flops = 0.0;
+  long long launches = 0;
+};
+bool g_prof_on = false;
+ProfSlot g_prof[8];
+inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
+struct ProfScope {
+  ProfSlot* s = nullptr;
+  hipStream_t st;
+  ProfScope(int slot, double flops, hipStream_t st_) : st(st_) {
+    if (!g_prof_on) return;
+    s = &g_prof[slot];
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { s = nullptr; return; }
+    s->ev.push_back(a);
+    s->ev.push_back(b);
+    s->flops += flops;
+    s->launches += 1;
+    (void)hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (s) (void)hipEventRecord(s->ev.back(), st);
+  }
+};
+}  // namespace
+
+void gemm_profile_enable(int on) {
+  for (auto& s : g_prof) {
+    for (auto e : s.ev) (void)hipEventDestroy(e);
+    s.ev.clear();
+    s.flops = 0.0;
+    s.launches = 0;
+  }
+  g_prof_on = on != 0;
+}
+// caller must have synchronised the stream(s).  Returns 0 and fills totals for `slot`.
+int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
+  if (slot < 0 || slot >= 8) return -1;
+  ProfSlot& s = g_prof[slot];
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, s.ev[i], s.ev[i + 1]) != hipSuccess) return -2;
+    ms += t;
+  }
+  *total_ms = ms;
+  *launches = s.launches;
+  *flops = s.flops;
+  return 0;
+}
 
 // bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
@@ -243,6 +301,7 @@ static int launch_nt(const GemmNT& p0, int splits, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(nbm * p.nbn, splits, 1);
+  ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (double)p.K, st);
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_nt");
   return FEDFR_OK;
@@ -498,6 +557,7 @@ static int launch_tn(GemmTN p, int splits, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(nbi * p.nbj, splits, 1);
+  ProfScope prof(prof_slot(true, TI, TJ), 2.0 * p.NI * p.NJ * (double)p.Kp, st);
   hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, USE_TR>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_tn");
   return FEDFR_OK;

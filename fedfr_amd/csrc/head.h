@@ -12,8 +12,12 @@ int head_margin_rowmax(float* z, const long long* label, int R, int C, int ldz, 
 int head_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float* row_sum, hipStream_t st);
 int head_softmax_grad(float* z, const long long* label, int R, int C, int ldz, const float* row_sum, const float* dmul, float s,
                       float inv_batch, float* prob_t, hipStream_t st);
+int head_margin_bwd(const float* dlogits, const long long* label, const float* dmul, float s, int R, int C, float* dcos,
+                    hipStream_t st);
 int head_nll_mean(const float* prob_t, int R, float floor_, float* loss, hipStream_t st);
-int head_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t, float lam,
-             float loss_scale, float* zout, float* dcos, float* dz, float* row_loss, hipStream_t st);
+int head_bce_logits(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
+                    float* z, unsigned char* gt, float* dzdcos, hipStream_t st);
+int head_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam, float loss_scale,
+                  float* dz, float* dcos, float* row_loss, hipStream_t st);
 int head_colsum_f32(const float* x, int R, int C, float* out, hipStream_t st);
 int head_sum_scale(const float* x, int n, float scale, float* out, hipStream_t st);

@@ -288,18 +288,18 @@ int head_nll_mean(const float* prob_t, int R, float floor_, float* loss, hipStre
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// BCE personalised head, elementwise part.  cos [B][C] in; z (logits) out; dcos = dL/dcos; per-row loss sums.
-//   g(x) = 2((x+1)/2)^t - 1 ; z = r*(g -/+ m) + bias ; loss_e = pos ? (lam/r) log(1+e^-z+1e-8) : ((1-lam)/r) log(1+e^z+1e-8)
-//   L = loss_scale * mean_b sum_c loss_e
+// BCE personalised head (client.py:45-58, losses.py:4-15), two elementwise kernels:
+//   bce_logits: cos [B][C] -> z = r*(g(cos) -/+ m) + bias, gt[b][c] = (label[b] == c), dzdcos = r*t*((cos+1)/2)^(t-1)
+//               with g(x) = 2((x+1)/2)^t - 1
+//   bce_loss:   z, gt -> row_loss[b] = sum_c (gt ? (lam/r) log(1+e^-z+1e-8) : ((1-lam)/r) log(1+e^z+1e-8)),
+//               dz = dL/dz for L = loss_scale * mean_b row_loss, and optionally dcos = dz * dzdcos
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ cosv, const long long* __restrict__ label,
-                                                  const float* __restrict__ bias, int C, float m, float r, float t, float lam,
-                                                  float loss_scale, float inv_batch, float* __restrict__ zout,
-                                                  float* __restrict__ dcos, float* __restrict__ dz, float* __restrict__ row_loss) {
-  __shared__ float sh[4];
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ cosv, const long long* __restrict__ label,
+                                                         const float* __restrict__ bias, int C, float m, float r, float t,
+                                                         float* __restrict__ z, unsigned char* __restrict__ gt,
+                                                         float* __restrict__ dzdcos) {
   const int row = blockIdx.x;
   const long long y = label[row];
-  float ls = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
     const size_t i = (size_t)row * C + c;
     const float x = cosv[i];
@@ -307,32 +307,71 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ cosv
     const float pw1 = powf(hb, t - 1.f);
     const float g = 2.f * pw1 * hb - 1.f;
     const bool pos = (c == y);
-    const float z = r * (pos ? g - m : g + m) + bias[c];
-    if (zout) zout[i] = z;
-    float le, dldz;
-    if (pos) {
-      const float e = expf(-z);
+    z[i] = r * (pos ? g - m : g + m) + bias[c];
+    if (gt) gt[i] = pos ? 1 : 0;
+    if (dzdcos) dzdcos[i] = r * t * pw1;
+  }
+}
+int head_bce_logits(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
+                    float* z, unsigned char* gt, float* dzdcos, hipStream_t st) {
+  FEDFR_REQUIRE(cosv && label && bias && z && B > 0 && C > 0, "bce_logits: bad args");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(B), dim3(256), 0, st, cosv, label, bias, C, m, r, t, z, gt, dzdcos);
+  FEDFR_LAUNCH_CHECK("bce_logits");
+  return FEDFR_OK;
+}
+
+__global__ __launch_bounds__(256) void bce_loss_kernel(const float* __restrict__ z, const unsigned char* __restrict__ gt,
+                                                       const float* __restrict__ dzdcos, int C, float r, float lam,
+                                                       float loss_scale, float inv_batch, float* __restrict__ dz,
+                                                       float* __restrict__ dcos, float* __restrict__ row_loss) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  float ls = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const size_t i = (size_t)row * C + c;
+    const float zz = z[i];
+    float le, dl;
+    if (gt[i]) {
+      const float e = expf(-zz);
       le = (lam / r) * logf(1.f + e + 1e-8f);
-      dldz = (lam / r) * (-e) / (1.f + e + 1e-8f);
+      dl = (lam / r) * (-e) / (1.f + e + 1e-8f);
     } else {
-      const float e = expf(z);
+      const float e = expf(zz);
       le = ((1.f - lam) / r) * logf(1.f + e + 1e-8f);
-      dldz = ((1.f - lam) / r) * e / (1.f + e + 1e-8f);
+      dl = ((1.f - lam) / r) * e / (1.f + e + 1e-8f);
     }
     ls += le;
-    const float gz = dldz * inv_batch * loss_scale;
+    const float gz = dl * inv_batch * loss_scale;
     if (dz) dz[i] = gz;
-    if (dcos) dcos[i] = gz * r * t * pw1;      // dz/dcos = r * g'(x) = r * t * ((x+1)/2)^(t-1)
+    if (dcos) dcos[i] = gz * dzdcos[i];
   }
   ls = block_sum(ls, sh);
   if (threadIdx.x == 0) row_loss[row] = ls;
 }
-int head_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t, float lam,
-             float loss_scale, float* zout, float* dcos, float* dz, float* row_loss, hipStream_t st) {
-  FEDFR_REQUIRE(cosv && label && bias && row_loss && B > 0 && C > 0, "bce: bad args");
-  hipLaunchKernelGGL(bce_kernel, dim3(B), dim3(256), 0, st, cosv, label, bias, C, m, r, t, lam, loss_scale, 1.f / B, zout, dcos,
-                     dz, row_loss);
-  FEDFR_LAUNCH_CHECK("bce");
+int head_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam, float loss_scale,
+                  float* dz, float* dcos, float* row_loss, hipStream_t st) {
+  FEDFR_REQUIRE(z && gt && row_loss && B > 0 && C > 0 && (!dcos || dzdcos), "bce_loss: bad args");
+  hipLaunchKernelGGL(bce_loss_kernel, dim3(B), dim3(256), 0, st, z, gt, dzdcos, C, r, lam, loss_scale, 1.f / B, dz, dcos, row_loss);
+  FEDFR_LAUNCH_CHECK("bce_loss");
+  return FEDFR_OK;
+}
+
+// margin backward: dcos = dlogits * (c == label ? dmul[row] : s)     (autograd bridge of losses.CosFace/ArcFace)
+__global__ __launch_bounds__(256) void margin_bwd_kernel(const float* __restrict__ dlogits, const long long* __restrict__ label,
+                                                         const float* __restrict__ dmul, float s, int C, float* __restrict__ dcos) {
+  const int row = blockIdx.x;
+  const long long y = label[row];
+  const float dm = dmul[row];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const size_t i = (size_t)row * C + c;
+    dcos[i] = dlogits[i] * (c == y ? dm : s);
+  }
+}
+int head_margin_bwd(const float* dlogits, const long long* label, const float* dmul, float s, int R, int C, float* dcos,
+                    hipStream_t st) {
+  FEDFR_REQUIRE(dlogits && label && dmul && dcos && R > 0 && C > 0, "margin_bwd: bad args");
+  hipLaunchKernelGGL(margin_bwd_kernel, dim3(R), dim3(256), 0, st, dlogits, label, dmul, s, C, dcos);
+  FEDFR_LAUNCH_CHECK("margin_bwd");
   return FEDFR_OK;
 }
 

@@ -1,0 +1,183 @@
+"""Thin tensor-level wrappers over the fp32 head kernels + autograd bridges.
+
+Everything here runs in libfedfr_hip.so; torch is used only to own device memory and to connect the
+hand-written backward passes to ``loss.backward()`` for callers that use the reference's eager style
+(``logits = margin(fc(feat), y); F.cross_entropy(logits, y).backward()``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _C
+
+f32 = torch.float32
+
+
+def _chk(t: torch.Tensor, name: str, dtype=f32) -> torch.Tensor:
+    t = t if t.is_contiguous() else t.contiguous()
+    return _C.require_gpu_tensor(t, dtype, name)
+
+
+# ------------------------------------------------------------------------------------------ raw ops
+def normalize_rows(x: torch.Tensor, eps: float = 1e-12) -> Tuple[torch.Tensor, torch.Tensor]:
+    """F.normalize(x) (p=2, dim=1) -> (x_hat, 1/max(||x||, eps))."""
+    x = _chk(x, "x")
+    R, D = x.shape
+    xn = torch.empty_like(x)
+    inv = torch.empty(R, dtype=f32, device=x.device)
+    _C.call("fedfr_normalize_rows", x.data_ptr(), xn.data_ptr(), inv.data_ptr(), R, D, eps, _C.stream())
+    return xn, inv
+
+
+def normalize_rows_bwd(xn: torch.Tensor, inv: torch.Tensor, dxn: torch.Tensor) -> torch.Tensor:
+    dxn = _chk(dxn, "dxn")
+    dx = torch.empty_like(xn)
+    _C.call("fedfr_normalize_rows_bwd", xn.data_ptr(), inv.data_ptr(), dxn.data_ptr(), dx.data_ptr(), xn.shape[0], xn.shape[1],
+            0.0, _C.stream())
+    return dx
+
+
+def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
+          bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = op(A) @ op(B) (+bias) in exact fp32 (v_mfma_f32_16x16x4_f32); A, B row-major contiguous."""
+    a, b = _chk(a, "A"), _chk(b, "B")
+    if trans_a:
+        K, M = a.shape
+        sam, sak = 1, M
+    else:
+        M, K = a.shape
+        sam, sak = K, 1
+    if trans_b:
+        N, Kb = b.shape
+        sbk, sbn = 1, Kb
+    else:
+        Kb, N = b.shape
+        sbk, sbn = N, 1
+    if K != Kb:
+        raise RuntimeError("sgemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if out is None:
+        out = torch.empty(M, N, dtype=f32, device=a.device)
+    _C.call("fedfr_sgemm", a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, sam, sak, sbk, sbn, N, 1.0, 0.0,
+            _C.ptr(bias), _C.stream())
+    return out
+
+
+def softmax_ce_grad(cosine: torch.Tensor, label: torch.Tensor, s: float, m: float, arcface: bool,
+                    inv_batch: float, all_reduce=None):
+    """In place on ``cosine`` [R,C]: margin -> softmax -> gradient wrt the cosine matrix.
+    Returns (prob_target [R], grad == cosine storage).  ``all_reduce(t, op)`` (op in {"max","sum"}) is
+    applied to the row max / row sum / target prob between the three kernels (PartialFC C3-C5)."""
+    cosine = _chk(cosine, "cosine")
+    label = _chk(label, "label", torch.int64)
+    R, Cc = cosine.shape
+    dev = cosine.device
+    row_max = torch.empty(R, dtype=f32, device=dev)
+    row_sum = torch.empty(R, dtype=f32, device=dev)
+    dmul = torch.empty(R, dtype=f32, device=dev)
+    prob_t = torch.empty(R, dtype=f32, device=dev)
+    st = _C.stream()
+    _C.call("fedfr_margin_rowmax", cosine.data_ptr(), label.data_ptr(), R, Cc, Cc, s, m, 1 if arcface else 0,
+            row_max.data_ptr(), dmul.data_ptr(), st)
+    if all_reduce is not None:
+        all_reduce(row_max, "max")
+    _C.call("fedfr_exp_rowsum", cosine.data_ptr(), R, Cc, Cc, row_max.data_ptr(), row_sum.data_ptr(), st)
+    if all_reduce is not None:
+        all_reduce(row_sum, "sum")
+    _C.call("fedfr_softmax_grad", cosine.data_ptr(), label.data_ptr(), R, Cc, Cc, row_sum.data_ptr(), dmul.data_ptr(), s,
+            inv_batch, prob_t.data_ptr(), st)
+    if all_reduce is not None:
+        all_reduce(prob_t, "sum")
+    return prob_t, cosine
+
+
+def nll_mean(prob_t: torch.Tensor, floor: float = 0.0) -> torch.Tensor:
+    loss = torch.empty((), dtype=f32, device=prob_t.device)
+    _C.call("fedfr_nll_mean", prob_t.data_ptr(), prob_t.numel(), floor, loss.data_ptr(), _C.stream())
+    return loss
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    x = _chk(x, "x")
+    out = torch.empty(x.shape[1], dtype=f32, device=x.device)
+    _C.call("fedfr_colsum_f32", x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _C.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ autograd bridges
+class CosineLinearFn(torch.autograd.Function):
+    """normalize(x) @ normalize(w).T  (reference FC_module.forward, client.py:69-74)."""
+
+    @staticmethod
+    def forward(ctx, x, w, normalize_feat=True):
+        x, w = _chk(x.detach(), "features"), _chk(w.detach(), "fc")
+        if normalize_feat:
+            xn, xinv = normalize_rows(x)
+        else:
+            xn, xinv = x, None
+        wn, winv = normalize_rows(w)
+        ctx.save_for_backward(xn, wn, winv, xinv if xinv is not None else torch.empty(0, device=x.device))
+        ctx.normalize_feat = normalize_feat
+        return sgemm(xn, wn, trans_b=True)
+
+    @staticmethod
+    def backward(ctx, dcos):
+        xn, wn, winv, xinv = ctx.saved_tensors
+        dcos = _chk(dcos, "dcos")
+        dxn = sgemm(dcos, wn)                       # [B,C] @ [C,D]
+        dwn = sgemm(dcos, xn, trans_a=True)         # [C,B] @ [B,D]
+        dx = normalize_rows_bwd(xn, xinv, dxn) if ctx.normalize_feat else dxn
+        dw = normalize_rows_bwd(wn, winv, dwn)
+        return dx, dw, None
+
+
+class MarginFn(torch.autograd.Function):
+    """CosFace / ArcFace on a cosine matrix (losses.py:23-29, :38-45); rows with label == -1 get no margin."""
+
+    @staticmethod
+    def forward(ctx, cosine, label, s, m, arcface):
+        z = _chk(cosine.detach().clone(), "cosine")
+        label = _chk(label, "label", torch.int64)
+        R, Cc = z.shape
+        row_max = torch.empty(R, dtype=f32, device=z.device)
+        dmul = torch.empty(R, dtype=f32, device=z.device)
+        _C.call("fedfr_margin_rowmax", z.data_ptr(), label.data_ptr(), R, Cc, Cc, s, m, 1 if arcface else 0, row_max.data_ptr(),
+                dmul.data_ptr(), _C.stream())
+        ctx.save_for_backward(label, dmul)
+        ctx.s = s
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        label, dmul = ctx.saved_tensors
+        dz = _chk(dz, "dlogits")
+        out = torch.empty_like(dz)
+        _C.call("fedfr_margin_bwd", dz.data_ptr(), label.data_ptr(), dmul.data_ptr(), ctx.s, dz.shape[0], dz.shape[1],
+                out.data_ptr(), _C.stream())
+        return out, None, None, None, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """mean softmax cross-entropy (F.cross_entropy as used in client.py:545) with the gradient from the fused kernels."""
+
+    @staticmethod
+    def forward(ctx, logits, label):
+        z = _chk(logits.detach().clone(), "logits")
+        label = _chk(label, "label", torch.int64)
+        prob_t, grad = softmax_ce_grad(z, label, 1.0, 0.0, False, 1.0 / z.shape[0])
+        ctx.save_for_backward(grad)
+        return nll_mean(prob_t, 0.0)
+
+    @staticmethod
+    def backward(ctx, dl):
+        (grad,) = ctx.saved_tensors
+        return grad * dl, None
+
+
+def cosine_linear(x, w, normalize_feat=True):
+    return CosineLinearFn.apply(x, w, normalize_feat)
+
+
+def cross_entropy(logits, label):
+    return CrossEntropyFn.apply(logits, label)

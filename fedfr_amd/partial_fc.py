@@ -1,0 +1,207 @@
+"""PartialFC on MI355X — class-sharded, negatively-sampled margin softmax with hand-written gradient.
+
+Same constructor / attributes / ``forward_backward(label, features, optimizer) -> (x_grad, loss_v)`` /
+``update()`` / ``save_params()`` as the reference (reference partial_fc.py:19-176).  The six collectives
+(partial_fc.py:122,134,142,147,161,173) go through ``torch.distributed`` (backend "nccl" == RCCL over xGMI);
+sampling (RNG, top-k select, ordered compaction, label remap), row gather/scatter, normalisation, the cosine
+GEMMs and the margin/softmax/grad are HIP kernels (fedfr_pfc_*, fedfr_rows_*, fedfr_sgemm, fedfr_margin_*).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch.nn import Module
+from torch.nn.parameter import Parameter
+
+from . import _C, ops
+
+f32 = torch.float32
+
+
+def _is_dist(world_size: int) -> bool:
+    return world_size > 1 and dist.is_available() and dist.is_initialized()
+
+
+class PartialFC(Module):
+    @torch.no_grad()
+    def __init__(self, rank, local_rank, world_size, batch_size, resume, margin_softmax, num_classes, sample_rate=1.0,
+                 embedding_size=512, prefix="./", seed: int = 100):
+        super().__init__()
+        self.num_classes: int = num_classes
+        self.rank: int = rank
+        self.local_rank: int = local_rank
+        self.device = torch.device("cuda:{}".format(self.local_rank))
+        self.world_size: int = world_size
+        self.batch_size: int = batch_size
+        self.margin_softmax = margin_softmax
+        self.sample_rate: float = sample_rate
+        self.embedding_size: int = embedding_size
+        self.prefix: str = prefix
+        self.num_local: int = num_classes // world_size + int(rank < num_classes % world_size)         # partial_fc.py:34
+        self.class_start: int = num_classes // world_size * rank + min(rank, num_classes % world_size)  # :35
+        self.num_sample: int = int(self.sample_rate * self.num_local)
+        self.weight_name = os.path.join(self.prefix, "rank:{}_softmax_weight.pt".format(self.rank))
+        self.weight_mom_name = os.path.join(self.prefix, "rank:{}_softmax_weight_mom.pt".format(self.rank))
+        logger = logging.getLogger("FL_face.partial")
+        self.weight = None
+        if resume:
+            try:
+                self.weight = torch.load(self.weight_name).to(self.device)
+                logger.info("softmax weight resume successfully!")
+            except (FileNotFoundError, KeyError, IndexError):
+                logger.info("softmax weight resume fail!")
+            try:
+                self.weight_mom = torch.load(self.weight_mom_name).to(self.device)
+                logger.info("softmax weight mom resume successfully!")
+            except (FileNotFoundError, KeyError, IndexError):
+                self.weight_mom = None
+                logger.info("softmax weight mom resume fail!")
+        if self.weight is None:
+            self.weight = torch.normal(0, 0.01, (self.num_local, self.embedding_size), device=self.device)
+            self.weight_mom = None
+        if getattr(self, "weight_mom", None) is None:
+            self.weight_mom = torch.zeros_like(self.weight)
+        # the reference keeps a side stream for label gather + sampling (partial_fc.py:61,119)
+        self.stream = torch.cuda.Stream(self.device)
+        self.index = None
+        self._seed, self._step = int(seed) * 1000003 + rank, 0
+        self._perm = torch.empty(self.num_local, dtype=f32, device=self.device)
+        self._npos = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # margin parameters for the fused softmax kernels
+        name = margin_softmax.__class__.__name__
+        if name not in ("CosFace", "ArcFace"):
+            raise ValueError("margin_softmax must be a fedfr_amd.losses.CosFace/ArcFace instance")
+        self._arc, self._s, self._m = name == "ArcFace", float(margin_softmax.s), float(margin_softmax.m)
+        if int(self.sample_rate) == 1:
+            self.update = lambda: 0
+            self.sub_weight = Parameter(self.weight)
+            self.sub_weight_mom = self.weight_mom
+        else:
+            self.sub_weight = Parameter(torch.empty((0, 0), device=self.device))
+
+    # ------------------------------------------------------------------ persistence (partial_fc.py:71-87)
+    def save_params(self):
+        torch.save(self.weight.data, self.weight_name)
+        torch.save(self.weight_mom, self.weight_mom_name)
+
+    def save_FC(self):
+        torch.save(self.weight.data, os.path.join(self.prefix, "FC_rank_%d.pth" % (self.local_rank)))
+
+    def update_FC(self):
+        model_path = os.path.join(self.prefix, "FC_rank_%d.pth" % (self.local_rank))
+        self.weight.data = torch.load(model_path).to(self.device)
+        self.sub_weight = Parameter(self.weight)
+
+    def update_from_tensor(self, tensor):
+        self.weight.data = tensor.to(self.device)
+        self.sub_weight = Parameter(self.weight)
+
+    # ------------------------------------------------------------------ sampling (partial_fc.py:89-106)
+    @torch.no_grad()
+    def sample(self, total_label, perm: Optional[torch.Tensor] = None):
+        """In place on ``total_label``: labels outside this shard -> -1, inside -> local (then sampled) ids.
+        ``perm`` injects the uniform draw (parity tests); by default a counter-based HIP RNG fills it."""
+        st = _C.stream()
+        n = total_label.numel()
+        sampling = int(self.sample_rate) != 1
+        if sampling:
+            if perm is not None:
+                self._perm.copy_(perm)
+            else:
+                _C.call("fedfr_pfc_rand", self._perm.data_ptr(), self.num_local, self._seed, self._step, st)
+            self._step += 1
+        _C.call("fedfr_pfc_localize", total_label.data_ptr(), n, self.class_start, self.num_local,
+                self._perm.data_ptr() if sampling else None, st)
+        if not sampling:
+            return
+        index = torch.empty(self.num_sample, dtype=torch.int64, device=self.device)
+        _C.call("fedfr_pfc_topk", self._perm.data_ptr(), self.num_local, self.num_sample, index.data_ptr(), self._npos.data_ptr(), st)
+        npos = int(self._npos.item())                       # host sync, as torch.unique in the reference
+        if npos > self.num_sample:                          # more positives than samples: index = positives (:101-102)
+            index = torch.empty(npos, dtype=torch.int64, device=self.device)
+            _C.call("fedfr_pfc_positive", self._perm.data_ptr(), self.num_local, index.data_ptr(), self._npos.data_ptr(), st)
+        self.index = index
+        _C.call("fedfr_pfc_remap", total_label.data_ptr(), n, index.data_ptr(), index.numel(), st)
+        k = index.numel()
+        sub_w = torch.empty(k, self.embedding_size, dtype=f32, device=self.device)
+        sub_m = torch.empty(k, self.embedding_size, dtype=f32, device=self.device)
+        _C.call("fedfr_rows_gather", sub_w.data_ptr(), self.weight.data_ptr(), index.data_ptr(), k, self.embedding_size, st)
+        _C.call("fedfr_rows_gather", sub_m.data_ptr(), self.weight_mom.data_ptr(), index.data_ptr(), k, self.embedding_size, st)
+        self.sub_weight = Parameter(sub_w)
+        self.sub_weight_mom = sub_m
+
+    def forward(self, total_features, norm_weight):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return ops.sgemm(total_features, norm_weight, trans_b=True)
+
+    @torch.no_grad()
+    def update(self):
+        """scatter the sampled rows back (partial_fc.py:113-116)."""
+        st = _C.stream()
+        k = self.index.numel()
+        _C.call("fedfr_rows_scatter", self.weight_mom.data_ptr(), self.sub_weight_mom.data_ptr(), self.index.data_ptr(), k,
+                self.embedding_size, st)
+        _C.call("fedfr_rows_scatter", self.weight.data_ptr(), self.sub_weight.data.contiguous().data_ptr(), self.index.data_ptr(), k,
+                self.embedding_size, st)
+
+    # ------------------------------------------------------------------ collectives
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        if not _is_dist(self.world_size):
+            return t.clone()
+        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous())
+        return out.view((-1,) + tuple(t.shape[1:]))
+
+    def _all_reduce(self, t: torch.Tensor, op: str):
+        if _is_dist(self.world_size):
+            dist.all_reduce(t, dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+
+    def prepare(self, label, optimizer, perm=None):
+        """partial_fc.py:118-128: gather labels, sample, alias the sampled rows into the optimiser's last group."""
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_stream(torch.cuda.current_stream())
+            total_label = self._all_gather(label.to(torch.int64).contiguous())       # C1
+            self.sample(total_label, perm)
+            if optimizer is not None:
+                optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
+                optimizer.param_groups[-1]["params"][0] = self.sub_weight
+                optimizer.state[self.sub_weight]["momentum_buffer"] = self.sub_weight_mom
+            norm_weight, winv = ops.normalize_rows(self.sub_weight.data)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return total_label, norm_weight, winv
+
+    def forward_backward(self, label, features, optimizer, perm=None):
+        """partial_fc.py:130-176.  Returns (x_grad [B, D], loss_v scalar); ``self.sub_weight.grad`` is set."""
+        features = _C.require_gpu_tensor(features.detach().contiguous(), f32, "features")
+        total_label, norm_weight, winv = self.prepare(label, optimizer, perm)
+        total_features = self._all_gather(features)                                        # C2
+        logits = self.forward(total_features, norm_weight)
+        inv_batch = 1.0 / (self.batch_size * self.world_size)
+        prob_t, grad = ops.softmax_ce_grad(logits, total_label, self._s, self._m, self._arc, inv_batch,
+                                           all_reduce=self._all_reduce if _is_dist(self.world_size) else None)   # C3-C5
+        loss_v = ops.nll_mean(prob_t, 1e-30)
+        # logits.backward(grad): d total_features = grad @ norm_weight ; d norm_weight = grad^T @ total_features
+        dfeat = ops.sgemm(grad, norm_weight)
+        dwn = ops.sgemm(grad, total_features, trans_a=True)
+        self.sub_weight.grad = ops.normalize_rows_bwd(norm_weight, winv, dwn)
+        if _is_dist(self.world_size):                                                        # C6
+            x_grad = torch.empty_like(features)
+            dist.reduce_scatter_tensor(x_grad, dfeat)
+        else:
+            x_grad = dfeat
+        x_grad = x_grad * self.world_size                                                    # partial_fc.py:174
+        return x_grad, loss_v
+
+    @torch.no_grad()
+    def fused_sgd_update(self, lr, momentum=0.9, weight_decay=5e-4):
+        """Caller-side ``opt.step(); pfc.update()`` for the sampled rows as two HIP calls (momentum rows already
+        exist, so this is never a 'first' step — partial_fc.py:124-126)."""
+        sw = self.sub_weight.data
+        _C.call("fedfr_sgd_step", sw.data_ptr(), self.sub_weight.grad.data_ptr(), self.sub_weight_mom.data_ptr(), None, sw.numel(),
+                float(lr), float(momentum), float(weight_decay), 0, _C.stream())
+        if int(self.sample_rate) != 1:
+            self.update()

@@ -1,0 +1,160 @@
+"""Server side of the federated loop (reference server.py:25-46, :265-338): dataset-size-weighted
+averaging of client models, as HIP kernels over flat buffers (single process) or one RCCL all-reduce over
+xGMI when every client is its own rank (one client = one MI355X)."""
+from __future__ import annotations
+
+import copy
+import logging
+import random
+from collections import OrderedDict
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _C, backbones
+from .client import FlatStateDict, flat_state_dict
+
+f32 = torch.float32
+
+
+def _axpy(dst: torch.Tensor, src: torch.Tensor, w: float, accumulate: bool):
+    _C.call("fedfr_fedavg_axpy", dst.data_ptr(), src.data_ptr(), float(np.float32(w)), dst.numel(), 1 if accumulate else 0,
+            _C.stream())
+
+
+def FedPavg(models: List[dict], weights: Sequence[float]):
+    """Σ_i (n_i/Σn)·sd_i[k] for every key k (reference server.py:25-34).
+
+    Same op order as the reference (ascending client index, fp32 mul then add), so float entries are
+    bit-identical to it.  int64 ``num_batches_tracked`` entries come back as float32, like the reference (F9).
+    Fast path: FlatStateDicts → 3 kernels per client; generic path: one kernel per key per client.
+    """
+    tot = sum(weights)
+    ws = [w / tot for w in weights]
+    if all(isinstance(m, FlatStateDict) and m.flat is not None for m in models):
+        p0, b0, n0 = models[0].flat
+        dev = p0.device
+        if not p0.is_cuda:
+            raise RuntimeError("fedfr_amd.FedPavg: state tensors must be on the GPU (no CPU fallback)")
+        P, Bf = torch.empty_like(p0), torch.empty_like(b0)
+        N = torch.empty(n0.numel(), dtype=f32, device=dev)
+        for i, (m, w) in enumerate(zip(models, ws)):
+            p, b, n = m.flat
+            _axpy(P, p, w, i > 0)
+            _axpy(Bf, b, w, i > 0)
+            _C.call("fedfr_fedavg_i64", N.data_ptr(), n.data_ptr(), float(np.float32(w)), n.numel(), 1 if i else 0, None, _C.stream())
+        out = FlatStateDict()
+        out.flat = (P, Bf, N)
+        out.table, out.layers = models[0].table, models[0].layers
+        for name, kind, region, off, shape in out.table:
+            if region == 0:
+                if kind == backbones.iresnet.KIND_CONV:
+                    o, i_, r, _ = shape
+                    out[name] = P[off: off + o * i_ * r * r].view(o, r, r, i_).permute(0, 3, 1, 2)
+                else:
+                    num = 1
+                    for s_ in shape:
+                        num *= s_
+                    out[name] = P[off: off + num].view(shape)
+            elif region == 1:
+                out[name] = Bf[off: off + shape[0]]
+            else:
+                out[name] = N[off]
+        return out
+    aggr = OrderedDict()
+    for name in models[0]:
+        t0 = models[0][name]
+        if not t0.is_cuda:
+            raise RuntimeError("fedfr_amd.FedPavg: tensor '%s' is on %s; move state_dicts to the GPU" % (name, t0.device))
+        if t0.is_floating_point():
+            acc = torch.empty(t0.shape, dtype=f32, device=t0.device)
+            for i, (m, w) in enumerate(zip(models, ws)):
+                _axpy(acc, m[name].contiguous(), w, i > 0)
+        else:
+            acc = torch.empty(t0.shape, dtype=f32, device=t0.device)
+            for i, (m, w) in enumerate(zip(models, ws)):
+                src = m[name].contiguous().view(-1)
+                _C.call("fedfr_fedavg_i64", acc.data_ptr(), src.data_ptr(), float(np.float32(w)), src.numel(), 1 if i else 0, None,
+                        _C.stream())
+        aggr[name] = acc
+    return aggr
+
+
+def FedAvg_on_FC(pretrain_fc, models, weights, p):
+    """reference server.py:36-46."""
+    tot = sum(weights)
+    ws = [w / tot for w in weights]
+    m0 = models[0].contiguous()
+    if not m0.is_cuda:
+        raise RuntimeError("fedfr_amd.FedAvg_on_FC: tensors must be on the GPU")
+    aggr = torch.empty_like(m0)
+    for i, (m, w) in enumerate(zip(models, ws)):
+        _axpy(aggr, m.contiguous(), w, i > 0)
+    if p == 1:
+        return aggr
+    out = torch.empty_like(aggr)
+    _axpy(out, pretrain_fc.contiguous(), 1 - p, False)
+    _axpy(out, aggr, p, True)
+    return out
+
+
+def _i64_scale(acc: torch.Tensor, src: torch.Tensor, w: float):
+    _C.call("fedfr_fedavg_i64", acc.data_ptr(), src.data_ptr(), float(np.float32(w)), src.numel(), 0, None, _C.stream())
+
+
+def fedavg_all_reduce(backbone, data_size: float, group=None, _axpy=_axpy, _i64=_i64_scale):
+    """One client per rank: scale the local flat state by n_i/Σn and SUM all-reduce it over RCCL/xGMI
+    (replaces the CPU loop of server.py:25-34 + the state_dict hand-offs of server.py:286,311).  In place.
+    ``_axpy`` / ``_i64`` are the HIP scale kernels (injectable only so the collective plumbing can be exercised
+    by the 2-rank gloo CPU test)."""
+    import torch.distributed as dist
+    p, b, n = backbone.flat_state()
+    tot = torch.tensor([float(data_size)], dtype=torch.float64, device=p.device)
+    dist.all_reduce(tot, group=group)
+    w = float(data_size) / float(tot.item())
+    _axpy(p, p, w, False)
+    _axpy(b, b, w, False)
+    nf = torch.empty(n.numel(), dtype=f32, device=p.device)
+    _i64(nf, n, w)
+    dist.all_reduce(p, group=group)
+    dist.all_reduce(b, group=group)
+    dist.all_reduce(nf, group=group)
+    n.copy_(nf.to(torch.int64))          # load_state_dict's float -> int64 truncation (F9)
+    backbone.mark_weights_dirty()
+    return w
+
+
+class Server(object):
+    """Round driver (reference server.py:68-133, :265-338) for the plain FedAvg path: clients are trained
+    sequentially in one process (as the reference does, server.py:283) and averaged with ``FedPavg``."""
+
+    def __init__(self, clients, data, args, device=None):
+        self.data = data
+        self.clients = clients
+        self.args = args
+        self.num_client = len(clients)
+        self.local_epoch = args.local_epoch
+        self.global_epoch = 0
+        self.global_round = 0
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.federated_model = getattr(backbones, args.network)(False, dropout=0, fp16=True).to(self.device)
+        self.current_client_list = list(range(self.num_client))
+        self.logger = logging.getLogger("FL_face.server")
+
+    def train(self):
+        models, losses_, data_sizes = [], [], []
+        for idx, i in enumerate(self.current_client_list):
+            self.clients[i].backbone_state_dict = flat_state_dict(self.federated_model)       # "server sends backbone"
+            self.clients[i].local_epoch = self.local_epoch
+            self.clients[i].train(self.global_epoch)
+            losses_.append(self.clients[i].get_train_loss())
+            models.append(self.clients[i].get_model())
+            data_sizes.append(self.clients[i].get_data_size())
+        self.avg_loss = sum(losses_) / len(losses_)
+        if getattr(self.args, "aggr_alg", "FedAvg") in ("FedAvg", "FedProx"):
+            aggr_state_dict = FedPavg(models, data_sizes)
+            self.federated_model.load_state_dict(aggr_state_dict)
+        self.global_round += 1
+        self.global_epoch += self.local_epoch
+        return self.avg_loss

@@ -30,6 +30,11 @@ int fedfr_version(void);
 const char* fedfr_last_error_string(void);
 /* options: "tn_use_tr" (1 = ds_read_b64_tr_b16 wgrad fragments [default], 0 = scalar LDS fallback) */
 int fedfr_set_option(const char* name, int value);
+/* HIP-event timing of every MFMA GEMM launch on its own stream (bench.py roofline leg).  Slots 0..3: conv fwd/dgrad
+ * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order.
+ * enable(1) resets the counters; read() requires the stream to be synchronised; flops = sum of 2*M*N*K. */
+int fedfr_profile_enable(int on);
+int fedfr_profile_read(int slot, double* total_ms, long long* launches, double* flops);
 
 /* ------------------------------------------------------------------------------------------------
  * iresnet plan — replaces IResNet.__init__/_make_layer/forward (backbones/iresnet.py:60-172) and,
@@ -54,6 +59,11 @@ int fedfr_net_query(const fedfr_net_t* net, int what, long long* out);
  * 5 fc.bias 6 running_mean 7 running_var 8 num_batches_tracked; region: 0 params 1 bufs 2 nbt. */
 int fedfr_net_tensor_info(const fedfr_net_t* net, int i, char* name, int name_cap, int* kind, int* region,
                           long long* offset, int* ndim, int* shape4);
+/* debug/inspection: where a saved activation lives inside `act` (bf16 element offset, [rows][channels] NHWC view).
+ * block < 0: which = 0 stem conv output, 1 stem activation, 2 flattened bn2 output [B][fc_in] (NCHW order);
+ * block >= 0: which = 0 block input, 1 bn1 out, 2 conv1 out, 3 prelu(bn2) out, 4 conv2 out, 5 downsample conv out
+ * (offset -1 if the block has none), 6 block output. */
+int fedfr_net_act_info(const fedfr_net_t* net, int block, int which, long long* offset, int* rows, int* channels);
 /* refresh the bf16 weight shadows from fp32 params (after load_state_dict / an external optimizer step);
  * fwd_shadow_too = 0 when fedfr_sgd_step already wrote the mirror region. */
 int fedfr_net_prepare_weights(const fedfr_net_t* net, const float* params, uint16_t* shadow, int fwd_shadow_too,
@@ -124,9 +134,15 @@ int fedfr_margin_rowmax(float* z, const long long* label, int R, int C, int ldz,
 int fedfr_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float* row_sum, void* stream);
 int fedfr_softmax_grad(float* z, const long long* label, int R, int C, int ldz, const float* row_sum,
                        const float* dmul, float s, float inv_batch, float* prob_t, void* stream);
+int fedfr_margin_bwd(const float* dlogits, const long long* label, const float* dmul, float s, int R, int C, float* dcos,
+                     void* stream);
 int fedfr_nll_mean(const float* prob_t, int R, float floor_, float* loss, void* stream);
-int fedfr_bce(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
-              float lam, float loss_scale, float* z_out, float* dcos, float* dz, float* row_loss, void* stream);
+/* BCE personalised head: z = r*(g(cos) -/+ m) + bias, g(x) = 2((x+1)/2)^t - 1; gt[b][c] = (label[b] == c) */
+int fedfr_bce_logits(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
+                     float* z, unsigned char* gt, float* dzdcos, void* stream);
+/* row_loss[b] = sum_c bce(z, gt); dz = d(loss_scale * mean_b row_loss)/dz; dcos = dz * dzdcos (optional) */
+int fedfr_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam,
+                   float loss_scale, float* dz, float* dcos, float* row_loss, void* stream);
 int fedfr_colsum_f32(const float* x, int R, int C, float* out, void* stream);
 int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream);
 

@@ -92,18 +92,62 @@ def closed_form(shape: Sequence[int], a: float, b: float, scale: float = 1.0,
     return v.to(torch.float32).reshape(tuple(shape))
 
 
-def closed_form_state_dict(layers: Sequence[int], num_features: int = 512,
-                           in_hw: int = 112, tag: float = 0.0) -> "OrderedDict[str, torch.Tensor]":
-    """Deterministic, well-conditioned iresnet state (no RNG; ``tag`` decorrelates variants)."""
+_M64 = (1 << 64) - 1
+
+
+def _s64(v: int) -> int:
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(x: torch.Tensor, k: int) -> torch.Tensor:
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _splitmix64(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (two's-complement wrap-around == uint64 arithmetic)."""
+    x = x + _s64(0x9E3779B97F4A7C15)
+    x = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * _s64(0x94D049BB133111EB)
+    return x ^ _lsr(x, 31)
+
+
+def hash_normal(shape: Sequence[int], seed: int) -> torch.Tensor:
+    """N(0,1) samples defined by integer hashing + Box-Muller (portable: no library RNG involved)."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    i = torch.arange(n, dtype=torch.int64) + _s64(seed * 0x100000001B3 + 0x1234567)
+    h1 = _splitmix64(i)
+    h2 = _splitmix64(h1 ^ _s64(0xD6E8FEB86659FD93))
+    u1 = (_lsr(h1, 11).double() + 0.5) / float(1 << 53)
+    u2 = (_lsr(h2, 11).double() + 0.5) / float(1 << 53)
+    z = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * math.pi * u2)
+    return z.to(torch.float32).reshape(tuple(shape))
+
+
+def head_fc(num_classes: int, dim: int = 512, seed: int = 7) -> torch.Tensor:
+    """cosine-head class weights ~ N(0, 0.01) (reference init client.py:66)."""
+    return hash_normal((num_classes, dim), 900 + seed) * 0.01
+
+
+def closed_form_state_dict(layers: Sequence[int], num_features: int = 512, in_hw: int = 112, tag: float = 0.0,
+                           residual_gain: float = 0.25) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic iresnet state (no RNG; ``tag`` decorrelates variants).
+
+    ``residual_gain`` scales every block's last BN weight (bn3): like a trained ResNet, residual branches are
+    small perturbations of the identity path, which keeps the 50-100-layer train-mode-BN network well conditioned
+    (an untrained net with unit gains amplifies single bf16 roundings chaotically: emulated bf16 storage alone
+    moves iresnet100's embeddings by 20 %, which would make any end-to-end tolerance meaningless)."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for idx, (key, shape, kind) in enumerate(iresnet_spec(layers, num_features, in_hw)):
         a = 0.37 + 0.011 * (idx % 89) + 0.0007 * tag
         b = 0.13 * idx + tag
-        if kind == "conv":
+        if kind == "conv":      # He-scaled hashed Gaussians (sinusoidal filters are low-rank and collapse deep features)
             fan_in = shape[1] * shape[2] * shape[3]
-            t = closed_form(shape, a, b, scale=math.sqrt(2.0 / fan_in) * 1.5)
+            t = hash_normal(shape, idx + 1000 * int(tag)) * math.sqrt(2.0 / fan_in)
         elif kind == "fc_w":
-            t = closed_form(shape, a, b, scale=1.0 / math.sqrt(shape[1]))
+            t = hash_normal(shape, idx + 1000 * int(tag)) / math.sqrt(shape[1])
         elif kind == "fc_b":
             t = closed_form(shape, a, b, scale=0.05)
         elif kind == "bn_w":
@@ -111,6 +155,8 @@ def closed_form_state_dict(layers: Sequence[int], num_features: int = 512,
                 t = torch.ones(shape)
             else:
                 t = closed_form(shape, a, b, scale=0.25, offset=1.0)
+                if key.endswith(".bn3.weight"):
+                    t = t * residual_gain
         elif kind == "bn_b":
             t = closed_form(shape, a, b, scale=0.1)
         elif kind == "bn_rm":
@@ -128,8 +174,21 @@ def closed_form_state_dict(layers: Sequence[int], num_features: int = 512,
 
 
 def closed_form_images(batch: int, hw: int = 112, tag: float = 0.0) -> torch.Tensor:
-    """Synthetic faces in [-1, 1] (reference normalisation dataset.py:81-86)."""
-    return closed_form((batch, 3, hw, hw), 0.0173 + 0.001 * tag, 0.5 + tag, scale=1.0)
+    """Synthetic faces in [-1, 1] (reference normalisation dataset.py:81-86): every image is its own mix of
+    two plane waves + a radial blob, so a batch is as diverse as distinct identities (well-conditioned batch
+    statistics even at batch 4-8), still RNG-free."""
+    ys = torch.arange(hw, dtype=torch.float64).view(1, 1, hw, 1) / hw
+    xs = torch.arange(hw, dtype=torch.float64).view(1, 1, 1, hw) / hw
+    i = torch.arange(batch, dtype=torch.float64).view(batch, 1, 1, 1) + 1.7 * tag
+    c = torch.arange(3, dtype=torch.float64).view(1, 3, 1, 1)
+    f1, f2 = 3.0 + 1.3 * ((i * 0.618) % 1.0) * 7.0, 2.0 + ((i * 0.414) % 1.0) * 9.0
+    ph = 2.399963 * i + 0.7 * c
+    w1 = torch.sin(2 * math.pi * (f1 * xs + 0.5 * f2 * ys) + ph)
+    w2 = torch.sin(2 * math.pi * (f2 * ys - 0.3 * f1 * xs) + 1.3 * ph + c)
+    cx, cy = 0.3 + 0.4 * ((i * 0.7548) % 1.0), 0.3 + 0.4 * ((i * 0.5698) % 1.0)
+    blob = torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) * (8.0 + 4.0 * c))
+    img = 0.45 * w1 + 0.35 * w2 + 0.6 * blob - 0.2
+    return img.clamp(-1.0, 1.0).to(torch.float32)
 
 
 def closed_form_labels(batch: int, num_classes: int, tag: int = 0) -> torch.Tensor:

@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads without a GPU and exports exactly the
+symbols include/fedfr_hip.h declares; the ctypes table in fedfr_amd/_C.py covers all of them."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "fedfr_hip.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fedfr_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from fedfr_amd import _C
+    return _C
+
+
+def test_header_and_ctypes_table_agree(built_lib):
+    syms = header_symbols()
+    assert len(syms) >= 45
+    assert sorted(built_lib.SIGNATURES.keys()) == syms
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\sT\s+(fedfr_[a-z0-9_]+)", out))
+    missing = [s for s in header_symbols() if s not in exported]
+    assert not missing, missing
+    lib = built_lib.lib()
+    assert lib.fedfr_version() >= 100
+    assert lib.fedfr_last_error_string() is not None
+
+
+def test_plan_layout_matches_reference_inventory(built_lib):
+    """The C plan (host-only code, runs on CPU) reproduces the reference's parameter inventory."""
+    import ctypes as C
+    lib = built_lib.lib()
+    for layers, ntens, nparam, nbuf in (((3, 13, 30, 3), 925, 65156160, 69786), ((3, 4, 14, 3), 475, 43590848, 38223)):
+        h = lib.fedfr_net_create((C.c_int * 4)(*layers), 128, 112, 512)
+        assert h
+        q = C.c_longlong()
+        def query(k):
+            assert lib.fedfr_net_query(h, k, C.byref(q)) == 0
+            return q.value
+        assert query(built_lib.Q_NUM_TENSORS) == ntens
+        assert query(built_lib.Q_PARAM_COUNT) == nparam
+        assert query(built_lib.Q_BUFFER_COUNT) + query(built_lib.Q_NBT_COUNT) == nbuf
+        assert query(built_lib.Q_FC_IN) == 25088
+        assert query(built_lib.Q_ACT_BYTES) < 16 * 2 ** 30 and query(built_lib.Q_WS_BYTES) < 4 * 2 ** 30    # fits 288 GB easily
+        lib.fedfr_net_destroy(h)
+    # bad arguments are reported through the error string, not a crash
+    assert not lib.fedfr_net_create((C.c_int * 4)(2, 2, 2, 2), 0, 112, 512)
+    assert b"net_create" in lib.fedfr_last_error_string()
+    assert lib.fedfr_set_option(b"no_such_option", 1) != 0

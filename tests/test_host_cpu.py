@@ -1,0 +1,84 @@
+"""Host-side logic that needs no GPU: reference-compatible module tree / state_dict, flat-storage aliasing,
+loud failure without a device, FedAvg collective plumbing over 2 gloo ranks."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from fedfr_amd import backbones, client, server
+
+
+def test_state_dict_keys_shapes_and_aliasing():
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sd = R.closed_form_state_dict(layers)
+    m = backbones.iresnet18(False, dropout=0, fp16=True)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    out = m.state_dict()
+    for k, v in sd.items():
+        assert out[k].dtype == v.dtype and out[k].shape == v.shape and torch.equal(out[k], v), k
+    # conv weights are channels_last views (KRSC storage) of one flat tensor; SGD/FedAvg see one buffer
+    w = m.layer2[0].conv1.weight
+    assert w.shape == (128, 64, 3, 3) and w.stride() == (576, 1, 192, 64)
+    flat, bufs, nbt = m.flat_state()
+    assert w.data_ptr() >= flat.data_ptr() and w.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    assert not m.features.weight.requires_grad and m.fc.weight.requires_grad
+    assert sum(p.numel() for p in m.parameters()) == 24025600
+    # in-place updates through a stock optimizer hit the flat storage
+    opt = torch.optim.SGD(m.parameters(), lr=1.0)
+    m.bn1.weight.grad = torch.ones_like(m.bn1.weight)
+    before = float(flat.sum())
+    opt.step()
+    assert abs(float(flat.sum()) - (before - 64.0)) < 1e-2
+    m2 = copy.deepcopy(m)
+    m2.conv1.weight.data.zero_()
+    assert float(m.conv1.weight.abs().sum()) > 0 and float(m2._flat_params[:1728].abs().sum()) == 0.0
+
+
+def test_no_cpu_fallback():
+    m = backbones.iresnet18()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(2, 3, 112, 112))
+    with pytest.raises(RuntimeError, match="GPU"):
+        server.FedPavg([{"a": torch.ones(3)}, {"a": torch.ones(3)}], [1, 1])
+    with pytest.raises(ValueError):
+        backbones.iresnet50(pretrained=True)
+
+
+def _fedavg_worker(rank, port, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        layers = R.IRESNET_LAYERS["iresnet18"]
+        m = backbones.iresnet18()
+        m.load_state_dict(R.closed_form_state_dict(layers, tag=float(rank + 1)))
+        sizes = [300.0, 100.0]
+
+        def cpu_scale(dst, src, w, accumulate):      # test double for the HIP axpy: the collective plumbing is under test
+            assert not accumulate
+            dst.copy_(src * np.float32(w))
+        w = server.fedavg_all_reduce(m, sizes[rank], _axpy=cpu_scale, _i64=lambda acc, src, w_: acc.copy_(src.float() * np.float32(w_)))
+        assert abs(w - sizes[rank] / 400.0) < 1e-12
+        torch.save({k: v.clone() for k, v in m.state_dict().items()}, os.path.join(tmp, "r%d.pt" % rank))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_fedavg_all_reduce_two_ranks_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_fedavg_worker, args=(29655, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    ref = R.fedpavg([R.closed_form_state_dict(layers, tag=1.0), R.closed_form_state_dict(layers, tag=2.0)], [300, 100])
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                   # every client ends the round with the same model
+        if a[k].is_floating_point():
+            torch.testing.assert_close(a[k], ref[k], rtol=1e-6, atol=1e-7)
+        else:
+            assert int(a[k]) == int(ref[k])                 # F9: float average truncated back to int64

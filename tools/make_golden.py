@@ -7,7 +7,7 @@ outputs + the few generator parameters.  Re-run:  python tools/make_golden.py
 
 What is captured (reference symbol → fixture):
   backbones.iresnet.IBasicBlock           → block.npz
-  backbones.iresnet50 / iresnet100        → r50_b4.npz / r100_b2.npz  (train fwd+bwd, eval fwd)
+  backbones.iresnet50 / iresnet100        → r50_b8.npz / r100_b6.npz  (train fwd+bwd, eval fwd)
   client.FC_module, losses.CosFace/ArcFace, F.cross_entropy → heads.npz
   client.BCE_module, losses.BCE_loss      → bce.npz
   torch.optim.SGD (momentum .9, wd 5e-4)  → sgd.npz
@@ -126,7 +126,7 @@ def gen_backbone(arch, layers, batch, fname, num_classes=1000):
     model = getattr(backbones, arch)(False, dropout=0, fp16=False)
     load_closed_form(model, layers)
     fcm = client.FC_module(512, num_classes, "/tmp")
-    fcm.fc.data = R.closed_form((num_classes, 512), 0.41, 0.3, 0.01)
+    fcm.fc.data = R.head_fc(num_classes)
     x = R.closed_form_images(batch)
     lab = R.closed_form_labels(batch, num_classes)
     out = {"batch": batch, "num_classes": num_classes}
@@ -401,17 +401,17 @@ def _pfc_single_entry(q, B, C, rate, mn, s, m, steps):
 # ---- 7. client loop on iresnet18 ------------------------------------------------------------------------------
 def gen_client():
     layers = R.IRESNET_LAYERS["iresnet18"]
-    C, B, steps = 20, 4, 3
+    C, B, steps, lr = 20, 8, 3, 0.01
     model = backbones.iresnet18(False, dropout=0, fp16=False)
     load_closed_form(model, layers, tag=2.0)
     fcm = client.FC_module(512, C, "/tmp")
-    fcm.fc.data = R.closed_form((C, 512), 0.41, 0.3, 0.01)
+    fcm.fc.data = R.head_fc(C)
     model.train()
     fcm.train()
     seq = torch.nn.Sequential(model, fcm)
-    opt = torch.optim.SGD(params=seq.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    opt = torch.optim.SGD(params=seq.parameters(), lr=lr, momentum=0.9, weight_decay=5e-4)
     margin = losses.CosFace(s=30, m=0.4)
-    out = {"B": B, "C": C, "steps": steps}
+    out = {"B": B, "C": C, "steps": steps, "lr": lr}
     ls = []
     for st in range(steps):
         imgs = R.closed_form_images(B, tag=float(st))
@@ -444,9 +444,9 @@ if __name__ == "__main__":
     if "block" in which:
         gen_block()
     if "r50" in which:
-        gen_backbone("iresnet50", R.IRESNET_LAYERS["iresnet50"], 4, "r50_b4")
+        gen_backbone("iresnet50", R.IRESNET_LAYERS["iresnet50"], 8, "r50_b8")
     if "r100" in which:
-        gen_backbone("iresnet100", R.IRESNET_LAYERS["iresnet100"], 2, "r100_b2")
+        gen_backbone("iresnet100", R.IRESNET_LAYERS["iresnet100"], 6, "r100_b6")
     if "heads" in which:
         gen_heads()
     if "bce" in which:

@@ -12,6 +12,8 @@
 
 static thread_local char g_err[512] = "";
 extern int g_tn_use_tr;
+extern int g_nt_nbuf;
+extern int g_tn_target_blocks;
 
 void fedfr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -38,6 +40,14 @@ const char* fedfr_last_error_string(void) { return g_err; }
 int fedfr_set_option(const char* name, int value) {
   if (name && !strcmp(name, "tn_use_tr")) {
     g_tn_use_tr = value ? 1 : 0;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "tn_target_blocks")) {
+    g_tn_target_blocks = value > 0 ? value : 768;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "nt_nbuf")) {
+    g_nt_nbuf = value == 1 ? 1 : 2;
     return FEDFR_OK;
   }
   fedfr_set_error("set_option: unknown option '%s'", name ? name : "(null)");

@@ -46,29 +46,42 @@ __global__ __launch_bounds__(1024) void colsum_stage_kernel(const float* __restr
   }
 }
 
+// block = 32 channels x 32 row-groups.  Loads are 4-way unrolled (independent accumulators) and the cross-row-group
+// reduction is two-level (8 partial sums x 4) so the serial dependent chain stays short: these kernels are pure latency.
+__device__ __forceinline__ double rg_reduce(double v, double (*red)[33], int rg, int cl) {
+  red[rg][cl] = v;
+  __syncthreads();
+  if (rg < 4) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[rg + 4 * i][cl];
+    red[rg][cl] = t;
+  }
+  __syncthreads();
+  return (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int P, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum, float eps,
                                                           float* scale, float* shift, float* save_mean, float* save_rstd) {
   __shared__ double rs[32][33], rq[32][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int row = rg; row < P; row += 32) {
-      s += (double)part[(size_t)row * 2 * C + c];
-      q += (double)part[(size_t)row * 2 * C + C + c];
-    }
-  rs[rg][cl] = s;
-  rq[rg][cl] = q;
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    double ts = 0.0, tq = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-      ts += rs[i][cl];
-      tq += rq[i][cl];
-    }
+  const int c = min(blockIdx.x * 32 + cl, C - 1);
+  double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
+  int row = rg;
+  for (; row + 32 < P; row += 64) {
+    const float a0 = part[(size_t)row * 2 * C + c], b0 = part[(size_t)row * 2 * C + C + c];
+    const float a1 = part[(size_t)(row + 32) * 2 * C + c], b1 = part[(size_t)(row + 32) * 2 * C + C + c];
+    s0 += (double)a0; q0 += (double)b0; s1 += (double)a1; q1 += (double)b1;
+  }
+  if (row < P) {
+    s0 += (double)part[(size_t)row * 2 * C + c];
+    q0 += (double)part[(size_t)row * 2 * C + C + c];
+  }
+  const double ts = rg_reduce(s0 + s1, rs, rg, cl);
+  const double tq = rg_reduce(q0 + q1, rq, rg, cl);
+  if (rg == 0 && blockIdx.x * 32 + cl < C) {
     const double mean = ts / count;
     double var = tq / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -299,27 +312,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                               float* dbeta, float* dalpha, float* coef) {
   __shared__ double r1[32][33], r2[32][33], r3[32][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double a = 0.0, b = 0.0, d = 0.0;
-  if (c < C)
-    for (int row = rg; row < P; row += 32) {
-      const float* pr = part + (size_t)row * 3 * C;
-      a += (double)pr[c];
-      b += (double)pr[C + c];
-      d += (double)pr[2 * C + c];
-    }
-  r1[rg][cl] = a;
-  r2[rg][cl] = b;
-  r3[rg][cl] = d;
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-      t1 += r1[i][cl];
-      t2 += r2[i][cl];
-      t3 += r3[i][cl];
-    }
+  const int c = min(blockIdx.x * 32 + cl, C - 1);
+  double a0 = 0.0, b0 = 0.0, d0 = 0.0, a1 = 0.0, b1 = 0.0, d1 = 0.0;
+  int row = rg;
+  for (; row + 32 < P; row += 64) {
+    const float* p0 = part + (size_t)row * 3 * C;
+    const float* p1 = part + (size_t)(row + 32) * 3 * C;
+    const float x0 = p0[c], y0 = p0[C + c], z0 = p0[2 * C + c], x1 = p1[c], y1 = p1[C + c], z1 = p1[2 * C + c];
+    a0 += (double)x0; b0 += (double)y0; d0 += (double)z0; a1 += (double)x1; b1 += (double)y1; d1 += (double)z1;
+  }
+  if (row < P) {
+    const float* p0 = part + (size_t)row * 3 * C;
+    a0 += (double)p0[c]; b0 += (double)p0[C + c]; d0 += (double)p0[2 * C + c];
+  }
+  const double t1 = rg_reduce(a0 + a1, r1, rg, cl);
+  const double t2 = rg_reduce(b0 + b1, r2, rg, cl);
+  const double t3 = rg_reduce(d0 + d1, r3, rg, cl);
+  if (rg == 0 && blockIdx.x * 32 + cl < C) {
     if (dgamma) dgamma[c] = (float)t2;
     if (dbeta) dbeta[c] = (float)t1;
     if (dalpha) dalpha[c] = (float)t3;

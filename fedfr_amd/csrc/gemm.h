@@ -24,6 +24,7 @@ struct GemmNT {
   float* stats;           // [gridM*WM][2][N] per-column partial (sum, sumsq) of the bf16-rounded output
   int ksteps_total, ksteps_per_split;
   int nbn;                // number of N tiles (for the 1-D XCD-swizzled grid)
+  unsigned a_bytes, b_bytes;   // buffer-descriptor ranges (filled by the launcher)
 };
 
 struct GemmTN {
@@ -38,6 +39,7 @@ struct GemmTN {
   int ksteps_total, ksteps_per_split;
   int nbj;                // number of j tiles
   int use_tr;             // 1: ds_read_b64_tr_b16 fragments; 0: scalar LDS gathers (validation fallback)
+  unsigned p_bytes, q_bytes;   // buffer-descriptor ranges (filled by the launcher)
 };
 
 // rows of partial stats the NT kernel writes for a given M (needed to size / finalize)

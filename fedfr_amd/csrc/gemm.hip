@@ -63,6 +63,18 @@ int gemm_profile_read(int slot, double* total_ms, long long* launches, double* f
   return 0;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+// Tile loads are BRANCH-FREE raw buffer loads: an out-of-range lane gets voffset = num_records and the hardware
+// bounds check returns zeros.  (Predicated `if (ok) v = *p` loads made hipcc emit s_waitcnt vmcnt(0) after every
+// load, serialising the 8 loads of a K-step: 2x slower.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = id & 7, loc = id >> 3;
@@ -72,14 +84,14 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 // =====================================================================================================
 // NT kernel
 // =====================================================================================================
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   constexpr int AI = BM / 32, BI = BN / 32;             // 16-B chunks per thread per tile
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;   // 16x16 fragments per wave
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * A_BYTES;
+  unsigned char* sB = smem + NBUF * A_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -115,38 +127,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   int r = tap / p.S, s = tap - r * p.S;
 
   uint4 ra[AI], rb[BI];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  const int upm = p.up - 1, ups = p.up >> 1;     // up in {1,2}: parity mask / shift
   auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      uint4 v = zero4;
+      unsigned off;
+      bool ok = a_ok[i];
       if (p.mode == 1) {
         int hp = a_hb[i] + r, wp = a_wb[i] + s;
-        bool ok = a_ok[i];
-        if (p.up == 2) {
-          ok = ok && (((hp | wp) & 1) == 0);
-          hp >>= 1;
-          wp >>= 1;
-        }
+        ok = ok && (((hp | wp) & upm) == 0);
+        hp >>= ups;
+        wp >>= ups;
         ok = ok && (unsigned)hp < (unsigned)p.H && (unsigned)wp < (unsigned)p.W;
-        if (ok) {
-          const size_t off = (size_t)(a_pix[i] + hp * p.W + wp) * p.C + cc * 64 + ch * 8;
-          v = *reinterpret_cast<const uint4*>(p.A + off);
-        }
+        off = ((unsigned)(a_pix[i] + hp * p.W + wp) * (unsigned)p.C + (unsigned)(cc * 64 + ch * 8)) * 2u;
       } else {
         const int k = kt * 64 + ch * 8;
-        if (a_ok[i] && k < p.K) v = *reinterpret_cast<const uint4*>(p.A + (size_t)a_pix[i] * p.lda + k);
+        ok = ok && k < p.K;
+        off = ((unsigned)a_pix[i] * (unsigned)p.lda + (unsigned)k) * 2u;
       }
-      ra[i] = v;
+      ra[i] = buf_load16(rsA, ok ? off : p.a_bytes);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int n = n0 + rbase + 32 * i;
       const int k = kt * 64 + ch * 8;
-      uint4 v = zero4;
-      if (n < p.N && k < p.K) v = *reinterpret_cast<const uint4*>(p.B + (size_t)n * p.K + k);
-      rb[i] = v;
+      const unsigned off = ((unsigned)n * (unsigned)p.K + (unsigned)k) * 2u;
+      rb[i] = buf_load16(rsB, (n < p.N && k < p.K) ? off : p.b_bytes);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 
   const int l15 = lane & 15, lg = lane >> 4;
   for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
+    const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
     const bool more = kt + 1 < kt1;
     if (more) {
       advance();
@@ -212,7 +220,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = MFMA16(fb[ni], fa[mi], acc[ni][mi]);
     }
-    if (more) store_tiles(buf ^ 1);
+    if (NBUF == 1) __syncthreads();          // every wave is done reading the single buffer
+    if (more) store_tiles(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -285,24 +294,36 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   }
 }
 
+int g_nt_nbuf = 2;   // option "nt_nbuf": LDS stages of the NT kernel (1 -> 4 blocks/CU, 2 -> one barrier per K-step)
+
+template <int BM, int BN, int WM, int WN, int NBUF>
+static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st);
+
 template <int BM, int BN, int WM, int WN>
 static int launch_nt(const GemmNT& p0, int splits, hipStream_t st) {
+  if (g_nt_nbuf == 1) return launch_nt_impl<BM, BN, WM, WN, 1>(p0, splits, st);
+  return launch_nt_impl<BM, BN, WM, WN, 2>(p0, splits, st);
+}
+
+template <int BM, int BN, int WM, int WN, int NBUF>
+static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st) {
   GemmNT p = p0;
   const int nbm = ceil_div(p.M, BM);
   p.nbn = ceil_div(p.N, BN);
   p.ksteps_per_split = ceil_div(p.ksteps_total, splits);
   const int real_splits = ceil_div(p.ksteps_total, p.ksteps_per_split);
   FEDFR_REQUIRE(real_splits == splits, "gemm_nt: splits=%d leaves an empty split (ksteps=%d)", splits, p.ksteps_total);
-  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t kStage = (size_t)(BM + BN) * 128, kEpi = (size_t)BM * (BN * 2 + 16);
+  const size_t lds = (NBUF * kStage > kEpi) ? NBUF * kStage : kEpi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, NBUF>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(nbm * p.nbn, splits, 1);
   ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_nt");
   return FEDFR_OK;
 }
@@ -350,6 +371,14 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
     p.S = 1;
   }
   p.ksteps_total = ceil_div(p.K, 64);
+  {
+    const unsigned long long ab = p.mode == 1 ? 2ull * ((unsigned long long)ceil_div(p.M, p.Ho * p.Wo)) * p.H * p.W * p.C
+                                              : 2ull * (unsigned long long)p.M * p.lda;
+    const unsigned long long bb = 2ull * (unsigned long long)p.N * p.K;
+    FEDFR_REQUIRE(ab < (1ull << 32) - 64 && bb < (1ull << 32) - 64, "gemm_nt: operand larger than 4 GiB (32-bit buffer offsets)");
+    p.a_bytes = (unsigned)ab;
+    p.b_bytes = (unsigned)bb;
+  }
   const int BM = nt_bm(p.M, p.N);
   if (BM == 128) {
     if (p.N <= 64) return launch_nt<128, 64, 2, 2>(p, splits, st);
@@ -430,37 +459,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   }
   const int pc = tid % CPRP, prow = tid / CPRP;
   const int qc = tid % CPRQ, qrow = tid / CPRQ;
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
   uint4 rp[PI], rq[QI];
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(p.P, p.p_bytes), rsQ = make_rsrc(p.Q, p.q_bytes);
 
   auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < PI; ++i) {
       const int m = kt * 64 + prow + RSP * i;
       const int col = i0 + pc * 8;
-      uint4 v = zero4;
-      if (m < p.Kp && col < p.NI) v = *reinterpret_cast<const uint4*>(p.P + (size_t)m * p.ldp + col);
-      rp[i] = v;
+      const unsigned off = ((unsigned)m * (unsigned)p.ldp + (unsigned)col) * 2u;
+      rp[i] = buf_load16(rsP, (m < p.Kp && col < p.NI) ? off : p.p_bytes);
     }
 #pragma unroll
     for (int i = 0; i < QI; ++i) {
       const int m = kt * 64 + qrow + RSQ * i;
-      uint4 v = zero4;
-      if (m < p.Kp) {
-        if (p.mode == 1) {
-          const unsigned img = fdiv((unsigned)m, p.dHoWo);
-          const unsigned rem = (unsigned)m - img * p.dHoWo.d;
-          const unsigned ho = fdiv(rem, p.dWo);
-          const unsigned wo = rem - ho * p.dWo.d;
-          const int hp = (int)ho * p.stride + r - p.pad, wp = (int)wo * p.stride + s - p.pad;
-          if ((unsigned)hp < (unsigned)p.H && (unsigned)wp < (unsigned)p.W)
-            v = *reinterpret_cast<const uint4*>(p.Q + ((size_t)(img * p.H + hp) * p.W + wp) * p.C + cj0 + qc * 8);
-        } else {
-          const int col = j0 + qc * 8;
-          if (col < p.NJ) v = *reinterpret_cast<const uint4*>(p.Q + (size_t)m * p.ldq + col);
-        }
+      bool ok = m < p.Kp;
+      unsigned off;
+      if (p.mode == 1) {
+        const unsigned img = fdiv((unsigned)m, p.dHoWo);
+        const unsigned rem = (unsigned)m - img * p.dHoWo.d;
+        const unsigned ho = fdiv(rem, p.dWo);
+        const unsigned wo = rem - ho * p.dWo.d;
+        const int hp = (int)ho * p.stride + r - p.pad, wp = (int)wo * p.stride + s - p.pad;
+        ok = ok && (unsigned)hp < (unsigned)p.H && (unsigned)wp < (unsigned)p.W;
+        off = (((img * (unsigned)p.H + (unsigned)hp) * (unsigned)p.W + (unsigned)wp) * (unsigned)p.C + (unsigned)(cj0 + qc * 8)) * 2u;
+      } else {
+        const int col = j0 + qc * 8;
+        ok = ok && col < p.NJ;
+        off = ((unsigned)m * (unsigned)p.ldq + (unsigned)col) * 2u;
       }
-      rq[i] = v;
+      rq[i] = buf_load16(rsQ, ok ? off : p.q_bytes);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -527,12 +555,14 @@ void gemm_tn_tiles(int NI, int NJ, int C, int* TI, int* TJ) {
   *TJ = (w <= 64 || (w % 128) != 0) ? 64 : 128;
 }
 
+int g_tn_target_blocks = 416;   // option "tn_target_blocks"
+
 int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C) {
   int TI, TJ;
   gemm_tn_tiles(NI, NJ, C, &TI, &TJ);
   const int tiles = ceil_div(NI, TI) * ceil_div(NJ, TJ);
   const int ksteps = ceil_div(Kp, 64);
-  int splits = ceil_div(768, tiles);
+  int splits = ceil_div(g_tn_target_blocks, tiles);
   if (splits > ksteps) splits = ksteps;
   // keep >= 4 k-steps per split so the slab write does not dominate
   while (splits > 1 && ksteps / splits < 4) --splits;
@@ -567,6 +597,14 @@ int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
   FEDFR_REQUIRE(p.P && p.Q && p.out && p.Kp > 0 && p.NI > 0 && p.NJ > 0, "gemm_tn: null/empty operand");
   FEDFR_REQUIRE((p.NI & 7) == 0 && (p.NJ & 7) == 0 && (p.ldp & 7) == 0, "gemm_tn: NI, NJ, ldp must be multiples of 8");
   int TI, TJ;
+  {
+    const unsigned long long pb = 2ull * (unsigned long long)p.Kp * p.ldp;
+    const unsigned long long qb = p.mode == 1 ? 2ull * ((unsigned long long)ceil_div(p.Kp, p.Ho * p.Wo)) * p.H * p.W * p.C
+                                              : 2ull * (unsigned long long)p.Kp * p.ldq;
+    FEDFR_REQUIRE(pb < (1ull << 32) - 64 && qb < (1ull << 32) - 64, "gemm_tn: operand larger than 4 GiB (32-bit buffer offsets)");
+    p.p_bytes = (unsigned)pb;
+    p.q_bytes = (unsigned)qb;
+  }
   if (p.mode == 1) {
     FEDFR_REQUIRE((p.C & 63) == 0 && p.NJ % p.C == 0, "gemm_tn: gather needs C%%64==0 and NJ=taps*C");
     p.dHoWo = make_fastdiv((unsigned)(p.Ho * p.Wo));

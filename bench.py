@@ -28,8 +28,9 @@ import torch.distributed as dist
 
 FWD_GFLOP_PER_IMG = {"iresnet100": 24.18, "iresnet50": 12.62}       # SURVEY.md §8(d), measured on the reference
 BF16_DENSE_PEAK_TFLOPS = 2500.0                                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
-SLOT_NAMES = ["gemm_nt<128,128>", "gemm_nt<128,64>", "gemm_nt<64,128>", "gemm_nt<64,64>",
-              "gemm_tn<128,128>", "gemm_tn<128,64>", "gemm_tn<64,128>", "gemm_tn<64,64>"]
+SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kernel<64,128>", "gemm_nt_kernel<64,64>",
+              "gemm_tn_kernel<128,128>", "gemm_tn_kernel<128,64>", "gemm_tn_kernel<64,128>", "gemm_tn_kernel<64,64>",
+              "conv3x3_halo2_kernel<128,14>", "conv3x3_halo2_kernel<128,28>", "conv3x3_halo2_kernel<64,*>", "conv3x3_halo_kernel<*>"]
 
 
 def cpu_baseline(arch, batch=16, steps=2):
@@ -71,8 +72,10 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FEDFR_FORCE_DIST") == "1"      # FORCE_DIST: exercise the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from fedfr_amd import _C, backbones, client, server
@@ -87,13 +90,13 @@ def main():
     labs = [torch.randint(0, NC, (B,), generator=g).to(dev) for _ in range(nbuf)]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         tr.step(imgs[i % nbuf], labs[i % nbuf])
-    if world > 1:
+    if use_dist:
         server.fedavg_all_reduce(model, 1000.0 + rank)            # warm the RCCL communicator
         model.refresh_shadows(True)
     barrier()
@@ -101,13 +104,14 @@ def main():
     for i in range(args.steps):
         loss = tr.step(imgs[i % nbuf], labs[i % nbuf])
     t_local = None
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         t_local = time.perf_counter() - t0
         server.fedavg_all_reduce(model, 1000.0 + rank)
+        model.refresh_shadows(True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt, t_local], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, dist.ReduceOp.MAX)
         dt, t_local = float(tt[0]), float(tt[1])
@@ -122,7 +126,7 @@ def main():
             tr.step(imgs[i % nbuf], labs[i % nbuf])
         torch.cuda.synchronize()
         rows = []
-        for slot in range(8):
+        for slot in range(len(SLOT_NAMES)):
             ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
             _C.call("fedfr_profile_read", slot, C.byref(ms), C.byref(n), C.byref(fl))
             if n.value:
@@ -166,11 +170,11 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        if world > 1:
+        if use_dist:
             out["fedavg_round_ms"] = round(dt * 1e3, 3)
             out["fedavg_exchange_ms"] = round((dt - t_local) * 1e3, 3)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -13,6 +13,7 @@
 static thread_local char g_err[512] = "";
 extern int g_tn_use_tr;
 extern int g_nt_nbuf;
+extern int g_conv_halo;
 extern int g_tn_target_blocks;
 
 void fedfr_set_error(const char* fmt, ...) {
@@ -44,6 +45,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "tn_target_blocks")) {
     g_tn_target_blocks = value > 0 ? value : 768;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "conv_halo")) {
+    g_conv_halo = value;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "nt_nbuf")) {

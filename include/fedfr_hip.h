@@ -31,7 +31,8 @@ const char* fedfr_last_error_string(void);
 /* options: "tn_use_tr" (1 = ds_read_b64_tr_b16 wgrad fragments [default], 0 = scalar LDS fallback) */
 int fedfr_set_option(const char* name, int value);
 /* HIP-event timing of every MFMA GEMM launch on its own stream (bench.py roofline leg).  Slots 0..3: conv fwd/dgrad
- * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order.
+ * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order; 8..11: the
+ * LDS-halo 3x3 conv kernels conv3x3_halo2<128,14>, <128,28>, <64,*>, conv3x3_halo (v1).
  * enable(1) resets the counters; read() requires the stream to be synchronised; flops = sum of 2*M*N*K. */
 int fedfr_profile_enable(int on);
 int fedfr_profile_read(int slot, double* total_ms, long long* launches, double* flops);

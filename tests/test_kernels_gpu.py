@@ -44,6 +44,14 @@ CONV_CASES = [
     (1, 14, 256, 256, 3, 1),     # M = 196: ragged M tile
     (5, 8, 512, 512, 3, 2),
     (40, 14, 256, 256, 3, 1),    # M = 7840 -> 128-row tiles with tail
+    # large-M 3x3/s1 shapes take the LDS-halo kernel (fwd + dgrad): every halo size, BN = 64 / 128, ragged M
+    (131, 14, 256, 256, 3, 1),
+    (17, 56, 64, 64, 3, 1),
+    (4, 112, 64, 128, 3, 1),
+    (9, 112, 64, 64, 3, 1),
+    (65, 28, 128, 128, 3, 1),
+    (260, 14, 64, 64, 3, 1),     # zero-padded-image kernel, BN = 64 instantiation
+    (131, 28, 128, 256, 3, 1),
 ]
 
 

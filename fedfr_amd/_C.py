@@ -38,6 +38,7 @@ SIGNATURES = {
     "fedfr_conv2d_stat_rows": (i32, [i32, i32, i32]),
     "fedfr_conv2d_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fedfr_conv2d_dgrad_bnbwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp]),
     "fedfr_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "fedfr_conv2d_wgrad": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_weight_shadows": (i32, [vp, vp, vp, i32, i32, i32, vp]),
@@ -95,6 +96,11 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        # tuning / validation switches: FEDFR_OPTIONS="halo_waves=8,conv_halo=1" (see fedfr_set_option)
+        for kv in filter(None, os.environ.get("FEDFR_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            if l.fedfr_set_option(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError("FEDFR_OPTIONS: " + l.fedfr_last_error_string().decode())
     return _lib
 
 

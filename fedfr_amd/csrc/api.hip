@@ -14,6 +14,8 @@ static thread_local char g_err[512] = "";
 extern int g_tn_use_tr;
 extern int g_nt_nbuf;
 extern int g_conv_halo;
+extern int g_halo_bn64;
+extern int g_halo_waves;
 extern int g_tn_target_blocks;
 
 void fedfr_set_error(const char* fmt, ...) {
@@ -45,6 +47,14 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "tn_target_blocks")) {
     g_tn_target_blocks = value > 0 ? value : 768;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "halo_waves")) {
+    g_halo_waves = value == 8 ? 8 : 4;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "halo_bn64")) {
+    g_halo_bn64 = value ? 1 : 0;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "conv_halo")) {
@@ -172,6 +182,21 @@ int fedfr_conv2d_dgrad(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int
     p.mode = 1; p.M = batch * hin * hin; p.H = hout; p.W = hout; p.C = cout; p.Ho = hin; p.Wo = hin; p.S = 3;
     p.stride = 1; p.pad = 1; p.up = stride;
   }
+  return gemm_nt_launch(p, 1, ST(stream));
+}
+int fedfr_conv2d_dgrad_bnbwd(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int batch, int hin, int cin, int cout, int ksize,
+                             int stride, const uint16_t* bn_x, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, const float* alpha, float* partials, int* fused_rows, void* stream) {
+  FEDFR_TRY(conv_args_ok(batch, hin, cin, cout, ksize, stride));
+  FEDFR_REQUIRE(dy && wd && dx && bn_x && mean && rstd && partials && fused_rows && ksize == 3, "conv2d_dgrad_bnbwd: bad args");
+  const int hout = hin / stride;
+  GemmNT p{};
+  p.A = BF(dy); p.B = BF(wd); p.N = cin; p.K = 9 * cout; p.Cb = BFM(dx); p.ldc = cin;
+  p.mode = 1; p.M = batch * hin * hin; p.H = hout; p.W = hout; p.C = cout; p.Ho = hin; p.Wo = hin; p.S = 3;
+  p.stride = 1; p.pad = 1; p.up = stride;
+  p.bx = BF(bn_x); p.bmean = mean; p.brstd = rstd; p.bgamma = gamma; p.bbeta = beta; p.balpha = alpha; p.bpart = partials;
+  *fused_rows = 0;
+  p.bwd_fused = fused_rows;
   return gemm_nt_launch(p, 1, ST(stream));
 }
 size_t fedfr_conv2d_wgrad_ws_bytes(int batch, int hin, int cin, int cout, int ksize, int stride) {

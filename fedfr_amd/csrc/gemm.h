@@ -25,6 +25,14 @@ struct GemmNT {
   int ksteps_total, ksteps_per_split;
   int nbn;                // number of N tiles (for the 1-D XCD-swizzled grid)
   unsigned a_bytes, b_bytes;   // buffer-descriptor ranges (filled by the launcher)
+  // optional fused BatchNorm-backward reduction on the OUTPUT tile (dgrad launches): with dy = this GEMM's bf16
+  // output and x = the BN input [M][N], writes per-M-tile partials [ceil(M/128)][3][N] of (sum dz, sum dz*xhat,
+  // sum dy*min(z,0)) exactly like ew_bn_bwd_reduce.  Only the halo2 kernel implements it: *bwd_fused (host) is set
+  // to the number of partial rows when it did, left untouched otherwise.
+  const bf16_t* bx;
+  const float *bmean, *brstd, *bgamma, *bbeta, *balpha;
+  float* bpart;
+  int* bwd_fused;
 };
 
 struct GemmTN {
@@ -33,7 +41,7 @@ struct GemmTN {
   int Kp, NI, NJ;
   int mode;               // 0 plain; 1 conv gather (row p -> (img,ho,wo) of the dy tensor)
   int H, W, C, Ho, Wo, S, stride, pad;
-  FastDiv dHoWo, dWo;
+  FastDiv dHoWo, dWo, dHo;
   int ldp, ldq;
   float* out;             // [splits][NI][NJ]
   int ksteps_total, ksteps_per_split;

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
       advance();
       load_tiles(kt + 1);
     }
-    const unsigned char* cA = sA + buf * A_BYTES;
+        const unsigned char* cA = sA + buf * A_BYTES;
     const unsigned char* cB = sB + buf * B_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -522,6 +522,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmNT p, int a_bytes
   }
 }
 
+int g_halo_waves = 4;  // option "halo_waves": 4 or 8 waves per 128x128 tile in the halo2 kernel
+int g_halo_bn64 = 0;   // option "halo_bn64": 64-wide N tiles in the halo2 kernel (more, smaller blocks)
 int g_conv_halo = 2;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1
 
 template <int BN, int AH>
@@ -552,14 +554,14 @@ static int launch_halo(GemmNT p, hipStream_t st) {
 // 160-byte row stride (conflict-free for ds_read_b128 without XOR) + W as a template constant the 9 tap offsets
 // are instruction immediates.  v1 spent 136 VALU instructions per 32 MFMAs on masks and swizzled addresses.
 // =====================================================================================================
-template <int BN, int W_>
-__global__ __launch_bounds__(256) void conv3x3_halo2_kernel(GemmNT p, int nr_rows) {
-  constexpr int BM = 128, WM = 2, WN = 2, PW = W_ + 2, RS = 160;
-  constexpr int BI = BN / 32;
+template <int BN, int W_, int WN>   // WN = 2: 4 waves (64x64 wave tiles at BN=128); WN = 4: 8 waves (64x32)
+__global__ __launch_bounds__(128 * WN) void conv3x3_halo2_kernel(GemmNT p, int nr_rows) {
+  constexpr int BM = 128, WM = 2, PW = W_ + 2, RS = 160, NT = 64 * WM * WN;
+  constexpr int BI = BN * 8 / NT, BROWS = NT / 8;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int B_BYTES = BN * 128;
   constexpr int NSRC = BM + 2 * W_ + 2;                 // source pixels a tile can touch
-  constexpr int AH = (NSRC * 8 + 255) / 256;
+  constexpr int AH = (NSRC * 8 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
   const int a_bytes_lds = (nr_rows * RS + 255) & ~255;
@@ -582,14 +584,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo2_kernel(GemmNT p, int nr_row
   const int qb = qof(m0) - (PW + 1);
 
   // zero the whole image once: padding positions are never written afterwards
-  for (int i = tid * 16; i < a_bytes_lds; i += 256 * 16) *reinterpret_cast<uint4*>(sA + i) = make_uint4(0, 0, 0, 0);
+  for (int i = tid * 16; i < a_bytes_lds; i += NT * 16) *reinterpret_cast<uint4*>(sA + i) = make_uint4(0, 0, 0, 0);
 
   // staging plan (same rows every chunk): source byte offset (without the channel-chunk term) and LDS destination
   unsigned src_off[AH];
   int dst_off[AH];
 #pragma unroll
   for (int i = 0; i < AH; ++i) {
-    const int e = tid + 256 * i;
+    const int e = tid + NT * i;
     const int rl = e >> 3, c = e & 7;
     const int pix = m0 - (W_ + 1) + rl;
     bool ok = rl < NSRC && (unsigned)pix < (unsigned)npix;
@@ -627,14 +629,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo2_kernel(GemmNT p, int nr_row
     const unsigned koff = (unsigned)(tap * p.C + cc * 64) * 2u;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int n = n0 + rbase + 32 * i;
-      rb[i] = buf_load16(rsB, n < p.N ? b_row0 + (unsigned)(32 * i) * (unsigned)p.K * 2u + koff : p.b_bytes);
+      const int n = n0 + rbase + BROWS * i;
+      rb[i] = buf_load16(rsB, n < p.N ? b_row0 + (unsigned)(BROWS * i) * (unsigned)p.K * 2u + koff : p.b_bytes);
     }
   };
   const int b_st = rbase * 128 + ((ch ^ (rbase & 7)) << 4);
   auto store_b = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + b_st + i * 32 * 128) = rb[i];
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + b_st + i * BROWS * 128) = rb[i];
   };
   int b_addr[TN];
 #pragma unroll
@@ -738,15 +740,72 @@ __global__ __launch_bounds__(256) void conv3x3_halo2_kernel(GemmNT p, int nr_row
   }
   __syncthreads();
   constexpr int CPR = BN / 8;
-  for (int idx = tid; idx < BM * CPR; idx += 256) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    const int m = m0 + row, n = n0 + c * 8;
-    if (m < p.M && n < p.N)
-      *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+  if (p.bpart == nullptr) {
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int m = m0 + row, n = n0 + c * 8;
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+    }
+    return;
+  }
+  // ---- fused BN-backward reduction: this thread owns chunk column c (8 channels) of rows rg, rg + NT/CPR, ... ----
+  constexpr int RG = NT / CPR;
+  const int c = tid % CPR, rg = tid / CPR;
+  const int n = n0 + c * 8;
+  const bool n_ok = n < p.N;
+  float mean[8], rstd[8], ga[8], be[8], al[8], s1[8], s2[8], s3[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int nn = n_ok ? n + q : 0;
+    mean[q] = p.bmean[nn]; rstd[q] = p.brstd[nn];
+    ga[q] = p.bgamma ? p.bgamma[nn] : 1.f; be[q] = p.bbeta ? p.bbeta[nn] : 0.f; al[q] = p.balpha ? p.balpha[nn] : 1.f;
+    s1[q] = s2[q] = s3[q] = 0.f;
+  }
+  const bool has_alpha = p.balpha != nullptr;
+  for (int row = rg; row < BM; row += RG) {
+    const int m = m0 + row;
+    if (m < p.M && n_ok) {
+      const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+      *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = dv;
+      float dy[8], xv[8];
+      unpack8(dv, dy);
+      unpack8(*reinterpret_cast<const uint4*>(p.bx + (size_t)m * p.N + n), xv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float xh = (xv[q] - mean[q]) * rstd[q];
+        float dz = dy[q];
+        if (has_alpha) {
+          const float z = ga[q] * xh + be[q];
+          if (z <= 0.f) {
+            s3[q] += dy[q] * z;
+            dz = dy[q] * al[q];
+          }
+        }
+        s1[q] += dz;
+        s2[q] += dz * xh;
+      }
+    }
+  }
+  __syncthreads();                                   // everyone is done reading the staged C tile
+  float* red = reinterpret_cast<float*>(smem);       // [RG][3][BN]
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    red[(rg * 3 + 0) * BN + c * 8 + q] = s1[q];
+    red[(rg * 3 + 1) * BN + c * 8 + q] = s2[q];
+    red[(rg * 3 + 2) * BN + c * 8 + q] = s3[q];
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * BN; i += NT) {
+    const int which = i / BN, col = i - which * BN;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) t += red[(r * 3 + which) * BN + col];
+    if (n0 + col < p.N) p.bpart[((size_t)bm * 3 + which) * p.N + n0 + col] = t;
   }
 }
 
-template <int BN, int W_>
+template <int BN, int W_, int WN>
 static int launch_halo2(GemmNT p, hipStream_t st) {
   const int nbm = ceil_div(p.M, 128);
   p.nbn = ceil_div(p.N, BN);
@@ -763,18 +822,23 @@ static int launch_halo2(GemmNT p, hipStream_t st) {
   }
   const int nr = span + 2 * (PW + 1) + 1;
   const size_t a_lds = ((size_t)nr * 160 + 255) & ~(size_t)255;
-  constexpr size_t kEpi = (size_t)128 * (BN * 2 + 16);
+  constexpr size_t kEpi = (size_t)128 * (BN * 2 + 16), kRed = (size_t)(128 * WN / (BN / 8)) * 3 * BN * sizeof(float);
   size_t lds = a_lds + 2 * (size_t)BN * 128;
   if (lds < kEpi) lds = kEpi;
+  if (lds < kRed) lds = kRed;
   FEDFR_REQUIRE(lds <= 160 * 1024, "conv3x3_halo2: LDS image too large (%zu bytes)", lds);
+  if (p.bpart) {
+    FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_halo2: fused BN-bwd reduction needs bx/mean/rstd and ldc == N");
+    if (p.bwd_fused) *p.bwd_fused = nbm;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<BN, W_>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<BN, W_, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
     attr_set = true;
   }
   ProfScope prof(BN == 64 ? 10 : (W_ == 14 ? 8 : 9), 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_halo2_kernel<BN, W_>), dim3(nbm * p.nbn), dim3(256), lds, st, p, nr);
+  hipLaunchKernelGGL((conv3x3_halo2_kernel<BN, W_, WN>), dim3(nbm * p.nbn), dim3(128 * WN), lds, st, p, nr);
   FEDFR_LAUNCH_CHECK("conv3x3_halo2");
   return FEDFR_OK;
 }
@@ -834,8 +898,9 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
   if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
     if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
-      if (p.W == 14) return p.N <= 64 ? launch_halo2<64, 14>(p, st) : launch_halo2<128, 14>(p, st);
-      return p.N <= 64 ? launch_halo2<64, 28>(p, st) : launch_halo2<128, 28>(p, st);
+      const bool bn64 = p.N <= 64 || g_halo_bn64;
+      if (p.W == 14) return bn64 ? launch_halo2<64, 14, 2>(p, st) : (g_halo_waves == 8 ? launch_halo2<128, 14, 4>(p, st) : launch_halo2<128, 14, 2>(p, st));
+      return bn64 ? launch_halo2<64, 28, 2>(p, st) : (g_halo_waves == 8 ? launch_halo2<128, 28, 4>(p, st) : launch_halo2<128, 28, 2>(p, st));
     }
     const int ah = ceil_div((128 + 2 * p.W + 2) * 8, 256);
     if (p.N <= 64) {
@@ -864,35 +929,39 @@ __device__ __forceinline__ int tn_swz(int row) {
   return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
 }
 
-template <int RB, bool USE_TR>
-__device__ __forceinline__ bf16x8_t tn_frag(const unsigned char* tile, int ks, int colblk, int lane) {
-  // returns this lane's 8 reduction-consecutive elements (pixels ks*32 + 8*(lane>>4) + j) of column colblk + (lane&15)
+// per-lane byte offset (inside one LDS stage) of the first tr-read of the fragment for column block `colblk`;
+// the second read is +4*RB, the ks=1 half +32*RB (the swizzle only depends on row bits 0-1 and 3, which those
+// offsets do not touch), so every in-loop address is base + register + immediate.
+template <int RB>
+__device__ __forceinline__ int tn_frag_off(int colblk, int lane) {
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int col = colblk + 4 * pp;
+  const int r0 = 8 * g + q;
+  return r0 * RB + (((col >> 3) ^ tn_swz<RB>(r0)) << 4) + ((col >> 2) & 1) * 8;
+}
+template <int RB>
+__device__ __forceinline__ bf16x8_t tn_frag_tr(const unsigned char* stage, int off, int ks) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const unsigned char* a0 = stage + off + ks * 32 * RB;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * RB));
+  s16x8_t v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+template <int RB>   // validation fallback: scalar LDS gathers (no transpose-read instruction)
+__device__ __forceinline__ bf16x8_t tn_frag_scalar(const unsigned char* tile, int ks, int colblk, int lane) {
   const int g = lane >> 4, li = lane & 15;
-  if (USE_TR) {
-    const int q = li >> 2, pp = li & 3;
-    const int col = colblk + 4 * pp;
-    const int c = col >> 3, half = (col >> 2) & 1;
-    const int r0 = ks * 32 + 8 * g + q, r1 = r0 + 4;
-    const unsigned char* a0 = tile + r0 * RB + ((c ^ tn_swz<RB>(r0)) << 4) + half * 8;
-    const unsigned char* a1 = tile + r1 * RB + ((c ^ tn_swz<RB>(r1)) << 4) + half * 8;
-    typedef __attribute__((address_space(3))) s16x4_t* lds_p;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
-    s16x8_t v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(bf16x8_t, v);
-  } else {
-    const int col = colblk + li;
-    const int c = col >> 3, e = col & 7;
-    s16x8_t v;
+  const int col = colblk + li;
+  const int c = col >> 3, e = col & 7;
+  s16x8_t v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int rr = ks * 32 + 8 * g + j;
-      v[j] = *reinterpret_cast<const short*>(tile + rr * RB + ((c ^ tn_swz<RB>(rr)) << 4) + e * 2);
-    }
-    return __builtin_bit_cast(bf16x8_t, v);
+  for (int j = 0; j < 8; ++j) {
+    const int rr = ks * 32 + 8 * g + j;
+    v[j] = *reinterpret_cast<const short*>(tile + rr * RB + ((c ^ tn_swz<RB>(rr)) << 4) + e * 2);
   }
+  return __builtin_bit_cast(bf16x8_t, v);
 }
 
 template <int TI, int TJ, bool USE_TR>
@@ -900,8 +969,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   constexpr int WI = 2, WJ = 2;
   constexpr int RBP = TI * 2, RBQ = TJ * 2;             // tile row bytes
   constexpr int CPRP = TI / 8, CPRQ = TJ / 8;           // chunks per row
-  constexpr int RSP = 256 / CPRP, RSQ = 256 / CPRQ;     // rows covered per pass
-  constexpr int PI = 64 / RSP, QI = 64 / RSQ;           // chunks per thread
+  constexpr int PI = 64 * CPRP / 256, QI = 64 * CPRQ / 256;   // chunks per thread = CONSECUTIVE rows per thread
   constexpr int FI = TI / WI / 16, FJ = TJ / WJ / 16;
   constexpr int P_BYTES = 64 * RBP, Q_BYTES = 64 * RBQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -917,59 +985,90 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   const int kt0 = split * p.ksteps_per_split;
   const int kt1 = min(kt0 + p.ksteps_per_split, p.ksteps_total);
 
-  int r = 0, s = 0, cj0 = j0;
+  // thread -> (chunk column, PI/QI consecutive rows)
+  const int pc = tid % CPRP, prow0 = (tid / CPRP) * PI;
+  const int qc = tid % CPRQ, qrow0 = (tid / CPRQ) * QI;
+  // filter tap of THIS THREAD's column chunk (a 128-wide j tile spans two taps when Cin == 64)
+  int r = 0, s = 0, cj0 = j0 + qc * 8;
   if (p.mode == 1) {
-    const int tap = j0 / p.C;
-    cj0 = j0 - tap * p.C;
+    const int col = min(j0 + qc * 8, p.NJ - 8);
+    const int tap = col / p.C;
+    cj0 = col - tap * p.C;
     r = tap / p.S;
     s = tap - r * p.S;
   }
-  const int pc = tid % CPRP, prow = tid / CPRP;
-  const int qc = tid % CPRQ, qrow = tid / CPRQ;
-  uint4 rp[PI], rq[QI];
   const __amdgpu_buffer_rsrc_t rsP = make_rsrc(p.P, p.p_bytes), rsQ = make_rsrc(p.Q, p.q_bytes);
+  uint4 rp[PI], rq[QI];
+  int pst[PI], qst[QI];                                  // LDS store offsets (loop invariant)
+#pragma unroll
+  for (int i = 0; i < PI; ++i) pst[i] = (prow0 + i) * RBP + ((pc ^ tn_swz<RBP>(prow0 + i)) << 4);
+#pragma unroll
+  for (int i = 0; i < QI; ++i) qst[i] = (qrow0 + i) * RBQ + ((qc ^ tn_swz<RBQ>(qrow0 + i)) << 4);
+  const bool pcol_ok = i0 + pc * 8 < p.NI;
+  unsigned poff = ((unsigned)(kt0 * 64 + prow0) * (unsigned)p.ldp + (unsigned)(i0 + pc * 8)) * 2u;   // row prow0 of step kt0
+  const unsigned pstep = 64u * (unsigned)p.ldp * 2u, prow_b = (unsigned)p.ldp * 2u;
+  // gather state of this thread's first Q row: pixel (img, ho, wo) of m = kt*64 + qrow0, advanced by 64 pixels per step
+  int q_img = 0, q_ho = 0, q_wo = 0;
+  const int dW = 64 % max(p.Wo, 1), dH = 64 / max(p.Wo, 1);
+  unsigned qoff_plain = 0;
+  const bool qcol_ok = j0 + qc * 8 < p.NJ;
+  if (p.mode == 1) {
+    const unsigned m = (unsigned)(kt0 * 64 + qrow0);
+    const unsigned img = fdiv(m, p.dHoWo), rem = m - img * p.dHoWo.d;
+    const unsigned ho = fdiv(rem, p.dWo);
+    q_img = (int)img; q_ho = (int)ho; q_wo = (int)(rem - ho * p.dWo.d);
+  } else {
+    qoff_plain = ((unsigned)(kt0 * 64 + qrow0) * (unsigned)p.ldq + (unsigned)(j0 + qc * 8)) * 2u;
+  }
+  const unsigned qstep = 64u * (unsigned)p.ldq * 2u, qrow_b = (unsigned)p.ldq * 2u;
+  const unsigned qchan = (unsigned)cj0;
 
   auto load_tiles = [&](int kt) {
+    const int mrow = kt * 64;
 #pragma unroll
-    for (int i = 0; i < PI; ++i) {
-      const int m = kt * 64 + prow + RSP * i;
-      const int col = i0 + pc * 8;
-      const unsigned off = ((unsigned)m * (unsigned)p.ldp + (unsigned)col) * 2u;
-      rp[i] = buf_load16(rsP, (m < p.Kp && col < p.NI) ? off : p.p_bytes);
-    }
+    for (int i = 0; i < PI; ++i)
+      rp[i] = buf_load16(rsP, (pcol_ok && mrow + prow0 + i < p.Kp) ? poff + (unsigned)i * prow_b : p.p_bytes);
+    poff += pstep;
+    if (p.mode == 1) {
+      int img = q_img, ho = q_ho, wo = q_wo;
 #pragma unroll
-    for (int i = 0; i < QI; ++i) {
-      const int m = kt * 64 + qrow + RSQ * i;
-      bool ok = m < p.Kp;
-      unsigned off;
-      if (p.mode == 1) {
-        const unsigned img = fdiv((unsigned)m, p.dHoWo);
-        const unsigned rem = (unsigned)m - img * p.dHoWo.d;
-        const unsigned ho = fdiv(rem, p.dWo);
-        const unsigned wo = rem - ho * p.dWo.d;
-        const int hp = (int)ho * p.stride + r - p.pad, wp = (int)wo * p.stride + s - p.pad;
-        ok = ok && (unsigned)hp < (unsigned)p.H && (unsigned)wp < (unsigned)p.W;
-        off = (((img * (unsigned)p.H + (unsigned)hp) * (unsigned)p.W + (unsigned)wp) * (unsigned)p.C + (unsigned)(cj0 + qc * 8)) * 2u;
-      } else {
-        const int col = j0 + qc * 8;
-        ok = ok && col < p.NJ;
-        off = ((unsigned)m * (unsigned)p.ldq + (unsigned)col) * 2u;
+      for (int i = 0; i < QI; ++i) {
+        const int hp = ho * p.stride + r - p.pad, wp = wo * p.stride + s - p.pad;
+        const bool ok = qcol_ok && mrow + qrow0 + i < p.Kp && (unsigned)hp < (unsigned)p.H && (unsigned)wp < (unsigned)p.W;
+        const unsigned off = (((unsigned)(img * p.H + hp) * (unsigned)p.W + (unsigned)wp) * (unsigned)p.C + qchan) * 2u;
+        rq[i] = buf_load16(rsQ, ok ? off : p.q_bytes);
+        if (++wo == p.Wo) {                      // next consecutive output pixel
+          wo = 0;
+          if (++ho == p.Ho) { ho = 0; ++img; }
+        }
       }
-      rq[i] = buf_load16(rsQ, ok ? off : p.q_bytes);
+      // advance the first row by 64 pixels
+      q_wo += dW;
+      int carry = q_wo >= p.Wo ? 1 : 0;
+      q_wo -= carry * p.Wo;
+      q_ho += dH + carry;
+      const unsigned t = fdiv((unsigned)q_ho, p.dHo);
+      q_ho -= (int)t * p.Ho;
+      q_img += (int)t;
+    } else {
+#pragma unroll
+      for (int i = 0; i < QI; ++i)
+        rq[i] = buf_load16(rsQ, (qcol_ok && mrow + qrow0 + i < p.Kp) ? qoff_plain + (unsigned)i * qrow_b : p.q_bytes);
+      qoff_plain += qstep;
     }
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < PI; ++i) {
-      const int row = prow + RSP * i;
-      *reinterpret_cast<uint4*>(sP + buf * P_BYTES + row * RBP + ((pc ^ tn_swz<RBP>(row)) << 4)) = rp[i];
-    }
+    for (int i = 0; i < PI; ++i) *reinterpret_cast<uint4*>(sP + buf * P_BYTES + pst[i]) = rp[i];
 #pragma unroll
-    for (int i = 0; i < QI; ++i) {
-      const int row = qrow + RSQ * i;
-      *reinterpret_cast<uint4*>(sQ + buf * Q_BYTES + row * RBQ + ((qc ^ tn_swz<RBQ>(row)) << 4)) = rq[i];
-    }
+    for (int i = 0; i < QI; ++i) *reinterpret_cast<uint4*>(sQ + buf * Q_BYTES + qst[i]) = rq[i];
   };
+
+  int foq[FJ], fop[FI];
+#pragma unroll
+  for (int tj = 0; tj < FJ; ++tj) foq[tj] = tn_frag_off<RBQ>(wj * (TJ / WJ) + tj * 16, lane);
+#pragma unroll
+  for (int ti = 0; ti < FI; ++ti) fop[ti] = tn_frag_off<RBP>(wi * (TI / WI) + ti * 16, lane);
 
   f32x4_t acc[FJ][FI];
 #pragma unroll
@@ -992,9 +1091,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t fq[FJ], fp[FI];
 #pragma unroll
-      for (int tj = 0; tj < FJ; ++tj) fq[tj] = tn_frag<RBQ, USE_TR>(cQ, ks, wj * (TJ / WJ) + tj * 16, lane);
+      for (int tj = 0; tj < FJ; ++tj)
+        fq[tj] = USE_TR ? tn_frag_tr<RBQ>(cQ, foq[tj], ks) : tn_frag_scalar<RBQ>(cQ, ks, wj * (TJ / WJ) + tj * 16, lane);
 #pragma unroll
-      for (int ti = 0; ti < FI; ++ti) fp[ti] = tn_frag<RBP, USE_TR>(cP, ks, wi * (TI / WI) + ti * 16, lane);
+      for (int ti = 0; ti < FI; ++ti)
+        fp[ti] = USE_TR ? tn_frag_tr<RBP>(cP, fop[ti], ks) : tn_frag_scalar<RBP>(cP, ks, wi * (TI / WI) + ti * 16, lane);
 #pragma unroll
       for (int tj = 0; tj < FJ; ++tj)
 #pragma unroll
@@ -1018,8 +1119,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 
 void gemm_tn_tiles(int NI, int NJ, int C, int* TI, int* TJ) {
   *TI = (NI <= 64) ? 64 : 128;
-  const int w = C > 0 ? C : NJ;
-  *TJ = (w <= 64 || (w % 128) != 0) ? 64 : 128;
+  (void)C;                                   // tiles may straddle taps: the tap is decoded per thread column chunk
+  *TJ = (NJ <= 64) ? 64 : 128;
 }
 
 int g_tn_target_blocks = 416;   // option "tn_target_blocks"
@@ -1076,6 +1177,7 @@ int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
     FEDFR_REQUIRE((p.C & 63) == 0 && p.NJ % p.C == 0, "gemm_tn: gather needs C%%64==0 and NJ=taps*C");
     p.dHoWo = make_fastdiv((unsigned)(p.Ho * p.Wo));
     p.dWo = make_fastdiv((unsigned)p.Wo);
+    p.dHo = make_fastdiv((unsigned)p.Ho);
     FEDFR_REQUIRE((long long)p.Kp * (long long)(p.Ho * p.Wo) < (1ll << 40), "gemm_tn: fastdiv range");
     gemm_tn_tiles(p.NI, p.NJ, p.C, &TI, &TJ);
   } else {

@@ -211,9 +211,15 @@ static int conv_fwd(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* out
   p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = stats ? c.part() : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
-// dx (at the conv's INPUT resolution) = conv_transpose(dy)
-static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* dx) {
+// dx (at the conv's INPUT resolution) = conv_transpose(dy).  If `bn` is given, the kernel may also produce the
+// BN-backward partial sums of (dx, bn_x) in its epilogue; *fused_rows > 0 then (else run ew_bn_bwd_reduce).
+static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* dx, const BnD* bn = nullptr,
+                      const bf16_t* bn_x = nullptr, const float* alpha = nullptr, int* fused_rows = nullptr) {
   GemmNT p{};
+  if (bn && fused_rows) {
+    p.bx = bn_x; p.bmean = c.save(*bn, 2); p.brstd = c.save(*bn, 3); p.bgamma = c.gamma(*bn); p.bbeta = c.beta(*bn);
+    p.balpha = alpha; p.bpart = c.part(); p.bwd_fused = fused_rows;
+  }
   p.B = c.shadow + cv.wd_off; p.A = dy;
   p.N = cv.Cin; p.K = cv.R * cv.R * cv.Cout;
   p.Cb = dx; p.ldc = cv.Cin; p.Cf = nullptr; p.stats = nullptr;
@@ -323,12 +329,12 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
 }
 
 static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
-                  const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off) {
+                  const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, int fused_rows = 0) {
   BnBwd p{};
   p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.beta = c.beta(b); p.alpha = alpha;
   p.M = M; p.C = b.C; p.partials = c.part(); p.coef = c.coef(); p.add = add; p.add_up = add_up; p.H = H; p.W = H; p.dx = dx;
-  FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));
-  FEDFR_TRY(ew_bn_bwd_finalize(c.part(), ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 3), c.grads + b.g_off,
+  if (fused_rows <= 0) FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));      // else: the producing dgrad kernel already wrote the partials
+  FEDFR_TRY(ew_bn_bwd_finalize(c.part(), fused_rows > 0 ? fused_rows : ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 3), c.grads + b.g_off,
                                c.grads + b.b_off, alpha ? c.grads + alpha_off : nullptr, c.coef(), c.st));
   return ew_bn_bwd_apply(p, c.st);
 }
@@ -372,19 +378,24 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     // out = bn3(c2) + identity
     FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, c.t(0), 0));
     FEDFR_TRY(conv_wgrad(c, k.conv2, A + k.a2_off, c.t(0)));
-    FEDFR_TRY(conv_dgrad(c, k.conv2, c.t(0), c.t(1)));
+    int f2 = 0, f1 = 0;
+    FEDFR_TRY(conv_dgrad(c, k.conv2, c.t(0), c.t(1), &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
     // a2 = prelu(bn2(c1))
-    FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, c.t(1), A + k.c1_off, Mi, nullptr, nullptr, 0, c.t(2), k.alpha_off));
+    FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, c.t(1), A + k.c1_off, Mi, nullptr, nullptr, 0, c.t(2), k.alpha_off, f2));
     FEDFR_TRY(conv_wgrad(c, k.conv1, A + k.a1_off, c.t(2)));
-    FEDFR_TRY(conv_dgrad(c, k.conv1, c.t(2), c.t(3)));
-    // a1 = bn1(x); identity path
+    // identity path first (its BN reduction uses the shared partial buffer), then conv1's dgrad whose epilogue may
+    // leave bn1's partial sums there for the bn_bwd that follows immediately
     if (k.has_ds) {
       FEDFR_TRY(bn_bwd(c, k.bnds, nullptr, g, A + k.d_off, Mo, nullptr, nullptr, 0, c.t(4), 0));
       FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, c.t(4)));
       FEDFR_TRY(conv_dgrad(c, k.ds, c.t(4), c.t(5)));
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, nullptr, c.t(5), k.Hin, gin, 0));
+    }
+    FEDFR_TRY(conv_dgrad(c, k.conv1, c.t(2), c.t(3), &k.bn1, A + k.x_off, nullptr, &f1));
+    // a1 = bn1(x)
+    if (k.has_ds) {
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, nullptr, c.t(5), k.Hin, gin, 0, f1));
     } else {
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, g, nullptr, 0, gin, 0));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, g, nullptr, 0, gin, 0, f1));
     }
     cur ^= 1;
   }

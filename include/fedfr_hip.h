@@ -86,6 +86,13 @@ int fedfr_conv2d_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* s
                      int cout, int ksize, int stride, void* stream);
 int fedfr_conv2d_dgrad(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int batch, int hin, int cin, int cout,
                        int ksize, int stride, void* stream);
+/* dgrad whose epilogue may also reduce the BatchNorm backward sums of (dx, bn_x): partials [rows][3][cin] =
+ * (sum dz, sum dz*xhat, sum dx*min(z,0)).  *fused_rows (host int) = rows written, or 0 if this geometry is not fused
+ * (then call fedfr_bn_bwd, which reduces itself). */
+int fedfr_conv2d_dgrad_bnbwd(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int batch, int hin, int cin, int cout,
+                             int ksize, int stride, const uint16_t* bn_x, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, const float* alpha, float* partials, int* fused_rows,
+                             void* stream);
 size_t fedfr_conv2d_wgrad_ws_bytes(int batch, int hin, int cin, int cout, int ksize, int stride);
 int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* ws, size_t ws_bytes, int batch, int hin,
                        int cin, int cout, int ksize, int stride, void* stream);

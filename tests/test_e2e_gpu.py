@@ -245,6 +245,33 @@ def test_client_server_round():
     assert not torch.equal(m0["conv1.weight"], m1["conv1.weight"])
 
 
+def test_large_batch_train_step_vs_oracle():
+    """iresnet18 at batch 128: M = 25088..1.6M rows, so the conv layers run on the LDS-halo kernels (incl. the fused
+    BN-backward reduction) that the small-batch goldens never reach.  Compared with the fp32 oracle on the same inputs."""
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    B, C = 128, 100
+    m, sd, _ = make_model("iresnet18", tag=3.0)
+    m.train()
+    fcm = client.FC_module(512, C, "/tmp").to(DEV)
+    fc0 = R.head_fc(C)
+    fcm.fc.data = fc0.clone().to(DEV)
+    x, lab = R.closed_form_images(B), R.closed_form_labels(B, C)
+    cosine = client.Sequential_model(m, fcm)(x.to(DEV))
+    loss = ops.cross_entropy(losses.CosFace(s=30, m=0.4)(cosine, lab.to(DEV)), lab.to(DEV))
+    loss.backward()
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    f_ref, c_ref, l_ref, g_ref, fcg_ref = R.train_step_grads(sd, fc0.clone(), x, lab, layers)
+    assert rel(cosine, c_ref) < 5e-2, rel(cosine, c_ref)
+    assert abs(float(loss) - l_ref) < 5e-3 * abs(l_ref)
+    params = dict(m.named_parameters())
+    names = [k for k in R.trainable_keys(sd) if float(g_ref[k].norm()) > 1e-6 * max(float(v.norm()) for v in g_ref.values())]
+    nerr = np.array([abs(float(params[k].grad.norm()) - float(g_ref[k].norm())) / float(g_ref[k].norm()) for k in names])
+    derr = np.array([rel(params[k].grad, g_ref[k]) for k in names])
+    assert np.median(nerr) < 1e-2 and nerr.max() < 0.15, (np.median(nerr), nerr.max(), names[int(np.argmax(nerr))])
+    assert np.median(derr) < 0.15 and derr.max() < 0.6, (np.median(derr), derr.max(), names[int(np.argmax(derr))])
+    assert rel(fcm.fc.grad, fcg_ref) < 5e-2
+
+
 def test_heads_vs_reference():
     g = load_golden("heads")
     B, C = int(g["B"]), int(g["C"])

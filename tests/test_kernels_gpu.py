@@ -110,6 +110,50 @@ def test_conv_dgrad(B, H, Cin, Cout, k, s):
     assert torch.equal(wb.float().cpu(), w.permute(0, 2, 3, 1))   # shadow cast is exact for bf16-valued weights
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,prelu", [(131, 14, 256, 256, True), (65, 28, 128, 128, False), (2, 14, 64, 64, True)])
+def test_conv_dgrad_fused_bn_bwd_reduction(B, H, Cin, Cout, prelu):
+    """dgrad epilogue also reduces (sum dz, sum dz*xhat, sum dx*min(z,0)) of the BN that precedes the conv."""
+    x, w = _conv_inputs(B, H, Cin, Cout, 3, 1)
+    dy = bf(rnd((B, Cout, H, H), 7))
+    d = dev()
+    wk = w.permute(0, 2, 3, 1).contiguous().to(d)
+    wdb = torch.empty(Cin, 3, 3, Cout, dtype=torch.bfloat16, device=d)
+    _C.call("fedfr_weight_shadows", wk.data_ptr(), None, wdb.data_ptr(), Cout, 3, Cin, _C.stream())
+    dyd = nhwc(dy).to(d)
+    bnx = bf(rnd((B * H * H, Cin), 9) * 1.5 + 0.2).to(d)
+    mean, rstd = (rnd((Cin,), 10) * 0.2).to(d), (rnd((Cin,), 11) * 0.2 + 1.0).to(d)
+    gamma, beta, alpha = (rnd((Cin,), 12) * 0.2 + 1).to(d), (rnd((Cin,), 13) * 0.3).to(d), (rnd((Cin,), 14) * 0.1 + 0.25).to(d)
+    dx = torch.empty(B, H, H, Cin, dtype=torch.bfloat16, device=d)
+    part = torch.full((((B * H * H + 127) // 128), 3, Cin), float("nan"), device=d)
+    rows = C.c_int(0)
+    _C.call("fedfr_conv2d_dgrad_bnbwd", dyd.data_ptr(), wdb.data_ptr(), dx.data_ptr(), B, H, Cin, Cout, 3, 1, bnx.data_ptr(),
+            mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), alpha.data_ptr() if prelu else None,
+            part.data_ptr(), C.byref(rows), _C.stream())
+    torch.cuda.synchronize()
+    # plain dgrad result is unchanged by the fusion
+    dx_ref = torch.empty_like(dx)
+    _C.call("fedfr_conv2d_dgrad", dyd.data_ptr(), wdb.data_ptr(), dx_ref.data_ptr(), B, H, Cin, Cout, 3, 1, _C.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    if B * H * H < 384 * 128 // 2:          # small problems take the generic kernel: no fusion, caller reduces itself
+        assert rows.value == 0
+        return
+    assert rows.value == (B * H * H + 127) // 128
+    g = dx.float().reshape(-1, Cin).double()
+    xh = (bnx.float().double() - mean.double()) * rstd.double()
+    dz = g.clone()
+    s3 = torch.zeros(Cin, dtype=torch.float64, device=d)
+    if prelu:
+        z = gamma.double() * xh + beta.double()
+        neg = z <= 0
+        s3 = (g * z * neg).sum(0)
+        dz = torch.where(neg, g * alpha.double(), g)
+    got = part[: rows.value].double().sum(0)
+    for i, ref in enumerate((dz.sum(0), (dz * xh).sum(0), s3)):
+        scale = float(ref.abs().max()) + 1e-6
+        assert float((got[i] - ref).abs().max()) < 2e-4 * scale + 1e-2, i
+
+
 @pytest.mark.parametrize("use_tr", [1, 0])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,s", CONV_CASES)
 def test_conv_wgrad(B, H, Cin, Cout, k, s, use_tr):

@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--arch", default="iresnet100", choices=["iresnet100", "iresnet50"])
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--head", default="dense", choices=["dense", "pfc"],
+                    help="dense: CosFace + dense cosine head (headline); pfc: ArcFace + PartialFC sample_rate 0.1 (BASELINE config 3; use --classes 85000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -82,8 +84,15 @@ def main():
     torch.manual_seed(100 + rank)                                  # reference seed 100 (train.py:35)
     B, NC = args.batch, args.classes
     model = getattr(backbones, args.arch)(False, dropout=0, fp16=True).to(dev)     # reference init (random weights)
-    fc = (torch.randn(NC, 512) * 0.01).to(dev)                                    # client.py:66
-    tr = client.FusedTrainer(model, fc, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    if args.head == "pfc":
+        from fedfr_amd import losses
+        from fedfr_amd.partial_fc import PartialFC
+        fc = PartialFC(rank=0, local_rank=local_rank, world_size=1, batch_size=B, resume=False,
+                       margin_softmax=losses.ArcFace(s=30, m=0.4), num_classes=NC, sample_rate=0.1, embedding_size=512, prefix="/tmp")
+        tr = client.FusedTrainer(model, fc, "ArcFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    else:
+        fc = (torch.randn(NC, 512) * 0.01).to(dev)                                # client.py:66
+        tr = client.FusedTrainer(model, fc, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4)
     g = torch.Generator().manual_seed(100 + rank)
     nbuf = 4
     imgs = [(torch.rand(B, 3, 112, 112, generator=g) * 2 - 1).to(dev) for _ in range(nbuf)]   # already resident in HBM
@@ -144,7 +153,7 @@ def main():
                                               "tflops": round(f / (m_ * 1e-3) / 1e12, 1)} for m_, k, f, s in rows]}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
         cpu = cpu_baseline(args.arch)
 
     if rank == 0:
@@ -157,10 +166,11 @@ def main():
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s + CosFace(s=30,m=0.4) + dense %d-class cosine head, full train step "
+            "config": {"workload": "%s + %s, full train step "
                                    "(fwd+bwd+momentum-SGD), batch %d/GPU, 112x112 synthetic faces, random-init weights, "
                                    "bf16 activations/weights with fp32 accumulate + fp32 master weights, fp32 head"
-                                   % (args.arch, NC, B),
+                                   % (args.arch, ("CosFace(s=30,m=0.4) + dense %d-class cosine head" % NC) if args.head == "dense"
+                                      else ("ArcFace(s=30,m=0.4) + PartialFC sample_rate 0.1 over %d classes" % NC), B),
                        "global_batch": world * B, "parallelism": "1 client per GPU (FedAvg), dp%d" % world,
                        "clients": world},
             "images_per_sec_per_gpu": round(value / world, 1),

@@ -73,8 +73,8 @@ SIGNATURES = {
     "fedfr_pfc_topk": (i32, [vp, i32, i32, vp, vp, vp]),
     "fedfr_pfc_positive": (i32, [vp, i32, vp, vp, vp]),
     "fedfr_pfc_remap": (i32, [vp, i32, vp, i32, vp]),
-    "fedfr_rows_gather": (i32, [vp, vp, vp, i32, i32, vp]),
-    "fedfr_rows_scatter": (i32, [vp, vp, vp, i32, i32, vp]),
+    "fedfr_rows_gather": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "fedfr_rows_scatter": (i32, [vp, vp, vp, i32, i32, i32, vp]),
 }
 
 # query keys (include/fedfr_hip.h)

@@ -183,8 +183,14 @@ class FusedTrainer:
     zero_grad; logits = fc(backbone(imgs)); logits = margin(logits, labels); loss = CE; backward; SGD step.
     """
 
-    def __init__(self, backbone: "backbones.IResNet", fc: torch.Tensor, loss_name: str = "CosFace", s: float = 30.0,
+    def __init__(self, backbone: "backbones.IResNet", fc, loss_name: str = "CosFace", s: float = 30.0,
                  m: float = 0.4, lr: float = 0.1, momentum: float = 0.9, weight_decay: float = 5e-4):
+        """``fc``: a dense class-weight tensor [C, 512] (FC_module.fc.data), or a ``PartialFC`` instance — then the head is the
+        sampled / class-sharded softmax (its margin comes from the PartialFC's own ``margin_softmax``)."""
+        from .partial_fc import PartialFC
+        self.pfc = fc if isinstance(fc, PartialFC) else None
+        if self.pfc is not None:
+            fc = self.pfc.weight
         if loss_name not in ("CosFace", "ArcFace"):
             raise ValueError("loss must be CosFace or ArcFace")
         self.bb = backbone
@@ -196,8 +202,9 @@ class FusedTrainer:
         bb.train()
         self.n_train = bb.trainable_count()
         self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
-        self.fc_mom = torch.empty_like(self.fc)
-        self.fc_grad = torch.empty_like(self.fc)
+        if self.pfc is None:
+            self.fc_mom = torch.empty_like(self.fc)
+            self.fc_grad = torch.empty_like(self.fc)
         self.first = True
         bb.refresh_shadows(True)
 
@@ -216,6 +223,14 @@ class FusedTrainer:
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1, st)
         bb._flat_nbt += 1
         bb._fwd_generation += 1
+        if self.pfc is not None:
+            # upstream PartialFC protocol: normalised embeddings in, d(embedding) out
+            fn, finv = ops.normalize_rows(feats)
+            x_grad, loss = self.pfc.forward_backward(labels, fn, None)
+            dfeats = ops.normalize_rows_bwd(fn, finv, x_grad.contiguous())
+            _C.call("fedfr_net_backward", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                    bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st)
+            return loss
         # head: cosine logits -> margin -> softmax CE, gradient wrt cosine written in place
         fn, finv = ops.normalize_rows(feats)
         wn, winv = ops.normalize_rows(self.fc)
@@ -237,8 +252,11 @@ class FusedTrainer:
         first = 1 if self.first else 0
         _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                 bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, first, st)
-        _C.call("fedfr_sgd_step", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
-                self.lr, self.mu, self.wd, first, st)
+        if self.pfc is not None:
+            self.pfc.fused_sgd_update(self.lr, self.mu, self.wd)      # sampled rows: SGD + scatter back
+        else:
+            _C.call("fedfr_sgd_step", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
+                    self.lr, self.mu, self.wd, first, st)
         bb.refresh_shadows(False)       # dgrad-layout copies; the bf16 mirror was written by the SGD kernel
         self.first = False
 

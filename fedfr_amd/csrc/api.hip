@@ -354,11 +354,11 @@ int fedfr_pfc_positive(const float* perm, int n, long long* index, int* count, v
 int fedfr_pfc_remap(long long* label, int n, const long long* index, int k, void* stream) {
   return optim_pfc_remap(label, n, index, k, ST(stream));
 }
-int fedfr_rows_gather(float* dst, const float* src, const long long* index, int k, int D, void* stream) {
-  return optim_rows(dst, src, index, k, D, 0, ST(stream));
+int fedfr_rows_gather(float* dst, const float* src, const long long* index, int k, int D, int table_rows, void* stream) {
+  return optim_rows(dst, src, index, k, D, 0, table_rows, ST(stream));
 }
-int fedfr_rows_scatter(float* dst, const float* src, const long long* index, int k, int D, void* stream) {
-  return optim_rows(dst, src, index, k, D, 1, ST(stream));
+int fedfr_rows_scatter(float* dst, const float* src, const long long* index, int k, int D, int table_rows, void* stream) {
+  return optim_rows(dst, src, index, k, D, 1, table_rows, ST(stream));
 }
 
 }  // extern "C"

@@ -11,4 +11,4 @@ int optim_pfc_localize(long long* label, int n, long long class_start, int num_l
 int optim_pfc_topk(const float* perm, int n, int k, long long* index, int* npos_out, hipStream_t st);
 int optim_pfc_positive(const float* perm, int n, long long* index, int* count, hipStream_t st);
 int optim_pfc_remap(long long* label, int n, const long long* index, int k, hipStream_t st);
-int optim_rows(float* dst, const float* src, const long long* index, int k, int D, int scatter, hipStream_t st);
+int optim_rows(float* dst, const float* src, const long long* index, int k, int D, int scatter, int nrows, hipStream_t st);

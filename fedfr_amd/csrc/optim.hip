@@ -282,17 +282,18 @@ int optim_pfc_remap(long long* label, int n, const long long* index, int k, hipS
 
 // row gather / scatter (fp32 rows of D floats, D % 4 == 0), one wave per row
 __global__ __launch_bounds__(256) void rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                   const long long* __restrict__ index, int k, int D, int scatter) {
+                                                   const long long* __restrict__ index, int k, int D, int scatter, int nrows) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= k) return;
   const long long r = index[row];
+  if (r < 0 || r >= nrows) return;                     // never touch memory outside the indexed table
   const float4* s = reinterpret_cast<const float4*>(src + (scatter ? (size_t)row : (size_t)r) * D);
   float4* d = reinterpret_cast<float4*>(dst + (scatter ? (size_t)r : (size_t)row) * D);
   for (int i = lane; i < D / 4; i += 64) d[i] = s[i];
 }
-int optim_rows(float* dst, const float* src, const long long* index, int k, int D, int scatter, hipStream_t st) {
-  FEDFR_REQUIRE(dst && src && index && k > 0 && D > 0 && (D & 3) == 0, "rows gather/scatter: bad args");
-  hipLaunchKernelGGL(rows_kernel, dim3(ceil_div(k, 4)), dim3(256), 0, st, dst, src, index, k, D, scatter);
+int optim_rows(float* dst, const float* src, const long long* index, int k, int D, int scatter, int nrows, hipStream_t st) {
+  FEDFR_REQUIRE(dst && src && index && k > 0 && D > 0 && (D & 3) == 0 && nrows > 0, "rows gather/scatter: bad args");
+  hipLaunchKernelGGL(rows_kernel, dim3(ceil_div(k, 4)), dim3(256), 0, st, dst, src, index, k, D, scatter, nrows);
   FEDFR_LAUNCH_CHECK("rows");
   return FEDFR_OK;
 }

@@ -65,8 +65,10 @@ class PartialFC(Module):
             self.weight_mom = None
         if getattr(self, "weight_mom", None) is None:
             self.weight_mom = torch.zeros_like(self.weight)
-        # the reference keeps a side stream for label gather + sampling (partial_fc.py:61,119)
-        self.stream = torch.cuda.Stream(self.device)
+        # The reference overlaps label gather + sampling on a side stream (partial_fc.py:61,119).  Here sampling is ~30 us of
+        # kernels, and side-stream allocations consumed by main-stream kernels would need record_stream() bookkeeping, so
+        # everything is enqueued on the caller's current stream; the attribute is kept for API compatibility.
+        self.stream = torch.cuda.current_stream(self.device)
         self.index = None
         self._seed, self._step = int(seed) * 1000003 + rank, 0
         self._perm = torch.empty(self.num_local, dtype=f32, device=self.device)
@@ -129,13 +131,12 @@ class PartialFC(Module):
         k = index.numel()
         sub_w = torch.empty(k, self.embedding_size, dtype=f32, device=self.device)
         sub_m = torch.empty(k, self.embedding_size, dtype=f32, device=self.device)
-        _C.call("fedfr_rows_gather", sub_w.data_ptr(), self.weight.data_ptr(), index.data_ptr(), k, self.embedding_size, st)
-        _C.call("fedfr_rows_gather", sub_m.data_ptr(), self.weight_mom.data_ptr(), index.data_ptr(), k, self.embedding_size, st)
+        _C.call("fedfr_rows_gather", sub_w.data_ptr(), self.weight.data_ptr(), index.data_ptr(), k, self.embedding_size, self.num_local, st)
+        _C.call("fedfr_rows_gather", sub_m.data_ptr(), self.weight_mom.data_ptr(), index.data_ptr(), k, self.embedding_size, self.num_local, st)
         self.sub_weight = Parameter(sub_w)
         self.sub_weight_mom = sub_m
 
     def forward(self, total_features, norm_weight):
-        torch.cuda.current_stream().wait_stream(self.stream)
         return ops.sgemm(total_features, norm_weight, trans_b=True)
 
     @torch.no_grad()
@@ -143,10 +144,11 @@ class PartialFC(Module):
         """scatter the sampled rows back (partial_fc.py:113-116)."""
         st = _C.stream()
         k = self.index.numel()
+        sw = self.sub_weight.data.contiguous()
         _C.call("fedfr_rows_scatter", self.weight_mom.data_ptr(), self.sub_weight_mom.data_ptr(), self.index.data_ptr(), k,
-                self.embedding_size, st)
-        _C.call("fedfr_rows_scatter", self.weight.data_ptr(), self.sub_weight.data.contiguous().data_ptr(), self.index.data_ptr(), k,
-                self.embedding_size, st)
+                self.embedding_size, self.num_local, st)
+        _C.call("fedfr_rows_scatter", self.weight.data_ptr(), sw.data_ptr(), self.index.data_ptr(), k, self.embedding_size,
+                self.num_local, st)
 
     # ------------------------------------------------------------------ collectives
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
@@ -162,16 +164,13 @@ class PartialFC(Module):
 
     def prepare(self, label, optimizer, perm=None):
         """partial_fc.py:118-128: gather labels, sample, alias the sampled rows into the optimiser's last group."""
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_stream(torch.cuda.current_stream())
-            total_label = self._all_gather(label.to(torch.int64).contiguous())       # C1
-            self.sample(total_label, perm)
-            if optimizer is not None:
-                optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
-                optimizer.param_groups[-1]["params"][0] = self.sub_weight
-                optimizer.state[self.sub_weight]["momentum_buffer"] = self.sub_weight_mom
-            norm_weight, winv = ops.normalize_rows(self.sub_weight.data)
-        torch.cuda.current_stream().wait_stream(self.stream)
+        total_label = self._all_gather(label.to(torch.int64).contiguous())       # C1
+        self.sample(total_label, perm)
+        if optimizer is not None:
+            optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
+            optimizer.param_groups[-1]["params"][0] = self.sub_weight
+            optimizer.state[self.sub_weight]["momentum_buffer"] = self.sub_weight_mom
+        norm_weight, winv = ops.normalize_rows(self.sub_weight.data)
         return total_label, norm_weight, winv
 
     def forward_backward(self, label, features, optimizer, perm=None):

@@ -168,8 +168,9 @@ int fedfr_pfc_localize(long long* label, int n, long long class_start, int num_l
 int fedfr_pfc_topk(const float* perm, int n, int k, long long* index, int* npos_out, void* stream);
 int fedfr_pfc_positive(const float* perm, int n, long long* index, int* count, void* stream);
 int fedfr_pfc_remap(long long* label, int n, const long long* index, int k, void* stream);
-int fedfr_rows_gather(float* dst, const float* src, const long long* index, int k, int D, void* stream);
-int fedfr_rows_scatter(float* dst, const float* src, const long long* index, int k, int D, void* stream);
+/* dst[i] = table[index[i]] / table[index[i]] = src[i]; rows of D floats; indices outside [0, table_rows) are skipped */
+int fedfr_rows_gather(float* dst, const float* table, const long long* index, int k, int D, int table_rows, void* stream);
+int fedfr_rows_scatter(float* table, const float* src, const long long* index, int k, int D, int table_rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -388,6 +388,33 @@ def test_partial_fc_w1_vs_reference(name):
         assert abs(float(pfc.weight.double().sum()) - float(g[pre + "weight_sum"])) < 1e-3
 
 
+def test_partial_fc_config3_scale_properties():
+    """BASELINE config 3 head at full size (85 000 classes, sample_rate 0.1 -> 8 500 sampled rows, ArcFace) driven by
+    the fused trainer on iresnet18: size-independent properties of the sampled-softmax step."""
+    C, B = 85000, 64
+    m, sd, _ = make_model("iresnet18", tag=1.0)
+    pfc = PartialFC(rank=0, local_rank=0, world_size=1, batch_size=B, resume=False, margin_softmax=losses.ArcFace(s=30, m=0.4),
+                    num_classes=C, sample_rate=0.1, embedding_size=512, prefix="/tmp")
+    w0, m0 = pfc.weight.clone(), pfc.weight_mom.clone()
+    tr = client.FusedTrainer(m, pfc, "ArcFace", 30.0, 0.4, lr=0.01)
+    lab = ((R.closed_form_labels(B, C, tag=1) * 977) % C).to(DEV)
+    loss = tr.step(R.closed_form_images(B).to(DEV), lab)
+    torch.cuda.synchronize()
+    idx = pfc.index
+    assert idx.numel() == 8500 and bool((idx[1:] > idx[:-1]).all())                 # sorted, unique (partial_fc.py:100)
+    assert bool(torch.isin(lab, idx).all())                                        # every positive class is sampled (:98)
+    assert np.isfinite(float(loss)) and 5.0 < float(loss) < 40.0      # ~ ln(8500) + s*(1 - cos(theta + m)) for random weights
+    changed = (pfc.weight != w0).any(dim=1)
+    assert bool(changed[idx].all()) and int(changed.sum()) == 8500                 # only sampled rows were updated (:113-116)
+    assert bool(((pfc.weight_mom != m0).any(dim=1) == changed).all())
+    # further steps draw different negative sets and keep the invariants (also under back-to-back asynchronous enqueueing)
+    for st in range(6):
+        tr.step(R.closed_form_images(B, tag=1.0 + st).to(DEV), lab)
+    torch.cuda.synchronize()
+    assert pfc.index.numel() == 8500 and not torch.equal(pfc.index, idx)
+    assert bool(torch.isfinite(pfc.weight).all()) and float(pfc.weight.abs().max()) < 1.0
+
+
 def test_cpu_tensor_is_rejected_loudly():
     m = backbones.iresnet18()
     with pytest.raises(RuntimeError, match="MI355X"):

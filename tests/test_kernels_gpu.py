@@ -412,16 +412,22 @@ def test_rows_gather_scatter_and_remap():
     w = rnd((1000, 512), 1).to(d)
     index = torch.tensor(sorted(np.random.RandomState(0).choice(1000, 100, replace=False)), dtype=torch.int64, device=d)
     sub = torch.empty(100, 512, device=d)
-    _C.call("fedfr_rows_gather", sub.data_ptr(), w.data_ptr(), index.data_ptr(), 100, 512, _C.stream())
+    _C.call("fedfr_rows_gather", sub.data_ptr(), w.data_ptr(), index.data_ptr(), 100, 512, 1000, _C.stream())
     torch.cuda.synchronize()
     assert torch.equal(sub, w[index])
     w2 = w.clone()
     sub2 = (sub * 2).contiguous()
-    _C.call("fedfr_rows_scatter", w2.data_ptr(), sub2.data_ptr(), index.data_ptr(), 100, 512, _C.stream())
+    _C.call("fedfr_rows_scatter", w2.data_ptr(), sub2.data_ptr(), index.data_ptr(), 100, 512, 1000, _C.stream())
     torch.cuda.synchronize()
     ref = w.clone()
     ref[index] = sub * 2
     assert torch.equal(w2, ref)
+    # out-of-range indices are ignored (never a wild access)
+    bad = torch.tensor([5, -3, 10 ** 9, 7], dtype=torch.int64, device=d)
+    w3 = w.clone()
+    _C.call("fedfr_rows_scatter", w3.data_ptr(), sub2.data_ptr(), bad.data_ptr(), 4, 512, 1000, _C.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(w3[5], sub2[0]) and torch.equal(w3[7], sub2[3]) and torch.equal(w3[6], w[6])
     lab = torch.tensor([int(index[3]), -1, int(index[99]), int(index[0])], dtype=torch.int64, device=d)
     _C.call("fedfr_pfc_remap", lab.data_ptr(), 4, index.data_ptr(), 100, _C.stream())
     torch.cuda.synchronize()

@@ -206,6 +206,9 @@ class FusedTrainer:
             self.fc_mom = torch.empty_like(self.fc)
             self.fc_grad = torch.empty_like(self.fc)
         self.first = True
+        # weight-gradient GEMMs run on a second HIP stream (fedfr_net_backward2) unless FEDFR_DUAL_STREAM=0
+        import os
+        self.aux_stream = torch.cuda.Stream(device=bb.device) if os.environ.get("FEDFR_DUAL_STREAM", "1") != "0" else None
         bb.refresh_shadows(True)
 
     def set_lr(self, lr: float):
@@ -228,8 +231,7 @@ class FusedTrainer:
             fn, finv = ops.normalize_rows(feats)
             x_grad, loss = self.pfc.forward_backward(labels, fn, None)
             dfeats = ops.normalize_rows_bwd(fn, finv, x_grad.contiguous())
-            _C.call("fedfr_net_backward", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
-                    bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st)
+            self._backward(plan, imgs, dfeats, st)
             return loss
         # head: cosine logits -> margin -> softmax CE, gradient wrt cosine written in place
         fn, finv = ops.normalize_rows(feats)
@@ -242,9 +244,17 @@ class FusedTrainer:
         dfeats = ops.normalize_rows_bwd(fn, finv, dfn)
         _C.call("fedfr_normalize_rows_bwd", wn.data_ptr(), winv.data_ptr(), dwn.data_ptr(), self.fc_grad.data_ptr(),
                 wn.shape[0], wn.shape[1], 0.0, st)
-        _C.call("fedfr_net_backward", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
-                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st)
+        self._backward(plan, imgs, dfeats, st)
         return loss
+
+    def _backward(self, plan, imgs, dfeats, st):
+        bb = self.bb
+        if getattr(self, "_shadows_pending", False):
+            torch.cuda.current_stream().wait_stream(self.aux_stream)      # dgrad shadows rebuilt on aux after the last SGD step
+            self._shadows_pending = False
+        _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
+                self.aux_stream.cuda_stream if self.aux_stream is not None else None)
 
     def optimizer_step(self):
         bb = self.bb
@@ -257,7 +267,16 @@ class FusedTrainer:
         else:
             _C.call("fedfr_sgd_step", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
                     self.lr, self.mu, self.wd, first, st)
-        bb.refresh_shadows(False)       # dgrad-layout copies; the bf16 mirror was written by the SGD kernel
+        # dgrad-layout weight copies (only needed by the NEXT backward; the forward mirror was written by the SGD kernel):
+        # rebuilt on the aux stream so they overlap the next forward pass
+        if self.aux_stream is not None:
+            main = torch.cuda.current_stream()
+            self.aux_stream.wait_stream(main)
+            with torch.cuda.stream(self.aux_stream):
+                bb.refresh_shadows(False)
+            self._shadows_pending = True
+        else:
+            bb.refresh_shadows(False)
         self.first = False
 
     def step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:

@@ -88,7 +88,11 @@ fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_
   }
   return net_create(layers4, batch, in_hw, num_features);
 }
-void fedfr_net_destroy(fedfr_net_t* net) { delete net; }
+void fedfr_net_destroy(fedfr_net_t* net) {
+  if (!net) return;
+  for (auto e : net->events) (void)hipEventDestroy(e);
+  delete net;
+}
 int fedfr_net_query(const fedfr_net_t* n, int what, long long* out) {
   FEDFR_REQUIRE(n && out, "net_query: null");
   switch (what) {
@@ -147,7 +151,12 @@ int fedfr_net_forward(const fedfr_net_t* n, const float* x, const float* params,
 }
 int fedfr_net_backward(const fedfr_net_t* n, const float* x, const float* dfeats, const float* params, const uint16_t* shadow,
                        void* act, void* ws, float* grads, void* stream) {
-  return net_backward(n, x, dfeats, params, BF(shadow), (unsigned char*)act, (unsigned char*)ws, grads, ST(stream));
+  return net_backward(n, x, dfeats, params, BF(shadow), (unsigned char*)act, (unsigned char*)ws, grads, ST(stream), nullptr);
+}
+int fedfr_net_backward2(const fedfr_net_t* n, const float* x, const float* dfeats, const float* params, const uint16_t* shadow,
+                        void* act, void* ws, float* grads, void* stream, void* aux_stream) {
+  FEDFR_REQUIRE(aux_stream == nullptr || aux_stream != stream, "net_backward2: aux_stream must differ from stream (pass NULL for single-stream)");
+  return net_backward(n, x, dfeats, params, BF(shadow), (unsigned char*)act, (unsigned char*)ws, grads, ST(stream), ST(aux_stream));
 }
 
 // ---- single convolutions ---------------------------------------------------------------------------------

@@ -57,7 +57,8 @@ struct FedfrNet {
   long long act_bf16_count, act_float_off_bytes, act_bytes;
   // workspace layout (byte offsets)
   size_t ws_bytes;
-  size_t ws_g[2], ws_t[6], ws_part, ws_slab, ws_small, ws_fc;
+  size_t ws_g[2], ws_t[6], ws_t2[3], ws_part, ws_slab, ws_small, ws_fc;   // ws_t2: second copies of t0/t2/t4 (dual-stream backward)
+  mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;
 };
@@ -66,5 +67,7 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
 int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st);
 int net_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, const bf16_t* shadow,
                 unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st);
+// aux == nullptr: everything on `st`.  Otherwise all weight-gradient GEMMs (off the dgrad -> BN critical path) run on
+// `aux`, forked/joined with events; on return both streams' work is ordered before anything enqueued later on `st`.
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
-                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st);
+                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux);

@@ -173,6 +173,7 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
   auto wtake = [&](size_t bytes) { const size_t o = w; w += align_up(bytes, 256); return o; };
   for (int i = 0; i < 2; ++i) n->ws_g[i] = wtake(n->g_elems * 2);
   for (int i = 0; i < 6; ++i) n->ws_t[i] = wtake(n->g_elems * 2);
+  for (int i = 0; i < 3; ++i) n->ws_t2[i] = wtake(n->g_elems * 2);
   n->ws_part = wtake(n->part_floats * 4);
   n->ws_slab = wtake(n->slab_floats * 4);
   // small: coef[3*512] | finalize tmp [64*2*512] | dyfc f32 [B*F] | dyb bf16 [B*F] | dybt bf16 [F*Bp]
@@ -197,6 +198,8 @@ struct Ctx {
   bf16_t* dybt() const { return dyb() + (size_t)n->B * n->F; }
   bf16_t* g(int i) const { return reinterpret_cast<bf16_t*>(ws + n->ws_g[i]); }
   bf16_t* t(int i) const { return reinterpret_cast<bf16_t*>(ws + n->ws_t[i]); }
+  // tensors read by the weight-gradient GEMMs (dc2 = slot 0, dc1 = slot 1, dd = slot 2), double buffered per block parity
+  bf16_t* tw(int slot, int par) const { return reinterpret_cast<bf16_t*>(ws + (par ? n->ws_t2[slot] : n->ws_t[slot * 2])); }
   float* save(const BnD& b, int which) const { return actf + b.save_off + (long long)which * b.C; }   // 0 scale 1 shift 2 mean 3 rstd
   const float* gamma(const BnD& b) const { return params + b.g_off; }
   const float* beta(const BnD& b) const { return params + b.b_off; }
@@ -232,7 +235,7 @@ static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* d
   }
   return gemm_nt_launch(p, 1, c.st);
 }
-static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy) {
+static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy, hipStream_t st) {
   GemmTN p{};
   p.P = dy; p.Q = in;
   p.Kp = c.n->B * cv.Hout * cv.Hout; p.NI = cv.Cout; p.NJ = cv.R * cv.R * cv.Cin;
@@ -243,11 +246,11 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
   float* dst = c.grads + cv.w_off;
   if (splits == 1) {
     p.out = dst;
-    return gemm_tn_launch(p, 1, c.st);
+    return gemm_tn_launch(p, 1, st);
   }
   p.out = c.slab();
-  FEDFR_TRY(gemm_tn_launch(p, splits, c.st));
-  return ew_reduce_slabs(dst, c.slab(), splits, (size_t)p.NI * p.NJ, nullptr, 0, c.st);
+  FEDFR_TRY(gemm_tn_launch(p, splits, st));
+  return ew_reduce_slabs(dst, c.slab(), splits, (size_t)p.NI * p.NJ, nullptr, 0, st);
 }
 static int bn_coeffs(const Ctx& c, const BnD& b, int P, double count, bool training) {
   if (training)
@@ -339,12 +342,48 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   return ew_bn_bwd_apply(p, c.st);
 }
 
+// fork/join helpers for the dual-stream backward (events are created once per plan)
+namespace {
+struct Fork {
+  const FedfrNet* n;
+  hipStream_t main, aux;
+  size_t next = 0;
+  bool ok = true;
+  hipEvent_t ev() {
+    if (next == n->events.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ok = false; return nullptr; }
+      n->events.push_back(e);
+    }
+    return n->events[next++];
+  }
+  // everything enqueued so far on `from` happens before anything enqueued later on `to`
+  void order(hipStream_t from, hipStream_t to) {
+    if (!aux) return;
+    hipEvent_t e = ev();
+    if (!e || hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) ok = false;
+  }
+  hipEvent_t mark(hipStream_t s) {            // record now, wait later
+    if (!aux) return nullptr;
+    hipEvent_t e = ev();
+    if (!e || hipEventRecord(e, s) != hipSuccess) ok = false;
+    return e;
+  }
+  void wait(hipStream_t s, hipEvent_t e) {
+    if (aux && e && hipStreamWaitEvent(s, e, 0) != hipSuccess) ok = false;
+  }
+};
+}  // namespace
+
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
-                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st) {
+                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux) {
   FEDFR_REQUIRE(n && x && dfeats && params && shadow && act && ws && grads, "net_backward: null buffer");
   Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
   const int B = n->B, F = n->F, HW = n->HW;
   bf16_t* A = c.actb;
+  Fork fk{n, st, aux};
+  const hipStream_t wst = aux ? aux : st;          // stream of the weight-gradient GEMMs
+  fk.order(st, wst);                                // aux starts after everything already queued on main (forward pass)
   // ---- features (BN1d) backward; fc.bias grad = colsum(d y_fc) ----
   if (hipMemsetAsync(c.dybt(), 0, (size_t)F * n->Bp * 2, st) != hipSuccess) {
     fedfr_set_error("net_backward: hipMemsetAsync failed");
@@ -370,37 +409,51 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dxfc, c.g(0), B, n->final_C, hw, st));
   FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0));
   int cur = 1;
+  hipEvent_t wdone[2] = {nullptr, nullptr};        // "all weight GEMMs of the block with this parity have finished"
   for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
     const BlockD& k = n->blocks[bi];
     const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
+    const int par = bi & 1;
     const bf16_t* g = c.g(cur);
     bf16_t* gin = c.g(cur ^ 1);
+    bf16_t *dc2 = c.tw(0, par), *da2 = c.t(1), *dc1 = c.tw(1, par), *da1 = c.t(3), *dd = c.tw(2, par), *dxd = c.t(5);
+    fk.wait(st, wdone[par]);                         // the weight GEMMs two blocks ago were the last readers of dc2/dc1/dd[par]
     // out = bn3(c2) + identity
-    FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, c.t(0), 0));
-    FEDFR_TRY(conv_wgrad(c, k.conv2, A + k.a2_off, c.t(0)));
+    FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0));
+    fk.order(st, wst);
+    FEDFR_TRY(conv_wgrad(c, k.conv2, A + k.a2_off, dc2, wst));
     int f2 = 0, f1 = 0;
-    FEDFR_TRY(conv_dgrad(c, k.conv2, c.t(0), c.t(1), &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
+    FEDFR_TRY(conv_dgrad(c, k.conv2, dc2, da2, &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
     // a2 = prelu(bn2(c1))
-    FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, c.t(1), A + k.c1_off, Mi, nullptr, nullptr, 0, c.t(2), k.alpha_off, f2));
-    FEDFR_TRY(conv_wgrad(c, k.conv1, A + k.a1_off, c.t(2)));
+    FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, da2, A + k.c1_off, Mi, nullptr, nullptr, 0, dc1, k.alpha_off, f2));
+    fk.order(st, wst);
+    FEDFR_TRY(conv_wgrad(c, k.conv1, A + k.a1_off, dc1, wst));
     // identity path first (its BN reduction uses the shared partial buffer), then conv1's dgrad whose epilogue may
     // leave bn1's partial sums there for the bn_bwd that follows immediately
     if (k.has_ds) {
-      FEDFR_TRY(bn_bwd(c, k.bnds, nullptr, g, A + k.d_off, Mo, nullptr, nullptr, 0, c.t(4), 0));
-      FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, c.t(4)));
-      FEDFR_TRY(conv_dgrad(c, k.ds, c.t(4), c.t(5)));
+      FEDFR_TRY(bn_bwd(c, k.bnds, nullptr, g, A + k.d_off, Mo, nullptr, nullptr, 0, dd, 0));
+      fk.order(st, wst);
+      FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, dd, wst));
+      FEDFR_TRY(conv_dgrad(c, k.ds, dd, dxd));
     }
-    FEDFR_TRY(conv_dgrad(c, k.conv1, c.t(2), c.t(3), &k.bn1, A + k.x_off, nullptr, &f1));
+    wdone[par] = fk.mark(wst);
+    FEDFR_TRY(conv_dgrad(c, k.conv1, dc1, da1, &k.bn1, A + k.x_off, nullptr, &f1));
     // a1 = bn1(x)
     if (k.has_ds) {
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, nullptr, c.t(5), k.Hin, gin, 0, f1));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, nullptr, dxd, k.Hin, gin, 0, f1));
     } else {
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, c.t(3), A + k.x_off, Mi, g, nullptr, 0, gin, 0, f1));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, g, nullptr, 0, gin, 0, f1));
     }
     cur ^= 1;
   }
+  fk.order(wst, st);                                 // join: the stem wgrad below reuses the slab workspace; callers see all grads
   // ---- stem: a0 = prelu(bn1(conv1(x))) ----
   const int M0 = B * HW * HW;
   FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, c.t(0), n->stem_alpha_off));
-  return ew_stem_wgrad(x, c.t(0), grads + n->stem.w_off, c.slab(), B, HW, HW, st);
+  FEDFR_TRY(ew_stem_wgrad(x, c.t(0), grads + n->stem.w_off, c.slab(), B, HW, HW, st));
+  if (!fk.ok) {
+    fedfr_set_error("net_backward: HIP event record/wait failed");
+    return FEDFR_ERR_HIP;
+  }
+  return FEDFR_OK;
 }

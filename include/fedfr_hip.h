@@ -76,6 +76,12 @@ int fedfr_net_forward(const fedfr_net_t* net, const float* x, const float* param
 int fedfr_net_backward(const fedfr_net_t* net, const float* x, const float* dfeats, const float* params,
                        const uint16_t* shadow, void* act, void* ws, float* grads, void* stream);
 
+/* same, with the weight-gradient GEMMs (off the dgrad->BatchNorm critical path) on a second caller-owned stream so
+ * they fill the CUs the main chain leaves idle; fork/join uses HIP events; when the call returns, everything is ordered
+ * before later work on `stream`.  aux_stream == NULL behaves like fedfr_net_backward. */
+int fedfr_net_backward2(const fedfr_net_t* net, const float* x, const float* dfeats, const float* params,
+                        const uint16_t* shadow, void* act, void* ws, float* grads, void* stream, void* aux_stream);
+
 /* ------------------------------------------------------------------------------------------------
  * single convolutions — replace nn.Conv2d fwd / dgrad / wgrad at the call sites iresnet.py:38,41,76,121
  * (implicit GEMM on v_mfma_f32_16x16x32_bf16).  w: bf16 KRSC; wd: bf16 dgrad shadow [Cin][kh'][kw'][Cout].

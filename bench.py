@@ -130,10 +130,17 @@ def main():
     roofline = None
     if rank == 0 and not args.no_profile:
         psteps = 3
+        # kernels are timed one at a time: the weight-gradient GEMMs normally share the GPU with the dgrad/BN chain on a
+        # second stream, which stretches every kernel's wall time; for a per-kernel roofline the pass runs single-stream
+        # (rocprof summary of the matching command: FEDFR_DUAL_STREAM=0 python bench.py ..., profiles/*_single_stream*)
+        saved_aux = tr.aux_stream
+        torch.cuda.synchronize()
+        tr.aux_stream = None
         _C.call("fedfr_profile_enable", 1)
         for i in range(psteps):
             tr.step(imgs[i % nbuf], labs[i % nbuf])
         torch.cuda.synchronize()
+        tr.aux_stream = saved_aux
         rows = []
         for slot in range(len(SLOT_NAMES)):
             ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
@@ -147,6 +154,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": SLOT_NAMES[slot], "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                        "timing": "HIP events around each launch, single-stream pass of %d steps" % psteps,
                         "launches_per_step": n // psteps, "avg_launch_us": round(ms * 1e3 / n, 2),
                         "gflop_per_launch": round(fl / n / 1e9, 3),
                         "all_gemm_kernels": [{"kernel": SLOT_NAMES[s], "ms_per_step": round(m_ / psteps, 3), "launches_per_step": k // psteps,

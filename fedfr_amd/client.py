@@ -249,9 +249,9 @@ class FusedTrainer:
 
     def _backward(self, plan, imgs, dfeats, st):
         bb = self.bb
-        if getattr(self, "_shadows_pending", False):
-            torch.cuda.current_stream().wait_stream(self.aux_stream)      # dgrad shadows rebuilt on aux after the last SGD step
-            self._shadows_pending = False
+        if getattr(self, "_shadows_pending", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._shadows_pending)   # dgrad shadows rebuilt on aux after the last SGD step
+            self._shadows_pending = None
         _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
                 self.aux_stream.cuda_stream if self.aux_stream is not None else None)
@@ -274,7 +274,7 @@ class FusedTrainer:
             self.aux_stream.wait_stream(main)
             with torch.cuda.stream(self.aux_stream):
                 bb.refresh_shadows(False)
-            self._shadows_pending = True
+            self._shadows_pending = self.aux_stream
         else:
             bb.refresh_shadows(False)
         self.first = False

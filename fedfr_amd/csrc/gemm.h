@@ -45,7 +45,7 @@ struct GemmTN {
   int ldp, ldq;
   float* out;             // [splits][NI][NJ]
   int ksteps_total, ksteps_per_split;
-  int nbj;                // number of j tiles
+  int nbj, ntiles;        // number of j tiles / of (i,j) tiles
   int use_tr;             // 1: ds_read_b64_tr_b16 fragments; 0: scalar LDS gathers (validation fallback)
   unsigned p_bytes, q_bytes;   // buffer-descriptor ranges (filled by the launcher)
 };

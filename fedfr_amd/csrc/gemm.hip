@@ -978,9 +978,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
+  // 1-D grid over (split, tile), split-major, XCD-remapped: each XCD owns whole K-splits, i.e. 1/8 of the pixel rows for
+  // ALL output tiles -> the dy / x rows it streams (a few MB) stay in its private L2 while ~36 tiles re-read them
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bj = lid % p.nbj, bi = lid / p.nbj;
-  const int split = blockIdx.y;
+  const int split = lid / p.ntiles, tile = lid - split * p.ntiles;
+  const int bj = tile % p.nbj, bi = tile / p.nbj;
   const int i0 = bi * TI, j0 = bj * TJ;
   const int kt0 = split * p.ksteps_per_split;
   const int kt1 = min(kt0 + p.ksteps_per_split, p.ksteps_total);
@@ -1154,7 +1156,8 @@ static int launch_tn(GemmTN p, int splits, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(nbi * p.nbj, splits, 1);
+  p.ntiles = nbi * p.nbj;
+  dim3 grid(p.ntiles * splits, 1, 1);
   ProfScope prof(prof_slot(true, TI, TJ), 2.0 * p.NI * p.NJ * (double)p.Kp, st);
   hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, USE_TR>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_tn");

@@ -65,6 +65,7 @@ SIGNATURES = {
     "fedfr_bce_logits": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp]),
     "fedfr_bce_loss": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp]),
     "fedfr_colsum_f32": (i32, [vp, i32, i32, vp, vp]),
+    "fedfr_contrastive": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     "fedfr_sum_scale": (i32, [vp, i32, f32, vp, vp]),
     "fedfr_sgd_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, i32, vp]),
     "fedfr_fedavg_axpy": (i32, [vp, vp, f32, sz, i32, vp]),

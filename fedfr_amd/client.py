@@ -285,6 +285,96 @@ class FusedTrainer:
         return loss
 
 
+class FusedHeadTrainer:
+    """Fused backbone step with an arbitrary differentiable head — the training body of ``train_with_public_data``
+    (reference client.py:354-441): the backbone runs as ``fedfr_net_forward`` / ``fedfr_net_backward2`` + the flat SGD
+    kernel exactly as in ``FusedTrainer``; the head (FC_module / BCE_module / margin / CE / contrastive — each a HIP-backed
+    autograd Function of this package) is evaluated on the embedding leaf, and its few parameters get the same
+    ``fedfr_sgd_step`` (torch.optim.SGD semantics: coupled weight decay, momentum buffer created on first use)."""
+
+    def __init__(self, backbone: "backbones.IResNet", head_params: Iterable[nn.Parameter], lr: float = 0.1,
+                 momentum: float = 0.9, weight_decay: float = 5e-4):
+        import os
+        self.bb = backbone
+        self.head_params = list(head_params)
+        self.lr, self.mu, self.wd = float(lr), float(momentum), float(weight_decay)
+        bb = backbone
+        bb._ensure_device_state()
+        bb.train()
+        for hp in self.head_params:
+            _C.require_gpu_tensor(hp.data, f32, "head parameter")
+        self.n_train = bb.trainable_count()
+        self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
+        self.head_mom = {}
+        self.first = True
+        self.aux_stream = torch.cuda.Stream(device=bb.device) if os.environ.get("FEDFR_DUAL_STREAM", "1") != "0" else None
+        self._shadows_pending = None
+        bb.refresh_shadows(True)
+
+    def set_lr(self, lr: float):
+        self.lr = float(lr)
+
+    def step(self, imgs: torch.Tensor, labels: torch.Tensor, head_loss):
+        """``head_loss(feats, labels) -> (loss, *extras)``; returns that tuple (loss detached)."""
+        bb = self.bb
+        bb._check_input(imgs)
+        labels = _C.require_gpu_tensor(labels, torch.int64, "labels")
+        B = imgs.shape[0]
+        plan = bb._plan(B)
+        st = _C.stream()
+        feats = torch.empty(B, bb.num_features, dtype=f32, device=bb.device)
+        _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1, st)
+        bb._flat_nbt += 1
+        bb._fwd_generation += 1
+        for hp in self.head_params:                                   # opt.zero_grad()
+            hp.grad = None
+        feats.requires_grad_(True)
+        with torch.enable_grad():
+            out = head_loss(feats, labels)
+            loss = out[0] if isinstance(out, tuple) else out
+            loss.backward()
+        dfeats = _C.require_gpu_tensor(feats.grad.contiguous(), f32, "d(loss)/d(features)")
+        if self._shadows_pending is not None:
+            torch.cuda.current_stream().wait_stream(self._shadows_pending)
+            self._shadows_pending = None
+        _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
+                self.aux_stream.cuda_stream if self.aux_stream is not None else None)
+        # ---- opt.step()
+        _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, st)
+        for hp in self.head_params:
+            if hp.grad is None:                                       # torch.optim.SGD skips parameters without a gradient
+                continue
+            if not hp.data.is_contiguous() or not hp.grad.is_contiguous():
+                raise RuntimeError("fedfr_amd: head parameters and their gradients must be contiguous")
+            buf = self.head_mom.get(hp)
+            first = buf is None
+            if first:
+                buf = self.head_mom[hp] = torch.empty_like(hp.data)
+            _C.call("fedfr_sgd_step", hp.data.data_ptr(), hp.grad.data_ptr(), buf.data_ptr(), None, hp.numel(), self.lr, self.mu,
+                    self.wd, 1 if first else 0, st)
+        if self.aux_stream is not None:
+            main = torch.cuda.current_stream()
+            self.aux_stream.wait_stream(main)
+            with torch.cuda.stream(self.aux_stream):
+                bb.refresh_shadows(False)
+            self._shadows_pending = self.aux_stream
+        else:
+            bb.refresh_shadows(False)
+        self.first = False
+        if isinstance(out, tuple):
+            return tuple(o.detach() if torch.is_tensor(o) else o for o in out)
+        return loss.detach()
+
+    def finish(self):
+        """Order the aux-stream shadow rebuild before anything the caller does next on the current stream."""
+        if self._shadows_pending is not None:
+            torch.cuda.current_stream().wait_stream(self._shadows_pending)
+            self._shadows_pending = None
+
+
 # ------------------------------------------------------------------------------------------------
 # Client
 # ------------------------------------------------------------------------------------------------
@@ -302,6 +392,27 @@ class AverageMeter:
         self.sum += val * n
         self.count += n
         self.avg = self.sum / self.count
+
+
+class CombineDataset(torch.utils.data.Dataset):
+    """Local identities followed by the (hard-negative subset of the) public identities, public labels shifted behind the
+    local classes (reference dataset.py:170-187, MXFaceDataset_Combine).  Both datasets expose ``num_classes``."""
+
+    def __init__(self, first_dataset, second_dataset):
+        super().__init__()
+        self.first_dataset, self.second_dataset = first_dataset, second_dataset
+        self.first_nclass = first_dataset.num_classes
+        self.first_len, self.second_len = len(first_dataset), len(second_dataset)
+        self.num_class = first_dataset.num_classes + second_dataset.num_classes
+
+    def __getitem__(self, idx):
+        if idx < self.first_len:
+            return self.first_dataset[idx]
+        img, label = self.second_dataset[idx - self.first_len]
+        return img, label + self.first_nclass
+
+    def __len__(self):
+        return self.first_len + self.second_len
 
 
 class Client(object):
@@ -333,6 +444,11 @@ class Client(object):
         self.dropout = 0.4 if cfg.dataset == "webface" else 0
         self.backbone_state_dict = None
         self.fc_module = FC_module(512, self.num_classes, getattr(args, "output_dir", "."))
+        if getattr(self.args, "contrastive_bb", False):                          # client.py:151-155
+            self.last_model = getattr(backbones, self.args.network)(False, dropout=self.dropout, fp16=cfg.fp16)
+            self.temperature = 0.5
+        if hasattr(data, "public_train_loader"):
+            self.public_num_classes = data.public_train_loader.dataset.num_classes
         self.logger = logging.getLogger("FL_face.client")
         self._backbone = None
         self.loss_meter = AverageMeter()
@@ -371,6 +487,118 @@ class Client(object):
         self.loss_meter = loss_meter
         self.backbone_state_dict = flat_state_dict(backbone)
         self.fc_module.cpu()
+
+    def reweight_cosface(self, logits, labels):
+        """reference client.py:269-285: append (num_client-1) copies of the first ``num_classes`` non-target logits of every
+        row, so the softmax denominator weighs the local negatives as if every client contributed them.  Quirk kept on
+        purpose: the reference concatenates INSIDE torch.no_grad() (client.py:272-276), so the returned logits are detached —
+        the re-weighted CosFace loss is reported but contributes no gradient (and the non-BCE, non-contrastive branch then
+        fails in loss.backward(), here as there)."""
+        B, C = logits.shape
+        with torch.no_grad():
+            keep = torch.ones(B, C, dtype=torch.bool, device=logits.device)
+            keep[torch.arange(B, device=logits.device), labels] = False
+            tmp = logits.detach()[keep].reshape(B, C - 1)[:, :self.num_classes].repeat(1, self.args.num_client - 1)
+            logits = torch.cat([logits, tmp], dim=1)
+        return logits
+
+    def train_with_public_data(self, start_epoch=0, callback_verification=None, public_train_loader=None, pretrained_fc=None,
+                               choose_hard_negative=False, pretrained_label=None, pretrained_feats=None, combine_loader=None):
+        """reference client.py:287-508 — local + public identities, CosFace over [local | public] class centres, optional
+        personalised BCE branch (``args.BCE_local``, weight 10) and model-contrastive term (``args.contrastive_bb``,
+        weight cfg.mu), StepLR(cfg.train_decay, 0.1) re-created per call.
+
+        ``combine_loader`` (build extension, used by tests and synthetic benchmarks) supplies the combined batches directly;
+        otherwise the combined loader is built from ``self.train_loader.dataset`` + ``public_train_loader.dataset`` as the
+        reference does.  Hard-negative mining (``choose_hard_negative``, client.py:208-268) belongs to SURVEY §8(f) N2 and is
+        not built yet.  The reference's non-BCE contrastive branch unpacks ``model(imgs)`` into two values (client.py:413),
+        which only works if the model is called with ``contrastive=True``; that is what this method does."""
+        if choose_hard_negative:
+            raise NotImplementedError("fedfr_amd: hard-negative mining (client.py:208-268) is a SURVEY §8(f) 'next' row")
+        if combine_loader is None:
+            if not getattr(self.args, "combine_dataset", False):
+                raise NotImplementedError()                                        # client.py:303-304
+            combine_dataset = CombineDataset(self.train_loader.dataset, public_train_loader.dataset)
+            combine_loader = torch.utils.data.DataLoader(combine_dataset, batch_size=cfg.com_batch_size, shuffle=True, num_workers=0,
+                                                         pin_memory=True, drop_last=True)
+            self.dataset_size = len(combine_dataset)                               # for FedAvg (client.py:302)
+        elif hasattr(combine_loader, "dataset"):
+            self.dataset_size = len(combine_loader.dataset)
+        backbone = self._get_backbone()
+        backbone.load_state_dict(self.backbone_state_dict)
+        backbone.train()
+        self.fc_module.update_with_pretrain(pretrained_fc)                         # [local | public] rows (client.py:312)
+        self.fc_module.train()
+        self.fc_module.to(self.device)
+        use_bce = bool(getattr(self.args, "BCE_local", False))
+        use_con = bool(getattr(self.args, "contrastive_bb", False))
+        detach = bool(getattr(self.args, "BCE_detach", False))
+        reweight = bool(getattr(self.args, "reweight_cosface", False))
+        head_params = list(self.fc_module.parameters())
+        if use_bce:
+            self.bce_module.train()
+            self.bce_module.to(self.device)
+            head_params += list(self.bce_module.parameters())
+        if use_con:
+            import copy
+            global_model = copy.deepcopy(backbone).eval()                          # frozen copy of the incoming global model
+            self.last_model = self.last_model.to(self.device).eval()
+        trainer = FusedHeadTrainer(backbone, head_params, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+        margin, fc_module = self.margin_softmax, self.fc_module
+        state = {}
+
+        def head_loss(feats, labels):
+            cos_logits = margin(fc_module(feats), labels)
+            if reweight:
+                cos_logits = self.reweight_cosface(cos_logits, labels)
+            cos_loss = ops.cross_entropy(cos_logits, labels)
+            loss = cos_loss
+            bce = con = None
+            if use_bce:
+                bce_logits, bce_gts = self.bce_module(feats.detach() if detach else feats, labels)
+                bce = self.bce_loss(bce_logits, bce_gts)
+                loss = loss + 10 * bce
+            if use_con:
+                con = ops.contrastive_loss(feats, state["global_feats"], state["last_feats"], self.temperature)
+                loss = loss + cfg.mu * con
+            return loss, cos_loss, con, bce
+
+        loss_meter, cos_meter, con_meter, bce_meter = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+        pending = []
+
+        def drain():
+            for l, c, k, b in pending:
+                loss_meter.update(l.item(), 1)
+                cos_meter.update(c.item(), 1)
+                if k is not None:
+                    con_meter.update(k.item(), 1)
+                if b is not None:
+                    bce_meter.update(b.item(), 1)
+            pending.clear()
+
+        for epoch in range(start_epoch, start_epoch + self.local_epoch):
+            trainer.set_lr(cfg.lr * 0.1 ** ((epoch - start_epoch) // cfg.train_decay))     # StepLR (client.py:348,443)
+            for step, (imgs, labels) in enumerate(combine_loader):
+                imgs = imgs.to(self.device, non_blocking=True).contiguous()
+                labels = labels.to(self.device, non_blocking=True)
+                if use_con:
+                    with torch.no_grad():
+                        state["global_feats"] = global_model(imgs)
+                        state["last_feats"] = self.last_model(imgs)
+                pending.append(trainer.step(imgs, labels, head_loss))
+                if len(pending) >= self.sync_every:
+                    drain()
+        drain()
+        trainer.finish()
+        self.cos_meter, self.con_meter, self.bce_meter = cos_meter, con_meter, bce_meter
+        self.loss_meter = loss_meter
+        self.backbone_state_dict = flat_state_dict(backbone)
+        self.fc_module.cpu()
+        if use_bce:
+            self.bce_module.cpu()
+        if use_con:
+            self.last_model.load_state_dict(self.backbone_state_dict)               # client.py:499-501
+            del global_model
 
     def get_train_loss(self):
         return self.loss_meter.avg

@@ -17,6 +17,7 @@ extern int g_conv_halo;
 extern int g_halo_bn64;
 extern int g_halo_waves;
 extern int g_tn_target_blocks;
+extern int g_fuse_bnbwd;
 
 void fedfr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -59,6 +60,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "conv_halo")) {
     g_conv_halo = value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "fuse_bnbwd")) {
+    g_fuse_bnbwd = value ? 1 : 0;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "nt_nbuf")) {
@@ -333,6 +338,10 @@ int fedfr_bce_logits(const float* cosv, const long long* label, const float* bia
 int fedfr_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam, float loss_scale,
                    float* dz, float* dcos, float* row_loss, void* stream) {
   return head_bce_loss(z, gt, dzdcos, B, C, r, lam, loss_scale, dz, dcos, row_loss, ST(stream));
+}
+int fedfr_contrastive(const float* feats, const float* global_feats, const float* last_feats, int B, int D, float temperature,
+                      float* row_loss, float* dfeats, void* stream) {
+  return head_contrastive(feats, global_feats, last_feats, B, D, temperature, row_loss, dfeats, ST(stream));
 }
 int fedfr_colsum_f32(const float* x, int R, int C, float* out, void* stream) { return head_colsum_f32(x, R, C, out, ST(stream)); }
 int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream) { return head_sum_scale(x, n, scale, out, ST(stream)); }

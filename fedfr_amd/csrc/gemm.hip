@@ -1,12 +1,11 @@
 // MFMA implicit-GEMM kernels for gfx950 (see gemm.h).  256 threads = 4 waves, 16x16x32 bf16 MFMA,
 // BK = 64, register-staged double-buffered LDS tiles with XOR-swizzled 16-byte chunks
 // (conflict-free ds_read_b128 / ds_read_b64_tr_b16), one barrier per K-step, XCD-aware 1-D grid.
-#include "gemm.h"
+#include "gemm_dev.h"
 
 #include <algorithm>
 #include <vector>
 
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------
 // slots: 0..3 = gemm_nt <128,128> <128,64> <64,128> <64,64>; 4..7 = gemm_tn <128,128> <128,64> <64,128> <64,64>;
@@ -20,25 +19,23 @@ struct ProfSlot {
 bool g_prof_on = false;
 ProfSlot g_prof[12];
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
-struct ProfScope {
-  ProfSlot* s = nullptr;
-  hipStream_t st;
-  ProfScope(int slot, double flops, hipStream_t st_) : st(st_) {
-    if (!g_prof_on) return;
-    s = &g_prof[slot];
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { s = nullptr; return; }
-    s->ev.push_back(a);
-    s->ev.push_back(b);
-    s->flops += flops;
-    s->launches += 1;
-    (void)hipEventRecord(a, st);
-  }
-  ~ProfScope() {
-    if (s) (void)hipEventRecord(s->ev.back(), st);
-  }
-};
 }  // namespace
+
+ProfScope::ProfScope(int slot, double flops, hipStream_t st) : st_(st) {
+  if (!g_prof_on) return;
+  ProfSlot* s = &g_prof[slot];
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  s->ev.push_back(a);
+  s->ev.push_back(b);
+  s->flops += flops;
+  s->launches += 1;
+  (void)hipEventRecord(a, st);
+  slot_ = s;
+}
+ProfScope::~ProfScope() {
+  if (slot_) (void)hipEventRecord(static_cast<ProfSlot*>(slot_)->ev.back(), st_);
+}
 
 void gemm_profile_enable(int on) {
   for (auto& s : g_prof) {
@@ -65,23 +62,10 @@ int gemm_profile_read(int slot, double* total_ms, long long* launches, double* f
   return 0;
 }
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-// Tile loads are BRANCH-FREE raw buffer loads: an out-of-range lane gets voffset = num_records and the hardware
-// bounds check returns zeros.  (Predicated `if (ok) v = *p` loads made hipcc emit s_waitcnt vmcnt(0) after every
-// load, serialising the 8 loads of a K-step: 2x slower.)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
-  return make_uint4(v[0], v[1], v[2], v[3]);
-}
 
-// bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
-__device__ __forceinline__ int xcd_remap(int id, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, x = id & 7, loc = id >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-}
+int g_halo_waves = 4;  // option "halo_waves": 4 or 8 waves per 128x128 tile in the halo2 kernel
+int g_halo_bn64 = 0;   // option "halo_bn64": 64-wide N tiles in the halo2 kernel (more, smaller blocks)
+int g_conv_halo = 2;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1
 
 // =====================================================================================================
 // NT kernel
@@ -330,519 +314,6 @@ static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st) {
   return FEDFR_OK;
 }
 
-// =====================================================================================================
-// 3x3 / stride-1 / pad-1 convolution (fwd, and dgrad with the flipped shadow) with an LDS-resident HALO tile.
-// The generic kernel above re-fetches the 128-pixel activation tile for each of the 9 taps; here the
-// 128 + 2(W+1) consecutive NHWC pixels a tile can touch are staged ONCE per 64-channel chunk and every tap reads
-// its shifted window from LDS (row = pixel + r*W + s), masked per lane for image borders.  Activation traffic
-// through L2->CU and VGPR->LDS drops ~7x (14x14) .. 3x (112x112); the weight tile [BN][64] per (tap, chunk) stays
-// register-staged and double buffered.  K order: chunk outer, tap inner (only the fp32 summation order changes).
-// =====================================================================================================
-template <int BN, int AH>   // AH = halo 16-B chunks per thread = ceil((128 + 2W + 2) * 8 / 256)
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmNT p, int a_bytes_lds) {
-  constexpr int BM = 128, WM = 2, WN = 2;
-  constexpr int BI = BN / 32;
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int B_BYTES = BN * 128;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + a_bytes_lds;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bn = lid % p.nbn, bm = lid / p.nbn;
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int W = p.W, NR = BM + 2 * W + 2;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int ch = tid & 7, rbase = tid >> 3;
-  const int npix = p.M;                       // stride 1: input pixels == output pixels
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
-
-  // per-lane 9-bit tap validity for each of the TM fragment rows this lane feeds
-  unsigned vmask[TM];
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-    const int m = m0 + wm * (BM / WM) + mi * 16 + l15;
-    unsigned msk = 0;
-    if (m < p.M) {
-      const int hw = p.H * W;
-      const int rem = m % hw;
-      const int h = rem / W, w = rem - h * W;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-        if ((unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)W) msk |= 1u << t;
-      }
-    }
-    vmask[mi] = msk;
-  }
-
-  uint4 rh[AH], rb[BI];
-  auto load_halo = [&](int cc) {
-#pragma unroll
-    for (int i = 0; i < AH; ++i) {
-      const int e = tid + 256 * i;
-      const int rl = e >> 3, c = e & 7;
-      const int pix = m0 - (W + 1) + rl;
-      const bool ok = rl < NR && (unsigned)pix < (unsigned)npix;
-      const unsigned off = ((unsigned)pix * (unsigned)p.C + (unsigned)(cc * 64 + c * 8)) * 2u;
-      rh[i] = buf_load16(rsA, ok ? off : p.a_bytes);
-    }
-  };
-  auto store_halo = [&]() {
-#pragma unroll
-    for (int i = 0; i < AH; ++i) {
-      const int e = tid + 256 * i;
-      const int rl = e >> 3, c = e & 7;
-      if (rl < NR) *reinterpret_cast<uint4*>(sA + rl * 128 + ((c ^ (rl & 7)) << 4)) = rh[i];
-    }
-  };
-  auto load_b = [&](int tap, int cc) {
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int n = n0 + rbase + 32 * i;
-      const unsigned off = ((unsigned)n * (unsigned)p.K + (unsigned)(tap * p.C + cc * 64 + ch * 8)) * 2u;
-      rb[i] = buf_load16(rsB, n < p.N ? off : p.b_bytes);
-    }
-  };
-  auto store_b = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int row = rbase + 32 * i;
-      *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 128 + ((ch ^ (row & 7)) << 4)) = rb[i];
-    }
-  };
-
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int cpt = p.C >> 6;
-  load_halo(0);
-  load_b(0, 0);
-  store_halo();
-  store_b(0);
-  __syncthreads();
-  int buf = 0;
-  const bf16x8_t zfrag = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
-  for (int cc = 0; cc < cpt; ++cc) {
-    for (int tap = 0; tap < 9; ++tap) {
-      const bool last_tap = tap == 8;
-      const bool more = !(last_tap && cc + 1 == cpt);
-      if (more) load_b(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc);
-      if (last_tap && cc + 1 < cpt) load_halo(cc + 1);
-      const int r = tap / 3, sft = r * W + (tap - 3 * r);
-      const unsigned char* cB = sB + buf * B_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int c = ks * 4 + lg;
-        bf16x8_t fb[TN], fa[TM];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-          const int row = wn * (BN / WN) + ni * 16 + l15;
-          fb[ni] = *reinterpret_cast<const bf16x8_t*>(cB + row * 128 + ((c ^ (row & 7)) << 4));
-        }
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-          const int row = wm * (BM / WM) + mi * 16 + l15 + sft;
-          const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(sA + row * 128 + ((c ^ (row & 7)) << 4));
-          fa[mi] = ((vmask[mi] >> tap) & 1u) ? v : zfrag;
-        }
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = MFMA16(fb[ni], fa[mi], acc[ni][mi]);
-      }
-      if (more) store_b(buf ^ 1);
-      __syncthreads();                       // next weight tile visible; everyone is done with this tap's reads
-      if (last_tap && cc + 1 < cpt) {
-        store_halo();                        // safe: all waves passed the barrier above => no reader of the old halo
-        __syncthreads();
-      }
-      buf ^= 1;
-    }
-  }
-
-  // ---- epilogue (identical to gemm_nt_kernel's bf16 path) ----
-  constexpr int CST = BN * 2 + 16;
-  unsigned char* sC = smem;
-  float ssum[TN][4], ssq[TN][4];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-      const int ml = wm * (BM / WM) + mi * 16 + l15;
-      const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
-      bf16_t h[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        h[q] = f2bf(acc[ni][mi][q]);
-        const float v = bf2f(h[q]);
-        ssum[ni][q] += v;
-        ssq[ni][q] += v * v;
-      }
-      uint2 pk;
-      pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-      pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-      *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
-    }
-  if (p.stats) {
-    float* prow = p.stats + (size_t)(bm * WM + wm) * 2 * p.N;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float a = ssum[ni][q], b = ssq[ni][q];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
-        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
-        if (l15 == 0 && n < p.N) {
-          prow[n] = a;
-          prow[p.N + n] = b;
-        }
-      }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 8;
-  for (int idx = tid; idx < BM * CPR; idx += 256) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    const int m = m0 + row, n = n0 + c * 8;
-    if (m < p.M && n < p.N)
-      *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-  }
-}
-
-int g_halo_waves = 4;  // option "halo_waves": 4 or 8 waves per 128x128 tile in the halo2 kernel
-int g_halo_bn64 = 0;   // option "halo_bn64": 64-wide N tiles in the halo2 kernel (more, smaller blocks)
-int g_conv_halo = 2;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1
-
-template <int BN, int AH>
-static int launch_halo(GemmNT p, hipStream_t st) {
-  const int nbm = ceil_div(p.M, 128);
-  p.nbn = ceil_div(p.N, BN);
-  const int NR = 128 + 2 * p.W + 2;
-  const int a_lds = (int)align_up((size_t)NR * 128, 256);
-  constexpr size_t kEpi = (size_t)128 * (BN * 2 + 16);
-  size_t lds = (size_t)a_lds + 2 * (size_t)BN * 128;
-  if (lds < kEpi) lds = kEpi;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, AH>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    attr_set = true;
-  }
-  ProfScope prof(11, 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BN, AH>), dim3(nbm * p.nbn), dim3(256), lds, st, p, a_lds);
-  FEDFR_LAUNCH_CHECK("conv3x3_halo");
-  return FEDFR_OK;
-}
-
-// =====================================================================================================
-// halo kernel v2 (W = 14 / 28, i.e. 84 of iresnet100's 103 convs): the LDS image is laid out in ZERO-PADDED image
-// coordinates — every image row gets a zero pixel left and right, every image a zero row above and below — so a
-// filter tap is a pure constant shift ((r*(W+2) + s) rows) with NO per-lane border masks, and with a linear
-// 160-byte row stride (conflict-free for ds_read_b128 without XOR) + W as a template constant the 9 tap offsets
-// are instruction immediates.  v1 spent 136 VALU instructions per 32 MFMAs on masks and swizzled addresses.
-// =====================================================================================================
-template <int BN, int W_, int WN>   // WN = 2: 4 waves (64x64 wave tiles at BN=128); WN = 4: 8 waves (64x32)
-__global__ __launch_bounds__(128 * WN) void conv3x3_halo2_kernel(GemmNT p, int nr_rows) {
-  constexpr int BM = 128, WM = 2, PW = W_ + 2, RS = 160, NT = 64 * WM * WN;
-  constexpr int BI = BN * 8 / NT, BROWS = NT / 8;
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int B_BYTES = BN * 128;
-  constexpr int NSRC = BM + 2 * W_ + 2;                 // source pixels a tile can touch
-  constexpr int AH = (NSRC * 8 + NT - 1) / NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  const int a_bytes_lds = (nr_rows * RS + 255) & ~255;
-  unsigned char* sB = smem + a_bytes_lds;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bn = lid % p.nbn, bm = lid / p.nbn;
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int ch = tid & 7, rbase = tid >> 3;
-  const int npix = p.M, HW = p.H * W_, PIMG = (p.H + 2) * PW;
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
-  auto qof = [&](int pix) {                             // padded coordinate of a flattened (img, h, w) pixel
-    const int img = pix / HW, rem = pix - img * HW;
-    const int h = rem / W_, w = rem - h * W_;
-    return img * PIMG + (h + 1) * PW + w + 1;
-  };
-  const int qb = qof(m0) - (PW + 1);
-
-  // zero the whole image once: padding positions are never written afterwards
-  for (int i = tid * 16; i < a_bytes_lds; i += NT * 16) *reinterpret_cast<uint4*>(sA + i) = make_uint4(0, 0, 0, 0);
-
-  // staging plan (same rows every chunk): source byte offset (without the channel-chunk term) and LDS destination
-  unsigned src_off[AH];
-  int dst_off[AH];
-#pragma unroll
-  for (int i = 0; i < AH; ++i) {
-    const int e = tid + NT * i;
-    const int rl = e >> 3, c = e & 7;
-    const int pix = m0 - (W_ + 1) + rl;
-    bool ok = rl < NSRC && (unsigned)pix < (unsigned)npix;
-    int row = 0;
-    if (ok) {
-      row = qof(pix) - qb;
-      ok = (unsigned)row < (unsigned)nr_rows;
-    }
-    src_off[i] = ok ? ((unsigned)pix * (unsigned)p.C + (unsigned)(c * 8)) * 2u : 0xffffffffu;
-    dst_off[i] = ok ? row * RS + c * 16 : -1;
-  }
-  // A-fragment base addresses (tap (0,0)); rows >= M are clamped (their results are masked in the epilogue)
-  int a_addr[TM];
-  bool m_ok[TM];
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-    const int m = m0 + wm * (BM / WM) + mi * 16 + l15;
-    m_ok[mi] = m < p.M;
-    a_addr[mi] = (qof(m_ok[mi] ? m : p.M - 1) - (PW + 1) - qb) * RS + lg * 16;
-  }
-
-  uint4 rh[AH], rb[BI];
-  auto load_halo = [&](int cc) {
-#pragma unroll
-    for (int i = 0; i < AH; ++i)
-      rh[i] = buf_load16(rsA, src_off[i] == 0xffffffffu ? p.a_bytes : src_off[i] + (unsigned)(cc * 128));
-  };
-  auto store_halo = [&]() {
-#pragma unroll
-    for (int i = 0; i < AH; ++i)
-      if (dst_off[i] >= 0) *reinterpret_cast<uint4*>(sA + dst_off[i]) = rh[i];
-  };
-  const unsigned b_row0 = ((unsigned)(n0 + rbase) * (unsigned)p.K + (unsigned)(ch * 8)) * 2u;
-  auto load_b = [&](int tap, int cc) {
-    const unsigned koff = (unsigned)(tap * p.C + cc * 64) * 2u;
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int n = n0 + rbase + BROWS * i;
-      rb[i] = buf_load16(rsB, n < p.N ? b_row0 + (unsigned)(BROWS * i) * (unsigned)p.K * 2u + koff : p.b_bytes);
-    }
-  };
-  const int b_st = rbase * 128 + ((ch ^ (rbase & 7)) << 4);
-  auto store_b = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + b_st + i * BROWS * 128) = rb[i];
-  };
-  int b_addr[TN];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int row = wn * (BN / WN) + ni * 16 + l15;
-    b_addr[ni] = row * 128 + ((lg ^ (row & 7)) << 4);      // ks = 1 flips chunk bit 2: XOR 64
-  }
-
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int cpt = p.C >> 6;
-  load_halo(0);
-  load_b(0, 0);
-  __syncthreads();                   // zero fill complete before real pixels land
-  store_halo();
-  store_b(0);
-  __syncthreads();
-  int buf = 0;
-  for (int cc = 0; cc < cpt; ++cc) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      constexpr int kDummy = 0;
-      (void)kDummy;
-      const bool last_tap = tap == 8;
-      const bool more = !(last_tap && cc + 1 == cpt);
-      if (more) load_b(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc);
-      if (last_tap && cc + 1 < cpt) load_halo(cc + 1);
-      const int toff = ((tap / 3) * PW + (tap % 3)) * RS;          // compile-time per unrolled tap
-      const unsigned char* cB = sB + buf * B_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t fb[TN], fa[TM];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(cB + (b_addr[ni] ^ (ks * 64)));
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_addr[mi] + toff + ks * 64);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = MFMA16(fb[ni], fa[mi], acc[ni][mi]);
-      }
-      if (more) store_b(buf ^ 1);
-      __syncthreads();
-      if (last_tap && cc + 1 < cpt) {
-        store_halo();
-        __syncthreads();
-      }
-      buf ^= 1;
-    }
-  }
-
-  // ---- epilogue: as gemm_nt_kernel's bf16 path; rows >= M contribute nothing to the statistics ----
-  constexpr int CST = BN * 2 + 16;
-  unsigned char* sC = smem;
-  float ssum[TN][4], ssq[TN][4];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-      const int ml = wm * (BM / WM) + mi * 16 + l15;
-      const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
-      bf16_t h[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        h[q] = f2bf(acc[ni][mi][q]);
-        const float v = m_ok[mi] ? bf2f(h[q]) : 0.f;
-        ssum[ni][q] += v;
-        ssq[ni][q] += v * v;
-      }
-      uint2 pk;
-      pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-      pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-      *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
-    }
-  if (p.stats) {
-    float* prow = p.stats + (size_t)(bm * WM + wm) * 2 * p.N;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float a = ssum[ni][q], b = ssq[ni][q];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
-        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
-        if (l15 == 0 && n < p.N) {
-          prow[n] = a;
-          prow[p.N + n] = b;
-        }
-      }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 8;
-  if (p.bpart == nullptr) {
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
-      const int row = idx / CPR, c = idx - row * CPR;
-      const int m = m0 + row, n = n0 + c * 8;
-      if (m < p.M && n < p.N)
-        *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-    }
-    return;
-  }
-  // ---- fused BN-backward reduction: this thread owns chunk column c (8 channels) of rows rg, rg + NT/CPR, ... ----
-  constexpr int RG = NT / CPR;
-  const int c = tid % CPR, rg = tid / CPR;
-  const int n = n0 + c * 8;
-  const bool n_ok = n < p.N;
-  float mean[8], rstd[8], ga[8], be[8], al[8], s1[8], s2[8], s3[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int nn = n_ok ? n + q : 0;
-    mean[q] = p.bmean[nn]; rstd[q] = p.brstd[nn];
-    ga[q] = p.bgamma ? p.bgamma[nn] : 1.f; be[q] = p.bbeta ? p.bbeta[nn] : 0.f; al[q] = p.balpha ? p.balpha[nn] : 1.f;
-    s1[q] = s2[q] = s3[q] = 0.f;
-  }
-  const bool has_alpha = p.balpha != nullptr;
-  for (int row = rg; row < BM; row += RG) {
-    const int m = m0 + row;
-    if (m < p.M && n_ok) {
-      const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-      *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = dv;
-      float dy[8], xv[8];
-      unpack8(dv, dy);
-      unpack8(*reinterpret_cast<const uint4*>(p.bx + (size_t)m * p.N + n), xv);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float xh = (xv[q] - mean[q]) * rstd[q];
-        float dz = dy[q];
-        if (has_alpha) {
-          const float z = ga[q] * xh + be[q];
-          if (z <= 0.f) {
-            s3[q] += dy[q] * z;
-            dz = dy[q] * al[q];
-          }
-        }
-        s1[q] += dz;
-        s2[q] += dz * xh;
-      }
-    }
-  }
-  __syncthreads();                                   // everyone is done reading the staged C tile
-  float* red = reinterpret_cast<float*>(smem);       // [RG][3][BN]
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    red[(rg * 3 + 0) * BN + c * 8 + q] = s1[q];
-    red[(rg * 3 + 1) * BN + c * 8 + q] = s2[q];
-    red[(rg * 3 + 2) * BN + c * 8 + q] = s3[q];
-  }
-  __syncthreads();
-  for (int i = tid; i < 3 * BN; i += NT) {
-    const int which = i / BN, col = i - which * BN;
-    float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < RG; ++r) t += red[(r * 3 + which) * BN + col];
-    if (n0 + col < p.N) p.bpart[((size_t)bm * 3 + which) * p.N + n0 + col] = t;
-  }
-}
-
-template <int BN, int W_, int WN>
-static int launch_halo2(GemmNT p, hipStream_t st) {
-  const int nbm = ceil_div(p.M, 128);
-  p.nbn = ceil_div(p.N, BN);
-  // exact LDS image height: max over tiles of the padded-coordinate span, plus the halo on both sides
-  const int PW = W_ + 2, HW = p.H * W_, PIMG = (p.H + 2) * PW;
-  auto qof = [&](int pix) {
-    const int img = pix / HW, rem = pix - img * HW;
-    return img * PIMG + (rem / W_ + 1) * PW + rem % W_ + 1;
-  };
-  int span = 0;
-  for (int t = 0; t < nbm; ++t) {
-    const int a = t * 128, b = (a + 127 < p.M - 1) ? a + 127 : p.M - 1;
-    span = std::max(span, qof(b) - qof(a));
-  }
-  const int nr = span + 2 * (PW + 1) + 1;
-  const size_t a_lds = ((size_t)nr * 160 + 255) & ~(size_t)255;
-  constexpr size_t kEpi = (size_t)128 * (BN * 2 + 16), kRed = (size_t)(128 * WN / (BN / 8)) * 3 * BN * sizeof(float);
-  size_t lds = a_lds + 2 * (size_t)BN * 128;
-  if (lds < kEpi) lds = kEpi;
-  if (lds < kRed) lds = kRed;
-  FEDFR_REQUIRE(lds <= 160 * 1024, "conv3x3_halo2: LDS image too large (%zu bytes)", lds);
-  if (p.bpart) {
-    FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_halo2: fused BN-bwd reduction needs bx/mean/rstd and ldc == N");
-    if (p.bwd_fused) *p.bwd_fused = nbm;
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<BN, W_, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    attr_set = true;
-  }
-  ProfScope prof(BN == 64 ? 10 : (W_ == 14 ? 8 : 9), 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_halo2_kernel<BN, W_, WN>), dim3(nbm * p.nbn), dim3(128 * WN), lds, st, p, nr);
-  FEDFR_LAUNCH_CHECK("conv3x3_halo2");
-  return FEDFR_OK;
-}
-
 static inline int nt_bm(int M, int N) {
   // 128-row tiles unless that leaves fewer than ~1.5 tiles per CU (256 CUs)
   const int bn = (N <= 64) ? 64 : 128;
@@ -899,18 +370,11 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
     if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
       const bool bn64 = p.N <= 64 || g_halo_bn64;
-      if (p.W == 14) return bn64 ? launch_halo2<64, 14, 2>(p, st) : (g_halo_waves == 8 ? launch_halo2<128, 14, 4>(p, st) : launch_halo2<128, 14, 2>(p, st));
-      return bn64 ? launch_halo2<64, 28, 2>(p, st) : (g_halo_waves == 8 ? launch_halo2<128, 28, 4>(p, st) : launch_halo2<128, 28, 2>(p, st));
+      if (bn64 || g_halo_waves == 8) return launch_conv_halo2_misc(p, bn64, g_halo_waves == 8, st);
+      if (p.bpart) return p.W == 14 ? launch_conv_halo2_fused_w14(p, st) : launch_conv_halo2_fused_w28(p, st);
+      return p.W == 14 ? launch_conv_halo2_w14(p, st) : launch_conv_halo2_w28(p, st);
     }
-    const int ah = ceil_div((128 + 2 * p.W + 2) * 8, 256);
-    if (p.N <= 64) {
-      if (ah <= 6) return launch_halo<64, 6>(p, st);
-      if (ah <= 8) return launch_halo<64, 8>(p, st);
-      return launch_halo<64, 12>(p, st);
-    }
-    if (ah <= 6) return launch_halo<128, 6>(p, st);
-    if (ah <= 8) return launch_halo<128, 8>(p, st);
-    return launch_halo<128, 12>(p, st);
+    return launch_conv_halo1(p, st);
   }
   if (BM == 128) {
     if (p.N <= 64) return launch_nt<128, 64, 2, 2>(p, splits, st);

@@ -1,0 +1,42 @@
+// device helpers + launch-side profiling scope shared by the GEMM translation units.
+// Each kernel family lives in its own .hip file ON PURPOSE: hipcc lets co-compiled template instantiations perturb each
+// other's register allocation (accumulators rotating through misaligned AGPR ranges cost the conv kernel 15-50 %).
+#pragma once
+#include <vector>
+#include "gemm.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+// Tile loads are BRANCH-FREE raw buffer loads: an out-of-range lane gets voffset = num_records and the hardware
+// bounds check returns zeros.  (Predicated `if (ok) v = *p` loads made hipcc emit s_waitcnt vmcnt(0) after every
+// load, serialising the 8 loads of a K-step: 2x slower.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = id & 7, loc = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+}
+
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg); state lives in gemm.hip
+struct ProfScope {
+  void* slot_ = nullptr;
+  hipStream_t st_;
+  ProfScope(int slot, double flops, hipStream_t st);
+  ~ProfScope();
+};
+extern int g_conv_halo, g_halo_bn64, g_halo_waves, g_nt_nbuf, g_tn_target_blocks;
+int launch_conv_halo1(GemmNT p, hipStream_t st);          // conv_halo.hip
+int launch_conv_halo2_w14(GemmNT p, hipStream_t st);       // conv_halo2_w14.hip   plain, 128x128 tiles, 4 waves
+int launch_conv_halo2_w28(GemmNT p, hipStream_t st);       // conv_halo2_w28.hip
+int launch_conv_halo2_fused_w14(GemmNT p, hipStream_t st); // conv_halo2_fused14.hip  + BN-backward reduction epilogue
+int launch_conv_halo2_fused_w28(GemmNT p, hipStream_t st); // conv_halo2_fused28.hip
+int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   // conv_halo2_misc.hip  tuning variants

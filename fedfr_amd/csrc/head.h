@@ -21,3 +21,5 @@ int head_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, 
                   float* dz, float* dcos, float* row_loss, hipStream_t st);
 int head_colsum_f32(const float* x, int R, int C, float* out, hipStream_t st);
 int head_sum_scale(const float* x, int n, float scale, float* out, hipStream_t st);
+int head_contrastive(const float* x, const float* g, const float* l, int B, int D, float temperature, float* row_loss, float* dx,
+                     hipStream_t st);

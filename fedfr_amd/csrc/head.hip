@@ -402,3 +402,42 @@ int head_sum_scale(const float* x, int n, float scale, float* out, hipStream_t s
   FEDFR_LAUNCH_CHECK("sum_scale");
   return FEDFR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// model-contrastive term (reference client.py:372-375 / :415-418): per row, pos = cos(x, g)/T, neg = cos(x, l)/T with
+// nn.CosineSimilarity(dim=1, eps=1e-8) (each norm clamped from below by eps), loss_row = CE([pos, neg], label 0)
+// = logsumexp(pos, neg) - pos; dx = d(mean_b loss_row)/dx.  One wave per row.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void contrastive_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ l, int B, int D, float inv_t,
+                                                          float* __restrict__ row_loss, float* __restrict__ dx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const size_t o = (size_t)row * D;
+  float xx = 0.f, gg = 0.f, ll = 0.f, xg = 0.f, xl = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    const float a = x[o + i], b = g[o + i], c = l[o + i];
+    xx += a * a; gg += b * b; ll += c * c; xg += a * b; xl += a * c;
+  }
+  xx = wave_sum(xx); gg = wave_sum(gg); ll = wave_sum(ll); xg = wave_sum(xg); xl = wave_sum(xl);
+  const float eps = 1e-8f;
+  const float nx = fmaxf(sqrtf(xx), eps), ng = fmaxf(sqrtf(gg), eps), nl = fmaxf(sqrtf(ll), eps);
+  const float cg = xg / (nx * ng), cl = xl / (nx * nl);
+  const float pos = cg * inv_t, neg = cl * inv_t;
+  const float mx = fmaxf(pos, neg);
+  const float lse = mx + logf(expf(pos - mx) + expf(neg - mx));
+  if (lane == 0) row_loss[row] = lse - pos;
+  if (dx) {
+    const float p1 = expf(neg - lse);                  // softmax prob of the negative pair
+    const float w = p1 * inv_t / (float)B;             // d mean-loss / d neg-cos = +w ; / d pos-cos = -w
+    const float kg = -w / (nx * ng), kl = w / (nx * nl), kx = (w * cg - w * cl) / (nx * nx);
+    for (int i = lane; i < D; i += 64) dx[o + i] = kg * g[o + i] + kl * l[o + i] + kx * x[o + i];
+  }
+}
+int head_contrastive(const float* x, const float* g, const float* l, int B, int D, float temperature, float* row_loss, float* dx,
+                     hipStream_t st) {
+  FEDFR_REQUIRE(x && g && l && row_loss && B > 0 && D > 0 && temperature > 0.f, "contrastive: bad args");
+  hipLaunchKernelGGL(contrastive_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, x, g, l, B, D, 1.f / temperature, row_loss, dx);
+  FEDFR_LAUNCH_CHECK("contrastive");
+  return FEDFR_OK;
+}

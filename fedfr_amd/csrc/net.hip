@@ -214,12 +214,14 @@ static int conv_fwd(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* out
   p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = stats ? c.part() : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
+int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the halo2 dgrad epilogue.  Off by default: same-box A/B gives 25.07 ms/step with the
+                        // separate (HBM-bound) ew_bn_bwd_reduce, which overlaps the aux-stream wgrad GEMMs, vs 25.57 fused (+15 us serial epilogue).
 // dx (at the conv's INPUT resolution) = conv_transpose(dy).  If `bn` is given, the kernel may also produce the
 // BN-backward partial sums of (dx, bn_x) in its epilogue; *fused_rows > 0 then (else run ew_bn_bwd_reduce).
 static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* dx, const BnD* bn = nullptr,
                       const bf16_t* bn_x = nullptr, const float* alpha = nullptr, int* fused_rows = nullptr) {
   GemmNT p{};
-  if (bn && fused_rows) {
+  if (bn && fused_rows && g_fuse_bnbwd) {
     p.bx = bn_x; p.bmean = c.save(*bn, 2); p.brstd = c.save(*bn, 3); p.bgamma = c.gamma(*bn); p.bbeta = c.beta(*bn);
     p.balpha = alpha; p.bpart = c.part(); p.bwd_fused = fused_rows;
   }

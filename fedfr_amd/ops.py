@@ -175,6 +175,36 @@ class CrossEntropyFn(torch.autograd.Function):
         return grad * dl, None
 
 
+class ContrastiveFn(torch.autograd.Function):
+    """model-contrastive term of FedFR's local objective (reference client.py:372-375, :415-418):
+    CE([cos(f, f_global)/T, cos(f, f_last)/T], 0) averaged over the batch; only ``feats`` gets a gradient."""
+
+    @staticmethod
+    def forward(ctx, feats, global_feats, last_feats, temperature):
+        x = _chk(feats.detach(), "feats")
+        g, l = _chk(global_feats.detach(), "global_feats"), _chk(last_feats.detach(), "last_feats")
+        if g.shape != x.shape or l.shape != x.shape:
+            raise RuntimeError("contrastive: feats / global_feats / last_feats must have the same [B, D] shape")
+        B, D = x.shape
+        row_loss = torch.empty(B, dtype=f32, device=x.device)
+        dx = torch.empty_like(x)
+        _C.call("fedfr_contrastive", x.data_ptr(), g.data_ptr(), l.data_ptr(), B, D, float(temperature), row_loss.data_ptr(),
+                dx.data_ptr(), _C.stream())
+        loss = torch.empty((), dtype=f32, device=x.device)
+        _C.call("fedfr_sum_scale", row_loss.data_ptr(), B, 1.0 / B, loss.data_ptr(), _C.stream())
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        (dx,) = ctx.saved_tensors
+        return dx * dl, None, None, None
+
+
+def contrastive_loss(feats, global_feats, last_feats, temperature=0.5):
+    return ContrastiveFn.apply(feats, global_feats, last_feats, temperature)
+
+
 def cosine_linear(x, w, normalize_feat=True):
     return CosineLinearFn.apply(x, w, normalize_feat)
 

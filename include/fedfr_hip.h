@@ -157,6 +157,10 @@ int fedfr_bce_logits(const float* cosv, const long long* label, const float* bia
 /* row_loss[b] = sum_c bce(z, gt); dz = d(loss_scale * mean_b row_loss)/dz; dcos = dz * dzdcos (optional) */
 int fedfr_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam,
                    float loss_scale, float* dz, float* dcos, float* row_loss, void* stream);
+/* model-contrastive term (client.py:372-375, :415-418): row_loss[b] = CE([cos(x,g)/T, cos(x,l)/T], 0) with
+ * nn.CosineSimilarity(dim=1, eps=1e-8); dx = d(mean_b row_loss)/dx (optional).  g, l: frozen global / last-round embeddings. */
+int fedfr_contrastive(const float* feats, const float* global_feats, const float* last_feats, int B, int D, float temperature,
+                      float* row_loss, float* dfeats, void* stream);
 int fedfr_colsum_f32(const float* x, int R, int C, float* out, void* stream);
 int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream);
 

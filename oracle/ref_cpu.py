@@ -403,6 +403,84 @@ def client_train(sd: Dict[str, torch.Tensor], fc: torch.Tensor, batches, layers:
     return losses, sd, fc
 
 
+def client_train_public(sd: Dict[str, torch.Tensor], fc: torch.Tensor, bce: Optional[Dict[str, torch.Tensor]], batches,
+                        layers: Sequence[int], *, loss_name: str = "CosFace", s: float = 30.0, m: float = 0.4, lr: float = 0.05,
+                        momentum: float = 0.9, weight_decay: float = 5e-4, bce_detach: bool = False,
+                        global_sd: Optional[Dict[str, torch.Tensor]] = None, last_sd: Optional[Dict[str, torch.Tensor]] = None,
+                        temperature: float = 0.5, mu: float = 5.0, reweight: Optional[Tuple[int, int]] = None):
+    """One local epoch of ``Client.train_with_public_data`` (client.py:354-441) as a function:
+    ``fc`` = [local | public] class centres (client.py:312); ``bce`` = {'converter.0.weight','converter.0.bias','weight','bias'}
+    or None (args.BCE_local); ``global_sd``/``last_sd`` given => model-contrastive term (args.contrastive_bb) with the frozen
+    global / last-round backbones in eval mode (client.py:326-329); ``reweight`` = (num_classes, num_client) => client.py:269-285
+    (quirk kept: the reference concatenates under no_grad, so the re-weighted CosFace loss is reported but not differentiated).
+    loss = cos + 10*bce + mu*con.  Fresh SGD over backbone + fc + bce parameters (client.py:335).
+    Returns (rows of (loss, cos, con, bce) per step, sd, fc, bce) — updated in place."""
+    keys = trainable_keys(sd)
+    bkeys = ["converter.0.weight", "converter.0.bias", "weight", "bias"] if bce is not None else []
+    params = [sd[k] for k in keys] + [fc] + [bce[k] for k in bkeys]
+    bufs: List[Optional[torch.Tensor]] = [None] * len(params)
+    margin = MARGINS[loss_name]
+    rows = []
+    for imgs, labels in batches:
+        for p in params:
+            p.requires_grad_(True)
+            p.grad = None
+        con = bl = None
+        if global_sd is not None:
+            with torch.no_grad():
+                gfe = iresnet_forward(global_sd, imgs, layers, training=False)
+                lfe = iresnet_forward(last_sd, imgs, layers, training=False)
+        feats = iresnet_forward(sd, imgs, layers, training=True)
+        logits = margin(fc_module_forward(feats, fc), labels, s, m)
+        if reweight is not None:
+            ncls, nclient = reweight
+            with torch.no_grad():
+                keep = torch.ones(logits.shape, dtype=torch.bool)
+                keep[torch.arange(len(labels)), labels] = False
+                tmp = logits.detach().clone()[keep].reshape(len(labels), logits.shape[1] - 1)[:, :ncls].repeat(1, nclient - 1)
+                logits = torch.cat([logits, tmp], dim=1)     # INSIDE no_grad, as client.py:276: the CosFace term then carries no gradient
+        cos = F.cross_entropy(logits, labels)
+        loss = cos
+        if bce is not None:
+            z, gt = bce_module_forward(feats.detach() if bce_detach else feats, labels, bce["converter.0.weight"],
+                                       bce["converter.0.bias"], bce["weight"], bce["bias"])
+            bl = bce_loss(z, gt)
+            loss = loss + 10 * bl
+        if global_sd is not None:
+            con = contrastive_loss(feats, gfe, lfe, temperature)
+            loss = loss + mu * con
+        loss.backward()
+        grads = [p.grad for p in params]
+        for p in params:
+            p.requires_grad_(False)
+        sgd_step(params, grads, bufs, lr, momentum, weight_decay)
+        rows.append((float(loss.detach()), float(cos.detach()), None if con is None else float(con.detach()),
+                     None if bl is None else float(bl.detach())))
+    return rows, sd, fc, bce
+
+
+def public_fixture_state(g, variant: str):
+    """Initial state + batches of the tests/golden/client_public_*.npz fixtures (tools/make_golden.py gen_public), rebuilt from
+    the closed forms: returns (sd, fc, bce-or-None, batches, kwargs for client_train_public)."""
+    layers = IRESNET_LAYERS["iresnet18"]
+    nl, npub, B, steps = int(g["n_local"]), int(g["n_public"]), int(g["B"]), int(g["steps"])
+    C = nl + npub
+    sd = closed_form_state_dict(layers, tag=float(g["tag"]))
+    fc = torch.cat([head_fc(nl, seed=11), head_fc(npub, seed=12)], dim=0)
+    bce = None
+    if variant in ("full", "bce_rw"):
+        bce = {"converter.0.weight": torch.eye(512), "converter.0.bias": torch.zeros(512), "weight": head_fc(nl, seed=13),
+               "bias": torch.zeros(nl)}
+    kw = dict(lr=float(g["lr"]), mu=float(g["mu"]), temperature=float(g["temperature"]))
+    if variant == "full":
+        kw["global_sd"] = closed_form_state_dict(layers, tag=float(g["tag"]))
+        kw["last_sd"] = closed_form_state_dict(layers, tag=float(g["last_tag"]))
+    if variant == "bce_rw":
+        kw["reweight"] = (nl, 4)
+    batches = [(closed_form_images(B, tag=float(st)), closed_form_labels(B, C, tag=st)) for st in range(steps)]
+    return sd, fc, bce, batches, kw
+
+
 def train_step_grads(sd: Dict[str, torch.Tensor], fc: torch.Tensor, imgs: torch.Tensor,
                      labels: torch.Tensor, layers: Sequence[int], loss_name: str = "CosFace",
                      s: float = 30.0, m: float = 0.4):

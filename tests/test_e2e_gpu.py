@@ -211,6 +211,70 @@ def test_fused_client_loop_vs_reference():
     assert rel(fc, g["head_fc"]) < 5e-2
 
 
+@pytest.mark.parametrize("variant", ["full", "seq", "bce_rw"])
+def test_train_with_public_data_vs_reference(variant):
+    """Client.train_with_public_data (client.py:287-508) through the fused head trainer: iresnet18, 6 local + 14 public
+    classes, 3 SGD steps.  'full' = Branch_model + 10*BCE + mu*contrastive (frozen global / last-round backbones in eval
+    mode), 'seq' = plain Sequential model, 'bce_rw' = BCE + reweight_cosface (detached CosFace term, reference quirk).
+    Compared with the values captured from the imported reference modules."""
+    g = load_golden("client_public_" + variant)
+    nl, npub, B, steps = int(g["n_local"]), int(g["n_public"]), int(g["B"]), int(g["steps"])
+    layers = R.IRESNET_LAYERS["iresnet18"]
+
+    class Args:
+        network, loss, local_epoch, output_dir, aggr_alg, num_client = "iresnet18", "CosFace", 1, "/tmp", "FedAvg", 4
+        BCE_local = variant in ("full", "bce_rw")
+        contrastive_bb = variant == "full"
+        reweight_cosface = variant == "bce_rw"
+        BCE_detach, combine_dataset = False, True
+
+    class DS:
+        ID_base, num_classes = 0, nl
+
+    class Loader(list):
+        dataset = DS()
+
+    class Data:
+        train_class_sizes, train_dataset_sizes, train_loaders = [nl], [B * steps], [Loader()]
+
+    from fedfr_amd.config import config as cfg
+    saved = (cfg.lr, cfg.mu)
+    cfg.lr, cfg.mu = float(g["lr"]), float(g["mu"])
+    try:
+        cl = client.Client(0, Args, Data, device=DEV)
+        cl.backbone_state_dict = R.closed_form_state_dict(layers, tag=float(g["tag"]))
+        cl.fc_module.fc.data = R.head_fc(nl, seed=11)
+        if Args.BCE_local:
+            cl.bce_module.weight.data = R.head_fc(nl, seed=13)
+        if Args.contrastive_bb:
+            cl.last_model.load_state_dict(R.closed_form_state_dict(layers, tag=float(g["last_tag"])))
+        batches = [(R.closed_form_images(B, tag=float(st)), R.closed_form_labels(B, nl + npub, tag=st)) for st in range(steps)]
+        cl.train_with_public_data(pretrained_fc=R.head_fc(npub, seed=12), combine_loader=batches)
+    finally:
+        cfg.lr, cfg.mu = saved
+    rows = g["rows"]
+    assert abs(cl.get_train_loss() - rows[:, 0].mean()) < 1e-2 * abs(rows[:, 0].mean()), (cl.get_train_loss(), rows[:, 0].mean())
+    assert abs(cl.cos_meter.avg - rows[:, 1].mean()) < 1e-2 * abs(rows[:, 1].mean())
+    if variant == "full":
+        assert abs(cl.con_meter.avg - rows[:, 2].mean()) < 2e-2 * abs(rows[:, 2].mean()), (cl.con_meter.avg, rows[:, 2].mean())
+    if Args.BCE_local:
+        assert abs(cl.bce_meter.avg - rows[:, 3].mean()) < 1e-2 * abs(rows[:, 3].mean())
+    out = cl.get_model()
+    assert int(out["bn1.num_batches_tracked"]) == int(g["sd_bn1.num_batches_tracked"])
+    for k in ("bn1.running_mean", "layer4.1.bn3.running_var", "features.running_mean"):
+        assert rel(out[k], g["sd_" + k]) < 3e-2, (k, rel(out[k], g["sd_" + k]))
+    for k in ("conv1.weight", "layer2.0.downsample.0.weight", "bn1.weight", "prelu.weight", "fc.bias"):
+        assert rel(out[k], g["sd_" + k]) < 1e-2, (k, rel(out[k], g["sd_" + k]))
+    assert rel(cl.fc_module.fc.data, g["head_fc"]) < 5e-2
+    assert cl.fc_module.fc.shape[0] == nl + npub and cl.get_global_fc().shape[0] == npub
+    if Args.BCE_local:
+        assert rel(cl.bce_module.weight.data, g["bce_weight"]) < 5e-2
+        assert rel(cl.bce_module.converter[0].weight.data[:8, :64], g["bce_conv_w_slice"]) < 1e-2
+        assert float((cl.bce_module.bias.data - T(g["bce_bias"]).cpu()).abs().max()) < 2e-3
+    if variant == "full":       # last_model <- this round's local model (client.py:499-501)
+        assert torch.equal(cl.last_model.state_dict()["conv1.weight"].cpu(), out["conv1.weight"].cpu())
+
+
 def test_client_server_round():
     """Two clients, one FedAvg round through the reference-shaped Client / Server objects (server.py:265-338):
     the aggregate equals the data-size-weighted mean of the two locally trained models (bit exact, flat path)."""
@@ -245,9 +309,19 @@ def test_client_server_round():
     assert not torch.equal(m0["conv1.weight"], m1["conv1.weight"])
 
 
-def test_large_batch_train_step_vs_oracle():
-    """iresnet18 at batch 128: M = 25088..1.6M rows, so the conv layers run on the LDS-halo kernels (incl. the fused
-    BN-backward reduction) that the small-batch goldens never reach.  Compared with the fp32 oracle on the same inputs."""
+@pytest.mark.parametrize("fuse_bnbwd", [0, 1])
+def test_large_batch_train_step_vs_oracle(fuse_bnbwd):
+    """iresnet18 at batch 128: M = 25088..1.6M rows, so the conv layers run on the LDS-halo kernels that the small-batch
+    goldens never reach — with the BN-backward reduction as its own kernel (default) and fused into the dgrad epilogue
+    (option fuse_bnbwd).  Compared with the fp32 oracle on the same inputs."""
+    _C.call("fedfr_set_option", b"fuse_bnbwd", fuse_bnbwd)
+    try:
+        _large_batch_step()
+    finally:
+        _C.call("fedfr_set_option", b"fuse_bnbwd", 0)
+
+
+def _large_batch_step():
     layers = R.IRESNET_LAYERS["iresnet18"]
     B, C = 128, 100
     m, sd, _ = make_model("iresnet18", tag=3.0)

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from fedfr_amd import _C  # noqa: E402
+from fedfr_amd import _C, ops  # noqa: E402
 
 
 def dev():
@@ -432,3 +432,23 @@ def test_rows_gather_scatter_and_remap():
     _C.call("fedfr_pfc_remap", lab.data_ptr(), 4, index.data_ptr(), 100, _C.stream())
     torch.cuda.synchronize()
     assert lab.tolist() == [3, -1, 99, 0]
+
+
+@pytest.mark.parametrize("B,D,temp", [(8, 512, 0.5), (37, 512, 0.5), (5, 96, 0.07)])
+def test_contrastive_vs_torch(B, D, temp):
+    """fedfr_contrastive == CE([cos(x,g)/T, cos(x,l)/T], 0) built from nn.CosineSimilarity + F.cross_entropy (client.py:372-375)."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(B * 7 + D)
+    x = torch.randn(B, D, generator=gen, dtype=torch.float64, requires_grad=True)
+    g_ = x.detach() + 0.5 * torch.randn(B, D, generator=gen, dtype=torch.float64)
+    l_ = torch.randn(B, D, generator=gen, dtype=torch.float64)
+    cs = torch.nn.CosineSimilarity(dim=1)
+    ref = F.cross_entropy(torch.stack([cs(x, g_) / temp, cs(x, l_) / temp], dim=1), torch.zeros(B, dtype=torch.long))
+    ref.backward()
+    xd = x.detach().float().to(dev()).requires_grad_(True)
+    gd, ld = g_.float().to(dev()), l_.float().to(dev())
+    loss = ops.contrastive_loss(xd, gd, ld, temp)
+    (loss * 3.0).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    err = (xd.grad.double().cpu() / 3.0 - x.grad).abs().max() / x.grad.abs().max()
+    assert float(err) < 1e-4, float(err)

@@ -212,3 +212,24 @@ def test_client_loop_matches_reference():
             close(sd[k[3:]], g[k], 5e-3, 2e-4)      # 3 SGD steps: fp32 thread-order noise compounds
     close(sd["fc.weight"][:4, :2048], g["sd_fc.weight_slice"], 5e-3, 2e-4)
     close(fc, g["head_fc"], 5e-3, 2e-4)
+
+
+@pytest.mark.parametrize("variant", ["full", "seq", "bce_rw"])
+def test_public_data_loop_matches_reference(variant):
+    """train_with_public_data body (client.py:354-441): Branch_model + 10*BCE + mu*contrastive / plain Sequential /
+    BCE + reweight_cosface (detached CosFace term), captured from the imported reference modules."""
+    g = load_golden("client_public_" + variant)
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sd, fc, bce, batches, kw = R.public_fixture_state(g, variant)
+    rows, sd, fc, bce = R.client_train_public(sd, fc, bce, batches, layers, **kw)
+    got = np.array([[np.nan if v is None else v for v in r] for r in rows])
+    np.testing.assert_allclose(got, g["rows"], rtol=3e-4, equal_nan=True)
+    for k in g.files:
+        if k.startswith("sd_") and k[3:] in sd:
+            close(sd[k[3:]], g[k], 5e-3, 2e-4)
+    close(fc, g["head_fc"], 5e-3, 2e-4)
+    if bce is not None:
+        close(bce["weight"], g["bce_weight"], 5e-3, 2e-4)
+        close(bce["bias"], g["bce_bias"], 5e-3, 2e-4)
+        close(bce["converter.0.weight"][:8, :64], g["bce_conv_w_slice"], 5e-3, 2e-4)
+        close(bce["converter.0.bias"], g["bce_conv_b"], 5e-3, 2e-4)

@@ -49,6 +49,14 @@ for name, H, Cin, Cout, k, s, cnt in SHAPES:
         t = timeit(lambda: _C.call("fedfr_conv2d_fwd", x.data_ptr(), wb.data_ptr(), y.data_ptr(), stats.data_ptr(), B, H, Cin, Cout, k, s, st)); tot["fwd"] += t * cnt; res.append("fwd %7.1f us %6.0f TF" % (t * 1e3, flop / t / 1e9))
     if "dgrad" in which:
         t = timeit(lambda: _C.call("fedfr_conv2d_dgrad", dy.data_ptr(), wdb.data_ptr(), dx.data_ptr(), B, H, Cin, Cout, k, s, st)); tot["dgrad"] += t * cnt; res.append("dgrad %7.1f us %6.0f TF" % (t * 1e3, flop / t / 1e9))
+    if "fdgrad" in which and k == 3 and s == 1:      # dgrad with the fused BN-backward reduction epilogue (PReLU variant)
+        import ctypes
+        bnx = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
+        cv = [torch.rand(Cin, device=dev) + 0.5 for _ in range(5)]
+        part = torch.empty((B * H * H + 127) // 128, 3, Cin, device=dev); rows = ctypes.c_int(0)
+        t = timeit(lambda: _C.call("fedfr_conv2d_dgrad_bnbwd", dy.data_ptr(), wdb.data_ptr(), dx.data_ptr(), B, H, Cin, Cout, k, s, bnx.data_ptr(),
+                                   cv[0].data_ptr(), cv[1].data_ptr(), cv[2].data_ptr(), cv[3].data_ptr(), cv[4].data_ptr(), part.data_ptr(),
+                                   ctypes.byref(rows), st)); res.append("fdgrad %7.1f us (rows %d)" % (t * 1e3, rows.value))
     if "wgrad" in which:
         t = timeit(lambda: _C.call("fedfr_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, B, H, Cin, Cout, k, s, st)); tot["wgrad"] += t * cnt; res.append("wgrad %7.1f us %6.0f TF" % (t * 1e3, flop / t / 1e9))
     print("%-18s x%-2d %s" % (name, cnt, " | ".join(res)))

@@ -14,6 +14,7 @@ What is captured (reference symbol → fixture):
   server.FedPavg / FedAvg_on_FC           → fedavg.npz
   partial_fc.PartialFC (W=1, and W=2 over gloo) → pfc_w1_*.npz / pfc_w2.npz
   a 3-step Client.train-equivalent loop on iresnet18 → client_r18.npz
+  the train_with_public_data loop body (Branch_model + BCE + contrastive; Sequential + reweight) → client_public_{full,seq}.npz
 """
 import os
 import sys
@@ -439,8 +440,113 @@ def gen_client():
     save("client_r18", **out)
 
 
+# ---- 8. train_with_public_data loop body (client.py:354-441) on iresnet18 ---------------------------------------
+PUB_KEYS = ("conv1.weight", "bn1.weight", "bn1.running_mean", "bn1.num_batches_tracked", "prelu.weight",
+            "layer2.0.downsample.0.weight", "layer4.1.bn3.running_var", "fc.bias", "features.running_mean")
+
+
+def public_setup():
+    """shared by the generator and the tests' oracle run: sizes + deterministic initial state (no RNG)."""
+    return dict(n_local=6, n_public=14, B=8, steps=3, lr=0.01, mu=5.0, temperature=0.5, tag=2.0, last_tag=5.0)
+
+
+def gen_public(variant):
+    """variant 'full': Branch_model + BCE (weight 10) + model-contrastive (weight mu) — the FedFR objective;
+    variant 'seq': Sequential_model, CosFace over [local | public] only;
+    variant 'bce_rw': Branch_model + BCE + reweight_cosface (num_client 4), no contrastive.  NB the reference concatenates inside
+    torch.no_grad() (client.py:272-276), so with reweighting the CosFace term reaches the reported loss but carries NO gradient —
+    reproduced as is (quirks are kept)."""
+    cfgp = public_setup()
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    nl, npub, B, steps, lr = cfgp["n_local"], cfgp["n_public"], cfgp["B"], cfgp["steps"], cfgp["lr"]
+    C = nl + npub
+    backbone = backbones.iresnet18(False, dropout=0, fp16=False)
+    load_closed_form(backbone, layers, tag=cfgp["tag"])
+    backbone.train()
+    fcm = client.FC_module(512, nl, "/tmp")
+    fcm.fc.data = R.head_fc(nl, seed=11)
+    fcm.update_with_pretrain(R.head_fc(npub, seed=12))              # client.py:312
+    fcm.train()
+    margin = losses.CosFace(s=30, m=0.4)
+    out = dict(cfgp)
+    out["variant"] = np.array(variant)
+    has_bce, has_con, has_rw = variant in ("full", "bce_rw"), variant == "full", variant == "bce_rw"
+    num_client, num_classes = 4, nl
+    if has_bce:
+        bcem = client.BCE_module(512, nl, 1)
+        bcem.weight.data = R.head_fc(nl, seed=13)
+        bcem.train()
+        bce_crit = losses.BCE_loss()
+        model = client.Branch_model(backbone, fcm, bcem)
+    else:
+        model = client.Sequential_model(backbone, fcm)
+    if has_con:
+        import copy
+        global_model = copy.deepcopy(backbone).eval()
+        last_model = backbones.iresnet18(False, dropout=0, fp16=False)
+        load_closed_form(last_model, layers, tag=cfgp["last_tag"])
+        last_model.eval()
+        con_criterion = torch.nn.CosineSimilarity(dim=1)
+
+    def reweight(logits, labels):                                     # client.py:269-285, verbatim semantics
+        with torch.no_grad():
+            idx_bool = torch.ones(logits.shape).bool()
+            idx_bool[torch.arange(len(labels)), labels] = False
+            tmp = logits.detach().clone()[idx_bool].reshape(len(labels), logits.shape[1] - 1)[:, :num_classes].repeat(1, num_client - 1)
+            logits = torch.cat([logits, tmp], dim=1)
+        return logits
+    opt = torch.optim.SGD(params=model.parameters(), lr=lr, momentum=0.9, weight_decay=5e-4)
+    rows = []
+    for st in range(steps):
+        imgs = R.closed_form_images(B, tag=float(st))
+        labels = R.closed_form_labels(B, C, tag=st)
+        opt.zero_grad()
+        if variant == "full":
+            with torch.no_grad():
+                global_feats = global_model(imgs)
+                last_feats = last_model(imgs)
+            cos_logits, bce_logits, bce_gts, feats = model(imgs, labels, contrastive=True, detach=False)
+            pos_sim = con_criterion(feats, global_feats) / cfgp["temperature"]
+            neg_sim = con_criterion(feats, last_feats) / cfgp["temperature"]
+            con_label = torch.zeros(len(labels)).long()
+            con_loss = F.cross_entropy(torch.stack([pos_sim, neg_sim], dim=1), con_label)
+            cos_logits = margin(cos_logits, labels)
+            cos_loss = F.cross_entropy(cos_logits, labels)
+            bce_loss = bce_crit(bce_logits, bce_gts)
+            loss = cos_loss + 10 * bce_loss + cfgp["mu"] * con_loss
+            rows.append([float(loss), float(cos_loss), float(con_loss), float(bce_loss)])
+        elif variant == "bce_rw":
+            cos_logits, bce_logits, bce_gts = model(imgs, labels, contrastive=False, detach=False)
+            cos_logits = reweight(margin(cos_logits, labels), labels)
+            cos_loss = F.cross_entropy(cos_logits, labels)
+            bce_loss = bce_crit(bce_logits, bce_gts)
+            loss = cos_loss + 10 * bce_loss
+            rows.append([float(loss), float(cos_loss), float("nan"), float(bce_loss)])
+        else:
+            logits = model(imgs)
+            logits = margin(logits, labels)
+            loss = F.cross_entropy(logits, labels)
+            rows.append([float(loss), float(loss), float("nan"), float("nan")])
+        loss.backward()
+        opt.step()
+    out["rows"] = np.array(rows, dtype=np.float64)
+    sd = backbone.state_dict()
+    for k in PUB_KEYS:
+        out["sd_" + k] = sd[k]
+    out["sd_layer3.1.conv2.weight_slice"] = sd["layer3.1.conv2.weight"][:4, :32]
+    out["head_fc"] = fcm.fc.data
+    out["sd_abs_checksum"] = sum(float(v.double().abs().sum()) for v in sd.values())
+    if has_bce:
+        out["bce_weight"] = bcem.weight.data
+        out["bce_bias"] = bcem.bias.data
+        out["bce_conv_w_diag"] = torch.diagonal(bcem.converter[0].weight.data).clone()
+        out["bce_conv_w_slice"] = bcem.converter[0].weight.data[:8, :64]
+        out["bce_conv_b"] = bcem.converter[0].bias.data
+    save("client_public_" + variant, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client"]
+    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public"]
     if "block" in which:
         gen_block()
     if "r50" in which:
@@ -459,3 +565,6 @@ if __name__ == "__main__":
         gen_pfc()
     if "client" in which:
         gen_client()
+    if "public" in which:
+        for v in ("full", "seq", "bce_rw"):
+            gen_public(v)

@@ -154,9 +154,22 @@ class PartialFC(Module):
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
         if not _is_dist(self.world_size):
             return t.clone()
-        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t.contiguous())
+        if dist.get_backend() == "gloo":      # gloo moves device tensors only through broadcast / all_reduce (debug + test path)
+            out = torch.zeros((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            out[self.rank] = t
+            dist.all_reduce(out)
+        else:
+            out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t.contiguous())
         return out.view((-1,) + tuple(t.shape[1:]))
+
+    def _reduce_scatter(self, full: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        if dist.get_backend() == "gloo":
+            dist.all_reduce(full)
+            return full.view((self.world_size,) + tuple(like.shape))[self.rank].clone()
+        out = torch.empty_like(like)
+        dist.reduce_scatter_tensor(out, full)
+        return out
 
     def _all_reduce(self, t: torch.Tensor, op: str):
         if _is_dist(self.world_size):
@@ -188,8 +201,7 @@ class PartialFC(Module):
         dwn = ops.sgemm(grad, total_features, trans_a=True)
         self.sub_weight.grad = ops.normalize_rows_bwd(norm_weight, winv, dwn)
         if _is_dist(self.world_size):                                                        # C6
-            x_grad = torch.empty_like(features)
-            dist.reduce_scatter_tensor(x_grad, dfeat)
+            x_grad = self._reduce_scatter(dfeat, features)
         else:
             x_grad = dfeat
         x_grad = x_grad * self.world_size                                                    # partial_fc.py:174

@@ -1,6 +1,8 @@
 """End-to-end parity of the HIP path (through the reference-shaped Python surface) against the golden vectors
 captured from the imported reference and, where finer detail is needed, the CPU oracle on identical
 closed-form inputs.  Tolerances: bf16 backbone 1e-2-class (stated per assert), fp32 head 1e-4-class."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -460,6 +462,61 @@ def test_partial_fc_w1_vs_reference(name):
         assert maxrel(pfc.weight[:: max(1, num_local // 64)][:64], g[pre + "weight_rows"]) < 1e-5
         assert maxrel(pfc.weight_mom[:: max(1, num_local // 64)][:64], g[pre + "mom_rows"]) < 1e-4
         assert abs(float(pfc.weight.double().sum()) - float(g[pre + "weight_sum"])) < 1e-3
+
+
+def _pfc_w2_gpu_worker(rank, port, q):
+    """one rank of the class-sharded PartialFC (uneven shards 501/500, sample_rate 0.2) — both ranks share cuda:0, collectives go
+    through gloo (RCCL refuses two ranks on one device); kernels, sampling and the update are the product's HIP path."""
+    import traceback
+    import torch.distributed as dist
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        g = load_golden("pfc_w2")
+        B, C, rate = int(g["B"]), int(g["C"]), float(g["rate"])
+        s, m, steps, mn = float(g["s"]), float(g["m"]), int(g["steps"]), str(g["margin"])
+        pfc = PartialFC(rank=rank, local_rank=0, world_size=2, batch_size=B, resume=False, margin_softmax=getattr(losses, mn)(s=s, m=m),
+                        num_classes=C, sample_rate=rate, embedding_size=512, prefix="/tmp")
+        num_local, class_start = R.pfc_shard(C, 2, rank)
+        assert (pfc.num_local, pfc.class_start) == (num_local, class_start)
+        pfc.weight.copy_(R.closed_form((num_local, 512), 0.071 + 0.003 * rank, 1.1, 0.01).to(DEV))
+        pfc.weight_mom.zero_()
+        for st in range(steps):
+            feats = F.normalize(R.closed_form((B, 512), 0.113 + 0.01 * rank + 0.001 * st, 0.2 + st, 1.0)).to(DEV)
+            lab = ((R.closed_form_labels(B, C, tag=st + 3 * rank) * 31 + rank) % C).to(DEV)
+            perm = R.closed_form((num_local,), 0.77 + 0.1 * st, 0.3 + rank, 0.5, 0.5).to(DEV)
+            x_grad, loss_v = pfc.forward_backward(lab, feats, None, perm=perm)
+            pre = "r%d_s%d_" % (rank, st)
+            assert torch.equal(pfc.index.cpu(), T(g[pre + "index"])), "sampled class set differs"
+            assert maxrel(x_grad, g[pre + "x_grad"]) < 1e-4
+            assert abs(float(loss_v) - float(g[pre + "loss_v"])) < 1e-4 * max(1.0, abs(float(g[pre + "loss_v"])))
+            swg = pfc.sub_weight.grad
+            assert maxrel(swg[:: max(1, swg.shape[0] // 48)][:48], g[pre + "sub_weight_grad_rows"]) < 1e-4
+            assert maxrel(swg.norm(dim=1), g[pre + "sub_weight_grad_rownorm"]) < 1e-4
+            pfc.fused_sgd_update(0.1, 0.9, 5e-4)
+            assert maxrel(pfc.weight[:: max(1, num_local // 64)][:64], g[pre + "weight_rows"]) < 1e-5
+            assert maxrel(pfc.weight_mom[:: max(1, num_local // 64)][:64], g[pre + "mom_rows"]) < 1e-4
+            assert abs(float(pfc.weight.double().sum()) - float(g[pre + "weight_sum"])) < 1e-3
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:                                            # noqa: BLE001 — reported to the parent
+        q.put((rank, traceback.format_exc()))
+
+
+def test_partial_fc_w2_vs_reference():
+    """world_size 2 product path against the reference captured over gloo with mp.spawn: all six exchange points
+    (label/feature all-gather, max + 2 sum all-reduces, reduce-scatter) with uneven class shards and negative sampling."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pfc_w2_gpu_worker, args=(r, 29655, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: "ok", 1: "ok"}, res
 
 
 def test_partial_fc_config3_scale_properties():

@@ -126,8 +126,12 @@ def fedavg_all_reduce(backbone, data_size: float, group=None, _axpy=_axpy, _i64=
 
 
 class Server(object):
-    """Round driver (reference server.py:68-133, :265-338) for the plain FedAvg path: clients are trained
-    sequentially in one process (as the reference does, server.py:283) and averaged with ``FedPavg``."""
+    """Round driver (reference server.py:68-133, :265-338): clients are trained sequentially in one process (as the
+    reference does, server.py:283) and averaged with ``FedPavg``; with ``args.add_pretrained_data`` every client trains on
+    local + public identities (``Client.train_with_public_data``) and, with ``args.return_all``, the public class centres
+    are averaged with ``FedAvg_on_FC`` (server.py:316-327).  The public-set embedding sweep and hard-negative mining
+    (server.py:242-263, client.py:208-268) are SURVEY §8(f) rows N1/N2: the caller provides ``public_train_loader`` /
+    ``pretrained_fc`` and the whole public set is used."""
 
     def __init__(self, clients, data, args, device=None):
         self.data = data
@@ -141,17 +145,36 @@ class Server(object):
         self.federated_model = getattr(backbones, args.network)(False, dropout=0, fp16=True).to(self.device)
         self.current_client_list = list(range(self.num_client))
         self.logger = logging.getLogger("FL_face.server")
+        self.public_train_loader = getattr(data, "public_train_loader", None)
+        self.pretrained_fc = None                    # [n_public, 512] class centres of the public identities (server.py:182-240)
 
     def train(self):
-        models, losses_, data_sizes = [], [], []
+        from .config import config as cfg
+        models, models_fc, losses_, data_sizes = [], [], [], []
+        public = bool(getattr(self.args, "add_pretrained_data", False))
+        return_all = bool(getattr(self.args, "return_all", False))
+        if getattr(self.args, "adaptive_local_epoch", False) and self.global_round != 0:        # server.py:277-280
+            self.local_epoch = max(4, self.local_epoch - 2)
+            cfg.train_decay = max(1, int(3 / 4 * self.local_epoch))
         for idx, i in enumerate(self.current_client_list):
             self.clients[i].backbone_state_dict = flat_state_dict(self.federated_model)       # "server sends backbone"
             self.clients[i].local_epoch = self.local_epoch
-            self.clients[i].train(self.global_epoch)
+            if public:
+                if self.pretrained_fc is None:
+                    raise RuntimeError("Server.train: add_pretrained_data needs server.pretrained_fc ([n_public, 512] class centres)")
+                self.clients[i].train_with_public_data(self.global_epoch, public_train_loader=self.public_train_loader,
+                                                       pretrained_fc=self.pretrained_fc, choose_hard_negative=False)
+            else:
+                self.clients[i].train(self.global_epoch)
             losses_.append(self.clients[i].get_train_loss())
             models.append(self.clients[i].get_model())
+            if return_all:
+                models_fc.append(self.clients[i].get_global_fc().to(self.device))
+                self.clients[i].fc_module.remove_pretrain()
             data_sizes.append(self.clients[i].get_data_size())
         self.avg_loss = sum(losses_) / len(losses_)
+        if return_all:                                                                           # server.py:316-327
+            self.pretrained_fc = FedAvg_on_FC(self.pretrained_fc, models_fc, data_sizes, p=1.0)
         if getattr(self.args, "aggr_alg", "FedAvg") in ("FedAvg", "FedProx"):
             aggr_state_dict = FedPavg(models, data_sizes)
             self.federated_model.load_state_dict(aggr_state_dict)

@@ -311,6 +311,64 @@ def test_client_server_round():
     assert not torch.equal(m0["conv1.weight"], m1["conv1.weight"])
 
 
+def test_public_data_server_round():
+    """One FedFR round with public data (server.py:265-338, add_pretrained_data + return_all): both clients train the
+    [local | public] CosFace head + BCE branch, the server averages backbones (FedPavg) and public class centres (FedAvg_on_FC)."""
+    nl, npub, B = 5, 9, 4
+
+    class Args:
+        network, loss, local_epoch, output_dir, aggr_alg, num_client = "iresnet18", "CosFace", 1, "/tmp", "FedAvg", 2
+        BCE_local, contrastive_bb, reweight_cosface, BCE_detach, combine_dataset = True, False, False, False, True
+        add_pretrained_data, return_all = True, True
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, n, ncls, tag, id_base=0):
+            self.num_classes, self.ID_base = ncls, id_base
+            self.x, self.y = R.closed_form_images(n, tag=tag), R.closed_form_labels(n, ncls, tag=int(tag))
+
+        def __len__(self):
+            return len(self.x)
+
+        def __getitem__(self, i):
+            return self.x[i], self.y[i]
+
+    class Loader(list):
+        pass
+
+    def loader(ds):
+        l = Loader()
+        l.dataset = ds
+        return l
+
+    class Data:
+        train_class_sizes = [nl, nl]
+        train_dataset_sizes = [8, 4]
+        train_loaders = [loader(DS(8, nl, 1.0)), loader(DS(4, nl, 2.0, id_base=nl))]
+        public_train_loader = loader(DS(8, npub, 3.0))
+
+    from fedfr_amd.config import config as cfg
+    saved = (cfg.lr, cfg.com_batch_size)
+    cfg.lr, cfg.com_batch_size = 0.01, B
+    try:
+        clients = [client.Client(c, Args, Data, device=DEV) for c in range(2)]
+        srv = server.Server(clients, Data, Args, device=DEV)
+        srv.federated_model.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet18"], tag=2.0))
+        pre = R.head_fc(npub, seed=12).to(DEV)
+        srv.pretrained_fc = pre.clone()
+        avg_loss = srv.train()
+    finally:
+        cfg.lr, cfg.com_batch_size = saved
+    assert np.isfinite(avg_loss)
+    assert [c.get_data_size() for c in clients] == [16, 12]                    # combined dataset sizes drive FedAvg (client.py:302)
+    assert all(c.fc_module.fc.shape[0] == nl for c in clients)                 # remove_pretrain() after the round
+    assert srv.pretrained_fc.shape == (npub, 512) and not torch.equal(srv.pretrained_fc, pre)
+    m0, m1 = clients[0].get_model(), clients[1].get_model()
+    w0, w1 = np.float32(16 / 28), np.float32(12 / 28)
+    agg = srv.federated_model.state_dict()
+    for k in ("conv1.weight", "layer3.1.conv2.weight", "fc.bias"):
+        assert torch.equal(agg[k], w0 * m0[k] + w1 * m1[k]), k
+
+
 @pytest.mark.parametrize("fuse_bnbwd", [0, 1])
 def test_large_batch_train_step_vs_oracle(fuse_bnbwd):
     """iresnet18 at batch 128: M = 25088..1.6M rows, so the conv layers run on the LDS-halo kernels that the small-batch

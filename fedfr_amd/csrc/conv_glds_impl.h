@@ -1,0 +1,295 @@
+// conv3x3_glds_kernel + launcher template; one translation unit per instantiation (see gemm_dev.h).
+#pragma once
+#include <algorithm>
+#include "gemm_dev.h"
+
+// In-kernel phase stamps for tools/stamp (compiled out of the product)
+#ifdef FEDFR_HALO2_STAMPS
+#define GLDS_STAMP(i)                                                                       \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && p.dbg) {                                                        \
+      p.dbg[(size_t)blockIdx.x * 16 + 2 * (i)] = __builtin_readcyclecounter();             \
+      p.dbg[(size_t)blockIdx.x * 16 + 2 * (i) + 1] = wall_clock64();                        \
+    }                                                                                       \
+  } while (0)
+#else
+#define GLDS_STAMP(i) do { } while (0)
+#endif
+// timing ablations for tools/stamp (results are WRONG with any bit set): 1 no in-loop DMA, 2 no barrier, 4 no fragment reads
+#ifndef GLDS_ABLATE
+#define GLDS_ABLATE 0
+#endif
+
+// =====================================================================================================
+// 3x3 / stride-1 / pad-1 convolution (fwd, and dgrad with the flipped shadow) for 14x14 / 28x28 maps, Cout % 128 == 0,
+// C % 128 == 0, as an implicit GEMM whose operands reach LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`).
+//
+//   * Why: in-kernel stamps (tools/stamp) of the register-staged halo2 kernel showed its K loop at 32 % of the MFMA rate —
+//     hipcc sinks the next tap's global loads to just before their ds_write, so every tap paid an L2 round trip.  LDS-DMA has
+//     no register destination to sink towards: weight tiles 2-3 taps ahead and the next channel chunk's image are in flight
+//     while a tap computes, retired by COUNTED s_waitcnt vmcnt(N) + one raw s_barrier per tap (never vmcnt(0) in the loop).
+//   * Tile = 196 output pixels x 128 output channels: a whole 14x14 image, or 7 rows of a 28x28 image.  At the benchmark
+//     batch (128) every 14x14 layer is exactly 256 tiles = one per CU (the 128-pixel tiling gave 392 = 1.53 rounds), a tile
+//     never straddles images, and prologue / epilogue are paid once per 56 (not 32) MFMAs per tap and wave.
+//   * A operand: the tile's pixels plus halo as a ZERO-PADDED image in LDS, one 128-B row (64 channels) per padded pixel, so a
+//     filter tap is a constant row shift.  Out-of-image rows are fetched with an out-of-range buffer offset, which the hardware
+//     turns into zeros in LDS (tools/probe/glds_probe.hip): no zero-fill pass, no masks.  Two image buffers (chunk cc / cc+1).
+//   * B operand: one 128 (out channels) x 64 (k) slice of the KRSC weights per tap, ring of 4 buffers.
+//   * LDS rows are 128 B with the 16-B chunk index XOR-ed by (row & 7): conflict-free ds_read_b128 for both operands.  An
+//     LDS-DMA wave-instruction writes 1 KiB linearly (lane l -> base + 16 l), so the swizzle is applied to the per-lane SOURCE
+//     address: lane l of a piece covering rows 8p..8p+7 fetches row 8p + (l >> 3), logical chunk (l & 7) ^ (l >> 3).
+//   * 4 waves (2 x 2), wave tile 112 (7 fragments; 196 = 12.25 fragments, the tail is masked) x 64, v_mfma_f32_16x16x32_bf16.
+//     The barrier sits in the MIDDLE of a tap, the first fragments of the next tap are read behind it, and fragment reads /
+//     DMA issue are threaded between the MFMAs with sched_group_barrier.
+//   * Epilogue: bf16 tile through LDS, per-column sum / sum-of-squares partials for the following BatchNorm in the layout of
+//     the 128-row kernels (gemm_nt_stat_rows rows; the rows this tiling does not need are written as zeros).
+// =====================================================================================================
+template <int N_>
+__device__ __forceinline__ void glds_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+template <int W_, int R_, int AP>   // tile = R_ image rows; AP = LDS-DMA pieces (1 KiB = 8 image rows) per wave and image buffer
+__global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
+  constexpr int PT = R_ * W_, BN = 128, WM = 2, WN = 2, PW = W_ + 2, NT = 256;
+  constexpr int TM = 7, TN = 4, MW = TM * 16;           // 112 fragment rows per wave, 224 per tile (196 valid)
+  constexpr int TPI = W_ / R_;                          // tiles per image
+  constexpr int A_BYTES = AP * 4 * 1024, B_BYTES = BN * 128, NB = 4;
+  static_assert(PT == 196 && W_ % R_ == 0 && (R_ + 2) * PW <= AP * 32, "tile geometry");
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* sA = smem;                       // [2][A_BYTES]
+  unsigned char* sB = smem + 2 * A_BYTES;         // [NB][B_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  GLDS_STAMP(0);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = lid % p.nbn, bt = lid / p.nbn;
+  const int img = bt / TPI, y0 = (bt - img * TPI) * R_;
+  const int m0 = bt * PT, n0 = bn * BN;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+
+  // ---- LDS-DMA source plan.  Lane l of every piece: row (l >> 3) of the piece, logical 16-B chunk (l & 7) ^ (l >> 3).
+  // LDS image row r <-> padded pixel (y0 + r / PW, r % PW) of image img; padded row 0 / H+1 and column 0 / W+1 are zero.
+  const int prow = lane >> 3, pch = (lane & 7) ^ prow;
+  constexpr unsigned OOB = 0xfffffff0u;                 // beyond any buffer: the load writes zeros to LDS
+  unsigned a_src[AP];                                   // byte offset of this lane's pixel/chunk at channel chunk 0
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int r = (j * 4 + wave) * 8 + prow;
+    const int ry = r / PW, rx = r - ry * PW;
+    const int yy = y0 + ry;
+    const bool ok = ry < R_ + 2 && yy >= 1 && yy <= W_ && rx >= 1 && rx <= W_;
+    const unsigned pix = (unsigned)(img * (W_ * W_) + (yy - 1) * W_ + (rx - 1));
+    a_src[j] = ok ? (pix * (unsigned)p.C + (unsigned)(pch * 8)) * 2u : OOB;
+  }
+  const unsigned b_src = ((unsigned)(n0 + wave * 32 + prow) * (unsigned)p.K + (unsigned)(pch * 8)) * 2u;   // + j * 8 rows
+  const unsigned b_rstep = 8u * (unsigned)p.K * 2u;
+
+  auto issue_a = [&](int cc, int abuf, bool live) {
+    const unsigned coff = (unsigned)cc * 128u;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      const unsigned vo = (live && a_src[j] != OOB) ? a_src[j] + coff : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + abuf * A_BYTES + (j * 4 + wave) * 1024), 16, (int)vo, 0, 0, 0);
+    }
+  };
+  auto issue_b = [&](int tap, int cc, int bbuf, bool live) {
+    const unsigned koff = (unsigned)(tap * p.C + cc * 64) * 2u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned vo = live ? b_src + (unsigned)j * b_rstep + koff : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(sB + bbuf * B_BYTES + (wave * 4 + j) * 1024), 16, (int)vo, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses
+  int a_row[TM];                                        // LDS image row of this lane's pixel at tap (0, 0)
+  bool m_ok[TM];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const int t = wm * MW + mi * 16 + l15;              // pixel inside the tile
+    m_ok[mi] = t < PT;
+    const int tt = m_ok[mi] ? t : 0;
+    const int y = tt / W_, x = tt - y * W_;
+    a_row[mi] = y * PW + x;
+  }
+  int b_addr[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const int row = wn * (BN / WN) + ni * 16 + l15;
+    b_addr[ni] = row * 128 + ((lg ^ (row & 7)) << 4);      // ks = 1 flips chunk bit 2: XOR 64
+  }
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int cpt = p.C >> 6;
+  auto read_frags = [&](bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN], const unsigned char* cA, const unsigned char* cB, int toff, int ks) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(cB + (b_addr[ni] ^ (ks * 64)));
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int r = a_row[mi] + toff;
+      fa[mi] = *reinterpret_cast<const bf16x8_t*>(cA + r * 128 + (((lg + 4 * ks) ^ (r & 7)) << 4));
+    }
+  };
+  auto mfma_all = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) acc[ni][mi] = MFMA16(fb[ni], fa[mi], acc[ni][mi]);
+  };
+  // prologue: image of chunk 0, weight tiles of taps 0..2; wait for the image and tap 0, fetch tap 0's first fragments
+  issue_a(0, 0, true);
+  issue_b(0, 0, 0, true);
+  issue_b(1, 0, 1, true);
+  issue_b(2, 0, 2, true);
+  bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
+  glds_wait_vmcnt<8>();
+  __builtin_amdgcn_s_barrier();
+  read_frags(f0a, f0b, sA, sB, 0, 0);
+  GLDS_STAMP(1);
+
+  // Per tap (K = 64 = two MFMA k-steps): [28 MFMA k-step 0 | ds_read k-step 1] [vmcnt + barrier: tap+1's weights landed, everybody
+  // is done with tap-1's slot] [28 MFMA k-step 1 | ds_read tap+1 k-step 0 | DMA: weights of tap+3, at tap 0 the next chunk's image].
+  int bbuf = 0;                                          // ring slot of the current tap
+  for (int cc = 0; cc < cpt; ++cc) {
+    const unsigned char* cA = sA + (cc & 1) * A_BYTES;
+    const unsigned char* cAn = sA + ((cc + 1) & 1) * A_BYTES;
+    const bool more_c = cc + 1 < cpt;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * PW + (tap % 3);
+      const int tapn = tap == 8 ? 0 : tap + 1;
+      const int toffn = (tapn / 3) * PW + (tapn % 3);
+      const unsigned char* cB = sB + bbuf * B_BYTES;
+      // ---- first half: k-step 0 MFMAs, with the 11 fragment reads of k-step 1 (and their address VALU) threaded between them
+      if (!(GLDS_ABLATE & 4)) read_frags(f1a, f1b, cA, cB, toff, 1);
+      mfma_all(f0a, f0b);
+#pragma unroll
+      for (int i = 0; i < TM + TN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // Loads younger than the tile we need (tap+1, issued two taps ago) stay in flight: the tile of tap+2 (4) and the next
+      // chunk's image when it was issued after it (at tap 0 of this chunk: seen from taps 1 and 2).
+      if (!(GLDS_ABLATE & 1)) { if (tap == 1 || tap == 2) glds_wait_vmcnt<4 + AP>(); else glds_wait_vmcnt<4>(); }
+      if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- second half: k-step 1 MFMAs, threaded with the reads of tap+1 / k-step 0 and this tap's DMA issue
+      const int nb = (bbuf + 1) & (NB - 1);
+      if (!(GLDS_ABLATE & 4)) read_frags(f0a, f0b, tap == 8 ? cAn : cA, sB + nb * B_BYTES, toffn, 0);
+      if (!(GLDS_ABLATE & 1)) {
+        const int t3 = tap + 3;
+        const int tap3 = t3 >= 9 ? t3 - 9 : t3, cc3 = t3 >= 9 ? cc + 1 : cc;
+        issue_b(tap3, cc3, (bbuf + 3) & (NB - 1), cc3 < cpt);
+        if (tap == 0) issue_a(cc + 1, (cc + 1) & 1, more_c);
+      }
+      mfma_all(f1a, f1b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM (LDS-DMA piece)
+      }
+#pragma unroll
+      for (int i = 0; i < TM + TN - 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bbuf = nb;
+    }
+  }
+  // drain the (zero-writing) tail DMAs before the staging buffer is reused
+  glds_wait_vmcnt<0>();
+  __syncthreads();
+
+  GLDS_STAMP(2);
+  // ---- epilogue: bf16 tile through LDS; fragment rows >= 196 contribute nothing ----
+  constexpr int CST = BN * 2 + 16;
+  unsigned char* sC = smem;
+  float ssum[TN][4], ssq[TN][4];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int ml = wm * MW + mi * 16 + l15;
+      const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
+      bf16_t h[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h[q] = f2bf(acc[ni][mi][q]);
+        const float v = m_ok[mi] ? bf2f(h[q]) : 0.f;
+        ssum[ni][q] += v;
+        ssq[ni][q] += v * v;
+      }
+      uint2 pk;
+      pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+      pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+      if (m_ok[mi]) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
+    }
+  if (p.stats) {
+    const int ntile = gridDim.x / p.nbn;
+    float* prow_ = p.stats + (size_t)(bt * WM + wm) * 2 * p.N;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
+        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
+        if (l15 == 0) {
+          prow_[n] = a;
+          prow_[p.N + n] = b;
+        }
+      }
+    // the BatchNorm finalize sums gemm_nt_stat_rows(M, N) partial rows (128-pixel tiling): zero the ones this tiling leaves
+    for (int row = ntile * WM + bt * WM + wm; row < stat_rows; row += ntile * WM)
+      if (lane < 32) {
+        float* z = p.stats + (size_t)row * 2 * p.N + (lane >> 4) * p.N + n0 + wn * (BN / WN);
+        *reinterpret_cast<float4*>(z + (lane & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+  for (int idx = tid; idx < PT * CPR; idx += NT) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n0 + c * 8) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+  }
+  GLDS_STAMP(3);
+}
+
+template <int W_, int R_, int AP>
+static int launch_glds(GemmNT p, hipStream_t st) {
+  constexpr int PT = R_ * W_;
+  FEDFR_REQUIRE(p.N % 128 == 0 && p.C % 128 == 0 && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
+                "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
+  FEDFR_REQUIRE(p.bpart == nullptr, "conv3x3_glds: no fused BN-backward epilogue");
+  p.nbn = p.N / 128;
+  const int ntile = p.M / PT;
+  constexpr size_t lds = 2 * (size_t)AP * 4096 + 4 * (size_t)128 * 128;
+  static_assert(lds >= (size_t)PT * (128 * 2 + 16) && lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, AP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  ProfScope prof(W_ == 14 ? 8 : 9, 2.0 * p.M * p.N * (double)p.K, st);
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, AP>), dim3(ntile * p.nbn), dim3(256), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  FEDFR_LAUNCH_CHECK("conv3x3_glds");
+  return FEDFR_OK;
+}

@@ -171,12 +171,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmNT p, int a_bytes
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float a = ssum[ni][q], b = ssq[ni][q];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
+        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
         const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
         if (l15 == 0 && n < p.N) {
           prow[n] = a;

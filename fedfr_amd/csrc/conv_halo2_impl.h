@@ -3,6 +3,19 @@
 #include <algorithm>
 #include "gemm_dev.h"
 
+// In-kernel phase stamps (s_memtime shader clock + 100 MHz wall clock) for tools/stamp_halo2.hip; compiled out of the product.
+#ifdef FEDFR_HALO2_STAMPS
+#define HALO2_STAMP(i)                                                                      \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && p.dbg) {                                                        \
+      p.dbg[(size_t)blockIdx.x * 16 + 2 * (i)] = __builtin_readcyclecounter();             \
+      p.dbg[(size_t)blockIdx.x * 16 + 2 * (i) + 1] = wall_clock64();                        \
+    }                                                                                       \
+  } while (0)
+#else
+#define HALO2_STAMP(i) do { } while (0)
+#endif
+
 // =====================================================================================================
 // halo kernel v2 (W = 14 / 28, i.e. 84 of iresnet100's 103 convs): the LDS image is laid out in ZERO-PADDED image
 // coordinates — every image row gets a zero pixel left and right, every image a zero row above and below — so a
@@ -24,6 +37,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_halo2_kernel(GemmNT p, int n
   unsigned char* sB = smem + a_bytes_lds;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  HALO2_STAMP(0);
   const int wm = wave / WN, wn = wave % WN;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int bn = lid % p.nbn, bm = lid / p.nbn;
@@ -114,6 +128,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_halo2_kernel(GemmNT p, int n
   store_halo();
   store_b(0);
   __syncthreads();
+  HALO2_STAMP(1);
   int buf = 0;
   for (int cc = 0; cc < cpt; ++cc) {
 #pragma unroll
@@ -148,6 +163,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_halo2_kernel(GemmNT p, int n
     }
   }
 
+  HALO2_STAMP(2);
   // ---- epilogue: as gemm_nt_kernel's bf16 path; rows >= M contribute nothing to the statistics ----
   constexpr int CST = BN * 2 + 16;
   unsigned char* sC = smem;
@@ -181,12 +197,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_halo2_kernel(GemmNT p, int n
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float a = ssum[ni][q], b = ssq[ni][q];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
+        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
         const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
         if (l15 == 0 && n < p.N) {
           prow[n] = a;
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_halo2_kernel(GemmNT p, int n
       if (m < p.M && n < p.N)
         *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
     }
+    HALO2_STAMP(3);
   } else {
   // ---- fused BN-backward reduction: this thread owns chunk column c (8 channels) of rows rg, rg + NT/CPR, ... ----
   constexpr int RG = NT / CPR;

@@ -33,6 +33,7 @@ struct GemmNT {
   const float *bmean, *brstd, *bgamma, *bbeta, *balpha;
   float* bpart;
   int* bwd_fused;
+  unsigned long long* dbg;   // diagnostics builds only (tools/stamp_halo2.hip): per-block in-kernel clock stamps
 };
 
 struct GemmTN {

@@ -65,7 +65,8 @@ int gemm_profile_read(int slot, double* total_ms, long long* launches, double* f
 
 int g_halo_waves = 4;  // option "halo_waves": 4 or 8 waves per 128x128 tile in the halo2 kernel
 int g_halo_bn64 = 0;   // option "halo_bn64": 64-wide N tiles in the halo2 kernel (more, smaller blocks)
-int g_conv_halo = 2;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1
+int g_conv_halo = 3;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1,
+                       // 3 LDS-DMA pipeline (W=14/28, Cout%128==0) else 2
 
 // =====================================================================================================
 // NT kernel
@@ -257,12 +258,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float a = ssum[ni][q], b = ssq[ni][q];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
+        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
         const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
         if (l15 == 0 && n < p.N) {
           prow[n] = a;
@@ -369,6 +365,8 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
   if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
     if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
+      if (g_conv_halo >= 3 && !p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0)
+        return p.W == 14 ? launch_conv_glds_w14(p, st) : launch_conv_glds_w28(p, st);
       const bool bn64 = p.N <= 64 || g_halo_bn64;
       if (bn64 || g_halo_waves == 8) return launch_conv_halo2_misc(p, bn64, g_halo_waves == 8, st);
       if (p.bpart) return p.W == 14 ? launch_conv_halo2_fused_w14(p, st) : launch_conv_halo2_fused_w28(p, st);

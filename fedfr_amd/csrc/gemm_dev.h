@@ -19,6 +19,18 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: 4 VALU adds with DPP operands
+// (quad xor 1, quad xor 2, half-row mirror, row mirror) instead of 4 ds_bpermute round trips per value.
+__device__ __forceinline__ float row16_sum(float v) {
+#define FEDFR_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), (ctrl), 0xf, 0xf, true))
+  FEDFR_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  FEDFR_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  FEDFR_DPP_ADD(0x141);   // row_half_mirror
+  FEDFR_DPP_ADD(0x140);   // row_mirror
+#undef FEDFR_DPP_ADD
+  return v;
+}
+
 // bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = id & 7, loc = id >> 3;
@@ -39,4 +51,6 @@ int launch_conv_halo2_w14(GemmNT p, hipStream_t st);       // conv_halo2_w14.hip
 int launch_conv_halo2_w28(GemmNT p, hipStream_t st);       // conv_halo2_w28.hip
 int launch_conv_halo2_fused_w14(GemmNT p, hipStream_t st); // conv_halo2_fused14.hip  + BN-backward reduction epilogue
 int launch_conv_halo2_fused_w28(GemmNT p, hipStream_t st); // conv_halo2_fused28.hip
+int launch_conv_glds_w14(GemmNT p, hipStream_t st);        // conv_glds_w14.hip  LDS-DMA operands, counted vmcnt pipeline
+int launch_conv_glds_w28(GemmNT p, hipStream_t st);        // conv_glds_w28.hip
 int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   // conv_halo2_misc.hip  tuning variants

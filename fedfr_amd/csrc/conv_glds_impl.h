@@ -288,7 +288,7 @@ static int launch_glds(GemmNT p, hipStream_t st) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, AP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  ProfScope prof(W_ == 14 ? 8 : 9, 2.0 * p.M * p.N * (double)p.K, st);
+  ProfScope prof(W_ == 14 ? 12 : 13, 2.0 * p.M * p.N * (double)p.K, st);
   hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, AP>), dim3(ntile * p.nbn), dim3(256), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;

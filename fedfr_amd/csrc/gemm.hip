@@ -9,7 +9,8 @@
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------
 // slots: 0..3 = gemm_nt <128,128> <128,64> <64,128> <64,64>; 4..7 = gemm_tn <128,128> <128,64> <64,128> <64,64>;
-// 8 = conv3x3_halo2<128,14>, 9 = conv3x3_halo2<128,28>, 10 = conv3x3_halo2<64,*>, 11 = conv3x3_halo (v1, all)
+// 8 = conv3x3_halo2<128,14>, 9 = conv3x3_halo2<128,28>, 10 = conv3x3_halo2<64,*>, 11 = conv3x3_halo (v1, all),
+// 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>
 namespace {
 struct ProfSlot {
   std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -17,7 +18,7 @@ struct ProfSlot {
   long long launches = 0;
 };
 bool g_prof_on = false;
-ProfSlot g_prof[12];
+ProfSlot g_prof[14];
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
 }  // namespace
 
@@ -48,7 +49,7 @@ void gemm_profile_enable(int on) {
 }
 // caller must have synchronised the stream(s).  Returns 0 and fills totals for `slot`.
 int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
-  if (slot < 0 || slot >= 12) return -1;
+  if (slot < 0 || slot >= 14) return -1;
   ProfSlot& s = g_prof[slot];
   double ms = 0.0;
   for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {

@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfedfr_hip.so")
+# FEDFR_HIP_LIB_NAME selects another build of the same library in this directory (same-box A/B of compiler options)
+LIB_PATH = os.path.join(_HERE, os.environ.get("FEDFR_HIP_LIB_NAME", "libfedfr_hip.so"))
 
 _lib: Optional[C.CDLL] = None
 

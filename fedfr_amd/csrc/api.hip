@@ -18,6 +18,7 @@ extern int g_halo_bn64;
 extern int g_halo_waves;
 extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
+extern int g_tn_glds;
 
 void fedfr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -60,6 +61,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "conv_halo")) {
     g_conv_halo = value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "tn_glds")) {
+    g_tn_glds = value;          // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "fuse_bnbwd")) {

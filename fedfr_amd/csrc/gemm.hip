@@ -2,6 +2,7 @@
 // BK = 64, register-staged double-buffered LDS tiles with XOR-swizzled 16-byte chunks
 // (conflict-free ds_read_b128 / ds_read_b64_tr_b16), one barrier per K-step, XCD-aware 1-D grid.
 #include "gemm_dev.h"
+#include "gemm_tn_dev.h"
 
 #include <algorithm>
 #include <vector>
@@ -10,7 +11,7 @@
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------
 // slots: 0..3 = gemm_nt <128,128> <128,64> <64,128> <64,64>; 4..7 = gemm_tn <128,128> <128,64> <64,128> <64,64>;
 // 8 = conv3x3_halo2<128,14>, 9 = conv3x3_halo2<128,28>, 10 = conv3x3_halo2<64,*>, 11 = conv3x3_halo (v1, all),
-// 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>
+// 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>, 14 = gemm_tn_glds<128,128>
 namespace {
 struct ProfSlot {
   std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -18,7 +19,7 @@ struct ProfSlot {
   long long launches = 0;
 };
 bool g_prof_on = false;
-ProfSlot g_prof[14];
+ProfSlot g_prof[15];
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
 }  // namespace
 
@@ -49,7 +50,7 @@ void gemm_profile_enable(int on) {
 }
 // caller must have synchronised the stream(s).  Returns 0 and fills totals for `slot`.
 int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
-  if (slot < 0 || slot >= 14) return -1;
+  if (slot < 0 || slot >= 15) return -1;
   ProfSlot& s = g_prof[slot];
   double ms = 0.0;
   for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
@@ -386,47 +387,6 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
 // =====================================================================================================
 // TN kernel
 // =====================================================================================================
-template <int RB>   // tile row bytes (128 or 256): chunk swizzle that makes tr-reads and b128 writes conflict-free
-__device__ __forceinline__ int tn_swz(int row) {
-  if (RB == 256) return ((row & 3) << 1) | (((row >> 3) & 1) << 3);
-  return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
-}
-
-// per-lane byte offset (inside one LDS stage) of the first tr-read of the fragment for column block `colblk`;
-// the second read is +4*RB, the ks=1 half +32*RB (the swizzle only depends on row bits 0-1 and 3, which those
-// offsets do not touch), so every in-loop address is base + register + immediate.
-template <int RB>
-__device__ __forceinline__ int tn_frag_off(int colblk, int lane) {
-  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-  const int col = colblk + 4 * pp;
-  const int r0 = 8 * g + q;
-  return r0 * RB + (((col >> 3) ^ tn_swz<RB>(r0)) << 4) + ((col >> 2) & 1) * 8;
-}
-template <int RB>
-__device__ __forceinline__ bf16x8_t tn_frag_tr(const unsigned char* stage, int off, int ks) {
-  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
-  const unsigned char* a0 = stage + off + ks * 32 * RB;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * RB));
-  s16x8_t v;
-  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-  return __builtin_bit_cast(bf16x8_t, v);
-}
-template <int RB>   // validation fallback: scalar LDS gathers (no transpose-read instruction)
-__device__ __forceinline__ bf16x8_t tn_frag_scalar(const unsigned char* tile, int ks, int colblk, int lane) {
-  const int g = lane >> 4, li = lane & 15;
-  const int col = colblk + li;
-  const int c = col >> 3, e = col & 7;
-  s16x8_t v;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int rr = ks * 32 + 8 * g + j;
-    v[j] = *reinterpret_cast<const short*>(tile + rr * RB + ((c ^ tn_swz<RB>(rr)) << 4) + e * 2);
-  }
-  return __builtin_bit_cast(bf16x8_t, v);
-}
-
 template <int TI, int TJ, bool USE_TR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   constexpr int WI = 2, WJ = 2;
@@ -589,8 +549,11 @@ void gemm_tn_tiles(int NI, int NJ, int C, int* TI, int* TJ) {
 }
 
 int g_tn_target_blocks = 416;   // option "tn_target_blocks"
+int g_tn_glds = 2;              // option "tn_glds": LDS-DMA wgrad kernel for 128-multiple conv shapes: 2 = 8 waves (two per SIMD: one wave's VALU / DMA issue hides
+                                // behind the other's MFMAs, +20 % over 1 = 4 waves), 0 = register-staged kernel
 
 int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C) {
+  if (C > 0 && gemm_tn_glds_applies(NI, NJ, C, 1)) return gemm_tn_glds_pick_splits(Kp, NI, NJ);
   int TI, TJ;
   gemm_tn_tiles(NI, NJ, C, &TI, &TJ);
   const int tiles = ceil_div(NI, TI) * ceil_div(NJ, TJ);
@@ -645,6 +608,7 @@ int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
     p.dWo = make_fastdiv((unsigned)p.Wo);
     p.dHo = make_fastdiv((unsigned)p.Ho);
     FEDFR_REQUIRE((long long)p.Kp * (long long)(p.Ho * p.Wo) < (1ll << 40), "gemm_tn: fastdiv range");
+    if (p.use_tr && gemm_tn_glds_applies(p.NI, p.NJ, p.C, 1)) return launch_tn_glds(p, splits, st);
     gemm_tn_tiles(p.NI, p.NJ, p.C, &TI, &TJ);
   } else {
     FEDFR_REQUIRE((p.ldq & 7) == 0, "gemm_tn: ldq%%8");

@@ -45,7 +45,7 @@ struct ProfScope {
   ProfScope(int slot, double flops, hipStream_t st);
   ~ProfScope();
 };
-extern int g_conv_halo, g_halo_bn64, g_halo_waves, g_nt_nbuf, g_tn_target_blocks;
+extern int g_conv_halo, g_halo_bn64, g_halo_waves, g_nt_nbuf, g_tn_target_blocks, g_tn_glds;
 int launch_conv_halo1(GemmNT p, hipStream_t st);          // conv_halo.hip
 int launch_conv_halo2_w14(GemmNT p, hipStream_t st);       // conv_halo2_w14.hip   plain, 128x128 tiles, 4 waves
 int launch_conv_halo2_w28(GemmNT p, hipStream_t st);       // conv_halo2_w28.hip
@@ -54,3 +54,6 @@ int launch_conv_halo2_fused_w28(GemmNT p, hipStream_t st); // conv_halo2_fused28
 int launch_conv_glds_w14(GemmNT p, hipStream_t st);        // conv_glds_w14.hip  LDS-DMA operands, counted vmcnt pipeline
 int launch_conv_glds_w28(GemmNT p, hipStream_t st);        // conv_glds_w28.hip
 int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   // conv_halo2_misc.hip  tuning variants
+int launch_tn_glds(GemmTN p, int splits, hipStream_t st);   // gemm_tn_glds.hip  wgrad GEMM, LDS-DMA operand ring
+bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode);
+int gemm_tn_glds_pick_splits(int Kp, int NI, int NJ);

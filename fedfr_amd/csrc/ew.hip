@@ -5,6 +5,7 @@
 #include "ew.h"
 
 #define EW_THREADS 256
+#define EW_UNROLL 4       // rows whose loads are issued together in the streaming BN kernels
 
 static inline int rows_per_pass(int C) { return EW_THREADS / (C >> 3); }
 static int slab_rows(int M, int C, int max_blocks) {
@@ -167,41 +168,57 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int sla
   for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
   const int mbeg = blockIdx.x * slab;
   const int mend = min(p.M, mbeg + slab);
-  if (active) {
-    for (int m = mbeg + rl; m < mend; m += rpp) {
-      const size_t off = (size_t)m * p.C + c0;
-      float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.x1 + off), f);
+  auto one = [&](int m, const uint4& v1, const uint4& v2) {
+    const size_t off = (size_t)m * p.C + c0;
+    float f[8];
+    unpack8(v1, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = f[j] * sc1[j] + sh1[j];
+      if (has_alpha) v = v > 0.f ? v : al[j] * v;
+      f[j] = v;
+    }
+    if (p.x2) {
+      float g[8];
+      unpack8(v2, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += g[j] * sc2[j] + sh2[j];
+    }
+    const uint4 o = pack8(f);
+    if (p.stats) {
+      float r[8];
+      unpack8(o, r);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float v = f[j] * sc1[j] + sh1[j];
-        if (has_alpha) v = v > 0.f ? v : al[j] * v;
-        f[j] = v;
+        s[j] += r[j];
+        q[j] += r[j] * r[j];
       }
-      if (p.x2) {
-        float g[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.x2 + off), g);
+    }
+    if (p.nchw_hw > 0) {
+      const int img = m / p.nchw_hw, hw = m - img * p.nchw_hw;
+      const bf16_t* ob = reinterpret_cast<const bf16_t*>(&o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] += g[j] * sc2[j] + sh2[j];
-      }
-      const uint4 o = pack8(f);
-      if (p.stats) {
-        float r[8];
-        unpack8(o, r);
+      for (int j = 0; j < 8; ++j) p.y[((size_t)img * p.C + c0 + j) * p.nchw_hw + hw] = ob[j];
+    } else {
+      *reinterpret_cast<uint4*>(p.y + off) = o;
+    }
+  };
+  if (active) {
+    int m = mbeg + rl;
+    for (; m + (EW_UNROLL - 1) * rpp < mend; m += EW_UNROLL * rpp) {    // loads of EW_UNROLL rows first (see bn_bwd_reduce)
+      uint4 v1[EW_UNROLL], v2[EW_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          s[j] += r[j];
-          q[j] += r[j] * r[j];
-        }
+      for (int u = 0; u < EW_UNROLL; ++u) {
+        const size_t off = (size_t)(m + u * rpp) * p.C + c0;
+        v1[u] = *reinterpret_cast<const uint4*>(p.x1 + off);
+        v2[u] = p.x2 ? *reinterpret_cast<const uint4*>(p.x2 + off) : make_uint4(0, 0, 0, 0);
       }
-      if (p.nchw_hw > 0) {
-        const int img = m / p.nchw_hw, hw = m - img * p.nchw_hw;
-        const bf16_t* ob = reinterpret_cast<const bf16_t*>(&o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) p.y[((size_t)img * p.C + c0 + j) * p.nchw_hw + hw] = ob[j];
-      } else {
-        *reinterpret_cast<uint4*>(p.y + off) = o;
-      }
+      for (int u = 0; u < EW_UNROLL; ++u) one(m + u * rpp, v1[u], v2[u]);
+    }
+    for (; m < mend; m += rpp) {
+      const size_t off = (size_t)m * p.C + c0;
+      one(m, *reinterpret_cast<const uint4*>(p.x1 + off), p.x2 ? *reinterpret_cast<const uint4*>(p.x2 + off) : make_uint4(0, 0, 0, 0));
     }
   }
   if (p.stats) {
@@ -255,26 +272,43 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(BnBwd p, int 
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
   const int mbeg = blockIdx.x * slab, mend = min(p.M, mbeg + slab);
-  if (active) {
-    for (int m = mbeg + rl; m < mend; m += rpp) {
-      const size_t off = (size_t)m * p.C + c0;
-      float dy[8], x[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.dy + off), dy);
-      unpack8(*reinterpret_cast<const uint4*>(p.x + off), x);
+  auto accum = [&](const uint4& vd, const uint4& vx) {
+    float dy[8], x[8];
+    unpack8(vd, dy);
+    unpack8(vx, x);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xh = (x[j] - mean[j]) * rstd[j];
-        float dz = dy[j];
-        if (has_alpha) {
-          const float z = ga[j] * xh + be[j];
-          if (z <= 0.f) {
-            s3[j] += dy[j] * z;
-            dz = dy[j] * al[j];
-          }
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (x[j] - mean[j]) * rstd[j];
+      float dz = dy[j];
+      if (has_alpha) {
+        const float z = ga[j] * xh + be[j];
+        if (z <= 0.f) {
+          s3[j] += dy[j] * z;
+          dz = dy[j] * al[j];
         }
-        s1[j] += dz;
-        s2[j] += dz * xh;
       }
+      s1[j] += dz;
+      s2[j] += dz * xh;
+    }
+  };
+  if (active) {
+    // EW_UNROLL rows per trip with all their loads issued first: in the network dy / x come cold from HBM and one 16-B load
+    // pair in flight per thread left the kernel latency-bound (2x its warm-cache time)
+    int m = mbeg + rl;
+    for (; m + (EW_UNROLL - 1) * rpp < mend; m += EW_UNROLL * rpp) {
+      uint4 vd[EW_UNROLL], vx[EW_UNROLL];
+#pragma unroll
+      for (int u = 0; u < EW_UNROLL; ++u) {
+        const size_t off = (size_t)(m + u * rpp) * p.C + c0;
+        vd[u] = *reinterpret_cast<const uint4*>(p.dy + off);
+        vx[u] = *reinterpret_cast<const uint4*>(p.x + off);
+      }
+#pragma unroll
+      for (int u = 0; u < EW_UNROLL; ++u) accum(vd[u], vx[u]);
+    }
+    for (; m < mend; m += rpp) {
+      const size_t off = (size_t)m * p.C + c0;
+      accum(*reinterpret_cast<const uint4*>(p.dy + off), *reinterpret_cast<const uint4*>(p.x + off));
     }
   }
   const int W = 3 * p.C;
@@ -368,11 +402,11 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
   load8f(p.coef + 2 * p.C, c0, cc, 0.f);
   const bool has_alpha = p.alpha != nullptr;
   const int mbeg = blockIdx.x * slab, mend = min(p.M, mbeg + slab);
-  for (int m = mbeg + rl; m < mend; m += rpp) {
+  auto one = [&](int m, const uint4& vd, const uint4& vx) {
     const size_t off = (size_t)m * p.C + c0;
     float dy[8], x[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(p.dy + off), dy);
-    unpack8(*reinterpret_cast<const uint4*>(p.x + off), x);
+    unpack8(vd, dy);
+    unpack8(vx, x);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (x[j] - mean[j]) * rstd[j];
@@ -402,6 +436,22 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
       }
     }
     *reinterpret_cast<uint4*>(p.dx + off) = pack8(o);
+  };
+  int m = mbeg + rl;
+  for (; m + (EW_UNROLL - 1) * rpp < mend; m += EW_UNROLL * rpp) {      // loads of EW_UNROLL rows first (see bn_bwd_reduce)
+    uint4 vd[EW_UNROLL], vx[EW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const size_t off = (size_t)(m + u * rpp) * p.C + c0;
+      vd[u] = *reinterpret_cast<const uint4*>(p.dy + off);
+      vx[u] = *reinterpret_cast<const uint4*>(p.x + off);
+    }
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) one(m + u * rpp, vd[u], vx[u]);
+  }
+  for (; m < mend; m += rpp) {
+    const size_t off = (size_t)m * p.C + c0;
+    one(m, *reinterpret_cast<const uint4*>(p.dy + off), *reinterpret_cast<const uint4*>(p.x + off));
   }
 }
 

@@ -49,13 +49,18 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int W_, int R_, int AP>   // tile = R_ image rows; AP = LDS-DMA pieces (1 KiB = 8 image rows) per wave and image buffer
-__global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
-  constexpr int PT = R_ * W_, BN = 128, WM = 2, WN = 2, PW = W_ + 2, NT = 256;
-  constexpr int TM = 7, TN = 4, MW = TM * 16;           // 112 fragment rows per wave, 224 per tile (196 valid)
+template <int W_, int R_, int NPA, int WN>   // tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+                                             // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
+__global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
+  constexpr int PT = R_ * W_, BN = 128, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
+  constexpr int PWL = (PW + 7) & ~7;                      // LDS image pitch in rows: a multiple of 8, so that the swizzle key (row & 7) does not depend on
+                                                         // the vertical tap offset -> A addresses need 3 (horizontal) variants, dy is an instruction immediate
+  constexpr int TM = 7, TN = BN / WN / 16, MW = TM * 16;   // 112 fragment rows per wave, 224 per tile (196 valid)
+  constexpr int AP = NPA / NW, BP = 16 / NW;             // LDS-DMA pieces per wave: image buffer / weight tile
+  constexpr int NRD = TM + TN, MPR = (TM * TN) / NRD;    // fragment reads per k-half; MFMAs threaded per read
   constexpr int TPI = W_ / R_;                          // tiles per image
-  constexpr int A_BYTES = AP * 4 * 1024, B_BYTES = BN * 128, NB = 4;
-  static_assert(PT == 196 && W_ % R_ == 0 && (R_ + 2) * PW <= AP * 32, "tile geometry");
+  constexpr int A_BYTES = NPA * 1024, B_BYTES = BN * 128, NB = 4;
+  static_assert(PT == 196 && W_ % R_ == 0 && (R_ + 2) * PWL <= NPA * 8 && NPA % NW == 0 && MPR >= 1, "tile geometry");
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* sA = smem;                       // [2][A_BYTES]
@@ -73,20 +78,21 @@ __global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_ro
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
 
   // ---- LDS-DMA source plan.  Lane l of every piece: row (l >> 3) of the piece, logical 16-B chunk (l & 7) ^ (l >> 3).
-  // LDS image row r <-> padded pixel (y0 + r / PW, r % PW) of image img; padded row 0 / H+1 and column 0 / W+1 are zero.
+  // LDS image row r <-> padded pixel (y0 + r / PWL, r % PWL) of image img; padded row 0 / H+1, column 0 / W+1 and the pitch
+  // filler columns are zero.
   const int prow = lane >> 3, pch = (lane & 7) ^ prow;
   constexpr unsigned OOB = 0xfffffff0u;                 // beyond any buffer: the load writes zeros to LDS
   unsigned a_src[AP];                                   // byte offset of this lane's pixel/chunk at channel chunk 0
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
-    const int r = (j * 4 + wave) * 8 + prow;
-    const int ry = r / PW, rx = r - ry * PW;
+    const int r = (j * NW + wave) * 8 + prow;
+    const int ry = r / PWL, rx = r - ry * PWL;
     const int yy = y0 + ry;
     const bool ok = ry < R_ + 2 && yy >= 1 && yy <= W_ && rx >= 1 && rx <= W_;
     const unsigned pix = (unsigned)(img * (W_ * W_) + (yy - 1) * W_ + (rx - 1));
     a_src[j] = ok ? (pix * (unsigned)p.C + (unsigned)(pch * 8)) * 2u : OOB;
   }
-  const unsigned b_src = ((unsigned)(n0 + wave * 32 + prow) * (unsigned)p.K + (unsigned)(pch * 8)) * 2u;   // + j * 8 rows
+  const unsigned b_src = ((unsigned)(n0 + wave * BP * 8 + prow) * (unsigned)p.K + (unsigned)(pch * 8)) * 2u;   // + j * 8 rows
   const unsigned b_rstep = 8u * (unsigned)p.K * 2u;
 
   auto issue_a = [&](int cc, int abuf, bool live) {
@@ -94,20 +100,21 @@ __global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_ro
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       const unsigned vo = (live && a_src[j] != OOB) ? a_src[j] + coff : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + abuf * A_BYTES + (j * 4 + wave) * 1024), 16, (int)vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + abuf * A_BYTES + (j * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
     }
   };
   auto issue_b = [&](int tap, int cc, int bbuf, bool live) {
     const unsigned koff = (unsigned)(tap * p.C + cc * 64) * 2u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < BP; ++j) {
       const unsigned vo = live ? b_src + (unsigned)j * b_rstep + koff : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(sB + bbuf * B_BYTES + (wave * 4 + j) * 1024), 16, (int)vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(sB + bbuf * B_BYTES + (wave * BP + j) * 1024), 16, (int)vo, 0, 0, 0);
     }
   };
 
   // ---- fragment addresses
-  int a_row[TM];                                        // LDS image row of this lane's pixel at tap (0, 0)
+  // A-fragment byte offsets inside an image buffer for the three horizontal taps (vertical taps and the buffer are immediates)
+  int a_adr[3][TM];
   bool m_ok[TM];
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
@@ -115,7 +122,11 @@ __global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_ro
     m_ok[mi] = t < PT;
     const int tt = m_ok[mi] ? t : 0;
     const int y = tt / W_, x = tt - y * W_;
-    a_row[mi] = y * PW + x;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int r = y * PWL + x + dx;
+      a_adr[dx][mi] = r * 128 + ((lg ^ (r & 7)) << 4);  // k-step 1 flips chunk bit 2: XOR 64
+    }
   }
   int b_addr[TN];
 #pragma unroll
@@ -131,14 +142,11 @@ __global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_ro
     for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int cpt = p.C >> 6;
-  auto read_frags = [&](bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN], const unsigned char* cA, const unsigned char* cB, int toff, int ks) {
+  auto read_frags = [&](bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN], int aoff, int dx, const unsigned char* cB, int ks) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(cB + (b_addr[ni] ^ (ks * 64)));
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-      const int r = a_row[mi] + toff;
-      fa[mi] = *reinterpret_cast<const bf16x8_t*>(cA + r * 128 + (((lg + 4 * ks) ^ (r & 7)) << 4));
-    }
+    for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(sA + (a_adr[dx][mi] ^ (ks * 64)) + aoff);
   };
   auto mfma_all = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
 #pragma unroll
@@ -152,63 +160,65 @@ __global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_ro
   issue_b(1, 0, 1, true);
   issue_b(2, 0, 2, true);
   bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
-  glds_wait_vmcnt<8>();
+  glds_wait_vmcnt<2 * BP>();
   __builtin_amdgcn_s_barrier();
-  read_frags(f0a, f0b, sA, sB, 0, 0);
+  read_frags(f0a, f0b, 0, 0, sB, 0);
   GLDS_STAMP(1);
 
   // Per tap (K = 64 = two MFMA k-steps): [28 MFMA k-step 0 | ds_read k-step 1] [vmcnt + barrier: tap+1's weights landed, everybody
   // is done with tap-1's slot] [28 MFMA k-step 1 | ds_read tap+1 k-step 0 | DMA: weights of tap+3, at tap 0 the next chunk's image].
   int bbuf = 0;                                          // ring slot of the current tap
-  for (int cc = 0; cc < cpt; ++cc) {
-    const unsigned char* cA = sA + (cc & 1) * A_BYTES;
-    const unsigned char* cAn = sA + ((cc + 1) & 1) * A_BYTES;
-    const bool more_c = cc + 1 < cpt;
+  for (int cc2 = 0; cc2 < cpt; cc2 += 2) {               // channel chunks in pairs: the image buffer index is a compile-time constant
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = (tap / 3) * PW + (tap % 3);
-      const int tapn = tap == 8 ? 0 : tap + 1;
-      const int toffn = (tapn / 3) * PW + (tapn % 3);
-      const unsigned char* cB = sB + bbuf * B_BYTES;
-      // ---- first half: k-step 0 MFMAs, with the 11 fragment reads of k-step 1 (and their address VALU) threaded between them
-      if (!(GLDS_ABLATE & 4)) read_frags(f1a, f1b, cA, cB, toff, 1);
-      mfma_all(f0a, f0b);
+    for (int h = 0; h < 2; ++h) {
+      const int cc = cc2 + h;
+      const bool more_c = cc + 1 < cpt;
 #pragma unroll
-      for (int i = 0; i < TM + TN; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // Loads younger than the tile we need (tap+1, issued two taps ago) stay in flight: the tile of tap+2 (4) and the next
-      // chunk's image when it was issued after it (at tap 0 of this chunk: seen from taps 1 and 2).
-      if (!(GLDS_ABLATE & 1)) { if (tap == 1 || tap == 2) glds_wait_vmcnt<4 + AP>(); else glds_wait_vmcnt<4>(); }
-      if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- second half: k-step 1 MFMAs, threaded with the reads of tap+1 / k-step 0 and this tap's DMA issue
-      const int nb = (bbuf + 1) & (NB - 1);
-      if (!(GLDS_ABLATE & 4)) read_frags(f0a, f0b, tap == 8 ? cAn : cA, sB + nb * B_BYTES, toffn, 0);
-      if (!(GLDS_ABLATE & 1)) {
-        const int t3 = tap + 3;
-        const int tap3 = t3 >= 9 ? t3 - 9 : t3, cc3 = t3 >= 9 ? cc + 1 : cc;
-        issue_b(tap3, cc3, (bbuf + 3) & (NB - 1), cc3 < cpt);
-        if (tap == 0) issue_a(cc + 1, (cc + 1) & 1, more_c);
-      }
-      mfma_all(f1a, f1b);
+      for (int tap = 0; tap < 9; ++tap) {
+        const int aoff = h * A_BYTES + (tap / 3) * PWL * 128;                       // buffer + vertical tap: immediates
+        const int tapn = tap == 8 ? 0 : tap + 1;
+        const int aoffn = (tap == 8 ? (h ^ 1) : h) * A_BYTES + (tapn / 3) * PWL * 128;
+        const unsigned char* cB = sB + bbuf * B_BYTES;
+        // ---- first half: k-step 0 MFMAs, with the fragment reads of k-step 1 threaded between them
+        if (!(GLDS_ABLATE & 4)) read_frags(f1a, f1b, aoff, tap % 3, cB, 1);
+        mfma_all(f0a, f0b);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM (LDS-DMA piece)
-      }
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);   // MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // Loads younger than the tile we need (tap+1, issued two taps ago) stay in flight: the tile of tap+2 and the next
+        // chunk's image when it was issued after it (at tap 0 of this chunk: seen from taps 1 and 2).
+        if (!(GLDS_ABLATE & 1)) { if (tap == 1 || tap == 2) glds_wait_vmcnt<BP + AP>(); else glds_wait_vmcnt<BP>(); }
+        if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- second half: k-step 1 MFMAs, threaded with the reads of tap+1 / k-step 0 and this tap's DMA issue
+        const int nb = (bbuf + 1) & (NB - 1);
+        if (!(GLDS_ABLATE & 4)) read_frags(f0a, f0b, aoffn, tapn % 3, sB + nb * B_BYTES, 0);
+        if (!(GLDS_ABLATE & 1)) {
+          const int t3 = tap + 3;
+          const int tap3 = t3 >= 9 ? t3 - 9 : t3, cc3 = t3 >= 9 ? cc + 1 : cc;
+          issue_b(tap3, cc3, (bbuf + 3) & (NB - 1), cc3 < cpt);
+          if (tap == 0) issue_a(cc + 1, h ^ 1, more_c);
+        }
+        mfma_all(f1a, f1b);
 #pragma unroll
-      for (int i = 0; i < TM + TN - 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < BP; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);   // MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM (LDS-DMA piece)
+        }
+#pragma unroll
+        for (int i = 0; i < NRD - 2 * BP; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bbuf = nb;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      bbuf = nb;
     }
   }
   // drain the (zero-writing) tail DMAs before the staging buffer is reused
@@ -259,9 +269,10 @@ __global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_ro
       }
     // the BatchNorm finalize sums gemm_nt_stat_rows(M, N) partial rows (128-pixel tiling): zero the ones this tiling leaves
     for (int row = ntile * WM + bt * WM + wm; row < stat_rows; row += ntile * WM)
-      if (lane < 32) {
-        float* z = p.stats + (size_t)row * 2 * p.N + (lane >> 4) * p.N + n0 + wn * (BN / WN);
-        *reinterpret_cast<float4*>(z + (lane & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < 2 * (BN / WN / 4)) {                       // (sum, sumsq) x this wave's BN/WN columns, one float4 per lane
+        constexpr int LPR = BN / WN / 4;
+        float* z = p.stats + (size_t)row * 2 * p.N + (lane / LPR) * p.N + n0 + wn * (BN / WN);
+        *reinterpret_cast<float4*>(z + (lane % LPR) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
   __syncthreads();
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256) void conv3x3_glds_kernel(GemmNT p, int stat_ro
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int AP>
+template <int W_, int R_, int NPA, int WN>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
   FEDFR_REQUIRE(p.N % 128 == 0 && p.C % 128 == 0 && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
@@ -281,15 +292,15 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   FEDFR_REQUIRE(p.bpart == nullptr, "conv3x3_glds: no fused BN-backward epilogue");
   p.nbn = p.N / 128;
   const int ntile = p.M / PT;
-  constexpr size_t lds = 2 * (size_t)AP * 4096 + 4 * (size_t)128 * 128;
+  constexpr size_t lds = 2 * (size_t)NPA * 1024 + 4 * (size_t)128 * 128;
   static_assert(lds >= (size_t)PT * (128 * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, AP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   ProfScope prof(W_ == 14 ? 12 : 13, 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, AP>), dim3(ntile * p.nbn), dim3(256), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

@@ -67,8 +67,8 @@ int gemm_profile_read(int slot, double* total_ms, long long* launches, double* f
 
 int g_halo_waves = 4;  // option "halo_waves": 4 or 8 waves per 128x128 tile in the halo2 kernel
 int g_halo_bn64 = 0;   // option "halo_bn64": 64-wide N tiles in the halo2 kernel (more, smaller blocks)
-int g_conv_halo = 3;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1,
-                       // 3 LDS-DMA pipeline (W=14/28, Cout%128==0) else 2
+int g_conv_halo = 4;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1,
+                       // 3 LDS-DMA pipeline (W=14/28, Cout%128==0) else 2, 4 = 3 with 8 waves per tile
 
 // =====================================================================================================
 // NT kernel
@@ -368,7 +368,8 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
     if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
       if (g_conv_halo >= 3 && !p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0)
-        return p.W == 14 ? launch_conv_glds_w14(p, st) : launch_conv_glds_w28(p, st);
+        return g_conv_halo >= 4 ? (p.W == 14 ? launch_conv_glds8_w14(p, st) : launch_conv_glds8_w28(p, st))
+                                : (p.W == 14 ? launch_conv_glds_w14(p, st) : launch_conv_glds_w28(p, st));
       const bool bn64 = p.N <= 64 || g_halo_bn64;
       if (bn64 || g_halo_waves == 8) return launch_conv_halo2_misc(p, bn64, g_halo_waves == 8, st);
       if (p.bpart) return p.W == 14 ? launch_conv_halo2_fused_w14(p, st) : launch_conv_halo2_fused_w28(p, st);

@@ -452,3 +452,18 @@ def test_contrastive_vs_torch(B, D, temp):
     assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
     err = (xd.grad.double().cpu() / 3.0 - x.grad).abs().max() / x.grad.abs().max()
     assert float(err) < 1e-4, float(err)
+
+
+@pytest.mark.parametrize("opt,val", [("conv_halo", 2), ("conv_halo", 3), ("tn_glds", 0), ("tn_glds", 1)])
+def test_conv_halo_variants(opt, val):
+    """the non-default GEMM kernel variants kept for same-box A/B (register-staged halo2 conv, 4-wave LDS-DMA conv / wgrad,
+    register-staged wgrad) stay parity-correct: fwd + dgrad + wgrad of one 14x14 and one 28x28 layer."""
+    default = {"conv_halo": 4, "tn_glds": 2}[opt]
+    _C.call("fedfr_set_option", opt.encode(), val)
+    try:
+        for case in [(131, 14, 256, 256, 3, 1), (65, 28, 128, 128, 3, 1)]:
+            test_conv_fwd_and_stats(*case)
+            test_conv_dgrad(*case)
+            test_conv_wgrad(*case, 1)
+    finally:
+        _C.call("fedfr_set_option", opt.encode(), default)

@@ -415,6 +415,56 @@ class CombineDataset(torch.utils.data.Dataset):
         return self.first_len + self.second_len
 
 
+class SubsetDataset(torch.utils.data.Dataset):
+    """The images of ``dataset`` selected by ``indices``, labels and ``num_classes`` unchanged — what the reference gets by
+    overwriting ``dataset.imgidx`` of a deep-copied loader (client.py:228, :258)."""
+
+    def __init__(self, dataset, indices):
+        super().__init__()
+        self.dataset, self.indices = dataset, [int(i) for i in indices]
+        self.num_classes = dataset.num_classes
+        self.ID_base = getattr(dataset, "ID_base", None)
+
+    def __getitem__(self, i):
+        return self.dataset[self.indices[i]]
+
+    def __len__(self):
+        return len(self.indices)
+
+
+@torch.no_grad()
+def embed_dataset(backbone, loader, device, normalize=True):
+    """eval-mode embeddings of every image of ``loader`` (the inference sweep of server.py:242-263 / client.py:197-205):
+    returns ([N, 512] fp32 on ``device``, [N] int64 labels)."""
+    backbone.eval()
+    feats, labels = [], []
+    for img, label in loader:
+        f = backbone(img.to(device, non_blocking=True).contiguous())
+        if normalize:
+            f, _ = ops.normalize_rows(f)
+        feats.append(f)
+        labels.append(torch.as_tensor(label).to(device))
+    return torch.cat(feats, dim=0), torch.cat(labels, dim=0).to(torch.int64)
+
+
+@torch.no_grad()
+def class_centers(backbone, loader, num_classes, device, norm_before_avg):
+    """per-class mean embedding (client.py:159-188 data_update_fc, server.py:182-240 Initialize_pretrain_FC): eval forward,
+    optional F.normalize, per-batch per-class sums accumulated on the GPU, divided by the sample counts."""
+    backbone.eval()
+    sums = torch.zeros(num_classes, backbone.num_features, dtype=f32, device=device)
+    counts = torch.zeros(num_classes, dtype=f32, device=device)
+    labels = []
+    for img, label in loader:
+        f = backbone(img.to(device, non_blocking=True).contiguous())
+        if norm_before_avg:
+            f, _ = ops.normalize_rows(f)
+        lab = torch.as_tensor(label).to(device).to(torch.int64)
+        ops.class_accumulate(f, lab, sums, counts)
+        labels.append(lab)
+    return sums / counts.unsqueeze(1), torch.cat(labels)
+
+
 class Client(object):
     """Local trainer of one FL participant (reference client.py:116-157, :511-582).
 
@@ -449,6 +499,8 @@ class Client(object):
             self.temperature = 0.5
         if hasattr(data, "public_train_loader"):
             self.public_num_classes = data.public_train_loader.dataset.num_classes
+        if hasattr(data, "test_loaders"):
+            self.test_loaders = data.test_loaders[self.cid]                      # client.py:128-129
         self.logger = logging.getLogger("FL_face.client")
         self._backbone = None
         self.loss_meter = AverageMeter()
@@ -488,6 +540,37 @@ class Client(object):
         self.backbone_state_dict = flat_state_dict(backbone)
         self.fc_module.cpu()
 
+    def data_update_fc(self, fed_model_state_dict, norm_before_avg, fc_name="center_features", save_to_disk=False):
+        """reference client.py:159-188: class centres of the client's own identities under the incoming global model become the
+        local rows of the cosine head."""
+        backbone = self._get_backbone()
+        backbone.load_state_dict(fed_model_state_dict)
+        init_fc, _ = class_centers(backbone, self.test_loaders, self.num_classes, self.device, norm_before_avg)
+        init_fc = init_fc.cpu()
+        if save_to_disk:
+            import os
+            torch.save(init_fc, os.path.join(getattr(self, "client_output", "."), fc_name + ".pth"))
+        self.fc_module.update_from_tensor(init_fc)
+
+    def choose_hard_negative_2(self, public_train_loader, pretrained_label, pretrained_feats, threshold=0.2):
+        """reference client.py:191-236 (feature-based hard negatives): embed the local images with the current backbone, keep
+        every public image whose normalised embedding has cosine similarity > threshold with ANY local embedding.  The
+        [N_local, N_public] similarity matrix is never built: one fp32 MFMA GEMM whose epilogue ORs `> threshold` down each
+        column.  Returns a loader over the selected public images (same labels / num_classes); ``self.HN_index`` keeps the
+        sorted image indices."""
+        backbone = self._get_backbone()
+        backbone.load_state_dict(self.backbone_state_dict)
+        local_feats, _ = embed_dataset(backbone, self.test_loaders, self.device, normalize=True)
+        pretrained_feats = _C.require_gpu_tensor(pretrained_feats.to(self.device), f32, "pretrained_feats")
+        flags = ops.similarity_column_flags(local_feats, pretrained_feats, float(threshold))
+        unique_idx = torch.nonzero(flags, as_tuple=False).flatten()               # ascending == sorted(union of the row hits)
+        self.HN_index = unique_idx.cpu()
+        num_id = int(torch.unique(torch.as_tensor(pretrained_label)[self.HN_index]).numel()) if len(self.HN_index) else 0
+        self.logger.info("%d imgs (%d ID) are hard negative with similarity > %.2f" % (len(self.HN_index), num_id, threshold))
+        subset = SubsetDataset(public_train_loader.dataset, self.HN_index.tolist())
+        return torch.utils.data.DataLoader(subset, batch_size=getattr(public_train_loader, "batch_size", None) or cfg.public_batch_size,
+                                           shuffle=True, drop_last=False)
+
     def reweight_cosface(self, logits, labels):
         """reference client.py:269-285: append (num_client-1) copies of the first ``num_classes`` non-target logits of every
         row, so the softmax denominator weighs the local negatives as if every client contributed them.  Quirk kept on
@@ -509,16 +592,18 @@ class Client(object):
         weight cfg.mu), StepLR(cfg.train_decay, 0.1) re-created per call.
 
         ``combine_loader`` (build extension, used by tests and synthetic benchmarks) supplies the combined batches directly;
-        otherwise the combined loader is built from ``self.train_loader.dataset`` + ``public_train_loader.dataset`` as the
-        reference does.  Hard-negative mining (``choose_hard_negative``, client.py:208-268) belongs to SURVEY §8(f) N2 and is
-        not built yet.  The reference's non-BCE contrastive branch unpacks ``model(imgs)`` into two values (client.py:413),
+        otherwise the combined loader is built from ``self.train_loader.dataset`` + the (hard-negative subset of the) public
+        dataset as the reference does.  The reference's non-BCE contrastive branch unpacks ``model(imgs)`` into two values (client.py:413),
         which only works if the model is called with ``contrastive=True``; that is what this method does."""
-        if choose_hard_negative:
-            raise NotImplementedError("fedfr_amd: hard-negative mining (client.py:208-268) is a SURVEY §8(f) 'next' row")
         if combine_loader is None:
+            if choose_hard_negative:                                               # client.py:291-293
+                public_loader_subset = self.choose_hard_negative_2(public_train_loader, pretrained_label, pretrained_feats,
+                                                                   threshold=cfg.HN_threshold)
+            else:
+                public_loader_subset = public_train_loader
             if not getattr(self.args, "combine_dataset", False):
                 raise NotImplementedError()                                        # client.py:303-304
-            combine_dataset = CombineDataset(self.train_loader.dataset, public_train_loader.dataset)
+            combine_dataset = CombineDataset(self.train_loader.dataset, public_loader_subset.dataset)
             combine_loader = torch.utils.data.DataLoader(combine_dataset, batch_size=cfg.com_batch_size, shuffle=True, num_workers=0,
                                                          pin_memory=True, drop_last=True)
             self.dataset_size = len(combine_dataset)                               # for FedAvg (client.py:302)

@@ -344,6 +344,13 @@ int fedfr_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos,
                    float* dz, float* dcos, float* row_loss, void* stream) {
   return head_bce_loss(z, gt, dzdcos, B, C, r, lam, loss_scale, dz, dcos, row_loss, ST(stream));
 }
+int fedfr_sgemm_colflag(const float* A, const float* B, int M, int N, int K, long long sam, long long sak, long long sbk,
+                        long long sbn, float alpha, float thr, unsigned char* flags, void* stream) {
+  return head_sgemm_colflag(A, B, M, N, K, sam, sak, sbk, sbn, alpha, thr, flags, ST(stream));
+}
+int fedfr_class_accumulate(const float* feats, const long long* label, int B, int D, int C, float* sums, float* counts, void* stream) {
+  return head_class_accumulate(feats, label, B, D, C, sums, counts, ST(stream));
+}
 int fedfr_contrastive(const float* feats, const float* global_feats, const float* last_feats, int B, int D, float temperature,
                       float* row_loss, float* dfeats, void* stream) {
   return head_contrastive(feats, global_feats, last_feats, B, D, temperature, row_loss, dfeats, ST(stream));

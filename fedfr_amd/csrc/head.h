@@ -23,3 +23,6 @@ int head_colsum_f32(const float* x, int R, int C, float* out, hipStream_t st);
 int head_sum_scale(const float* x, int n, float scale, float* out, hipStream_t st);
 int head_contrastive(const float* x, const float* g, const float* l, int B, int D, float temperature, float* row_loss, float* dx,
                      hipStream_t st);
+int head_sgemm_colflag(const float* A, const float* B, int M, int N, int K, long long sam, long long sak, long long sbk,
+                       long long sbn, float alpha, float thr, unsigned char* flags, hipStream_t st);
+int head_class_accumulate(const float* x, const long long* label, int B, int D, int C, float* sums, float* counts, hipStream_t st);

@@ -62,6 +62,8 @@ struct SgemmP {
   int ldc;
   float alpha, beta;
   const float* bias;
+  unsigned char* colflag;   // != null: store nothing, set colflag[n] = 1 for every column with some alpha * (A B)[m][n] > thr
+  float thr;
 };
 
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
@@ -128,6 +130,22 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
     __syncthreads();
   }
   // D[row = m][col = n]: m = wm*32 + i*16 + lg*4 + reg, n = wn*32 + j*16 + l15
+  if (p.colflag) {            // threshold + column-OR epilogue (hard-negative mining): every hit stores the same 1 -> order-free
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + l15;
+      bool hit = false;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + wm * 32 + i * 16 + lg * 4 + q;
+          hit |= m < p.M && p.alpha * acc[i][j][q] > p.thr;
+        }
+      if (hit && n < p.N) p.colflag[n] = 1;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -148,9 +166,54 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
 int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak,
                long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, hipStream_t st) {
   FEDFR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "sgemm: bad args");
-  SgemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias};
+  SgemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, nullptr, 0.f};
   hipLaunchKernelGGL(sgemm_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
   FEDFR_LAUNCH_CHECK("sgemm");
+  return FEDFR_OK;
+}
+int head_sgemm_colflag(const float* A, const float* B, int M, int N, int K, long long sam, long long sak, long long sbk,
+                       long long sbn, float alpha, float thr, unsigned char* flags, hipStream_t st) {
+  FEDFR_REQUIRE(A && B && flags && M > 0 && N > 0 && K > 0, "sgemm_colflag: bad args");
+  SgemmP p{A, B, nullptr, M, N, K, sam, sak, sbk, sbn, N, alpha, 0.f, nullptr, flags, thr};
+  hipLaunchKernelGGL(sgemm_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  FEDFR_LAUNCH_CHECK("sgemm_colflag");
+  return FEDFR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-class feature sums of one batch (class-centre initialisation, reference client.py:171-178, server.py:213-222):
+// sums[c] += sum over rows b with label[b] == c of x[b] (rows in batch order -> deterministic), counts[c] += #rows.
+// One block per class; labels outside [0, C) are ignored.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void class_accumulate_kernel(const float* __restrict__ x, const long long* __restrict__ label, int B,
+                                                               int D, int C, float* __restrict__ sums, float* __restrict__ counts) {
+  const int c = blockIdx.x;
+  __shared__ int rows[1024];
+  __shared__ int nrows;
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    __syncthreads();
+    if (threadIdx.x == 0) {                            // ordered compaction of the matching rows of this slice (B is a batch size)
+      int n = 0;
+      const int e = min(B, b0 + 1024);
+      for (int b = b0; b < e; ++b)
+        if (label[b] == (long long)c) rows[n++] = b;
+      nrows = n;
+    }
+    __syncthreads();
+    const int n = nrows;
+    if (n == 0) continue;
+    for (int d = threadIdx.x; d < D; d += 256) {
+      float s = 0.f;
+      for (int i = 0; i < n; ++i) s += x[(size_t)rows[i] * D + d];
+      sums[(size_t)c * D + d] += s;
+    }
+    if (threadIdx.x == 0) counts[c] += (float)n;
+  }
+}
+int head_class_accumulate(const float* x, const long long* label, int B, int D, int C, float* sums, float* counts, hipStream_t st) {
+  FEDFR_REQUIRE(x && label && sums && counts && B > 0 && D > 0 && C > 0, "class_accumulate: bad args");
+  hipLaunchKernelGGL(class_accumulate_kernel, dim3(C), dim3(256), 0, st, x, label, B, D, C, sums, counts);
+  FEDFR_LAUNCH_CHECK("class_accumulate");
   return FEDFR_OK;
 }
 

@@ -205,6 +205,30 @@ def contrastive_loss(feats, global_feats, last_feats, temperature=0.5):
     return ContrastiveFn.apply(feats, global_feats, last_feats, temperature)
 
 
+@torch.no_grad()
+def class_accumulate(feats: torch.Tensor, label: torch.Tensor, sums: torch.Tensor, counts: torch.Tensor) -> None:
+    """sums[c] += sum of feats rows labelled c, counts[c] += their number (reference client.py:171-178, server.py:213-222)."""
+    feats, label = _chk(feats, "feats"), _chk(label, "label", torch.int64)
+    sums, counts = _chk(sums, "sums"), _chk(counts, "counts")
+    if sums.shape != (counts.shape[0], feats.shape[1]) or label.shape[0] != feats.shape[0]:
+        raise RuntimeError("class_accumulate: shape mismatch")
+    _C.call("fedfr_class_accumulate", feats.data_ptr(), label.data_ptr(), feats.shape[0], feats.shape[1], sums.shape[0],
+            sums.data_ptr(), counts.data_ptr(), _C.stream())
+
+
+@torch.no_grad()
+def similarity_column_flags(a: torch.Tensor, b: torch.Tensor, threshold: float) -> torch.Tensor:
+    """uint8 [N]: 1 where some row m has (a @ b.T)[m, n] > threshold — `torch.where(a @ b.T > thr)[1]` as a set, without the
+    [M, N] matrix (reference client.py:208-226).  a [M, K], b [N, K], fp32, exact fp32 MFMA."""
+    a, b = _chk(a, "a"), _chk(b, "b")
+    if a.shape[1] != b.shape[1]:
+        raise RuntimeError("similarity_column_flags: inner dimensions differ")
+    flags = torch.zeros(b.shape[0], dtype=torch.uint8, device=a.device)
+    _C.call("fedfr_sgemm_colflag", a.data_ptr(), b.data_ptr(), a.shape[0], b.shape[0], a.shape[1], a.stride(0), 1, 1, b.stride(0),
+            1.0, float(threshold), flags.data_ptr(), _C.stream())
+    return flags
+
+
 def cosine_linear(x, w, normalize_feat=True):
     return CosineLinearFn.apply(x, w, normalize_feat)
 

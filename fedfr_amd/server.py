@@ -129,9 +129,9 @@ class Server(object):
     """Round driver (reference server.py:68-133, :265-338): clients are trained sequentially in one process (as the
     reference does, server.py:283) and averaged with ``FedPavg``; with ``args.add_pretrained_data`` every client trains on
     local + public identities (``Client.train_with_public_data``) and, with ``args.return_all``, the public class centres
-    are averaged with ``FedAvg_on_FC`` (server.py:316-327).  The public-set embedding sweep and hard-negative mining
-    (server.py:242-263, client.py:208-268) are SURVEY §8(f) rows N1/N2: the caller provides ``public_train_loader`` /
-    ``pretrained_fc`` and the whole public set is used."""
+    are averaged with ``FedAvg_on_FC`` (server.py:316-327).  With ``server.pretrained_label`` set (``Initialize_pretrain_FC``)
+    every round starts with the public-set embedding sweep (``Generate_pretrain_feats``) and the clients mine hard negatives
+    from it (``Client.choose_hard_negative_2``), as server.py:272-275 / :294-304 do."""
 
     def __init__(self, clients, data, args, device=None):
         self.data = data
@@ -146,13 +146,47 @@ class Server(object):
         self.current_client_list = list(range(self.num_client))
         self.logger = logging.getLogger("FL_face.server")
         self.public_train_loader = getattr(data, "public_train_loader", None)
+        self.public_test_loader = getattr(data, "public_test_loader", self.public_train_loader)
+        self.pretrained_label = None                 # [N_public] identity of every public image
+        self.pretrained_feats = None                 # [N_public, 512] normalised embeddings (hard-negative mining)
         self.pretrained_fc = None                    # [n_public, 512] class centres of the public identities (server.py:182-240)
+
+    # ---- public-set inference sweeps (reference server.py:182-263)
+    def _eval_backbone(self):
+        bb = getattr(self, "_sweep_backbone", None)
+        if bb is None:
+            bb = self._sweep_backbone = getattr(backbones, self.args.network)(False, dropout=0, fp16=True).to(self.device)
+        bb.load_state_dict(flat_state_dict(self.federated_model))
+        return bb.eval()
+
+    @torch.no_grad()
+    def Generate_pretrain_feats(self):
+        """normalised embeddings of the whole public set under the current global model (server.py:242-263); stays on the GPU."""
+        from .client import embed_dataset
+        feats, _ = embed_dataset(self._eval_backbone(), self.public_test_loader, self.device, normalize=True)
+        return feats
+
+    @torch.no_grad()
+    def Initialize_pretrain_FC(self, only_labels=False):
+        """(init_matrix [n_public_ID, 512], raw_labels [N]) — per-identity mean embedding of the public set (server.py:182-240).
+        The reference's optional .pth cache (load_pth / save_pth) is checkpoint I/O, outside this path."""
+        from .client import class_centers
+        if only_labels:
+            return None, torch.cat([torch.as_tensor(l) for _, l in self.public_test_loader]).to(torch.int64)
+        n_id = self.public_test_loader.dataset.num_classes
+        init_matrix, raw_labels = class_centers(self._eval_backbone(), self.public_test_loader, n_id, self.device,
+                                                getattr(self, "norm_before_avg", getattr(self.args, "norm_before_avg", True)))
+        return init_matrix, raw_labels.cpu()
 
     def train(self):
         from .config import config as cfg
         models, models_fc, losses_, data_sizes = [], [], [], []
         public = bool(getattr(self.args, "add_pretrained_data", False))
         return_all = bool(getattr(self.args, "return_all", False))
+        mine = public and bool(getattr(self.args, "choose_hard_negative", True)) and self.public_test_loader is not None \
+            and self.pretrained_label is not None
+        if mine:                                                                                 # server.py:272-275
+            self.pretrained_feats = self.Generate_pretrain_feats()
         if getattr(self.args, "adaptive_local_epoch", False) and self.global_round != 0:        # server.py:277-280
             self.local_epoch = max(4, self.local_epoch - 2)
             cfg.train_decay = max(1, int(3 / 4 * self.local_epoch))
@@ -163,7 +197,8 @@ class Server(object):
                 if self.pretrained_fc is None:
                     raise RuntimeError("Server.train: add_pretrained_data needs server.pretrained_fc ([n_public, 512] class centres)")
                 self.clients[i].train_with_public_data(self.global_epoch, public_train_loader=self.public_train_loader,
-                                                       pretrained_fc=self.pretrained_fc, choose_hard_negative=False)
+                                                       pretrained_fc=self.pretrained_fc, choose_hard_negative=mine,
+                                                       pretrained_label=self.pretrained_label, pretrained_feats=self.pretrained_feats)
             else:
                 self.clients[i].train(self.global_epoch)
             losses_.append(self.clients[i].get_train_loss())

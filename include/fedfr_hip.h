@@ -157,6 +157,15 @@ int fedfr_bce_logits(const float* cosv, const long long* label, const float* bia
 /* row_loss[b] = sum_c bce(z, gt); dz = d(loss_scale * mean_b row_loss)/dz; dcos = dz * dzdcos (optional) */
 int fedfr_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam,
                    float loss_scale, float* dz, float* dcos, float* row_loss, void* stream);
+/* hard-negative mining (client.py:208-226, choose_hard_negative_2: `where(local @ public.T > thr)[1]`, union over rows):
+ * flags[n] = 1 for every column n with alpha * sum_k A[m][k] B[k][n] > thr for some row m (flags are only ever set: zero them
+ * first; exact fp32 MFMA, strided operands as fedfr_sgemm, the M x N similarity matrix is never materialised). */
+int fedfr_sgemm_colflag(const float* A, const float* B, int M, int N, int K, long long sam, long long sak, long long sbk,
+                        long long sbn, float alpha, float thr, unsigned char* flags, void* stream);
+/* class-centre accumulation (client.py:171-178 data_update_fc, server.py:213-222 Initialize_pretrain_FC):
+ * sums[c] += sum of the rows of feats whose label is c (batch order), counts[c] += their number. */
+int fedfr_class_accumulate(const float* feats, const long long* label, int B, int D, int C, float* sums, float* counts,
+                           void* stream);
 /* model-contrastive term (client.py:372-375, :415-418): row_loss[b] = CE([cos(x,g)/T, cos(x,l)/T], 0) with
  * nn.CosineSimilarity(dim=1, eps=1e-8); dx = d(mean_b row_loss)/dx (optional).  g, l: frozen global / last-round embeddings. */
 int fedfr_contrastive(const float* feats, const float* global_feats, const float* last_feats, int B, int D, float temperature,

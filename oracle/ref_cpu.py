@@ -459,6 +459,61 @@ def client_train_public(sd: Dict[str, torch.Tensor], fc: torch.Tensor, bce: Opti
     return rows, sd, fc, bce
 
 
+# --------------------------------------------------------------------------------------
+# inference sweeps + hard-negative mining
+# --------------------------------------------------------------------------------------
+def embed(sd: Dict[str, torch.Tensor], batches, layers: Sequence[int], normalize: bool = True) -> torch.Tensor:
+    """server.py:242-263 Generate_pretrain_feats / client.py:197-205: eval-mode backbone, F.normalize, concatenated."""
+    out = []
+    with torch.no_grad():
+        for imgs, _ in batches:
+            f = iresnet_forward(sd, imgs, layers, training=False)
+            out.append(F.normalize(f) if normalize else f)
+    return torch.cat(out, dim=0)
+
+
+def class_centers(sd: Dict[str, torch.Tensor], batches, layers: Sequence[int], num_classes: int, norm_before_avg: bool) -> torch.Tensor:
+    """client.py:159-188 data_update_fc / server.py:182-240 Initialize_pretrain_FC: per-batch per-class feature sums, divided by the
+    per-class sample counts (a class without samples gives 0/0 = NaN, as in the reference)."""
+    init_fc = torch.zeros(num_classes, 512)
+    num = torch.zeros(num_classes)
+    with torch.no_grad():
+        for imgs, label in batches:
+            f = iresnet_forward(sd, imgs, layers, training=False)
+            if norm_before_avg:
+                f = F.normalize(f)
+            for l in torch.unique(label):
+                init_fc[l:l + 1, :] += torch.sum(f[label == l, :], dim=0)
+                num[l] += torch.sum(label == l)
+    return init_fc / num.unsqueeze(1)
+
+
+def hard_negative_indices(local_feats: torch.Tensor, pretrained_feats: torch.Tensor, threshold: float) -> torch.Tensor:
+    """client.py:208-226 choose_hard_negative_2: sorted union over local rows of the public columns with similarity > threshold."""
+    sim = local_feats @ pretrained_feats.t()
+    return torch.unique(torch.where(sim > threshold)[1])
+
+
+def mining_fixture_state(g):
+    """inputs of tests/golden/mining_r18.npz rebuilt from the closed forms: (sd, local batches, public batches)."""
+    layers = IRESNET_LAYERS["iresnet18"]
+    sd = closed_form_state_dict(layers, tag=float(g["tag"]))
+    B, nb = int(g["B"]), int(g["nb"])
+    local = [(closed_form_images(B, tag=10.0 + i), closed_form_labels(B, int(g["n_local"]), tag=i)) for i in range(nb)]
+    # every third public image is a blend dominated by a local image (a true hard negative, cosine ~0.9 to it); the others are
+    # unrelated closed-form images (cosine ~0.5): the selected set is then stable under 1e-2-class embedding noise
+    allloc = torch.cat([x for x, _ in local], dim=0)
+    public = []
+    for i in range(nb):
+        x = closed_form_images(B, tag=20.0 + i).clone()
+        for s_ in range(B):
+            k = i * B + s_
+            if k % 3 == 0:
+                x[s_] = 0.85 * allloc[(5 * k + 1) % len(allloc)] + 0.15 * x[s_]
+        public.append((x, closed_form_labels(B, int(g["n_public"]), tag=5 + i)))
+    return sd, local, public
+
+
 def public_fixture_state(g, variant: str):
     """Initial state + batches of the tests/golden/client_public_*.npz fixtures (tools/make_golden.py gen_public), rebuilt from
     the closed forms: returns (sd, fc, bce-or-None, batches, kwargs for client_train_public)."""

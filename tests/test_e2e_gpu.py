@@ -311,6 +311,57 @@ def test_client_server_round():
     assert not torch.equal(m0["conv1.weight"], m1["conv1.weight"])
 
 
+def test_sweeps_and_hard_negative_mining_vs_reference():
+    """SURVEY §8f N1/N2 through the reference-shaped API: Client.data_update_fc (client.py:159-188), Server.Generate_pretrain_feats /
+    Initialize_pretrain_FC (server.py:182-263), Client.choose_hard_negative_2 (client.py:191-236) on iresnet18 against values
+    captured from the imported reference (bf16 backbone: 1e-2-class embeddings; the selected index set is exact)."""
+    g = load_golden("mining_r18")
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sd, local, public = R.mining_fixture_state(g)
+    nl, npub = int(g["n_local"]), int(g["n_public"])
+
+    class Args:
+        network, loss, local_epoch, output_dir, aggr_alg, num_client = "iresnet18", "CosFace", 1, "/tmp", "FedAvg", 2
+        BCE_local = contrastive_bb = False
+        norm_before_avg = True
+
+    class DS:
+        def __init__(self, n, idb=0):
+            self.num_classes, self.ID_base = n, idb
+
+    class Loader(list):
+        pass
+
+    def loader(batches, ds):
+        l = Loader(batches)
+        l.dataset = ds
+        return l
+
+    class Data:
+        train_class_sizes, train_dataset_sizes = [nl], [12]
+        train_loaders = [loader(local, DS(nl))]
+        test_loaders = [loader(local, DS(nl))]
+        public_train_loader = loader(public, DS(npub))
+        public_test_loader = loader(public, DS(npub))
+
+    cl = client.Client(0, Args, Data, device=DEV)
+    for nba in (True, False):
+        cl.data_update_fc(sd, nba)
+        assert rel(cl.fc_module.fc.data, g["local_centers_nba%d" % int(nba)]) < 2e-2, nba
+    srv = server.Server([cl], Data, Args, device=DEV)
+    srv.federated_model.load_state_dict(sd)
+    feats = srv.Generate_pretrain_feats()
+    assert rel(feats, g["public_feats"]) < 2e-2
+    assert float((feats.norm(dim=1) - 1).abs().max()) < 1e-5
+    init_matrix, raw_labels = srv.Initialize_pretrain_FC()
+    assert torch.equal(raw_labels, T(g["public_labels"]))
+    assert rel(init_matrix, g["public_centers"]) < 2e-2
+    cl.backbone_state_dict = sd
+    sub = cl.choose_hard_negative_2(Data.public_train_loader, raw_labels, feats, threshold=float(g["hn_threshold"]))
+    assert torch.equal(cl.HN_index, T(g["hn_index"]))                       # same hard-negative image set as the reference
+    assert len(sub.dataset) == len(g["hn_index"]) and sub.dataset.num_classes == npub
+
+
 def test_public_data_server_round():
     """One FedFR round with public data (server.py:265-338, add_pretrained_data + return_all): both clients train the
     [local | public] CosFace head + BCE branch, the server averages backbones (FedPavg) and public class centres (FedAvg_on_FC)."""
@@ -332,22 +383,19 @@ def test_public_data_server_round():
         def __getitem__(self, i):
             return self.x[i], self.y[i]
 
-    class Loader(list):
-        pass
-
     def loader(ds):
-        l = Loader()
-        l.dataset = ds
-        return l
+        return torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
 
     class Data:
         train_class_sizes = [nl, nl]
         train_dataset_sizes = [8, 4]
         train_loaders = [loader(DS(8, nl, 1.0)), loader(DS(4, nl, 2.0, id_base=nl))]
+        test_loaders = train_loaders
         public_train_loader = loader(DS(8, npub, 3.0))
+        public_test_loader = public_train_loader
 
     from fedfr_amd.config import config as cfg
-    saved = (cfg.lr, cfg.com_batch_size)
+    saved = (cfg.lr, cfg.com_batch_size, cfg.HN_threshold)
     cfg.lr, cfg.com_batch_size = 0.01, B
     try:
         clients = [client.Client(c, Args, Data, device=DEV) for c in range(2)]
@@ -355,10 +403,13 @@ def test_public_data_server_round():
         srv.federated_model.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet18"], tag=2.0))
         pre = R.head_fc(npub, seed=12).to(DEV)
         srv.pretrained_fc = pre.clone()
+        _, srv.pretrained_label = srv.Initialize_pretrain_FC(only_labels=True)      # enables the per-round sweep + hard-negative mining
+        cfg.HN_threshold = -1.0                                                      # every public image qualifies
         avg_loss = srv.train()
     finally:
-        cfg.lr, cfg.com_batch_size = saved
+        cfg.lr, cfg.com_batch_size, cfg.HN_threshold = saved
     assert np.isfinite(avg_loss)
+    assert srv.pretrained_feats.shape == (8, 512) and all(len(c.HN_index) == 8 for c in clients)
     assert [c.get_data_size() for c in clients] == [16, 12]                    # combined dataset sizes drive FedAvg (client.py:302)
     assert all(c.fc_module.fc.shape[0] == nl for c in clients)                 # remove_pretrain() after the round
     assert srv.pretrained_fc.shape == (npub, 512) and not torch.equal(srv.pretrained_fc, pre)

@@ -467,3 +467,33 @@ def test_conv_halo_variants(opt, val):
             test_conv_wgrad(*case, 1)
     finally:
         _C.call("fedfr_set_option", opt.encode(), default)
+
+
+@pytest.mark.parametrize("M,N,K,thr", [(37, 1000, 512, 0.12), (130, 4099, 512, 0.15), (5, 70, 96, 0.2)])
+def test_sgemm_colflag_vs_torch(M, N, K, thr):
+    """threshold + column-OR epilogue == set(torch.where(a @ b.T > thr)[1]) (client.py:213-222); entries within 1e-5 of the
+    threshold are excluded from the comparison (fp32 summation order)."""
+    gen = torch.Generator().manual_seed(M + N)
+    a = F.normalize(torch.randn(M, K, generator=gen))
+    b = F.normalize(torch.randn(N, K, generator=gen))
+    sim = (a.double() @ b.double().t())
+    flags = ops.similarity_column_flags(a.to(dev()), b.to(dev()), thr).cpu().bool()
+    sure_hit = (sim > thr + 1e-5).any(dim=0)
+    sure_miss = (sim < thr - 1e-5).all(dim=0)
+    assert bool(flags[sure_hit].all()) and not bool(flags[sure_miss].any())
+    assert 0 < int(flags.sum()) < N
+
+
+@pytest.mark.parametrize("B,D,C", [(512, 512, 6000), (7, 512, 5), (1500, 64, 33)])
+def test_class_accumulate_vs_torch(B, D, C):
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randn(B, D, generator=gen)
+    lab = torch.randint(0, C, (B,), generator=gen)
+    sums = torch.randn(C, D, generator=gen)
+    cnt = torch.randint(0, 5, (C,), generator=gen).float()
+    ref_s = sums.double().clone().index_add_(0, lab, x.double())
+    ref_c = cnt + torch.bincount(lab, minlength=C).float()
+    sd_, cd_ = sums.to(dev()), cnt.to(dev())
+    ops.class_accumulate(x.to(dev()), lab.to(dev()), sd_, cd_)
+    assert torch.equal(cd_.cpu(), ref_c)
+    assert float((sd_.cpu().double() - ref_s).abs().max()) < 1e-4

@@ -233,3 +233,21 @@ def test_public_data_loop_matches_reference(variant):
         close(bce["bias"], g["bce_bias"], 5e-3, 2e-4)
         close(bce["converter.0.weight"][:8, :64], g["bce_conv_w_slice"], 5e-3, 2e-4)
         close(bce["converter.0.bias"], g["bce_conv_b"], 5e-3, 2e-4)
+
+
+def test_sweeps_and_hard_negative_mining_match_reference():
+    """data_update_fc class centres (client.py:159-188), Generate_pretrain_feats / Initialize_pretrain_FC
+    (server.py:182-263) and choose_hard_negative_2's index set (client.py:191-236), captured from the imported reference modules."""
+    g = load_golden("mining_r18")
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sd, local, public = R.mining_fixture_state(g)
+    for nba in (True, False):
+        close(R.class_centers(sd, local, layers, int(g["n_local"]), nba), g["local_centers_nba%d" % int(nba)], 2e-4, 1e-5)
+    pub = R.embed(sd, public, layers)
+    close(pub, g["public_feats"], 2e-4, 1e-6)
+    close(R.class_centers(sd, public, layers, int(g["n_public"]), True), g["public_centers"], 2e-4, 1e-6)
+    loc = R.embed(sd, local, layers)
+    close(loc @ pub.t(), g["similarity"], 2e-4, 1e-5)
+    idx = R.hard_negative_indices(loc, pub, float(g["hn_threshold"]))
+    assert torch.equal(idx, T(g["hn_index"]))
+    assert 0 < len(idx) < pub.shape[0] and float(g["hn_gap"]) > 0.02        # a non-trivial subset, away from the threshold

@@ -14,6 +14,7 @@ What is captured (reference symbol → fixture):
   server.FedPavg / FedAvg_on_FC           → fedavg.npz
   partial_fc.PartialFC (W=1, and W=2 over gloo) → pfc_w1_*.npz / pfc_w2.npz
   a 3-step Client.train-equivalent loop on iresnet18 → client_r18.npz
+  eval-mode embedding sweeps, class centres and feature-based hard-negative mining → mining_r18.npz
   the train_with_public_data loop body (Branch_model + BCE + contrastive; Sequential + reweight) → client_public_{full,seq}.npz
 """
 import os
@@ -545,8 +546,68 @@ def gen_public(variant):
     save("client_public_" + variant, **out)
 
 
+# ---- 9. inference sweeps + hard-negative mining (client.py:159-236, server.py:182-263) on iresnet18 ------------------------------
+def gen_mining():
+    cfgm = dict(tag=2.0, B=4, nb=3, n_local=5, n_public=6)
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    backbone = backbones.iresnet18(False, dropout=0, fp16=False)
+    load_closed_form(backbone, layers, tag=cfgm["tag"])
+    backbone.eval()
+    _, local, public = R.mining_fixture_state(cfgm)
+    out = dict(cfgm)
+    with torch.no_grad():
+        # client.py:171-178 (data_update_fc), both norm_before_avg settings
+        for nba in (True, False):
+            init_fc = torch.zeros(cfgm["n_local"], 512)
+            num_samples = torch.zeros(cfgm["n_local"])
+            for img, label in local:
+                features = backbone(img)
+                if nba:
+                    features = F.normalize(features)
+                u_label = torch.unique(label)
+                for l in u_label:
+                    init_fc[l:l + 1, :] += torch.sum(features[label == l, :], dim=0)
+                    num_samples[l] += torch.sum(label == l)
+            init_fc /= num_samples.unsqueeze(1)
+            out["local_centers_nba%d" % int(nba)] = init_fc
+        # server.py:250-259 (Generate_pretrain_feats) and :204-229 (Initialize_pretrain_FC, norm_before_avg = True)
+        raw_feats, raw_labels, ID_feature = [], [], dict()
+        for img, label in public:
+            features = F.normalize(backbone(img))
+            raw_feats.append(features)
+            raw_labels.append(label)
+            for i, ID in enumerate(label):
+                ID = ID.item()
+                if ID not in ID_feature:
+                    ID_feature[ID] = [torch.zeros_like(features[0]), 0]
+                ID_feature[ID][0] += features[i]
+                ID_feature[ID][1] += 1
+        raw_feats, raw_labels = torch.cat(raw_feats, dim=0), torch.cat(raw_labels)
+        init_matrix = torch.zeros(len(ID_feature), 512)
+        for i in range(len(init_matrix)):
+            init_matrix[i] = ID_feature[i][0] / ID_feature[i][1]
+        out["public_feats"], out["public_labels"], out["public_centers"] = raw_feats, raw_labels, init_matrix
+        # client.py:197-226 (choose_hard_negative_2); the threshold sits in the widest gap of the per-column maxima so that the
+        # selected set is stable under the bf16 backbone's 1e-2-class embedding noise
+        local_feats = torch.cat([F.normalize(backbone(img)) for img, _ in local], dim=0)
+        similarity = torch.matmul(local_feats, raw_feats.t())
+        colmax = torch.sort(similarity.max(dim=0).values).values
+        gaps = colmax[1:] - colmax[:-1]
+        k = int(torch.argmax(gaps[2:-2])) + 2
+        thr = float((colmax[k] + colmax[k + 1]) / 2)
+        unique_idx = []
+        for i in range(len(similarity)):
+            unique_idx.append(torch.where(similarity[i:i + 1] > thr)[1].numpy())
+        from functools import reduce
+        unique_idx = sorted(reduce(np.union1d, unique_idx))
+        out["local_feats"], out["similarity"], out["hn_threshold"], out["hn_gap"] = local_feats, similarity, thr, float(gaps[k])
+        out["hn_index"] = np.array(unique_idx, dtype=np.int64)
+        out["hn_num_id"] = len(torch.unique(raw_labels[unique_idx]))
+    save("mining_r18", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public"]
+    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining"]
     if "block" in which:
         gen_block()
     if "r50" in which:
@@ -565,6 +626,8 @@ if __name__ == "__main__":
         gen_pfc()
     if "client" in which:
         gen_client()
+    if "mining" in which:
+        gen_mining()
     if "public" in which:
         for v in ("full", "seq", "bce_rw"):
             gen_public(v)

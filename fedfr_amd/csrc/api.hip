@@ -351,6 +351,9 @@ int fedfr_sgemm_colflag(const float* A, const float* B, int M, int N, int K, lon
 int fedfr_class_accumulate(const float* feats, const long long* label, int B, int D, int C, float* sums, float* counts, void* stream) {
   return head_class_accumulate(feats, label, B, D, C, sums, counts, ST(stream));
 }
+int fedfr_roc_histogram(const float* feats, const long long* label, int N, int D, int T, unsigned long long* hist, void* stream) {
+  return head_roc_histogram(feats, label, N, D, T, hist, ST(stream));
+}
 int fedfr_contrastive(const float* feats, const float* global_feats, const float* last_feats, int B, int D, float temperature,
                       float* row_loss, float* dfeats, void* stream) {
   return head_contrastive(feats, global_feats, last_feats, B, D, temperature, row_loss, dfeats, ST(stream));

@@ -26,3 +26,4 @@ int head_contrastive(const float* x, const float* g, const float* l, int B, int 
 int head_sgemm_colflag(const float* A, const float* B, int M, int N, int K, long long sam, long long sak, long long sbk,
                        long long sbn, float alpha, float thr, unsigned char* flags, hipStream_t st);
 int head_class_accumulate(const float* x, const long long* label, int B, int D, int C, float* sums, float* counts, hipStream_t st);
+int head_roc_histogram(const float* feat, const long long* label, int N, int D, int T, unsigned long long* hist, hipStream_t st);

@@ -504,3 +504,98 @@ int head_contrastive(const float* x, const float* g, const float* l, int B, int 
   FEDFR_LAUNCH_CHECK("contrastive");
   return FEDFR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// pairwise-similarity ROC histogram (reference roc_cuda.py:14-30 calc_ROC, the reference's only hand-written GPU
+// kernel: one thread per pair, a 512-long scalar dot product and fp64 global atomics).  Here: 64 x 64 pair tiles,
+// v_mfma_f64_16x16x4_f64 on the fp32 features widened to fp64 (the reference accumulates in float64 too, so the bin
+// index int((dot + 1) * 1000) agrees to the last pair), an LDS-private 4002-counter histogram per workgroup, flushed with
+// integer atomics (order-free -> deterministic).  Pairs (a, b): a < b, a < T (the T target rows come first), b < N.
+// hist[2 * bin] counts same-label pairs, hist[2 * bin + 1] different-label pairs.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+__global__ __launch_bounds__(256) void roc_hist_kernel(const float* __restrict__ feat, const long long* __restrict__ label, int N, int D,
+                                                       int T, unsigned long long* __restrict__ hist) {
+  constexpr int BK = 16, LD = 80, NBIN = 4002;
+  __shared__ float sA[2][BK][LD], sB[2][BK][LD];
+  __shared__ unsigned lh[NBIN];
+  const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+  if (b0 + 63 <= a0) return;                                  // tile entirely on / below the diagonal: no pair with a < b
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  for (int i = tid; i < NBIN; i += 256) lh[i] = 0u;
+  float ra[4], rb[4];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, k = e & 15, m = e >> 4;   // features are row-major: k fastest
+      const int ga = a0 + m, gb = b0 + m, gk = k0 + k;
+      ra[i] = (ga < T && gk < D) ? feat[(size_t)ga * D + gk] : 0.f;
+      rb[i] = (gb < N && gk < D) ? feat[(size_t)gb * D + gk] : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, k = e & 15, m = e >> 4;
+      sA[buf][k][m ^ ((k >> 1) << 1)] = ra[i];
+      sB[buf][k][m ^ ((k >> 1) << 1)] = rb[i];
+    }
+  };
+  f64x4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+  const int nk = ceil_div(D, BK);
+  load(0);
+  store(0);
+  __syncthreads();
+  const int l15 = lane & 15, lg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load((kt + 1) * BK);
+#pragma unroll
+    for (int k4 = 0; k4 < BK; k4 += 4) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = k4 + lg, sw = (kk >> 1) << 1;
+        fa[i] = (double)sA[buf][kk][(wm * 32 + i * 16 + l15) ^ sw];
+        fb[i] = (double)sB[buf][kk][(wn * 32 + i * 16 + l15) ^ sw];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store(buf ^ 1);
+    __syncthreads();
+  }
+  // f64 16x16x4 accumulator layout (differs from the f32 form): register q of lane l holds D[row = 4 q + (l >> 4)][col = l & 15]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int b = b0 + wn * 32 + j * 16 + l15;
+    const long long lb = b < N ? label[b] : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = a0 + wm * 32 + i * 16 + q * 4 + lg;
+        if (a < b && a < T && b < N) {
+          int bin = (int)((acc[i][j][q] + 1.0) * 1000.0);           // truncation, as int() in the reference
+          bin = bin < 0 ? 0 : (bin > 2000 ? 2000 : bin);             // (the reference would write out of bounds instead)
+          atomicAdd(&lh[2 * bin + (label[a] == lb ? 0 : 1)], 1u);
+        }
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < NBIN; i += 256)
+    if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+int head_roc_histogram(const float* feat, const long long* label, int N, int D, int T, unsigned long long* hist, hipStream_t st) {
+  FEDFR_REQUIRE(feat && label && hist && N > 0 && D > 0 && T > 0 && T <= N, "roc_histogram: bad args");
+  hipLaunchKernelGGL(roc_hist_kernel, dim3(ceil_div(N, 64), ceil_div(T, 64)), dim3(256), 0, st, feat, label, N, D, T, hist);
+  FEDFR_LAUNCH_CHECK("roc_histogram");
+  return FEDFR_OK;
+}

@@ -166,6 +166,10 @@ int fedfr_sgemm_colflag(const float* A, const float* B, int M, int N, int K, lon
  * sums[c] += sum of the rows of feats whose label is c (batch order), counts[c] += their number. */
 int fedfr_class_accumulate(const float* feats, const long long* label, int B, int D, int C, float* sums, float* counts,
                            void* stream);
+/* pairwise ROC histogram (roc_cuda.py:14-30 calc_ROC): over all pairs a < b with a < T (target rows first), b < N:
+ * bin = int((<feats[a], feats[b]> + 1) * 1000) in fp64; hist[2*bin] += same label, hist[2*bin+1] += different label.
+ * hist: 4002 uint64 counters, accumulated (zero them first). */
+int fedfr_roc_histogram(const float* feats, const long long* label, int N, int D, int T, unsigned long long* hist, void* stream);
 /* model-contrastive term (client.py:372-375, :415-418): row_loss[b] = CE([cos(x,g)/T, cos(x,l)/T], 0) with
  * nn.CosineSimilarity(dim=1, eps=1e-8); dx = d(mean_b row_loss)/dx (optional).  g, l: frozen global / last-round embeddings. */
 int fedfr_contrastive(const float* feats, const float* global_feats, const float* last_feats, int B, int D, float temperature,

@@ -494,6 +494,39 @@ def hard_negative_indices(local_feats: torch.Tensor, pretrained_feats: torch.Ten
     return torch.unique(torch.where(sim > threshold)[1])
 
 
+def roc_histogram(feature, label, target_size: int):
+    """roc_cuda.py:14-30 + the batching of :36-58 collapsed: pairs (a, b), a < b, a < target_size; float64 dot products of the
+    float32 features; bin int((dot + 1) * 1000); column 0 same label, column 1 different.  numpy int64 [2001, 2]."""
+    import numpy as np
+    f = np.asarray(feature, dtype=np.float32).astype(np.float64)
+    lab = np.asarray(label).astype(np.int64)
+    out = np.zeros((2001, 2), dtype=np.int64)
+    for a in range(int(target_size)):
+        if a + 1 >= len(f):
+            break
+        d = f[a + 1:] @ f[a]
+        b = ((d + 1.0) * 1000.0).astype(np.int64)              # truncation towards zero; the argument is >= 0
+        same = lab[a + 1:] == lab[a]
+        np.add.at(out[:, 0], b[same], 1)
+        np.add.at(out[:, 1], b[~same], 1)
+    return out
+
+
+def roc_tpr_at_fpr(hist):
+    """roc_cuda.py:61-78 plot_ROC: TPR (%) at FPR = 1e-1 ... 1e-6."""
+    import numpy as np
+    from scipy.interpolate import interp1d
+    data = np.cumsum(np.asarray(hist, dtype=np.int64), axis=0)
+    tpr, fpr = [1.0], [1.0]
+    for i in range(data.shape[0]):
+        tpr.append((data[-1, 0] - data[i, 0]) / data[-1, 0])
+        fpr.append((data[-1, 1] - data[i, 1]) / data[-1, 1])
+    tpr, fpr = np.array(tpr), np.array(fpr)
+    idx = np.argsort(fpr)
+    roc = interp1d(fpr[idx], tpr[idx])
+    return [float("%.2f" % (100 * roc(10 ** i))) for i in range(-1, -7, -1)]
+
+
 def mining_fixture_state(g):
     """inputs of tests/golden/mining_r18.npz rebuilt from the closed forms: (sd, local batches, public batches)."""
     layers = IRESNET_LAYERS["iresnet18"]

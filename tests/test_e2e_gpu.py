@@ -362,6 +362,17 @@ def test_sweeps_and_hard_negative_mining_vs_reference():
     assert len(sub.dataset) == len(g["hn_index"]) and sub.dataset.num_classes == npub
 
 
+def test_roc_vs_reference():
+    """roc_cuda.py end to end: histogram and TPR@FPR read-out equal the values produced by the reference's own kernel body."""
+    from fedfr_amd import eval_roc
+    g = load_golden("roc")
+    hist = eval_roc.roc_histogram(T(g["features"]).to(DEV), T(g["labels"]).to(DEV), int(g["target_size"]))
+    assert np.array_equal(hist.cpu().numpy(), g["hist"])
+    assert eval_roc.tpr_at_fpr(hist) == [float(v) for v in g["tpr"]]
+    f, l, t = eval_roc.order_targets(T(g["features"]).to(DEV), T(g["labels"]).to(DEV), [0, 1, 2])
+    assert t == int(g["target_size"]) and torch.equal(l.cpu(), T(g["labels"]))     # already target-first: a stable partition keeps it
+
+
 def test_public_data_server_round():
     """One FedFR round with public data (server.py:265-338, add_pretrained_data + return_all): both clients train the
     [local | public] CosFace head + BCE branch, the server averages backbones (FedPavg) and public class centres (FedAvg_on_FC)."""

@@ -497,3 +497,19 @@ def test_class_accumulate_vs_torch(B, D, C):
     ops.class_accumulate(x.to(dev()), lab.to(dev()), sd_, cd_)
     assert torch.equal(cd_.cpu(), ref_c)
     assert float((sd_.cpu().double() - ref_s).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("N,D,T", [(72, 64, 30), (300, 512, 131), (1000, 512, 1000), (65, 48, 1)])
+def test_roc_histogram_vs_oracle(N, D, T):
+    """fp64-MFMA pair histogram == the oracle (float64 dots of the float32 features, roc_cuda.py:14-30), bin for bin."""
+    from oracle import ref_cpu as R
+    from fedfr_amd import eval_roc
+    gen = torch.Generator().manual_seed(N + T)
+    nid = 11
+    lab = torch.randint(0, nid, (N,), generator=gen)
+    cen = F.normalize(torch.randn(nid, D, generator=gen))
+    f = F.normalize(cen[lab] + 0.3 * torch.randn(N, D, generator=gen))
+    ref = R.roc_histogram(f.numpy(), lab.numpy(), T)
+    got = eval_roc.roc_histogram(f.to(dev()), lab.to(dev()), T).cpu().numpy()
+    assert int(got.sum()) == T * (T - 1) // 2 + T * (N - T)
+    assert np.array_equal(got, ref)

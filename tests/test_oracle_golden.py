@@ -251,3 +251,18 @@ def test_sweeps_and_hard_negative_mining_match_reference():
     idx = R.hard_negative_indices(loc, pub, float(g["hn_threshold"]))
     assert torch.equal(idx, T(g["hn_index"]))
     assert 0 < len(idx) < pub.shape[0] and float(g["hn_gap"]) > 0.02        # a non-trivial subset, away from the threshold
+
+
+def test_roc_histogram_matches_reference_kernel_body():
+    """the oracle's pair histogram / TPR read-out against roc_cuda.py's own calc_ROC body and plot_ROC, executed on
+    the CPU through a numba stub (tools/make_golden.py gen_roc), plus a known-answer case."""
+    g = load_golden("roc")
+    hist = R.roc_histogram(g["features"], g["labels"], int(g["target_size"]))
+    assert np.array_equal(hist, g["hist"])
+    T_, N_ = int(g["target_size"]), len(g["labels"])
+    assert int(hist.sum()) == int(g["total_pairs"]) == T_ * (T_ - 1) // 2 + T_ * (N_ - T_)
+    assert R.roc_tpr_at_fpr(hist) == [float(v) for v in g["tpr"]]
+    # known answer: one-hot features -> dot is exactly 0 or 1 -> bins 1000 / 2000
+    f = np.eye(4, dtype=np.float32)[[0, 0, 1, 2, 1]]
+    h = R.roc_histogram(f, np.array([7, 7, 8, 9, 8]), 3)
+    assert h[2000, 0] == 2 and h[1000, 1] == 7 and h.sum() == 9

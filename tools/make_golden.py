@@ -14,6 +14,7 @@ What is captured (reference symbol → fixture):
   server.FedPavg / FedAvg_on_FC           → fedavg.npz
   partial_fc.PartialFC (W=1, and W=2 over gloo) → pfc_w1_*.npz / pfc_w2.npz
   a 3-step Client.train-equivalent loop on iresnet18 → client_r18.npz
+  roc_cuda.calc_ROC / plot_ROC (kernel body executed through a numba stub) → roc.npz
   eval-mode embedding sweeps, class centres and feature-based hard-negative mining → mining_r18.npz
   the train_with_public_data loop body (Branch_model + BCE + contrastive; Sequential + reweight) → client_public_{full,seq}.npz
 """
@@ -606,8 +607,60 @@ def gen_mining():
     save("mining_r18", **out)
 
 
+# ---- 10. pairwise ROC histogram (roc_cuda.py) ---------------------------------------------------------------------------
+def gen_roc():
+    """Runs the reference's own `calc_ROC` kernel BODY (roc_cuda.py:14-30) and its `plot_ROC` (:61-88): numba is absent, so a stub
+    makes `@cuda.jit` the identity, `cuda.grid(2)` return the (i, j) of a Python double loop and `cuda.atomic.add` a plain add."""
+    import tempfile
+    nb = types.ModuleType("numba")
+    cu = types.ModuleType("numba.cuda")
+    state = {"ij": (0, 0)}
+    cu.jit = lambda f: f
+    cu.grid = lambda n: state["ij"]
+
+    class _Atomic:
+        @staticmethod
+        def add(arr, idx, v):
+            arr[idx] += v
+    cu.atomic = _Atomic
+    nb.cuda = cu
+    sys.modules["numba"], sys.modules["numba.cuda"] = nb, cu
+    import roc_cuda                                            # noqa: E402  (reference)
+    N, D, T, nid = 72, 64, 30, 9
+    g = torch.Generator().manual_seed(5)
+    centers = F.normalize(torch.randn(nid, D, generator=g))
+    label = (torch.arange(N) * 5 + 2) % nid
+    feat = F.normalize(centers[label] + 0.35 * torch.randn(N, D, generator=g)).numpy().astype(np.float32)
+    label = label.numpy().astype(np.int32)
+    # main program of roc_cuda.py:129-136: target identities first
+    target_label = [0, 1, 2]
+    t_idx = np.isin(label, target_label)
+    feature = np.concatenate([feat[t_idx], feat[~t_idx]], axis=0)
+    lab = np.concatenate([label[t_idx], label[~t_idx]])
+    target_size = int(t_idx.sum())
+    out_sum = np.zeros(2001 * 2, dtype=np.int64)
+    batch_size = 8                                             # several producer batches (roc_cuda.py:32-37)
+    for bi in range((target_size + batch_size - 1) // batch_size):
+        start = bi * batch_size
+        index = np.arange(len(feature))[start:min(start + batch_size, target_size)]
+        feature_c, label_c = feature[start:, :].astype(np.float32), lab[start:].astype(np.int32)
+        subfeature, sublabel = feature[index, :].astype(np.float32), lab[index].astype(np.int32)
+        out = np.zeros(2001 * 2, dtype=np.float64)
+        for i in range(len(index)):
+            for j in range(feature_c.shape[0]):
+                state["ij"] = (i, j)
+                roc_cuda.calc_ROC(feature_c, label_c, subfeature, sublabel, out)
+        out_sum += out.astype(np.int64)
+    hist = out_sum.reshape([-1, 2])
+    with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(open(os.devnull, "w")):
+        roc_cuda.plot_ROC(hist, td, 0, target_label)
+        line = [l for l in open(os.path.join(td, "local_log.txt")) if "TPR" in l][0]
+    tpr = eval(line.split("=")[1])
+    save("roc", features=feature, labels=lab.astype(np.int64), target_size=target_size, hist=hist, tpr=np.array(tpr), total_pairs=int(hist.sum()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining"]
+    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining", "roc"]
     if "block" in which:
         gen_block()
     if "r50" in which:
@@ -626,6 +679,8 @@ if __name__ == "__main__":
         gen_pfc()
     if "client" in which:
         gen_client()
+    if "roc" in which:
+        gen_roc()
     if "mining" in which:
         gen_mining()
     if "public" in which:

@@ -439,11 +439,12 @@ def embed_dataset(backbone, loader, device, normalize=True):
     backbone.eval()
     feats, labels = [], []
     for img, label in loader:
-        f = backbone(img.to(device, non_blocking=True).contiguous())
+        img, label = to_device_batch(img, label, device, train=False)
+        f = backbone(img)
         if normalize:
             f, _ = ops.normalize_rows(f)
         feats.append(f)
-        labels.append(torch.as_tensor(label).to(device))
+        labels.append(label)
     return torch.cat(feats, dim=0), torch.cat(labels, dim=0).to(torch.int64)
 
 
@@ -456,13 +457,25 @@ def class_centers(backbone, loader, num_classes, device, norm_before_avg):
     counts = torch.zeros(num_classes, dtype=f32, device=device)
     labels = []
     for img, label in loader:
-        f = backbone(img.to(device, non_blocking=True).contiguous())
+        img, lab = to_device_batch(img, label, device, train=False)
+        f = backbone(img)
         if norm_before_avg:
             f, _ = ops.normalize_rows(f)
-        lab = torch.as_tensor(label).to(device).to(torch.int64)
         ops.class_accumulate(f, lab, sums, counts)
         labels.append(lab)
     return sums / counts.unsqueeze(1), torch.cat(labels)
+
+
+def to_device_batch(imgs, labels, device, train: bool):
+    """Host batch -> (fp32 [B,3,H,W] in [-1,1], int64 labels) on ``device``.  Already-normalised fp32 NCHW batches (what the
+    reference's DataLoader yields after its CPU transform, dataset.py:81-92) pass through; uint8 [B,H,W,3] batches take the
+    on-device transform instead (``ops.preprocess_u8``: ToTensor + Normalize(0.5, 0.5), with RandomHorizontalFlip(p=0.5) when
+    ``train``), so the host uploads one byte per pixel-channel."""
+    labels = torch.as_tensor(labels).to(device, non_blocking=True).to(torch.int64)
+    if imgs.dtype == torch.uint8:
+        flip = (torch.rand(imgs.shape[0]) < 0.5).to(torch.uint8).to(device) if train else None
+        return ops.preprocess_u8(imgs.to(device, non_blocking=True).contiguous(), flip), labels
+    return imgs.to(device, non_blocking=True).contiguous(), labels
 
 
 class Client(object):
@@ -527,8 +540,7 @@ class Client(object):
                 if len(imgs) == 1:                                              # client.py:538-540
                     imgs = torch.cat([imgs, imgs], dim=0)
                     labels = torch.cat([labels, labels])
-                imgs = imgs.to(self.device, non_blocking=True).contiguous()
-                labels = labels.to(self.device, non_blocking=True)
+                imgs, labels = to_device_batch(imgs, labels, self.device, train=True)
                 pending.append(trainer.step(imgs, labels))
                 if len(pending) >= self.sync_every:
                     for l in pending:
@@ -664,8 +676,7 @@ class Client(object):
         for epoch in range(start_epoch, start_epoch + self.local_epoch):
             trainer.set_lr(cfg.lr * 0.1 ** ((epoch - start_epoch) // cfg.train_decay))     # StepLR (client.py:348,443)
             for step, (imgs, labels) in enumerate(combine_loader):
-                imgs = imgs.to(self.device, non_blocking=True).contiguous()
-                labels = labels.to(self.device, non_blocking=True)
+                imgs, labels = to_device_batch(imgs, labels, self.device, train=True)
                 if use_con:
                     with torch.no_grad():
                         state["global_feats"] = global_model(imgs)

@@ -354,6 +354,9 @@ int fedfr_class_accumulate(const float* feats, const long long* label, int B, in
 int fedfr_roc_histogram(const float* feats, const long long* label, int N, int D, int T, unsigned long long* hist, void* stream) {
   return head_roc_histogram(feats, label, N, D, T, hist, ST(stream));
 }
+int fedfr_preprocess_u8(const unsigned char* src_hwc, const unsigned char* flip, float* dst_nchw, int B, int H, int W, void* stream) {
+  return ew_preprocess_u8(src_hwc, flip, dst_nchw, B, H, W, ST(stream));
+}
 int fedfr_contrastive(const float* feats, const float* global_feats, const float* last_feats, int B, int D, float temperature,
                       float* row_loss, float* dfeats, void* stream) {
   return head_contrastive(feats, global_feats, last_feats, B, D, temperature, row_loss, dfeats, ST(stream));

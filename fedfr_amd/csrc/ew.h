@@ -75,3 +75,4 @@ int ew_stem_fwd(const float* x, const float* w, bf16_t* y, float* stats, int B, 
 // dw (KRSC fp32 [64][3][3][3]) = sum over pixels; tmp holds stem_wgrad_blocks*64*32 floats
 int ew_stem_wgrad_blocks(int B, int H, int W);
 int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st);
+int ew_preprocess_u8(const unsigned char* src, const unsigned char* flip, float* dst, int B, int H, int W, hipStream_t st);

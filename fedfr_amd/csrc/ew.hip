@@ -901,3 +901,34 @@ int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B
   FEDFR_LAUNCH_CHECK("stem_wgrad_reduce");
   return FEDFR_OK;
 }
+
+// =====================================================================================================
+// input pipeline on the device (reference dataset.py:81-92: ToPILImage -> RandomHorizontalFlip -> ToTensor ->
+// Normalize(0.5, 0.5)): uint8 HWC images (as decoded) + one flip flag per image -> fp32 NCHW in [-1, 1], the backbone's input.
+// Same fp32 operations in the same order as torchvision (x / 255, then (t - 0.5) / 0.5): bit-exact.  The host uploads 1 byte
+// per pixel-channel instead of 4.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ src, const unsigned char* __restrict__ flip,
+                                                           float* __restrict__ dst, int B, int H, int W) {
+  const long long total = (long long)B * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const long long t = i / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    const int ws = (flip && flip[b]) ? W - 1 - w : w;
+    const unsigned char* sp = src + (((long long)b * H + h) * W + ws) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = __fdiv_rn((float)sp[c], 255.f);
+      dst[(((long long)b * 3 + c) * H + h) * W + w] = __fdiv_rn(__fsub_rn(v, 0.5f), 0.5f);
+    }
+  }
+}
+int ew_preprocess_u8(const unsigned char* src, const unsigned char* flip, float* dst, int B, int H, int W, hipStream_t st) {
+  FEDFR_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "preprocess_u8: bad args");
+  const long long total = (long long)B * H * W;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid), dim3(256), 0, st, src, flip, dst, B, H, W);
+  FEDFR_LAUNCH_CHECK("preprocess_u8");
+  return FEDFR_OK;
+}

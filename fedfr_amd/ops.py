@@ -206,6 +206,24 @@ def contrastive_loss(feats, global_feats, last_feats, temperature=0.5):
 
 
 @torch.no_grad()
+def preprocess_u8(images_hwc: torch.Tensor, flip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 [B, H, W, 3] (decoded images) -> fp32 [B, 3, H, W] in [-1, 1], optionally mirrored per image: the reference's
+    train / test transform (dataset.py:81-92) on the device, bit-exact with torchvision's ToTensor + Normalize(0.5, 0.5)."""
+    x = _chk(images_hwc, "images", torch.uint8)
+    if x.dim() != 4 or x.shape[3] != 3:
+        raise RuntimeError("preprocess_u8: expected uint8 [B, H, W, 3]")
+    B, H, W, _ = x.shape
+    f = None
+    if flip is not None:
+        f = _chk(flip.to(torch.uint8), "flip", torch.uint8)
+        if f.shape != (B,):
+            raise RuntimeError("preprocess_u8: flip must be [B]")
+    out = torch.empty(B, 3, H, W, dtype=f32, device=x.device)
+    _C.call("fedfr_preprocess_u8", x.data_ptr(), f.data_ptr() if f is not None else None, out.data_ptr(), B, H, W, _C.stream())
+    return out
+
+
+@torch.no_grad()
 def class_accumulate(feats: torch.Tensor, label: torch.Tensor, sums: torch.Tensor, counts: torch.Tensor) -> None:
     """sums[c] += sum of feats rows labelled c, counts[c] += their number (reference client.py:171-178, server.py:213-222)."""
     feats, label = _chk(feats, "feats"), _chk(label, "label", torch.int64)

@@ -166,6 +166,8 @@ int fedfr_sgemm_colflag(const float* A, const float* B, int M, int N, int K, lon
  * sums[c] += sum of the rows of feats whose label is c (batch order), counts[c] += their number. */
 int fedfr_class_accumulate(const float* feats, const long long* label, int B, int D, int C, float* sums, float* counts,
                            void* stream);
+/* input pipeline (dataset.py:81-92): uint8 [B][H][W][3] + optional per-image flip flags -> fp32 [B][3][H][W] = (x/255 - 0.5)/0.5 */
+int fedfr_preprocess_u8(const unsigned char* src_hwc, const unsigned char* flip, float* dst_nchw, int B, int H, int W, void* stream);
 /* pairwise ROC histogram (roc_cuda.py:14-30 calc_ROC): over all pairs a < b with a < T (target rows first), b < N:
  * bin = int((<feats[a], feats[b]> + 1) * 1000) in fp64; hist[2*bin] += same label, hist[2*bin+1] += different label.
  * hist: 4002 uint64 counters, accumulated (zero them first). */

@@ -82,3 +82,45 @@ def test_fedavg_all_reduce_two_ranks_gloo(tmp_path):
             torch.testing.assert_close(a[k], ref[k], rtol=1e-6, atol=1e-7)
         else:
             assert int(a[k]) == int(ref[k])                 # F9: float average truncated back to int64
+
+
+def test_checkpoint_interchange_with_reference():
+    """checkpoints in the reference's `torch.save(backbone.state_dict())` format (client.py:484-495, server.py:148)
+    load into this package's backbone and vice versa, key for key and bit for bit (runs where /root/reference is present)."""
+    import os
+    import sys
+    import tempfile
+    if not os.path.isdir("/root/reference/backbones"):
+        pytest.skip("reference checkout not present on this machine")
+    sys.path.insert(0, "/root/reference")
+    try:
+        import importlib
+        ref_backbones = importlib.import_module("backbones")
+        if not hasattr(ref_backbones, "iresnet18") or ref_backbones.__file__.startswith(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))):
+            pytest.skip("reference backbones shadowed")
+    finally:
+        sys.path.remove("/root/reference")
+    from fedfr_amd import backbones as my_backbones
+    torch.manual_seed(1)
+    ref = ref_backbones.iresnet18(False, dropout=0, fp16=False)
+    for m in ref.modules():                                     # non-trivial BN buffers
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2.0)
+            m.num_batches_tracked.fill_(7)
+    with tempfile.TemporaryDirectory() as td:
+        p1, p2 = os.path.join(td, "ref.pth"), os.path.join(td, "mine.pth")
+        torch.save(ref.state_dict(), p1)
+        mine = my_backbones.iresnet18(False, dropout=0, fp16=True)
+        missing = mine.load_state_dict(torch.load(p1))
+        assert not missing.missing_keys and not missing.unexpected_keys
+        sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
+        assert list(sd_ref.keys()) == list(sd_mine.keys())
+        for k in sd_ref:
+            assert sd_ref[k].shape == sd_mine[k].shape and sd_ref[k].dtype == sd_mine[k].dtype, k
+            assert torch.equal(sd_ref[k], sd_mine[k]), k
+        torch.save(mine.state_dict(), p2)
+        ref2 = ref_backbones.iresnet18(False, dropout=0, fp16=False)
+        ref2.load_state_dict(torch.load(p2))                    # strict
+        for k, v in ref2.state_dict().items():
+            assert torch.equal(v, sd_ref[k]), k

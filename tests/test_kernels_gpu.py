@@ -513,3 +513,17 @@ def test_roc_histogram_vs_oracle(N, D, T):
     got = eval_roc.roc_histogram(f.to(dev()), lab.to(dev()), T).cpu().numpy()
     assert int(got.sum()) == T * (T - 1) // 2 + T * (N - T)
     assert np.array_equal(got, ref)
+
+
+def test_preprocess_u8_bit_exact():
+    """dataset.py:81-92 on the device: ToTensor (x / 255) + Normalize(0.5, 0.5) (+ horizontal flip) — bit-exact with the same
+    fp32 torch ops; flipped images equal torch.flip of the unflipped result."""
+    gen = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (5, 112, 112, 3), generator=gen, dtype=torch.uint8)
+    u8[0] = torch.arange(112 * 112 * 3, dtype=torch.int64).remainder(256).to(torch.uint8).reshape(112, 112, 3)    # every byte value
+    flip = torch.tensor([0, 1, 0, 1, 1], dtype=torch.uint8)
+    ref = u8.permute(0, 3, 1, 2).float().div(255).sub(0.5).div(0.5)
+    ref = torch.where(flip.bool()[:, None, None, None], torch.flip(ref, dims=[3]), ref)
+    got = ops.preprocess_u8(u8.to(dev()), flip.to(dev())).cpu()
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.preprocess_u8(u8.to(dev())).cpu(), u8.permute(0, 3, 1, 2).float().div(255).sub(0.5).div(0.5))

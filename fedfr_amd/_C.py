@@ -68,6 +68,8 @@ SIGNATURES = {
     "fedfr_colsum_f32": (i32, [vp, i32, i32, vp, vp]),
     "fedfr_sgemm_colflag": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i64, f32, f32, vp, vp]),
     "fedfr_class_accumulate": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "fedfr_bias_prelu_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "fedfr_pad_input_nhwc": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "fedfr_preprocess_u8": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "fedfr_roc_histogram": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "fedfr_contrastive": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp]),

@@ -354,6 +354,13 @@ int fedfr_class_accumulate(const float* feats, const long long* label, int B, in
 int fedfr_roc_histogram(const float* feats, const long long* label, int N, int D, int T, unsigned long long* hist, void* stream) {
   return head_roc_histogram(feats, label, N, D, T, hist, ST(stream));
 }
+int fedfr_bias_prelu_bwd(const uint16_t* dy, const uint16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
+                         float* coef, float* dbias, float* dalpha, const uint16_t* add, uint16_t* dx, void* stream) {
+  return ew_bias_prelu_bwd(BF(dy), BF(x), bias, alpha, M, C, partials, coef, dbias, dalpha, BF(add), BFM(dx), ST(stream));
+}
+int fedfr_pad_input_nhwc(const float* src_nchw, uint16_t* dst_nhwc, int B, int C, int HW, int Cpad, void* stream) {
+  return ew_pad_input_nhwc(src_nchw, BFM(dst_nhwc), B, C, HW, Cpad, ST(stream));
+}
 int fedfr_preprocess_u8(const unsigned char* src_hwc, const unsigned char* flip, float* dst_nchw, int B, int H, int W, void* stream) {
   return ew_preprocess_u8(src_hwc, flip, dst_nchw, B, H, W, ST(stream));
 }

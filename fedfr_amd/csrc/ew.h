@@ -76,3 +76,6 @@ int ew_stem_fwd(const float* x, const float* w, bf16_t* y, float* stats, int B, 
 int ew_stem_wgrad_blocks(int B, int H, int W);
 int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st);
 int ew_preprocess_u8(const unsigned char* src, const unsigned char* flip, float* dst, int B, int H, int W, hipStream_t st);
+int ew_bias_prelu_bwd(const bf16_t* dy, const bf16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
+                      float* coef, float* dbias, float* dalpha, const bf16_t* add, bf16_t* dx, hipStream_t st);
+int ew_pad_input_nhwc(const float* src, bf16_t* dst, int B, int C, int HW, int Cpad, hipStream_t st);

@@ -332,7 +332,7 @@ int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 512)); }
 
 int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_reduce"));
-  FEDFR_REQUIRE(p.dy && p.x && p.mean && p.rstd && p.partials, "bn_bwd_reduce: null tensor");
+  FEDFR_REQUIRE(p.dy && p.x && p.partials, "bn_bwd_reduce: null tensor");   // mean / rstd null: 0 / 1 (bias + PReLU backward)
   const int slab = slab_rows(p.M, p.C, 512);
   const int grid = ceil_div(p.M, slab);
   const size_t lds = (size_t)rows_per_pass(p.C) * 3 * p.C * sizeof(float);
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
 
 int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_apply"));
-  FEDFR_REQUIRE(p.dy && p.x && p.mean && p.rstd && p.coef && p.dx, "bn_bwd_apply: null tensor");
+  FEDFR_REQUIRE(p.dy && p.x && p.coef && p.dx, "bn_bwd_apply: null tensor");
   BnBwdDiv dv;
   dv.dHW = make_fastdiv(1);
   dv.dW = make_fastdiv(1);
@@ -930,5 +930,60 @@ int ew_preprocess_u8(const unsigned char* src, const unsigned char* flip, float*
   const int grid = (int)std::min<long long>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid), dim3(256), 0, st, src, flip, dst, B, H, W);
   FEDFR_LAUNCH_CHECK("preprocess_u8");
+  return FEDFR_OK;
+}
+
+// =====================================================================================================
+// bias + PReLU backward without normalisation (sphnet: conv(+bias) -> PReLU, reference backbones/sphnet.py:4-13, :53-60):
+// z = x + bias, dz = dy * (z > 0 ? 1 : alpha), dbias = sum dz, dalpha = sum dy * z [z <= 0], dx = dz (+ add).
+// Runs on the BN-backward kernels with mean = 0, rstd = 1, gamma = 1, beta = bias and the coefficients (1, 0, 0).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void prelu_bwd_finalize_kernel(const float* __restrict__ part, int P, int C, float* dbias,
+                                                                float* dalpha, float* coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s3 = 0.0;
+  for (int r = 0; r < P; ++r) {
+    s1 += (double)part[(size_t)r * 3 * C + c];
+    s3 += (double)part[(size_t)r * 3 * C + 2 * C + c];
+  }
+  if (dbias) dbias[c] = (float)s1;
+  if (dalpha) dalpha[c] = (float)s3;
+  coef[c] = 1.f;
+  coef[C + c] = 0.f;
+  coef[2 * C + c] = 0.f;
+}
+int ew_bias_prelu_bwd(const bf16_t* dy, const bf16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
+                      float* coef, float* dbias, float* dalpha, const bf16_t* add, bf16_t* dx, hipStream_t st) {
+  FEDFR_REQUIRE(alpha && coef, "bias_prelu_bwd: alpha and coef are required");
+  BnBwd p{};
+  p.dy = dy; p.x = x; p.beta = bias; p.alpha = alpha; p.M = M; p.C = C; p.partials = partials; p.coef = coef; p.add = add; p.dx = dx;
+  FEDFR_TRY(ew_bn_bwd_reduce(p, st));
+  hipLaunchKernelGGL(prelu_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partials, ew_bn_bwd_grid(M, C), C, dbias, dalpha, coef);
+  FEDFR_LAUNCH_CHECK("prelu_bwd_finalize");
+  return ew_bn_bwd_apply(p, st);
+}
+
+// fp32 NCHW [B][C][HW] -> bf16 NHWC [B][HW][Cpad], channels >= C zero (sphnet's 3-channel input feeds the 64-channel-granular conv)
+__global__ __launch_bounds__(256) void pad_input_nhwc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int C, int HW, int Cpad) {
+  const long long total = (long long)B * HW * (Cpad / 8);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ch = (int)(i % (Cpad / 8));
+    const long long px = i / (Cpad / 8);
+    const int hw = (int)(px % HW), b = (int)(px / HW);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ch * 8 + j;
+      f[j] = c < C ? src[((long long)b * C + c) * HW + hw] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(dst + px * Cpad + ch * 8) = pack8(f);
+  }
+}
+int ew_pad_input_nhwc(const float* src, bf16_t* dst, int B, int C, int HW, int Cpad, hipStream_t st) {
+  FEDFR_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0 && Cpad >= C && (Cpad & 7) == 0, "pad_input_nhwc: bad args");
+  const long long total = (long long)B * HW * (Cpad / 8);
+  hipLaunchKernelGGL(pad_input_nhwc_kernel, dim3((int)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0, st, src, dst, B, C, HW, Cpad);
+  FEDFR_LAUNCH_CHECK("pad_input_nhwc");
   return FEDFR_OK;
 }

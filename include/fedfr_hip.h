@@ -166,6 +166,13 @@ int fedfr_sgemm_colflag(const float* A, const float* B, int M, int N, int K, lon
  * sums[c] += sum of the rows of feats whose label is c (batch order), counts[c] += their number. */
 int fedfr_class_accumulate(const float* feats, const long long* label, int B, int D, int C, float* sums, float* counts,
                            void* stream);
+/* sphnet building blocks (backbones/sphnet.py:4-13, :53-60: conv(+bias) -> PReLU, no normalisation).  Forward uses fedfr_bn_apply
+ * with scale 1 / shift = bias.  Backward: z = x + bias (bias may be NULL), dz = dy * (z > 0 ? 1 : alpha), dbias = sum dz,
+ * dalpha = sum dy * z over z <= 0, dx = dz (+ add).  partials: [fedfr_bn_bwd_rows][3][C], coef: [3][C] scratch. */
+int fedfr_bias_prelu_bwd(const uint16_t* dy, const uint16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
+                         float* coef, float* dbias, float* dalpha, const uint16_t* add, uint16_t* dx, void* stream);
+/* fp32 NCHW [B][C][HW] -> bf16 NHWC [B][HW][Cpad] with zero channels C..Cpad-1 (3-channel input of sphnet's first conv) */
+int fedfr_pad_input_nhwc(const float* src_nchw, uint16_t* dst_nhwc, int B, int C, int HW, int Cpad, void* stream);
 /* input pipeline (dataset.py:81-92): uint8 [B][H][W][3] + optional per-image flip flags -> fp32 [B][3][H][W] = (x/255 - 0.5)/0.5 */
 int fedfr_preprocess_u8(const unsigned char* src_hwc, const unsigned char* flip, float* dst_nchw, int B, int H, int W, void* stream);
 /* pairwise ROC histogram (roc_cuda.py:14-30 calc_ROC): over all pairs a < b with a < T (target rows first), b < N:

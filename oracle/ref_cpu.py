@@ -460,6 +460,59 @@ def client_train_public(sd: Dict[str, torch.Tensor], fc: torch.Tensor, bce: Opti
 
 
 # --------------------------------------------------------------------------------------
+# sphnet (reference backbones/sphnet.py:4-73) — functional restatement
+# --------------------------------------------------------------------------------------
+SPHERE_LAYERS = {20: (1, 2, 4, 1), 64: (3, 7, 16, 3)}
+
+
+def sphere_state_dict(type_: int = 20, tag: float = 0.0) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic sphnet state in reference key order (hash-generated Gaussians; fan-in scaled so activations stay O(1))."""
+    filt = [3, 64, 128, 256, 512]
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    seed = [7000 + int(tag * 17)]
+
+    def nxt(shape, scale):
+        seed[0] += 1
+        return hash_normal(shape, seed[0]) * scale
+
+    for L, nblk in enumerate(SPHERE_LAYERS[type_]):
+        cin, c = filt[L], filt[L + 1]
+        pre = "layer%d." % (L + 1)
+        sd[pre + "0.weight"] = nxt((c, cin, 3, 3), (2.0 / (9 * cin)) ** 0.5)
+        sd[pre + "0.bias"] = nxt((c,), 0.1)
+        sd[pre + "1.weight"] = 0.25 + nxt((c,), 0.05)
+        for b in range(nblk):
+            bp = pre + "%d." % (2 + b)
+            sd[bp + "conv1.weight"] = nxt((c, c, 3, 3), (1.0 / (9 * c)) ** 0.5)
+            sd[bp + "prelu1.weight"] = 0.25 + nxt((c,), 0.05)
+            sd[bp + "conv2.weight"] = nxt((c, c, 3, 3), (1.0 / (9 * c)) ** 0.5)
+            sd[bp + "prelu2.weight"] = 0.25 + nxt((c,), 0.05)
+    sd["fc.weight"] = nxt((512, 512 * 7 * 7), (1.0 / (512 * 49)) ** 0.5)
+    sd["fc.bias"] = nxt((512,), 0.05)
+    return sd
+
+
+def sphere_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, type_: int = 20) -> torch.Tensor:
+    """sphnet.py:62-71 (fp32): 4 stages of [conv3x3 s2 + bias -> PReLU -> n x (x + prelu(conv(prelu(conv(x)))))], flatten, fc."""
+    for L, nblk in enumerate(SPHERE_LAYERS[type_]):
+        pre = "layer%d." % (L + 1)
+        x = F.prelu(F.conv2d(x, sd[pre + "0.weight"], sd[pre + "0.bias"], 2, 1), sd[pre + "1.weight"])
+        for b in range(nblk):
+            bp = pre + "%d." % (2 + b)
+            t = F.prelu(F.conv2d(x, sd[bp + "conv1.weight"], None, 1, 1), sd[bp + "prelu1.weight"])
+            x = x + F.prelu(F.conv2d(t, sd[bp + "conv2.weight"], None, 1, 1), sd[bp + "prelu2.weight"])
+    return F.linear(x.reshape(x.shape[0], -1), sd["fc.weight"], sd["fc.bias"])
+
+
+def sphere_step_grads(sd: Dict[str, torch.Tensor], x: torch.Tensor, dfeats: torch.Tensor, type_: int = 20):
+    """(feats, {key: grad}) for the scalar <feats, dfeats>."""
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    feats = sphere_forward(ps, x, type_)
+    (feats * dfeats).sum().backward()
+    return feats.detach(), {k: v.grad for k, v in ps.items()}
+
+
+# --------------------------------------------------------------------------------------
 # inference sweeps + hard-negative mining (SURVEY §8f N1 / N2)
 # --------------------------------------------------------------------------------------
 def embed(sd: Dict[str, torch.Tensor], batches, layers: Sequence[int], normalize: bool = True) -> torch.Tensor:

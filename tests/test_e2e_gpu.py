@@ -362,6 +362,44 @@ def test_sweeps_and_hard_negative_mining_vs_reference():
     assert len(sub.dataset) == len(g["hn_index"]) and sub.dataset.num_classes == npub
 
 
+def test_sphnet_vs_reference():
+    """backbones.sphnet (sphere20) — reference state_dict keys / shapes, forward and all parameter gradients against
+    the imported reference module (bf16 activations: 1e-2-class), eval == train forward (no normalisation layers)."""
+    g = load_golden("sphnet20")
+    B = int(g["B"])
+    sd = R.sphere_state_dict(20, tag=1.0)
+    net = backbones.sphnet(False, dropout=0, fp16=True, type=20).to(DEV)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    assert all(tuple(v.shape) == tuple(sd[k].shape) for k, v in net.state_dict().items())
+    net.load_state_dict(sd)
+    back = net.state_dict()
+    assert all(torch.equal(back[k].cpu(), sd[k]) for k in sd)                        # KRSC storage is invisible through state_dict
+    net.train()
+    x = R.closed_form_images(B, tag=4.0).to(DEV)
+    dfe = R.closed_form((B, 512), 0.37, 0.9, 1.0).to(DEV)
+    feats = net(x)
+    assert rel(feats, g["feats"]) < 2e-2, rel(feats, g["feats"])
+    (feats * dfe).sum().backward()
+    nerr, derr = [], []
+    for k, p in net.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        nerr.append(abs(float(p.grad.norm()) - float(g["gnorm_" + k])) / float(g["gnorm_" + k]))
+        key = "g_" + k
+        if key in g.files:
+            derr.append((k, rel(p.grad, g[key])))
+    derr.append(("layer2.2.conv1.weight[:4,:16]", rel(net.layer2[2].conv1.weight.grad[:4, :16], g["g_layer2.2.conv1.weight_slice"])))
+    derr.append(("fc.weight[:4,:2048]", rel(net.fc.weight.grad[:4, :2048], g["g_fc.weight_slice"])))
+    # per-tensor gradient norms: median 0.4 %; the PReLU-slope / bias gradients are sign-filtered sums of bf16-rounded values -> up to ~6 %
+    assert np.median(nerr) < 1e-2 and max(nerr) < 0.12, (np.median(nerr), max(nerr))
+    # direction errors: bf16 storage noise through the whole backward chain; worst on the first layer's bias, a heavily cancelling
+    # sum over 4e5 pixels (same policy as the iresnet gradient test: median small, max bounded)
+    dvals = [e for _, e in derr]
+    assert np.median(dvals) < 0.15 and max(dvals) < 0.4, (np.median(dvals), max(derr, key=lambda t: t[1]))   # measured 0.106 / 0.16
+    net.eval()
+    with torch.no_grad():
+        assert torch.equal(net(x), feats.detach())
+
+
 def test_roc_vs_reference():
     """roc_cuda.py end to end: histogram and TPR@FPR read-out equal the values produced by the reference's own kernel body."""
     from fedfr_amd import eval_roc

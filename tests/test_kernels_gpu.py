@@ -527,3 +527,39 @@ def test_preprocess_u8_bit_exact():
     got = ops.preprocess_u8(u8.to(dev()), flip.to(dev())).cpu()
     assert torch.equal(got, ref)
     assert torch.equal(ops.preprocess_u8(u8.to(dev())).cpu(), u8.permute(0, 3, 1, 2).float().div(255).sub(0.5).div(0.5))
+
+
+@pytest.mark.parametrize("M,C,with_bias,with_add", [(3000, 64, True, False), (777, 256, False, True)])
+def test_bias_prelu_bwd_vs_torch(M, C, with_bias, with_add):
+    """fedfr_bias_prelu_bwd == autograd of prelu(x + bias) (sphnet.py:53-60)."""
+    gen = torch.Generator().manual_seed(M)
+    x = bf(torch.randn(M, C, generator=gen)).float()
+    dy = bf(torch.randn(M, C, generator=gen)).float()
+    add = bf(torch.randn(M, C, generator=gen)).float() if with_add else None
+    bias = (torch.randn(C, generator=gen) * 0.3).requires_grad_(True)
+    alpha = (0.25 + 0.1 * torch.randn(C, generator=gen)).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    F.prelu((xr + (bias if with_bias else 0.0)).t().reshape(1, C, M), alpha).backward(dy.t().reshape(1, C, M))
+    xd, dyd = bf(x).to(dev()), bf(dy).to(dev())
+    addd = bf(add).to(dev()) if with_add else None
+    rows = _C.lib().fedfr_bn_bwd_rows(M, C)
+    part = torch.empty(rows, 3, C, device=dev()); coef = torch.empty(3, C, device=dev())
+    db = torch.empty(C, device=dev()); da = torch.empty(C, device=dev()); dx = torch.empty(M, C, dtype=torch.bfloat16, device=dev())
+    bd, ad = bias.detach().to(dev()), alpha.detach().to(dev())
+    _C.call("fedfr_bias_prelu_bwd", dyd.data_ptr(), xd.data_ptr(), bd.data_ptr() if with_bias else None, ad.data_ptr(), M, C, part.data_ptr(),
+            coef.data_ptr(), db.data_ptr() if with_bias else None, da.data_ptr(), addd.data_ptr() if with_add else None, dx.data_ptr(), _C.stream())
+    torch.cuda.synchronize()
+    ref_dx = xr.grad + (add if with_add else 0.0)
+    assert relerr(dx.float(), ref_dx) < 6e-3                    # bf16 output rounding
+    assert relerr(da, alpha.grad) < 1e-4
+    if with_bias:
+        assert relerr(db, bias.grad) < 1e-4
+
+
+def test_pad_input_nhwc():
+    x = torch.randn(3, 3, 20, 20)
+    out = torch.empty(3, 20, 20, 64, dtype=torch.bfloat16, device=dev())
+    xd = x.to(dev())
+    _C.call("fedfr_pad_input_nhwc", xd.data_ptr(), out.data_ptr(), 3, 3, 400, 64, _C.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out[..., :3].cpu(), x.permute(0, 2, 3, 1).to(torch.bfloat16)) and float(out[..., 3:].float().abs().max()) == 0.0

@@ -266,3 +266,19 @@ def test_roc_histogram_matches_reference_kernel_body():
     f = np.eye(4, dtype=np.float32)[[0, 0, 1, 2, 1]]
     h = R.roc_histogram(f, np.array([7, 7, 8, 9, 8]), 3)
     assert h[2000, 0] == 2 and h[1000, 1] == 7 and h.sum() == 9
+
+
+def test_sphnet_matches_reference():
+    """sphere20 forward + parameter gradients of the functional restatement vs the imported reference module."""
+    g = load_golden("sphnet20")
+    B = int(g["B"])
+    sd = R.sphere_state_dict(20, tag=1.0)
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    x = R.closed_form_images(B, tag=4.0)
+    dfe = R.closed_form((B, 512), 0.37, 0.9, 1.0)
+    feats, grads = R.sphere_step_grads(sd, x, dfe, 20)
+    close(feats, g["feats"], 2e-4, 1e-5)
+    for k in sd:
+        assert abs(float(grads[k].norm()) - float(g["gnorm_" + k])) < 2e-4 * float(g["gnorm_" + k]) + 1e-6, k
+        if ("g_" + k) in g.files:
+            close(grads[k], g["g_" + k], 2e-3, 2e-4 * float(T(g["g_" + k]).abs().max()) + 1e-7)

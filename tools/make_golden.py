@@ -659,8 +659,34 @@ def gen_roc():
     save("roc", features=feature, labels=lab.astype(np.int64), target_size=target_size, hist=hist, tpr=np.array(tpr), total_pairs=int(hist.sum()))
 
 
+# ---- 11. sphnet (backbones/sphnet.py), sphere20 fwd + bwd ---------------------------------------------------------------------
+def gen_sphnet():
+    from backbones.sphnet import sphere as ref_sphere
+    B = 8
+    net = ref_sphere(20)
+    sd = R.sphere_state_dict(20, tag=1.0)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    net.train()
+    x = R.closed_form_images(B, tag=4.0)
+    dfe = R.closed_form((B, 512), 0.37, 0.9, 1.0)
+    feats = net(x)
+    (feats * dfe).sum().backward()
+    out = {"B": B, "feats": feats.detach()}
+    for k, p in net.named_parameters():
+        g = p.grad
+        out["gnorm_" + k] = g.norm()
+        if g.numel() <= 4096:
+            out["g_" + k] = g
+    out["g_layer2.2.conv1.weight_slice"] = net.layer2[2].conv1.weight.grad[:4, :16]
+    out["g_layer1.0.weight"] = net.layer1[0].weight.grad
+    out["g_fc.weight_slice"] = net.fc.weight.grad[:4, :2048]
+    out["keys"] = np.array(list(sd.keys()))
+    save("sphnet20", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining", "roc"]
+    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining", "roc", "sphnet"]
     if "block" in which:
         gen_block()
     if "r50" in which:
@@ -679,6 +705,8 @@ if __name__ == "__main__":
         gen_pfc()
     if "client" in which:
         gen_client()
+    if "sphnet" in which:
+        gen_sphnet()
     if "roc" in which:
         gen_roc()
     if "mining" in which:

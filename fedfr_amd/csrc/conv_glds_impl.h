@@ -49,7 +49,7 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int W_, int R_, int NPA, int WN>   // tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+template <int W_, int R_, int NPA, int WN, bool FUSED>   // FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
   constexpr int PT = R_ * W_, BN = 128, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
@@ -224,6 +224,20 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   // drain the (zero-writing) tail DMAs before the staging buffer is reused
   glds_wait_vmcnt<0>();
   __syncthreads();
+  // FUSED: the BN input tile x[196][128 ch] (same rows / columns as the output tile) travels by LDS-DMA into the weight-ring region
+  // while the accumulators are converted and staged; 49 pieces of 4 rows x 256 B, lane l -> row l >> 4, 16-B chunk l & 15
+  constexpr int XOFF = 2 * A_BYTES, XP = (PT * 256 / 1024 + NW) / NW;   // pieces per wave (>= 49 / NW)
+  static_assert(!FUSED || (PT * 256 <= NB * B_BYTES && (PT / (NT / 16) + 1) > 0), "x tile must fit the weight ring");
+  if constexpr (FUSED) {
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int piece = j * NW + wave, row = piece * 4 + (lane >> 4);
+      const unsigned vo = row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + (lane & 15) * 8)) * 2u : OOB;
+      if (piece * 1024 < NB * B_BYTES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(smem + XOFF + piece * 1024), 16, (int)vo, 0, 0, 0);
+    }
+  }
 
   GLDS_STAMP(2);
   // ---- epilogue: bf16 tile through LDS; fragment rows >= 196 contribute nothing ----
@@ -277,30 +291,90 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   }
   __syncthreads();
   constexpr int CPR = BN / 8;
-  for (int idx = tid; idx < PT * CPR; idx += NT) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n0 + c * 8) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+  if constexpr (!FUSED) {
+    for (int idx = tid; idx < PT * CPR; idx += NT) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n0 + c * 8) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+    }
+  } else {
+    // ---- fused BN-backward reduction (ew_bn_bwd_reduce on this tile): thread owns chunk column c (8 channels) of rows rg, rg + RG, ...
+    constexpr int RG = NT / CPR;
+    const int c = tid % CPR, rg = tid / CPR;
+    const int n = n0 + c * 8;
+    float mean[8], rstd[8], ga[8], be[8], al[8], s1[8], s2[8], s3[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mean[q] = p.bmean[n + q]; rstd[q] = p.brstd[n + q];
+      ga[q] = p.bgamma ? p.bgamma[n + q] : 1.f; be[q] = p.bbeta ? p.bbeta[n + q] : 0.f; al[q] = p.balpha ? p.balpha[n + q] : 1.f;
+      s1[q] = s2[q] = s3[q] = 0.f;
+    }
+    const bool has_alpha = p.balpha != nullptr;
+    glds_wait_vmcnt<0>();                              // own x pieces landed ...
+    __syncthreads();                                   // ... and everybody's
+    const unsigned char* sX = smem + XOFF;
+    for (int row = rg; row < PT; row += RG) {
+      const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+      *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+      float dy[8], xv[8];
+      unpack8(dv, dy);
+      unpack8(*reinterpret_cast<const uint4*>(sX + row * 256 + c * 16), xv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float xh = (xv[q] - mean[q]) * rstd[q];
+        float dz = dy[q];
+        if (has_alpha) {
+          const float z = ga[q] * xh + be[q];
+          if (z <= 0.f) {
+            s3[q] += dy[q] * z;
+            dz = dy[q] * al[q];
+          }
+        }
+        s1[q] += dz;
+        s2[q] += dz * xh;
+      }
+    }
+    __syncthreads();                                   // everyone is done with the x tile: its region becomes the reduction scratch
+    float* red = reinterpret_cast<float*>(smem + XOFF);      // [RG][3][BN]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      red[(rg * 3 + 0) * BN + c * 8 + q] = s1[q];
+      red[(rg * 3 + 1) * BN + c * 8 + q] = s2[q];
+      red[(rg * 3 + 2) * BN + c * 8 + q] = s3[q];
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * BN; i += NT) {
+      const int which = i / BN, col = i - which * BN;
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < RG; ++r) t += red[(r * 3 + which) * BN + col];
+      p.bpart[((size_t)bt * 3 + which) * p.N + n0 + col] = t;
+    }
   }
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int NPA, int WN>
+template <int W_, int R_, int NPA, int WN, bool FUSED>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
   FEDFR_REQUIRE(p.N % 128 == 0 && p.C % 128 == 0 && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
                 "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
-  FEDFR_REQUIRE(p.bpart == nullptr, "conv3x3_glds: no fused BN-backward epilogue");
+  FEDFR_REQUIRE(FUSED == (p.bpart != nullptr), "conv3x3_glds: fused / plain variant mismatch");
+  if (FUSED) {
+    FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");
+    static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
+    if (p.bwd_fused) *p.bwd_fused = p.M / PT;
+  }
   p.nbn = p.N / 128;
   const int ntile = p.M / PT;
   constexpr size_t lds = 2 * (size_t)NPA * 1024 + 4 * (size_t)128 * 128;
   static_assert(lds >= (size_t)PT * (128 * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   ProfScope prof(W_ == 14 ? 12 : 13, 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

@@ -367,6 +367,8 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
   if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
     if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
+      if (g_conv_halo >= 4 && p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0 && p.ldc == p.N)
+        return p.W == 14 ? launch_conv_glds8_fused_w14(p, st) : launch_conv_glds8_fused_w28(p, st);
       if (g_conv_halo >= 3 && !p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0)
         return g_conv_halo >= 4 ? (p.W == 14 ? launch_conv_glds8_w14(p, st) : launch_conv_glds8_w28(p, st))
                                 : (p.W == 14 ? launch_conv_glds_w14(p, st) : launch_conv_glds_w28(p, st));

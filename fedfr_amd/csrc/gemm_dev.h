@@ -55,6 +55,8 @@ int launch_conv_glds_w14(GemmNT p, hipStream_t st);        // conv_glds_w14.hip 
 int launch_conv_glds_w28(GemmNT p, hipStream_t st);        // conv_glds_w28.hip
 int launch_conv_glds8_w14(GemmNT p, hipStream_t st);       // conv_glds8_w14.hip  same, 8 waves per tile
 int launch_conv_glds8_w28(GemmNT p, hipStream_t st);       // conv_glds8_w28.hip
+int launch_conv_glds8_fused_w14(GemmNT p, hipStream_t st); // conv_glds8_fused_w14.hip  + BN-backward reduction epilogue
+int launch_conv_glds8_fused_w28(GemmNT p, hipStream_t st); // conv_glds8_fused_w28.hip
 int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   // conv_halo2_misc.hip  tuning variants
 int launch_tn_glds(GemmTN p, int splits, hipStream_t st);   // gemm_tn_glds.hip  wgrad GEMM, LDS-DMA operand ring
 bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode);

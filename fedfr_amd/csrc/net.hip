@@ -214,8 +214,9 @@ static int conv_fwd(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* out
   p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = stats ? c.part() : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
-int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the halo2 dgrad epilogue.  Off by default: same-box A/B gives 25.07 ms/step with the
-                        // separate (HBM-bound) ew_bn_bwd_reduce, which overlaps the aux-stream wgrad GEMMs, vs 25.57 fused (+15 us serial epilogue).
+int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the 3x3 dgrad epilogue (LDS-DMA kernel: x tile fetched by DMA after the
+                        // K loop; halo2 kernel otherwise).  Off by default — measured twice, same box: 21.48 ms/step separate vs 21.95 fused
+                        // (LDS-DMA kernel, +11 us of serial epilogue per dgrad vs a 7-12 us ew_bn_bwd_reduce that overlaps the aux stream).
 // dx (at the conv's INPUT resolution) = conv_transpose(dy).  If `bn` is given, the kernel may also produce the
 // BN-backward partial sums of (dx, bn_x) in its epilogue; *fused_rows > 0 then (else run ew_bn_bwd_reduce).
 static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* dx, const BnD* bn = nullptr,

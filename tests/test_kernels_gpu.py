@@ -138,7 +138,8 @@ def test_conv_dgrad_fused_bn_bwd_reduction(B, H, Cin, Cout, prelu):
     if B * H * H < 384 * 128 // 2:          # small problems take the generic kernel: no fusion, caller reduces itself
         assert rows.value == 0
         return
-    assert rows.value == (B * H * H + 127) // 128
+    # partial rows = M tiles of the kernel that ran: 196-pixel image tiles (LDS-DMA kernel) or 128-row tiles (halo2 kernel)
+    assert rows.value in ((B * H * H + 127) // 128, B * H * H // 196)
     g = dx.float().reshape(-1, Cin).double()
     xh = (bnx.float().double() - mean.double()) * rstd.double()
     dz = g.clone()

@@ -15,8 +15,8 @@ extern "C" int stamp_conv3x3(const void* x, const void* w, void* y, float* stats
   p.b_bytes = (unsigned)(2ull * cout * p.K);
   p.dbg = dbg;
   if (which == 3) {
-    if (h == 14) return launch_glds<14, 14, 32, 2>(p, (hipStream_t)stream);
-    if (h == 28) return launch_glds<28, 7, 36, 2>(p, (hipStream_t)stream);
+    if (h == 14) return launch_glds<14, 14, 32, 2, false>(p, (hipStream_t)stream);
+    if (h == 28) return launch_glds<28, 7, 36, 2, false>(p, (hipStream_t)stream);
     return -1;
   }
   if (h == 14) return launch_halo2<128, 14, 2, false>(p, (hipStream_t)stream);

@@ -5,7 +5,9 @@
 #include "ew.h"
 
 #define EW_THREADS 256
+#ifndef EW_UNROLL
 #define EW_UNROLL 4       // rows whose loads are issued together in the streaming BN kernels
+#endif
 
 static inline int rows_per_pass(int C) { return EW_THREADS / (C >> 3); }
 static int slab_rows(int M, int C, int max_blocks) {

@@ -19,6 +19,11 @@
 #ifndef GLDS_ABLATE
 #define GLDS_ABLATE 0
 #endif
+#ifdef GLDS_SETPRIO
+#define GLDS_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define GLDS_PRIO(x) do { } while (0)
+#endif
 
 // =====================================================================================================
 // 3x3 / stride-1 / pad-1 convolution (fwd, and dgrad with the flipped shadow) for 14x14 / 28x28 maps, Cout % 128 == 0,
@@ -181,7 +186,9 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         const unsigned char* cB = sB + bbuf * B_BYTES;
         // ---- first half: k-step 0 MFMAs, with the fragment reads of k-step 1 threaded between them
         if (!(GLDS_ABLATE & 4)) read_frags(f1a, f1b, aoff, tap % 3, cB, 1);
+        GLDS_PRIO(1);
         mfma_all(f0a, f0b);
+        GLDS_PRIO(0);
 #pragma unroll
         for (int i = 0; i < NRD; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);   // MFMAs
@@ -202,7 +209,9 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           issue_b(tap3, cc3, (bbuf + 3) & (NB - 1), cc3 < cpt);
           if (tap == 0) issue_a(cc + 1, h ^ 1, more_c);
         }
+        GLDS_PRIO(1);
         mfma_all(f1a, f1b);
+        GLDS_PRIO(0);
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);   // MFMAs

@@ -54,22 +54,24 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED>   // FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false>   // BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
-  constexpr int PT = R_ * W_, BN = 128, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
+  constexpr int PT = R_ * W_, BN = BN_, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
   constexpr int PWL = (PW + 7) & ~7;                      // LDS image pitch in rows: a multiple of 8, so that the swizzle key (row & 7) does not depend on
                                                          // the vertical tap offset -> A addresses need 3 (horizontal) variants, dy is an instruction immediate
   constexpr int TM = 7, TN = BN / WN / 16, MW = TM * 16;   // 112 fragment rows per wave, 224 per tile (196 valid)
-  constexpr int AP = NPA / NW, BP = 16 / NW;             // LDS-DMA pieces per wave: image buffer / weight tile
+  constexpr int AP = NPA / NW, BP = (BN / 8) / NW;       // LDS-DMA pieces per wave: image buffer / weight tile
+  constexpr int NABUF = ONECHUNK ? 1 : 2;
   constexpr int NRD = TM + TN, MPR = (TM * TN) / NRD;    // fragment reads per k-half; MFMAs threaded per read
   constexpr int TPI = W_ / R_;                          // tiles per image
   constexpr int A_BYTES = NPA * 1024, B_BYTES = BN * 128, NB = 4;
-  static_assert(PT == 196 && W_ % R_ == 0 && (R_ + 2) * PWL <= NPA * 8 && NPA % NW == 0 && MPR >= 1, "tile geometry");
+  static_assert(PT <= 2 * MW && PT > MW && W_ % R_ == 0 && (R_ + 2) * PWL <= NPA * 8 && NPA % NW == 0 && (BN / 8) % NW == 0 && MPR >= 1 &&
+                    !(FUSED && ONECHUNK), "tile geometry");
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* sA = smem;                       // [2][A_BYTES]
-  unsigned char* sB = smem + 2 * A_BYTES;         // [NB][B_BYTES]
+  unsigned char* sB = smem + NABUF * A_BYTES;     // [NB][B_BYTES]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,12 +179,13 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int cc = cc2 + h;
+      if (ONECHUNK && h == 1) break;
       const bool more_c = cc + 1 < cpt;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int aoff = h * A_BYTES + (tap / 3) * PWL * 128;                       // buffer + vertical tap: immediates
+        const int aoff = (ONECHUNK ? 0 : h) * A_BYTES + (tap / 3) * PWL * 128;       // buffer + vertical tap: immediates
         const int tapn = tap == 8 ? 0 : tap + 1;
-        const int aoffn = (tap == 8 ? (h ^ 1) : h) * A_BYTES + (tapn / 3) * PWL * 128;
+        const int aoffn = (ONECHUNK ? 0 : (tap == 8 ? (h ^ 1) : h)) * A_BYTES + (tapn / 3) * PWL * 128;
         const unsigned char* cB = sB + bbuf * B_BYTES;
         // ---- first half: k-step 0 MFMAs, with the fragment reads of k-step 1 threaded between them
         if (!(GLDS_ABLATE & 4)) read_frags(f1a, f1b, aoff, tap % 3, cB, 1);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         __builtin_amdgcn_sched_barrier(0);
         // Loads younger than the tile we need (tap+1, issued two taps ago) stay in flight: the tile of tap+2 and the next
         // chunk's image when it was issued after it (at tap 0 of this chunk: seen from taps 1 and 2).
-        if (!(GLDS_ABLATE & 1)) { if (tap == 1 || tap == 2) glds_wait_vmcnt<BP + AP>(); else glds_wait_vmcnt<BP>(); }
+        if (!(GLDS_ABLATE & 1)) { if (!ONECHUNK && (tap == 1 || tap == 2)) glds_wait_vmcnt<BP + AP>(); else glds_wait_vmcnt<BP>(); }
         if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- second half: k-step 1 MFMAs, threaded with the reads of tap+1 / k-step 0 and this tap's DMA issue
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           const int t3 = tap + 3;
           const int tap3 = t3 >= 9 ? t3 - 9 : t3, cc3 = t3 >= 9 ? cc + 1 : cc;
           issue_b(tap3, cc3, (bbuf + 3) & (NB - 1), cc3 < cpt);
-          if (tap == 0) issue_a(cc + 1, h ^ 1, more_c);
+          if (!ONECHUNK && tap == 0) issue_a(cc + 1, h ^ 1, more_c);
         }
         GLDS_PRIO(1);
         mfma_all(f1a, f1b);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   __syncthreads();
   // FUSED: the BN input tile x[196][128 ch] (same rows / columns as the output tile) travels by LDS-DMA into the weight-ring region
   // while the accumulators are converted and staged; 49 pieces of 4 rows x 256 B, lane l -> row l >> 4, 16-B chunk l & 15
-  constexpr int XOFF = 2 * A_BYTES, XP = (PT * 256 / 1024 + NW) / NW;   // pieces per wave (>= 49 / NW)
+  constexpr int XOFF = NABUF * A_BYTES, XP = (PT * 256 / 1024 + NW) / NW;   // pieces per wave (>= 49 / NW)
   static_assert(!FUSED || (PT * 256 <= NB * B_BYTES && (PT / (NT / 16) + 1) > 0), "x tile must fit the weight ring");
   if constexpr (FUSED) {
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
@@ -362,10 +365,10 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED>
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
-  FEDFR_REQUIRE(p.N % 128 == 0 && p.C % 128 == 0 && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
+  FEDFR_REQUIRE(p.N % BN_ == 0 && (ONECHUNK ? p.C == 64 : p.C % 128 == 0) && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
                 "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
   FEDFR_REQUIRE(FUSED == (p.bpart != nullptr), "conv3x3_glds: fused / plain variant mismatch");
   if (FUSED) {
@@ -373,17 +376,17 @@ static int launch_glds(GemmNT p, hipStream_t st) {
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
     if (p.bwd_fused) *p.bwd_fused = p.M / PT;
   }
-  p.nbn = p.N / 128;
+  p.nbn = p.N / BN_;
   const int ntile = p.M / PT;
-  constexpr size_t lds = 2 * (size_t)NPA * 1024 + 4 * (size_t)128 * 128;
-  static_assert(lds >= (size_t)PT * (128 * 2 + 16) && lds <= 160 * 1024, "LDS budget");
+  constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128;
+  static_assert(lds >= (size_t)PT * (BN_ * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  ProfScope prof(W_ == 14 ? 12 : 13, 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15), 2.0 * p.M * p.N * (double)p.K, st);
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

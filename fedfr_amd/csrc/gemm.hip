@@ -11,7 +11,7 @@
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------
 // slots: 0..3 = gemm_nt <128,128> <128,64> <64,128> <64,64>; 4..7 = gemm_tn <128,128> <128,64> <64,128> <64,64>;
 // 8 = conv3x3_halo2<128,14>, 9 = conv3x3_halo2<128,28>, 10 = conv3x3_halo2<64,*>, 11 = conv3x3_halo (v1, all),
-// 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>, 14 = gemm_tn_glds<128,128>
+// 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>, 14 = gemm_tn_glds<128,128>, 15 = conv3x3_glds<56,4> (64 channels)
 namespace {
 struct ProfSlot {
   std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -19,7 +19,7 @@ struct ProfSlot {
   long long launches = 0;
 };
 bool g_prof_on = false;
-ProfSlot g_prof[15];
+ProfSlot g_prof[16];
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
 }  // namespace
 
@@ -50,7 +50,7 @@ void gemm_profile_enable(int on) {
 }
 // caller must have synchronised the stream(s).  Returns 0 and fills totals for `slot`.
 int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
-  if (slot < 0 || slot >= 15) return -1;
+  if (slot < 0 || slot >= 16) return -1;
   ProfSlot& s = g_prof[slot];
   double ms = 0.0;
   for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
@@ -366,6 +366,7 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
   const int BM = nt_bm(p.M, p.N);
   if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
+    if (g_conv_halo >= 4 && p.H == 56 && p.W == 56 && p.C == 64 && p.N == 64 && !p.bpart && p.M % (56 * 56) == 0) return launch_conv_glds_w56(p, st);
     if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
       if (g_conv_halo >= 4 && p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0 && p.ldc == p.N)
         return p.W == 14 ? launch_conv_glds8_fused_w14(p, st) : launch_conv_glds8_fused_w28(p, st);

@@ -52,6 +52,8 @@ CONV_CASES = [
     (65, 28, 128, 128, 3, 1),
     (260, 14, 64, 64, 3, 1),     # zero-padded-image kernel, BN = 64 instantiation
     (131, 28, 128, 256, 3, 1),
+    (9, 56, 64, 128, 3, 1),      # LDS-DMA kernel, single input chunk -> 128-wide tile (fwd) / two chunks -> 64-wide tile (dgrad)
+    (3, 56, 128, 64, 3, 1),
 ]
 
 

@@ -33,6 +33,9 @@ struct GemmNT {
   const float *bmean, *brstd, *bgamma, *bbeta, *balpha;
   float* bpart;
   int* bwd_fused;
+  // stride-2 dgrad by output-parity class (gemm.hip: nt_launch_parity): this launch computes the output pixels (2 h2 + par_h, 2 w2 + par_w)
+  // of a [img][outH][outW] map with only the filter taps that reach a real (non-inserted-zero) input: 1, 2, 2 or 4 of the 9
+  int par_on, par_h, par_w, outH, outW;
   unsigned long long* dbg;   // diagnostics builds only (tools/stamp_halo2.hip): per-block in-kernel clock stamps
 };
 

@@ -102,7 +102,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
       const int mm = a_ok[i] ? m : 0;
       const int hw = p.Ho * p.Wo;
       const int img = mm / hw, rem = mm - img * hw;
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      if (p.par_on) {                                   // class row (img, h2, w2) -> output pixel (2 h2 + par_h, 2 w2 + par_w)
+        ho = 2 * ho + p.par_h;
+        wo = 2 * wo + p.par_w;
+      }
       a_hb[i] = ho * p.stride - p.pad;
       a_wb[i] = wo * p.stride - p.pad;
       a_pix[i] = img * p.H * p.W;
@@ -114,6 +118,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   // tap state for k-step kt: (r, s, cc)
   int tap = kt0 / p.cpt, cc = kt0 - tap * p.cpt;
   int r = tap / p.S, s = tap - r * p.S;
+  const int s0 = 1 - p.par_w, tstep = p.par_on ? 2 : 1;   // parity class: taps r = 1 - par_h (+2), s = 1 - par_w (+2) only
+  if (p.par_on) {
+    const int nS = 1 + p.par_w;
+    r = (1 - p.par_h) + 2 * (tap / nS);
+    s = s0 + 2 * (tap % nS);
+  }
 
   uint4 ra[AI], rb[BI];
 
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int n = n0 + rbase + 32 * i;
-      const int k = kt * 64 + ch * 8;
+      const int k = (p.mode == 1 ? ((r * p.S + s) * p.cpt + cc) * 64 : kt * 64) + ch * 8;   // == kt * 64 unless taps are skipped
       const unsigned off = ((unsigned)n * (unsigned)p.K + (unsigned)k) * 2u;
       rb[i] = buf_load16(rsB, (n < p.N && k < p.K) ? off : p.b_bytes);
     }
@@ -161,9 +171,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   auto advance = [&]() {
     if (++cc == p.cpt) {
       cc = 0;
-      if (++s == p.S) {
-        s = 0;
-        ++r;
+      s += tstep;
+      if (s >= p.S) {
+        s = p.par_on ? s0 : 0;
+        r += tstep;
       }
     }
   };
@@ -273,8 +284,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   for (int idx = tid; idx < BM * CPR; idx += 256) {
     const int row = idx / CPR, c = idx - row * CPR;
     const int m = m0 + row, n = n0 + c * 8;
-    if (m < p.M && n < p.N)
-      *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+    if (m < p.M && n < p.N) {
+      size_t mo = (size_t)m;
+      if (p.par_on) {
+        const int hw = p.Ho * p.Wo, img = m / hw, rem = m - img * hw, h2 = rem / p.Wo, w2 = rem - h2 * p.Wo;
+        mo = ((size_t)img * p.outH + 2 * h2 + p.par_h) * p.outW + 2 * w2 + p.par_w;
+      }
+      *reinterpret_cast<uint4*>(p.Cb + mo * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+    }
   }
 }
 
@@ -306,7 +323,7 @@ static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(nbm * p.nbn, splits, 1);
-  ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (double)p.K, st);
+  ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st);
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_nt");
   return FEDFR_OK;
@@ -338,7 +355,24 @@ int gemm_nt_stat_rows(int M, int N) {
   return ceil_div(M, BM) * WM;
 }
 
+int g_dgrad_parity = 1;   // option "dgrad_parity": stride-2 3x3 dgrad as 4 output-parity classes (9/4 instead of 9 taps per output pixel)
+
+static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
+  if (g_dgrad_parity && p.mode == 1 && p.up == 2 && p.S == 3 && p.pad == 1 && p.stride == 1 && p.Cb && !p.stats && splits == 1 &&
+      !(p.Ho & 1) && !(p.Wo & 1) && p.Ho == 2 * p.H && p.Wo == 2 * p.W && p.M % (p.Ho * p.Wo) == 0 && !p.par_on) {
+    for (int cls = 0; cls < 4; ++cls) {
+      GemmNT q = p;
+      q.par_on = 1; q.par_h = cls >> 1; q.par_w = cls & 1;
+      q.outH = p.Ho; q.outW = p.Wo;
+      q.Ho = p.Ho / 2; q.Wo = p.Wo / 2; q.M = p.M / 4;
+      FEDFR_TRY(gemm_nt_launch_one(q, 1, st));
+    }
+    return FEDFR_OK;
+  }
+  return gemm_nt_launch_one(p, splits, st);
+}
+static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
   FEDFR_REQUIRE(p.A && p.B && p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: null/empty operand");
   FEDFR_REQUIRE((p.K & 7) == 0, "gemm_nt: K=%d must be a multiple of 8", p.K);
   FEDFR_REQUIRE((p.Cb != nullptr) != (p.Cf != nullptr), "gemm_nt: exactly one of bf16 / fp32-slab outputs");
@@ -354,7 +388,7 @@ int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
     p.cpt = 1 << 30;
     p.S = 1;
   }
-  p.ksteps_total = ceil_div(p.K, 64);
+  p.ksteps_total = p.par_on ? (1 + p.par_h) * (1 + p.par_w) * p.cpt : ceil_div(p.K, 64);
   {
     const unsigned long long ab = p.mode == 1 ? 2ull * ((unsigned long long)ceil_div(p.M, p.Ho * p.Wo)) * p.H * p.W * p.C
                                               : 2ull * (unsigned long long)p.M * p.lda;

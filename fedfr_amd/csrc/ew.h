@@ -79,3 +79,8 @@ int ew_preprocess_u8(const unsigned char* src, const unsigned char* flip, float*
 int ew_bias_prelu_bwd(const bf16_t* dy, const bf16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
                       float* coef, float* dbias, float* dalpha, const bf16_t* add, bf16_t* dx, hipStream_t st);
 int ew_pad_input_nhwc(const float* src, bf16_t* dst, int B, int C, int HW, int Cpad, hipStream_t st);
+// all dgrad shadows of a network in one launch (one 64x64 transpose tile per workgroup, table passed by value)
+constexpr int kMaxShadowEntries = 112;     // 112 x 32 B: the by-value table stays under the 4 KiB kernel-argument limit
+struct ShadowEntry { unsigned long long src, dst; unsigned short cout64, cin64, rs, pad; unsigned first_blk; };   // offsets in elements
+struct ShadowTable { int n; int pad; ShadowEntry e[kMaxShadowEntries]; };
+int ew_weight_dgrad_shadow_multi(const float* params, bf16_t* shadow, ShadowTable& t, hipStream_t st);

@@ -649,6 +649,52 @@ __global__ __launch_bounds__(256) void weight_dgrad_shadow_kernel(const float* _
     *reinterpret_cast<uint4*>(dst + ((size_t)(ci0 + ci) * RS + tapf) * Cout + co0 + co8) = pack8(f);
   }
 }
+// the same transpose for every conv of a network: workgroup -> (layer, co tile, ci tile, tap) through the by-value table
+__global__ __launch_bounds__(256) void weight_dgrad_shadow_multi_kernel(const float* __restrict__ params, bf16_t* __restrict__ shadow, ShadowTable tb) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = tb.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tb.e[mid].first_blk <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ShadowEntry e = tb.e[lo];
+  int b = (int)(blockIdx.x - e.first_blk);
+  const int cob = b % e.cout64; b /= e.cout64;
+  const int cib = b % e.cin64;
+  const int tap = b / e.cin64;
+  const int Cout = e.cout64 * 64, Cin = e.cin64 * 64, RS = e.rs;
+  const float* w = params + e.src;
+  bf16_t* dst = shadow + e.dst;
+  const int co0 = cob * 64, ci0 = cib * 64, t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 4) + 16 * i, col = (t & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(w + ((size_t)(co0 + row) * RS + tap) * Cin + ci0 + col);
+    tile[row][col] = v.x; tile[row][col + 1] = v.y; tile[row][col + 2] = v.z; tile[row][col + 3] = v.w;
+  }
+  __syncthreads();
+  const int tapf = RS - 1 - tap;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = (t >> 3) + 32 * i, co8 = (t & 7) * 8;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = tile[co8 + j][ci];
+    *reinterpret_cast<uint4*>(dst + ((size_t)(ci0 + ci) * RS + tapf) * Cout + co0 + co8) = pack8(f);
+  }
+}
+int ew_weight_dgrad_shadow_multi(const float* params, bf16_t* shadow, ShadowTable& t, hipStream_t st) {
+  FEDFR_REQUIRE(params && shadow && t.n > 0 && t.n <= kMaxShadowEntries, "weight_dgrad_shadow_multi: bad table");
+  unsigned blk = 0;
+  for (int i = 0; i < t.n; ++i) {
+    t.e[i].first_blk = blk;
+    blk += (unsigned)t.e[i].cout64 * t.e[i].cin64 * t.e[i].rs;
+  }
+  hipLaunchKernelGGL(weight_dgrad_shadow_multi_kernel, dim3(blk), dim3(256), 0, st, params, shadow, t);
+  FEDFR_LAUNCH_CHECK("weight_dgrad_shadow_multi");
+  return FEDFR_OK;
+}
+
 int ew_weight_dgrad_shadow(const float* w, bf16_t* dst, int Cout, int R, int S, int Cin, hipStream_t st) {
   FEDFR_REQUIRE(w && dst && (Cout & 63) == 0 && (Cin & 63) == 0 && R > 0 && S > 0, "weight_dgrad_shadow: need Cout,Cin %%64==0");
   hipLaunchKernelGGL(weight_dgrad_shadow_kernel, dim3(Cout / 64, Cin / 64, R * S), dim3(256), 0, st, w, dst, Cout, R * S, Cin);

@@ -273,11 +273,24 @@ static int apply(const Ctx& c, const bf16_t* x1, const BnD& b1, const float* alp
 int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st) {
   FEDFR_REQUIRE(n && params && shadow, "prepare_weights: null");
   if (fwd_shadow_too) FEDFR_TRY(ew_cast_f32_bf16(params, shadow, (size_t)n->trainable_count, st));
+  // every conv's dgrad-layout copy ([Cin][taps flipped][Cout] bf16) in ONE launch (was one small kernel per conv: 105 per step)
+  ShadowTable t{};
+  auto add = [&](const ConvD& cv) {
+    ShadowEntry& e = t.e[t.n++];
+    e.src = (unsigned long long)cv.w_off; e.dst = (unsigned long long)cv.wd_off;
+    e.cout64 = (unsigned short)(cv.Cout / 64); e.cin64 = (unsigned short)(cv.Cin / 64); e.rs = (unsigned short)(cv.R * cv.R);
+  };
   for (const auto& k : n->blocks) {
-    FEDFR_TRY(ew_weight_dgrad_shadow(params + k.conv1.w_off, shadow + k.conv1.wd_off, k.conv1.Cout, 3, 3, k.conv1.Cin, st));
-    FEDFR_TRY(ew_weight_dgrad_shadow(params + k.conv2.w_off, shadow + k.conv2.wd_off, k.conv2.Cout, 3, 3, k.conv2.Cin, st));
-    if (k.has_ds) FEDFR_TRY(ew_weight_dgrad_shadow(params + k.ds.w_off, shadow + k.ds.wd_off, k.ds.Cout, 1, 1, k.ds.Cin, st));
+    FEDFR_REQUIRE(k.conv1.Cout % 64 == 0 && k.conv1.Cin % 64 == 0 && k.conv2.Cout % 64 == 0 && k.conv2.Cin % 64 == 0,
+                  "prepare_weights: channels not a multiple of 64");
+    if (t.n + 3 > kMaxShadowEntries) {                  // deeper nets than iresnet100: one launch per table-full
+      FEDFR_TRY(ew_weight_dgrad_shadow_multi(params, shadow, t, st));
+      t.n = 0;
+    }
+    add(k.conv1); add(k.conv2);
+    if (k.has_ds) add(k.ds);
   }
+  if (t.n) FEDFR_TRY(ew_weight_dgrad_shadow_multi(params, shadow, t, st));
   return FEDFR_OK;
 }
 

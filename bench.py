@@ -109,6 +109,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the step's critical path (forward, dgrad -> BN-backward chain) runs on a HIGH-priority stream, the trainer's auxiliary
+    # weight-gradient stream keeps the default priority: workgroups of critical-path kernels are dispatched first when both
+    # streams have work (FEDFR_MAIN_PRIORITY=0 turns this off)
+    hi = None
+    if os.environ.get("FEDFR_MAIN_PRIORITY", "1") != "0":
+        lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        hi = torch.cuda.Stream(device=dev, priority=hi_p)
+        hi.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hi)
     for i in range(args.warmup):
         tr.step(imgs[i % nbuf], labs[i % nbuf])
     if use_dist:

@@ -20,6 +20,7 @@ extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_dgrad_parity;
+extern int g_fuse_bnapply;
 
 void fedfr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -62,6 +63,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "conv_halo")) {
     g_conv_halo = value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "fuse_bnapply")) {
+    g_fuse_bnapply = value ? 1 : 0;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "dgrad_parity")) {

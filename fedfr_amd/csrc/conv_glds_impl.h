@@ -54,7 +54,7 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false>   // BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false>   // XFORM: BN(+PReLU) of the input applied to the LDS image; BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
   constexpr int PT = R_ * W_, BN = BN_, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
@@ -161,13 +161,60 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) acc[ni][mi] = MFMA16(fb[ni], fa[mi], acc[ni][mi]);
   };
+  // XFORM: per-channel (scale, shift, PReLU slope) of the input's BatchNorm staged in LDS behind the weight ring; every wave
+  // transforms the image pieces IT fetched (its own counted vmcnt covers them) just before a barrier that publishes them, so
+  // the pass needs no extra synchronisation; zero-padding rows (out-of-range DMA) are skipped and stay zero.
+  float* sCoef = reinterpret_cast<float*>(smem + NABUF * A_BYTES + NB * B_BYTES);     // [3][C]
+  const bool has_talpha = XFORM && p.talpha != nullptr;
+  auto transform_piece = [&](int abuf, int cc, int j) {
+    float sc[8], sh[8], al[8];
+    const float* cf = sCoef + cc * 64 + pch * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sc[q] = cf[q]; sh[q] = cf[p.C + q]; al[q] = cf[2 * p.C + q]; }
+    if (a_src[j] != OOB) {
+      uint4* q4 = reinterpret_cast<uint4*>(sA + abuf * A_BYTES + (j * NW + wave) * 1024 + lane * 16);
+      float f[8];
+      unpack8(*q4, f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float v = f[q] * sc[q] + sh[q];
+        if (has_talpha) v = v > 0.f ? v : al[q] * v;
+        f[q] = v;
+      }
+      *q4 = pack8(f);
+    }
+  };
+  auto transform = [&](int abuf, int cc) {
+#pragma unroll
+    for (int j = 0; j < AP; ++j) transform_piece(abuf, cc, j);
+  };
+  // the transformed centre rows of chunk cc (= the normalised activation, the wgrad operand) go back to global once per image tile
+  auto writeback = [&](int abuf, int cc) {
+    if (bn == 0 && p.aout)
+      for (int idx = tid; idx < PT * 8; idx += NT) {
+        const int t = idx >> 3, c8 = idx & 7;
+        const int y = t / W_, x = t - y * W_;
+        const int r = (y + 1) * PWL + x + 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(sA + abuf * A_BYTES + r * 128 + ((c8 ^ (r & 7)) << 4));
+        *reinterpret_cast<uint4*>(p.aout + (size_t)(m0 + t) * p.C + cc * 64 + c8 * 8) = v;
+      }
+  };
   // prologue: image of chunk 0, weight tiles of taps 0..2; wait for the image and tap 0, fetch tap 0's first fragments
   issue_a(0, 0, true);
   issue_b(0, 0, 0, true);
   issue_b(1, 0, 1, true);
   issue_b(2, 0, 2, true);
   bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
+  if constexpr (XFORM) {                               // coefficient staging overlaps the first DMA round trip
+    for (int i = tid; i < p.C; i += NT) {
+      sCoef[i] = p.tsc[i];
+      sCoef[p.C + i] = p.tsh[i];
+      sCoef[2 * p.C + i] = p.talpha ? p.talpha[i] : 1.f;
+    }
+    __syncthreads();
+  }
   glds_wait_vmcnt<2 * BP>();
+  if constexpr (XFORM) transform(0, 0);
   __builtin_amdgcn_s_barrier();
   read_frags(f0a, f0b, 0, 0, sB, 0);
   GLDS_STAMP(1);
@@ -187,6 +234,16 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         const int tapn = tap == 8 ? 0 : tap + 1;
         const int aoffn = (ONECHUNK ? 0 : (tap == 8 ? (h ^ 1) : h)) * A_BYTES + (tapn / 3) * PWL * 128;
         const unsigned char* cB = sB + bbuf * B_BYTES;
+        if constexpr (XFORM) {
+          if (tap == 1) {                                    // this chunk's transformed image is visible since the last barrier
+            writeback(ONECHUNK ? 0 : h, cc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (!ONECHUNK && tap == 8 && more_c) {             // next chunk's image landed (taps >= 3 retired it): normalise own pieces.
+            transform(h ^ 1, cc + 1);                        // (one piece per tap "under" the MFMAs measured slower: hipcc serialises it)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         // ---- first half: k-step 0 MFMAs, with the fragment reads of k-step 1 threaded between them
         if (!(GLDS_ABLATE & 4)) read_frags(f1a, f1b, aoff, tap % 3, cB, 1);
         GLDS_PRIO(1);
@@ -365,12 +422,13 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false>
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
   FEDFR_REQUIRE(p.N % BN_ == 0 && (ONECHUNK ? p.C == 64 : p.C % 128 == 0) && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
                 "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
   FEDFR_REQUIRE(FUSED == (p.bpart != nullptr), "conv3x3_glds: fused / plain variant mismatch");
+  FEDFR_REQUIRE(XFORM == (p.tsc != nullptr) && (!XFORM || (p.tsh && p.C <= 256)), "conv3x3_glds: input-transform variant mismatch");
   if (FUSED) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
@@ -378,15 +436,15 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   }
   p.nbn = p.N / BN_;
   const int ntile = p.M / PT;
-  constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128;
+  constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128 + (XFORM ? 3 * 256 * 4 : 0);
   static_assert(lds >= (size_t)PT * (BN_ * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15), 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

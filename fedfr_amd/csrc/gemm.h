@@ -33,6 +33,11 @@ struct GemmNT {
   const float *bmean, *brstd, *bgamma, *bbeta, *balpha;
   float* bpart;
   int* bwd_fused;
+  // optional INPUT transform of the LDS-DMA conv kernel (forward of a conv whose input is BatchNorm(+PReLU) of a stored tensor): the
+  // kernel reads the raw tensor, applies y = x * tsc[c] + tsh[c] (then PReLU with talpha[c] if given) to its LDS image, so the
+  // normalised activation needs no separate bn_apply pass; aout (optional) receives that activation (the wgrad operand).
+  const float *tsc, *tsh, *talpha;
+  bf16_t* aout;
   // stride-2 dgrad by output-parity class (gemm.hip: nt_launch_parity): this launch computes the output pixels (2 h2 + par_h, 2 w2 + par_w)
   // of a [img][outH][outW] map with only the filter taps that reach a real (non-inserted-zero) input: 1, 2, 2 or 4 of the 9
   int par_on, par_h, par_w, outH, outW;
@@ -56,6 +61,7 @@ struct GemmTN {
 
 // rows of partial stats the NT kernel writes for a given M (needed to size / finalize)
 int gemm_nt_stat_rows(int M, int N);
+bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride);
 // number of splits / workspace helpers
 int gemm_nt_pick_splits(int M, int N, int K);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st);

@@ -357,6 +357,14 @@ int gemm_nt_stat_rows(int M, int N) {
 
 int g_dgrad_parity = 1;   // option "dgrad_parity": stride-2 3x3 dgrad as 4 output-parity classes (9/4 instead of 9 taps per output pixel)
 
+// shapes whose forward conv can take its input's BatchNorm(+PReLU) as an LDS-image transform (conv_glds_x.hip)
+bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride) {
+  if (g_conv_halo < 4 || ksize != 3 || stride != 1 || M % (W * W) != 0 || C > 256) return false;
+  if (W == 14 || W == 28) return N % 128 == 0 && C % 128 == 0;
+  if (W == 56) return C == 64 && (N == 64 || N == 128);
+  return false;
+}
+
 static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
   if (g_dgrad_parity && p.mode == 1 && p.up == 2 && p.S == 3 && p.pad == 1 && p.stride == 1 && p.Cb && !p.stats && splits == 1 &&
@@ -396,6 +404,11 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
     FEDFR_REQUIRE(ab < (1ull << 32) - 64 && bb < (1ull << 32) - 64, "gemm_nt: operand larger than 4 GiB (32-bit buffer offsets)");
     p.a_bytes = (unsigned)ab;
     p.b_bytes = (unsigned)bb;
+  }
+  if (p.tsc) {
+    FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.H == p.W && p.H == p.Ho && p.Cb && splits == 1 && !p.bpart &&
+                  gemm_nt_conv_xform_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: input transform is not available for this convolution");
+    return launch_conv_glds_x(p, st);
   }
   const int BM = nt_bm(p.M, p.N);
   if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&

@@ -214,6 +214,30 @@ static int conv_fwd(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* out
   p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = stats ? c.part() : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
+// conv(act(bn(raw))): where the LDS-DMA kernel can normalise its input image itself the separate bn_apply pass disappears; the kernel
+// still leaves the normalised activation in `a` when training (the weight-gradient GEMM reads it), not in eval mode.
+int g_fuse_bnapply = 0;   // option "fuse_bnapply": BN(+PReLU) of a conv's input applied inside the LDS-DMA conv kernel (no bn_apply pass).  Off: measured
+                          // same box, it removes 98 bn_apply launches (-1.1 ms) but the un/re-packing VALU pass on the MFMA-bound SIMDs costs the
+                          // forward convs +0.7 ms and the activation still has to be written for wgrad: 20.39 ms/step without vs 20.51 with
+                          // (eval-mode forward, where nothing is written back: 5.87 -> 5.72 ms at batch 128).
+static int apply(const Ctx& c, const bf16_t* x1, const BnD& b1, const float* alpha, const bf16_t* x2, const BnD* b2, bf16_t* y, int M,
+                 bool stats, int nchw_hw);
+static int conv_fwd_bn(const Ctx& c, const ConvD& cv, const bf16_t* raw, const BnD& bn, const float* alpha, bf16_t* a, bf16_t* out,
+                       bool tr) {
+  const int M = c.n->B * cv.Hout * cv.Hout;
+  if (!g_fuse_bnapply || !gemm_nt_conv_xform_ok(cv.Hin, cv.Cin, cv.Cout, M, cv.R, cv.stride)) {
+    FEDFR_TRY(apply(c, raw, bn, alpha, nullptr, nullptr, a, c.n->B * cv.Hin * cv.Hin, false, 0));
+    return conv_fwd(c, cv, a, out, tr);
+  }
+  GemmNT p{};
+  p.A = raw; p.B = c.shadow + cv.w_off;
+  p.M = M; p.N = cv.Cout; p.K = cv.R * cv.R * cv.Cin;
+  p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = cv.R;
+  p.stride = cv.stride; p.pad = 1; p.up = 1;
+  p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = tr ? c.part() : nullptr;
+  p.tsc = c.save(bn, 0); p.tsh = c.save(bn, 1); p.talpha = alpha; p.aout = tr ? a : nullptr;
+  return gemm_nt_launch(p, 1, c.st);
+}
 int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the 3x3 dgrad epilogue (LDS-DMA kernel: x tile fetched by DMA after the
                         // K loop; halo2 kernel otherwise).  Off by default — measured twice, same box: 21.48 ms/step separate vs 21.95 fused
                         // (LDS-DMA kernel, +11 us of serial epilogue per dgrad vs a 7-12 us ew_bn_bwd_reduce that overlaps the aux stream).
@@ -311,13 +335,10 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
     // bn1(x)
     FEDFR_TRY(bn_coeffs(c, k.bn1, Pprev, (double)Mi, tr));
-    FEDFR_TRY(apply(c, A + k.x_off, k.bn1, nullptr, nullptr, nullptr, A + k.a1_off, Mi, false));
-    // conv1 -> bn2 -> prelu
-    FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, tr));
+    // a1 = bn1(x) -> conv1 -> bn2 -> a2 = prelu(bn2(c1)) -> conv2(stride) -> bn3
+    FEDFR_TRY(conv_fwd_bn(c, k.conv1, A + k.x_off, k.bn1, nullptr, A + k.a1_off, A + k.c1_off, tr));
     FEDFR_TRY(bn_coeffs(c, k.bn2, gemm_nt_stat_rows(Mi, k.Cout), (double)Mi, tr));
-    FEDFR_TRY(apply(c, A + k.c1_off, k.bn2, params + k.alpha_off, nullptr, nullptr, A + k.a2_off, Mi, false));
-    // conv2(stride) -> bn3
-    FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, tr));
+    FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, tr));
     FEDFR_TRY(bn_coeffs(c, k.bn3, gemm_nt_stat_rows(Mo, k.Cout), (double)Mo, tr));
     if (k.has_ds) {
       FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, tr));

@@ -411,6 +411,33 @@ def test_roc_vs_reference():
     assert t == int(g["target_size"]) and torch.equal(l.cpu(), T(g["labels"]))     # already target-first: a stable partition keeps it
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_bn_apply_in_conv_matches_separate_pass(training):
+    """option fuse_bnapply: BN(+PReLU) of a conv's input applied to the LDS image inside the LDS-DMA conv kernel (and, in training,
+    written back as the wgrad operand) gives the same embeddings / gradients as the separate bn_apply pass: same fp32 ops on the
+    same bf16 inputs, so the results are bit-identical."""
+    outs = []
+    for opt in (0, 1):
+        _C.call("fedfr_set_option", b"fuse_bnapply", opt)
+        try:
+            m, sd, _ = make_model("iresnet18", tag=3.0)
+            x = R.closed_form_images(128).to(DEV)
+            if training:
+                m.train()
+                f = m(x)
+                (f * R.closed_form((128, 512), 0.37, 0.9, 1.0).to(DEV)).sum().backward()
+                outs.append((f.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+            else:
+                m.eval()
+                with torch.no_grad():
+                    outs.append((m(x).clone(), {}))
+        finally:
+            _C.call("fedfr_set_option", b"fuse_bnapply", 0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
 def test_public_data_server_round():
     """One FedFR round with public data (server.py:265-338, add_pretrained_data + return_all): both clients train the
     [local | public] CosFace head + BCE branch, the server averages backbones (FedPavg) and public class centres (FedAvg_on_FC)."""

@@ -413,6 +413,7 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
   const int BM = nt_bm(p.M, p.N);
   if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
+    if (g_conv_halo >= 4 && p.H == 112 && p.W == 112 && !p.bpart && p.M % (112 * 112) == 0 && p.C == 64 && p.N == 64) return launch_conv_glds_w112(p, st);
     if (g_conv_halo >= 4 && p.H == 56 && p.W == 56 && !p.bpart && p.M % (56 * 56) == 0) {
       if (p.C == 64 && p.N == 64) return launch_conv_glds_w56(p, st);
       if (p.C == 64 && p.N == 128) return launch_conv_glds_w56_c64_n128(p, st);

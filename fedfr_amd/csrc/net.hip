@@ -389,7 +389,7 @@ struct Fork {
   hipEvent_t ev() {
     if (next == n->events.size()) {
       hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ok = false; return nullptr; }
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) { ok = false; return nullptr; }
       n->events.push_back(e);
     }
     return n->events[next++];
@@ -457,19 +457,21 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     fk.wait(st, wdone[par]);                         // the weight GEMMs two blocks ago were the last readers of dc2/dc1/dd[par]
     // out = bn3(c2) + identity
     FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0));
-    fk.order(st, wst);
-    FEDFR_TRY(conv_wgrad(c, k.conv2, A + k.a2_off, dc2, wst));
     int f2 = 0, f1 = 0;
     FEDFR_TRY(conv_dgrad(c, k.conv2, dc2, da2, &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
     // a2 = prelu(bn2(c1))
     FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, da2, A + k.c1_off, Mi, nullptr, nullptr, 0, dc1, k.alpha_off, f2));
-    fk.order(st, wst);
-    FEDFR_TRY(conv_wgrad(c, k.conv1, A + k.a1_off, dc1, wst));
     // identity path first (its BN reduction uses the shared partial buffer), then conv1's dgrad whose epilogue may
     // leave bn1's partial sums there for the bn_bwd that follows immediately
     if (k.has_ds) {
       FEDFR_TRY(bn_bwd(c, k.bnds, nullptr, g, A + k.d_off, Mo, nullptr, nullptr, 0, dd, 0));
-      fk.order(st, wst);
+    }
+    // ONE fork per block: every event record costs the main stream a ~8 us bubble (kernel trace), so the block's two or three
+    // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
+    fk.order(st, wst);
+    FEDFR_TRY(conv_wgrad(c, k.conv2, A + k.a2_off, dc2, wst));
+    FEDFR_TRY(conv_wgrad(c, k.conv1, A + k.a1_off, dc1, wst));
+    if (k.has_ds) {
       FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, dd, wst));
       FEDFR_TRY(conv_dgrad(c, k.ds, dd, dxd));
     }

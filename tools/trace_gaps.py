@@ -29,3 +29,18 @@ for s, e, n in ev:
         agg[n.split("(")[0][:60]][0] += e - s; agg[n.split("(")[0][:60]][1] += 1
 for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]:
     print("  %-62s %4d launches %7.3f ms" % (n, c, t / 1e6))
+
+# ---- largest idle gaps of the last step: which kernel ended before / started after
+a, b = steps[-1]
+ks = sorted([e for e in ev if e[0] >= a and e[1] <= b + 1])
+gaps, cur_e, last = [], None, None
+for s_, e_, n_ in ks:
+    if cur_e is not None and s_ > cur_e:
+        gaps.append((s_ - cur_e, last, n_.split("(")[0][:40], (cur_e - a) / 1e6))
+    if cur_e is None or e_ > cur_e:
+        cur_e, last = e_, n_.split("(")[0][:40]
+gaps.sort(reverse=True)
+print("idle gaps > 5 us: %d, total %.3f ms; gaps <= 5 us: %d, total %.3f ms" % (sum(1 for g in gaps if g[0] > 5000), sum(g[0] for g in gaps if g[0] > 5000) / 1e6,
+                                                                              sum(1 for g in gaps if g[0] <= 5000), sum(g[0] for g in gaps if g[0] <= 5000) / 1e6))
+for g in gaps[:12]:
+    print("  %6.1f us at t=%6.2f ms  after %-40s before %s" % (g[0] / 1e3, g[3], g[1], g[2]))

@@ -21,6 +21,7 @@ extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_dgrad_parity;
 extern int g_fuse_bnapply;
+extern int g_fuse_bnred_next;
 
 void fedfr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -63,6 +64,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "conv_halo")) {
     g_conv_halo = value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "fuse_bnred_next")) {
+    g_fuse_bnred_next = value ? 1 : 0;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "fuse_bnapply")) {

@@ -38,7 +38,13 @@ struct BnBwd {
   const bf16_t* add_up;   // optional compact [img][H/2][W/2][C] addend placed at even (h, w)
   int H, W;               // needed for add_up
   bf16_t* dx;
+  // optional: while dx is produced, also reduce it as the dy of the NEXT BatchNorm backward (the one that consumes dx; no PReLU):
+  // partial sums (sum dx, sum dx * xhat_next, 0) per workgroup -> npart [ew_bn_bwd_apply_grid][3][C], saving that BN's reduce pass
+  const bf16_t* nx;       // next BN's input tensor, same [M][C] shape
+  const float *nmean, *nrstd;
+  float* npart;
 };
+int ew_bn_bwd_apply_grid(int M, int C);
 int ew_bn_bwd_grid(int M, int C);
 int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st);
 int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* rstd,

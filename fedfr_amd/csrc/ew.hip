@@ -405,8 +405,15 @@ struct BnBwdDiv {
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab) {
   const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
   const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-  if (rl >= rpp) return;
+  const bool active = rl < rpp;
+  if (!active && !p.nx) return;
+  extern __shared__ float red[];                    // [rpp][2 C] when the next BN's reduction rides along
   const int c0 = cl * 8;
+  float nmean[8], nrstd[8], n1[8], n2[8];
+  load8f(p.nx ? p.nmean : nullptr, c0, nmean, 0.f);
+  load8f(p.nx ? p.nrstd : nullptr, c0, nrstd, 1.f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) n1[j] = n2[j] = 0.f;
   float mean[8], rstd[8], ga[8], be[8], al[8], ca[8], cb[8], cc[8];
   load8f(p.mean, c0, mean, 0.f);
   load8f(p.rstd, c0, rstd, 1.f);
@@ -451,9 +458,20 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
         for (int j = 0; j < 8; ++j) o[j] += a[j];
       }
     }
-    *reinterpret_cast<uint4*>(p.dx + off) = pack8(o);
+    const uint4 ov = pack8(o);
+    *reinterpret_cast<uint4*>(p.dx + off) = ov;
+    if (p.nx) {                                      // the next BN sees the bf16-rounded dx, exactly as its own reduce pass would
+      float dn[8], xn[8];
+      unpack8(ov, dn);
+      unpack8(*reinterpret_cast<const uint4*>(p.nx + off), xn);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        n1[j] += dn[j];
+        n2[j] += dn[j] * ((xn[j] - nmean[j]) * nrstd[j]);
+      }
+    }
   };
-  int m = mbeg + rl;
+  int m = active ? mbeg + rl : mend;
   for (; m + (EW_UNROLL - 1) * rpp < mend; m += EW_UNROLL * rpp) {      // loads of EW_UNROLL rows first (see bn_bwd_reduce)
     uint4 vd[EW_UNROLL], vx[EW_UNROLL];
 #pragma unroll
@@ -469,7 +487,26 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
     const size_t off = (size_t)m * p.C + c0;
     one(m, *reinterpret_cast<const uint4*>(p.dy + off), *reinterpret_cast<const uint4*>(p.x + off));
   }
+  if (p.nx) {
+    const int W2 = 2 * p.C;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[rl * W2 + c0 + j] = n1[j];
+        red[rl * W2 + p.C + c0 + j] = n2[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < W2; i += EW_THREADS) {
+      float t = 0.f;
+      for (int r = 0; r < rpp; ++r) t += red[r * W2 + i];
+      p.npart[(size_t)blockIdx.x * 3 * p.C + i] = t;
+    }
+    for (int i = threadIdx.x; i < p.C; i += EW_THREADS) p.npart[(size_t)blockIdx.x * 3 * p.C + W2 + i] = 0.f;
+  }
 }
+
+int ew_bn_bwd_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 2048)); }
 
 int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_apply"));
@@ -482,8 +519,10 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
     dv.dHW = make_fastdiv((unsigned)(p.H * p.W));
     dv.dW = make_fastdiv((unsigned)p.W);
   }
+  if (p.nx) FEDFR_REQUIRE(p.nmean && p.nrstd && p.npart, "bn_bwd_apply: next-BN reduction needs mean / rstd / partials");
   const int slab = slab_rows(p.M, p.C, 2048);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(p.M, slab)), dim3(EW_THREADS), 0, st, p, dv, slab);
+  const size_t lds = p.nx ? (size_t)rows_per_pass(p.C) * 2 * p.C * sizeof(float) : 0;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(p.M, slab)), dim3(EW_THREADS), lds, st, p, dv, slab);
   FEDFR_LAUNCH_CHECK("bn_bwd_apply");
   return FEDFR_OK;
 }

@@ -151,6 +151,7 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
   auto upd_part = [&](long long M, int C) {
     part = std::max(part, (long long)ew_bn_apply_grid((int)M, C) * 2 * C);
     part = std::max(part, (long long)ew_bn_bwd_grid((int)M, C) * 3 * C);
+    part = std::max(part, (long long)ew_bn_bwd_apply_grid((int)M, C) * 3 * C);
   };
   auto upd_conv = [&](const ConvD& c) {
     const long long Mo = Bq * c.Hout * c.Hout;
@@ -368,9 +369,17 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   return FEDFR_OK;
 }
 
+int g_fuse_bnred_next = 1;   // option "fuse_bnred_next": a BN-backward apply pass also reduces its output for the BN that consumes it
 static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
-                  const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, int fused_rows = 0) {
+                  const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, int fused_rows = 0, const BnD* next_bn = nullptr,
+                  const bf16_t* next_x = nullptr, int* next_rows = nullptr) {
   BnBwd p{};
+  if (next_bn && next_x && next_rows && g_fuse_bnred_next && next_bn->C == b.C) {
+    // dx is the dy of next_bn's backward: its (sum, sum * xhat) partials ride along in this apply pass (one tensor read instead of
+    // a separate two-tensor reduce kernel); they land in the shared partial buffer, which this BN's finalize has finished reading
+    p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part();
+    *next_rows = ew_bn_bwd_apply_grid(M, b.C);
+  }
   p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.beta = c.beta(b); p.alpha = alpha;
   p.M = M; p.C = b.C; p.partials = c.part(); p.coef = c.coef(); p.add = add; p.add_up = add_up; p.H = H; p.W = H; p.dx = dx;
   if (fused_rows <= 0) FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));      // else: the producing dgrad kernel already wrote the partials
@@ -444,7 +453,8 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   const BlockD& last = n->blocks.back();
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
   FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dxfc, c.g(0), B, n->final_C, hw, st));
-  FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0));
+  int pend_rows = 0;                               // partial rows of the next bn3 already reduced by the apply pass that produced its dy
+  FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0, 0, &last.bn3, A + last.c2_off, &pend_rows));
   int cur = 1;
   hipEvent_t wdone[2] = {nullptr, nullptr};        // "all weight GEMMs of the block with this parity have finished"
   for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
@@ -456,7 +466,8 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     bf16_t *dc2 = c.tw(0, par), *da2 = c.t(1), *dc1 = c.tw(1, par), *da1 = c.t(3), *dd = c.tw(2, par), *dxd = c.t(5);
     fk.wait(st, wdone[par]);                         // the weight GEMMs two blocks ago were the last readers of dc2/dc1/dd[par]
     // out = bn3(c2) + identity
-    FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0));
+    FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0, pend_rows));
+    pend_rows = 0;
     int f2 = 0, f1 = 0;
     FEDFR_TRY(conv_dgrad(c, k.conv2, dc2, da2, &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
     // a2 = prelu(bn2(c1))
@@ -478,10 +489,13 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     wdone[par] = fk.mark(wst);
     FEDFR_TRY(conv_dgrad(c, k.conv1, dc1, da1, &k.bn1, A + k.x_off, nullptr, &f1));
     // a1 = bn1(x)
+    const BlockD* prev = bi > 0 ? &n->blocks[bi - 1] : nullptr;      // its bn3 consumes gin next
     if (k.has_ds) {
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, nullptr, dxd, k.Hin, gin, 0, f1));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, nullptr, dxd, k.Hin, gin, 0, f1, prev ? &prev->bn3 : nullptr,
+                       prev ? A + prev->c2_off : nullptr, &pend_rows));
     } else {
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, g, nullptr, 0, gin, 0, f1));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, g, nullptr, 0, gin, 0, f1, prev ? &prev->bn3 : nullptr,
+                       prev ? A + prev->c2_off : nullptr, &pend_rows));
     }
     cur ^= 1;
   }

@@ -438,6 +438,24 @@ def test_fused_bn_apply_in_conv_matches_separate_pass(training):
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 
 
+def test_bn_backward_next_reduction_fusion_equivalence():
+    """option fuse_bnred_next (a BN-backward apply pass also reduces its output for the BatchNorm that consumes it): same gradients as
+    the separate reduce kernel up to fp32 summation order."""
+    outs = []
+    for opt in (0, 1):
+        _C.call("fedfr_set_option", b"fuse_bnred_next", opt)
+        try:
+            m, sd, _ = make_model("iresnet18", tag=3.0)
+            m.train()
+            f = m(R.closed_form_images(64).to(DEV))
+            (f * R.closed_form((64, 512), 0.37, 0.9, 1.0).to(DEV)).sum().backward()
+            outs.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            _C.call("fedfr_set_option", b"fuse_bnred_next", 1)
+    worst = max(rel(outs[1][k], outs[0][k]) for k in outs[0] if float(outs[0][k].norm()) > 1e-6 * max(float(v.norm()) for v in outs[0].values()))
+    assert worst < 2e-2, worst       # bf16 activations downstream of a differently-ordered fp32 sum: last-bit flips propagate
+
+
 def test_public_data_server_round():
     """One FedFR round with public data (server.py:265-338, add_pretrained_data + return_all): both clients train the
     [local | public] CosFace head + BCE branch, the server averages backbones (FedPavg) and public class centres (FedAvg_on_FC)."""

@@ -96,5 +96,11 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
   return (unsigned)(((unsigned long long)n * f.magic) >> 40);
 }
 
+// bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = id & 7, loc = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+}
+
 __host__ __device__ static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

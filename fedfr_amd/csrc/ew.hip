@@ -19,6 +19,19 @@ __device__ __forceinline__ uint4 ew_ld16(const bf16_t* p) {
   return *reinterpret_cast<const uint4*>(p);
 #endif
 }
+// EW_XCD=1: block -> row-slab mapping through xcd_remap, i.e. XCD x streams rows [x M/8, (x+1) M/8) = the images whose conv tiles
+// ran on XCD x (the conv kernels use the same remap), so a tensor is read from the L2 its producer left it in and the next conv finds
+// its input image in its own L2.  Partial rows stay indexed by the logical slab id: results are bit-identical.
+#ifndef EW_XCD
+#define EW_XCD 1
+#endif
+__device__ __forceinline__ int ew_block_id() {
+#if EW_XCD
+  return xcd_remap((int)blockIdx.x, (int)gridDim.x);
+#else
+  return (int)blockIdx.x;
+#endif
+}
 #ifndef EW_UNROLL
 #define EW_UNROLL 4       // rows whose loads are issued together in the streaming BN kernels
 #endif
@@ -117,6 +130,86 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   }
 }
 
+// ---- finalize, 8 channels per block ----------------------------------------------------------------
+// The 32-channel kernels above pull P x 2C (or 3C) floats through C/32 = 2..16 CUs: 150-300 KB per CU at one CU's ~0.1 TB/s, i.e. they
+// are bound by per-CU bandwidth, not by latency.  Here a block owns 8 channels (C/8 = 8..64 blocks), thread (row-group, half) loads one
+// float4 per statistic and row with every load of a trip issued before the first add, sums in fp64, and the 128 row-groups meet in LDS.
+#ifndef EW_FIN8
+#define EW_FIN8 1
+#endif
+#define FIN_RG 128
+template <int NS>
+__device__ __forceinline__ void fin8_accumulate(const float* __restrict__ part, int P, int C, int c0, int ns_live, double (*tot)[8]) {
+  __shared__ double red[NS * 8][FIN_RG + 1];
+  const int half = threadIdx.x & 1, rg = threadIdx.x >> 1;
+  const int W = NS * C;
+  double acc[NS][4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[s][j] = 0.0;
+  const float* base = part + c0 + half * 4;
+  for (int r = rg; r < P; r += 2 * FIN_RG) {
+    const int r1 = r + FIN_RG;
+    const bool ok1 = r1 < P;
+    float4 v0[NS], v1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bool live = s < ns_live;
+      v0[s] = live ? *reinterpret_cast<const float4*>(base + (size_t)r * W + s * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v1[s] = (live && ok1) ? *reinterpret_cast<const float4*>(base + (size_t)r1 * W + s * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      acc[s][0] += (double)v0[s].x + (double)v1[s].x; acc[s][1] += (double)v0[s].y + (double)v1[s].y;
+      acc[s][2] += (double)v0[s].z + (double)v1[s].z; acc[s][3] += (double)v0[s].w + (double)v1[s].w;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[s * 8 + half * 4 + j][rg] = acc[s][j];
+  __syncthreads();
+  // value v = (stat, channel) summed by 8 consecutive lanes: 16 entries each, then 3 xor steps inside the lane group
+  const int v = threadIdx.x >> 3, k = threadIdx.x & 7;
+  double t = 0.0;
+  if (v < NS * 8) {
+#pragma unroll
+    for (int i = 0; i < FIN_RG / 8; ++i) t += red[v][i * 8 + k];
+  }
+  t += __shfl_xor(t, 1, 64);
+  t += __shfl_xor(t, 2, 64);
+  t += __shfl_xor(t, 4, 64);
+  if (v < NS * 8 && k == 0) tot[v >> 3][v & 7] = t;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_finalize8_kernel(const float* __restrict__ part, int P, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps,
+                                                          float* scale, float* shift, float* save_mean, float* save_rstd) {
+  __shared__ double tot[2][8];
+  const int c0 = blockIdx.x * 8;
+  fin8_accumulate<2>(part, P, C, c0, 2, tot);
+  if (threadIdx.x < 8) {
+    const int c = c0 + threadIdx.x;
+    const double mean = tot[0][threadIdx.x] / count;
+    double var = tot[1][threadIdx.x] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = (float)((double)g * rstd);
+    shift[c] = (float)((double)b - mean * (double)g * rstd);
+    save_mean[c] = (float)mean;
+    save_rstd[c] = (float)rstd;
+    if (running_mean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  }
+}
+
 int ew_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* save_mean, float* save_rstd, float* tmp, hipStream_t st) {
@@ -130,8 +223,12 @@ int ew_bn_finalize(const float* partials, int P, int C, double count, const floa
     src = tmp;
     P = S;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, src, P, C, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
+  if (EW_FIN8 && (C & 7) == 0)
+    hipLaunchKernelGGL(bn_finalize8_kernel, dim3(C / 8), dim3(256), 0, st, src, P, C, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, src, P, C, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
   FEDFR_LAUNCH_CHECK("bn_finalize");
   return FEDFR_OK;
 }
@@ -182,7 +279,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int sla
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-  const int mbeg = blockIdx.x * slab;
+  const int bid = ew_block_id();
+  const int mbeg = bid * slab;
   const int mend = min(p.M, mbeg + slab);
   auto one = [&](int m, const uint4& v1, const uint4& v2) {
     const size_t off = (size_t)m * p.C + c0;
@@ -250,7 +348,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int sla
     for (int i = threadIdx.x; i < W; i += EW_THREADS) {
       float t = 0.f;
       for (int r = 0; r < rpp; ++r) t += red[r * W + i];
-      p.stats[(size_t)blockIdx.x * W + i] = t;
+      p.stats[(size_t)bid * W + i] = t;
     }
   }
 }
@@ -287,7 +385,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(BnBwd p, int 
   float s1[8], s2[8], s3[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
-  const int mbeg = blockIdx.x * slab, mend = min(p.M, mbeg + slab);
+  const int bid = ew_block_id();
+  const int mbeg = bid * slab, mend = min(p.M, mbeg + slab);
   auto accum = [&](const uint4& vd, const uint4& vx) {
     float dy[8], x[8];
     unpack8(vd, dy);
@@ -340,7 +439,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(BnBwd p, int 
   for (int i = threadIdx.x; i < W; i += EW_THREADS) {
     float t = 0.f;
     for (int r = 0; r < rpp; ++r) t += red[r * W + i];
-    p.partials[(size_t)blockIdx.x * W + i] = t;
+    p.partials[(size_t)bid * W + i] = t;
   }
 }
 
@@ -389,11 +488,34 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_finalize8_kernel(const float* __restrict__ part, int P, int C, double count,
+                                                              const float* gamma, const float* rstd, float* dgamma,
+                                                              float* dbeta, float* dalpha, float* coef) {
+  __shared__ double tot[3][8];
+  const int c0 = blockIdx.x * 8;
+  fin8_accumulate<3>(part, P, C, c0, dalpha ? 3 : 2, tot);      // the third statistic (sum dy z over z <= 0) only feeds dalpha
+  if (threadIdx.x < 8) {
+    const int c = c0 + threadIdx.x;
+    const double t1 = tot[0][threadIdx.x], t2 = tot[1][threadIdx.x];
+    if (dgamma) dgamma[c] = (float)t2;
+    if (dbeta) dbeta[c] = (float)t1;
+    if (dalpha) dalpha[c] = (float)tot[2][threadIdx.x];
+    const float g = gamma ? gamma[c] : 1.f;
+    coef[c] = g * rstd[c];
+    coef[C + c] = (float)(t1 / count);
+    coef[2 * C + c] = (float)(t2 / count);
+  }
+}
+
 int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* rstd,
                        float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st) {
   FEDFR_REQUIRE(partials && P > 0 && C > 0 && rstd && coef, "bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partials, P, C, count, gamma, rstd,
-                     dgamma, dbeta, dalpha, coef);
+  if (EW_FIN8 && (C & 7) == 0)
+    hipLaunchKernelGGL(bn_bwd_finalize8_kernel, dim3(C / 8), dim3(256), 0, st, partials, P, C, count, gamma, rstd,
+                       dgamma, dbeta, dalpha, coef);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partials, P, C, count, gamma, rstd,
+                       dgamma, dbeta, dalpha, coef);
   FEDFR_LAUNCH_CHECK("bn_bwd_finalize");
   return FEDFR_OK;
 }
@@ -424,7 +546,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
   load8f(p.coef + p.C, c0, cb, 0.f);
   load8f(p.coef + 2 * p.C, c0, cc, 0.f);
   const bool has_alpha = p.alpha != nullptr;
-  const int mbeg = blockIdx.x * slab, mend = min(p.M, mbeg + slab);
+  const int bid = ew_block_id();
+  const int mbeg = bid * slab, mend = min(p.M, mbeg + slab);
   auto one = [&](int m, const uint4& vd, const uint4& vx) {
     const size_t off = (size_t)m * p.C + c0;
     float dy[8], x[8], o[8];
@@ -500,9 +623,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
     for (int i = threadIdx.x; i < W2; i += EW_THREADS) {
       float t = 0.f;
       for (int r = 0; r < rpp; ++r) t += red[r * W2 + i];
-      p.npart[(size_t)blockIdx.x * 3 * p.C + i] = t;
+      p.npart[(size_t)bid * 3 * p.C + i] = t;
     }
-    for (int i = threadIdx.x; i < p.C; i += EW_THREADS) p.npart[(size_t)blockIdx.x * 3 * p.C + W2 + i] = 0.f;
+    for (int i = threadIdx.x; i < p.C; i += EW_THREADS) p.npart[(size_t)bid * 3 * p.C + W2 + i] = 0.f;
   }
 }
 

@@ -31,11 +31,6 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// bijective XCD remap (blocks b and b+8 share an XCD): gives every XCD a contiguous range of logical ids
-__device__ __forceinline__ int xcd_remap(int id, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, x = id & 7, loc = id >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-}
 
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg); state lives in gemm.hip

@@ -319,7 +319,7 @@ int fedfr_bn_bwd(const uint16_t* dy, const uint16_t* x, const float* mean, const
   p.dy = BF(dy); p.x = BF(x); p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha; p.M = M; p.C = C;
   p.partials = partials; p.coef = coef; p.add = BF(add); p.add_up = BF(add_up); p.H = H; p.W = H; p.dx = BFM(dx);
   FEDFR_TRY(ew_bn_bwd_reduce(p, ST(stream)));
-  FEDFR_TRY(ew_bn_bwd_finalize(partials, ew_bn_bwd_grid(M, C), C, (double)M, gamma, rstd, dgamma, dbeta, dalpha, coef, ST(stream)));
+  FEDFR_TRY(ew_bn_bwd_finalize(partials, ew_bn_bwd_grid(M, C), C, (double)M, gamma, mean, rstd, dgamma, dbeta, dalpha, coef, ST(stream)));
   return ew_bn_bwd_apply(p, ST(stream));
 }
 

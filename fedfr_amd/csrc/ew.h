@@ -30,10 +30,11 @@ struct BnBwd {
   const bf16_t* x;        // BN input (conv output)
   const float* mean; const float* rstd; const float* gamma; const float* beta;
   const float* alpha;     // non-null => PReLU after the BN
+  const float *sc, *sh;   // optional: the forward pass's (scale, shift) of this BN — the PReLU mask is then sign(x sc + sh), the forward's expression
   int M, C;
   float* partials;        // [grid][3][C]
   // apply stage
-  const float* coef;      // [3][C]: a = gamma*rstd, b = mean(dz), c = mean(dz*xhat)
+  const float* coef;      // [3][C] from ew_bn_bwd_finalize: dx = a dz + A x + B
   const bf16_t* add;      // optional same-shape addend (identity-path gradient)
   const bf16_t* add_up;   // optional compact [img][H/2][W/2][C] addend placed at even (h, w)
   int H, W;               // needed for add_up
@@ -47,7 +48,7 @@ struct BnBwd {
 int ew_bn_bwd_apply_grid(int M, int C);
 int ew_bn_bwd_grid(int M, int C);
 int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st);
-int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* rstd,
+int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* mean, const float* rstd,
                        float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st);
 int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st);
 

@@ -32,6 +32,9 @@ __device__ __forceinline__ int ew_block_id() {
   return (int)blockIdx.x;
 #endif
 }
+#ifndef EW_UNROLL_ALPHA
+#define EW_UNROLL_ALPHA 3
+#endif
 #ifndef EW_UNROLL
 #define EW_UNROLL 4       // rows whose loads are issued together in the streaming BN kernels
 #endif
@@ -369,22 +372,83 @@ int ew_bn_apply(const BnApply& p, hipStream_t st) {
 // =====================================================================================================
 // backward BN (+PReLU)
 // =====================================================================================================
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(BnBwd p, int slab) {
-  extern __shared__ float red[];   // [rpp][3C]
+// These kernels run on the main stream while the weight-gradient GEMMs occupy every CU from the aux stream (2 waves per SIMD x 104
+// VGPRs, 128 KB LDS): what is left per CU is ~300 VGPRs per lane and 32 KB of LDS, so they are written to be small — one template
+// instance per (PReLU, next-BN reduction) case so that unused per-channel vectors cost no registers, the normalisation folded into
+// two per-channel coefficients, and the cross-row reduction done in registers (wave shuffles) before 4 rows per statistic meet in LDS.
+
+// sums v[NV][8] (8 channels x NV statistics per thread) over all rows of the workgroup and writes dst[s * C + c].
+// shfl (host-decided: C/8 is a power of two <= 64): rows of a wave meet by xor-shuffles, LDS holds [4 waves][NV C]; otherwise [rpp][NV C].
+template <int NV>
+__device__ __forceinline__ void ew_block_colsum(float (*v)[8], int C, int tpr, int rpp, int cl, int rl, bool active, bool shfl,
+                                                float* red, float* dst) {
+  const int W = NV * C, c0 = cl * 8;
+  int rows = rpp, row = rl;
+  if (shfl) {
+    for (int o = 32; o >= tpr; o >>= 1)
+#pragma unroll
+      for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[s][j] += __shfl_xor(v[s][j], o, 64);
+    rows = EW_THREADS / 64;
+    row = threadIdx.x >> 6;
+    active = (threadIdx.x & 63) < tpr;
+  }
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[row * W + s * C + c0 + j] = v[s][j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < W; i += EW_THREADS) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += red[r * W + i];
+    dst[i] = t;
+  }
+}
+static inline bool ew_shfl_ok(int C) { const int tpr = C >> 3; return tpr <= 64 && (tpr & (tpr - 1)) == 0; }
+static inline size_t ew_colsum_lds(int C, int nv) {
+  return (size_t)(ew_shfl_ok(C) ? EW_THREADS / 64 : rows_per_pass(C)) * nv * C * sizeof(float);
+}
+
+// PReLU pre-activation z = G x + H: the forward's own (scale, shift) when the caller has them (same expression as bn_apply, so the
+// mask is the forward's), else derived from gamma / rstd / mean / beta
+__device__ __forceinline__ void ew_load_gh(const BnBwd& p, int c0, const float* mean, const float* rstd, float* G, float* H) {
+  if (p.sc) {
+    load8f(p.sc, c0, G, 1.f);
+    load8f(p.sh, c0, H, 0.f);
+  } else {
+    float ga[8], be[8];
+    load8f(p.gamma, c0, ga, 1.f);
+    load8f(p.beta, c0, be, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      G[j] = ga[j] * rstd[j];
+      H[j] = be[j] - mean[j] * G[j];
+    }
+  }
+}
+
+template <bool ALPHA>
+__global__ __launch_bounds__(EW_THREADS, ALPHA ? 4 : 5) void bn_bwd_reduce_kernel(BnBwd p, int slab, int shfl) {
+  extern __shared__ float red[];
+  constexpr int UNR = ALPHA ? EW_UNROLL_ALPHA : EW_UNROLL;     // rows of loads in flight (the PReLU variant carries 24 more per-channel registers)
   const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
   const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   const bool active = rl < rpp;
   const int c0 = cl * 8;
-  float mean[8], rstd[8], ga[8], be[8], al[8];
+  float mean[8], G[8], H[8], al[8];
   load8f(p.mean, c0, mean, 0.f);
-  load8f(p.rstd, c0, rstd, 1.f);
-  load8f(p.gamma, c0, ga, 1.f);
-  load8f(p.beta, c0, be, 0.f);
-  load8f(p.alpha, c0, al, 1.f);
-  const bool has_alpha = p.alpha != nullptr;
-  float s1[8], s2[8], s3[8];
+  if (ALPHA) {
+    float rstd[8];
+    load8f(p.rstd, c0, rstd, 1.f);
+    ew_load_gh(p, c0, mean, rstd, G, H);
+    load8f(p.alpha, c0, al, 1.f);
+  }
+  float acc[3][8];                  // sum dz | sum dz (x - mean), scaled by rstd at the end = sum dz xhat | sum dy z over z <= 0
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
   const int bid = ew_block_id();
   const int mbeg = bid * slab, mend = min(p.M, mbeg + slab);
   auto accum = [&](const uint4& vd, const uint4& vx) {
@@ -393,54 +457,48 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(BnBwd p, int 
     unpack8(vx, x);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xh = (x[j] - mean[j]) * rstd[j];
       float dz = dy[j];
-      if (has_alpha) {
-        const float z = ga[j] * xh + be[j];
+      if (ALPHA) {
+        const float z = x[j] * G[j] + H[j];
         if (z <= 0.f) {
-          s3[j] += dy[j] * z;
+          acc[2][j] += dy[j] * z;
           dz = dy[j] * al[j];
         }
       }
-      s1[j] += dz;
-      s2[j] += dz * xh;
+      acc[0][j] += dz;
+      acc[1][j] += dz * (x[j] - mean[j]);
     }
   };
   if (active) {
-    // EW_UNROLL rows per trip with all their loads issued first: in the network dy / x come cold from HBM and one 16-B load
+    // UNR rows per trip with all their loads issued first: in the network dy / x come cold from HBM and one 16-B load
     // pair in flight per thread left the kernel latency-bound (2x its warm-cache time)
     int m = mbeg + rl;
-    for (; m + (EW_UNROLL - 1) * rpp < mend; m += EW_UNROLL * rpp) {
-      uint4 vd[EW_UNROLL], vx[EW_UNROLL];
+    for (; m + (UNR - 1) * rpp < mend; m += UNR * rpp) {
+      uint4 vd[UNR], vx[UNR];
 #pragma unroll
-      for (int u = 0; u < EW_UNROLL; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         const size_t off = (size_t)(m + u * rpp) * p.C + c0;
         vd[u] = *reinterpret_cast<const uint4*>(p.dy + off);
         vx[u] = *reinterpret_cast<const uint4*>(p.x + off);
       }
 #pragma unroll
-      for (int u = 0; u < EW_UNROLL; ++u) accum(vd[u], vx[u]);
+      for (int u = 0; u < UNR; ++u) {
+        accum(vd[u], vx[u]);
+        __builtin_amdgcn_sched_barrier(0);          // one row's temporaries at a time (the scheduler otherwise interleaves all four: +50 VGPRs)
+      }
     }
     for (; m < mend; m += rpp) {
       const size_t off = (size_t)m * p.C + c0;
       accum(*reinterpret_cast<const uint4*>(p.dy + off), *reinterpret_cast<const uint4*>(p.x + off));
     }
   }
-  const int W = 3 * p.C;
-  if (active) {
+  {
+    float rstd[8];
+    load8f(p.rstd, c0, rstd, 1.f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      red[rl * W + c0 + j] = s1[j];
-      red[rl * W + p.C + c0 + j] = s2[j];
-      red[rl * W + 2 * p.C + c0 + j] = s3[j];
-    }
+    for (int j = 0; j < 8; ++j) acc[1][j] *= rstd[j];
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < W; i += EW_THREADS) {
-    float t = 0.f;
-    for (int r = 0; r < rpp; ++r) t += red[r * W + i];
-    p.partials[(size_t)bid * W + i] = t;
-  }
+  ew_block_colsum<3>(acc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, p.partials + (size_t)bid * 3 * p.C);
 }
 
 int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 512)); }
@@ -448,48 +506,21 @@ int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 512)); }
 int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_reduce"));
   FEDFR_REQUIRE(p.dy && p.x && p.partials, "bn_bwd_reduce: null tensor");   // mean / rstd null: 0 / 1 (bias + PReLU backward)
+  FEDFR_REQUIRE(!p.sc == !p.sh, "bn_bwd_reduce: scale and shift come together");
   const int slab = slab_rows(p.M, p.C, 512);
   const int grid = ceil_div(p.M, slab);
-  const size_t lds = (size_t)rows_per_pass(p.C) * 3 * p.C * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+  const size_t lds = ew_colsum_lds(p.C, 3);
+  const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
+  if (p.alpha) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
   FEDFR_LAUNCH_CHECK("bn_bwd_reduce");
   return FEDFR_OK;
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int P, int C, double count,
-                                                              const float* gamma, const float* rstd, float* dgamma,
-                                                              float* dbeta, float* dalpha, float* coef) {
-  __shared__ double r1[32][33], r2[32][33], r3[32][33];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = min(blockIdx.x * 32 + cl, C - 1);
-  double a0 = 0.0, b0 = 0.0, d0 = 0.0, a1 = 0.0, b1 = 0.0, d1 = 0.0;
-  int row = rg;
-  for (; row + 32 < P; row += 64) {
-    const float* p0 = part + (size_t)row * 3 * C;
-    const float* p1 = part + (size_t)(row + 32) * 3 * C;
-    const float x0 = p0[c], y0 = p0[C + c], z0 = p0[2 * C + c], x1 = p1[c], y1 = p1[C + c], z1 = p1[2 * C + c];
-    a0 += (double)x0; b0 += (double)y0; d0 += (double)z0; a1 += (double)x1; b1 += (double)y1; d1 += (double)z1;
-  }
-  if (row < P) {
-    const float* p0 = part + (size_t)row * 3 * C;
-    a0 += (double)p0[c]; b0 += (double)p0[C + c]; d0 += (double)p0[2 * C + c];
-  }
-  const double t1 = rg_reduce(a0 + a1, r1, rg, cl);
-  const double t2 = rg_reduce(b0 + b1, r2, rg, cl);
-  const double t3 = rg_reduce(d0 + d1, r3, rg, cl);
-  if (rg == 0 && blockIdx.x * 32 + cl < C) {
-    if (dgamma) dgamma[c] = (float)t2;
-    if (dbeta) dbeta[c] = (float)t1;
-    if (dalpha) dalpha[c] = (float)t3;
-    const float g = gamma ? gamma[c] : 1.f;
-    coef[c] = g * rstd[c];
-    coef[C + c] = (float)(t1 / count);
-    coef[2 * C + c] = (float)(t2 / count);
-  }
-}
-
+// coef [3][C] for the apply pass, dx = a dz + A x + B  (== a (dz - mean(dz) - xhat mean(dz xhat)), xhat = (x - mean) rstd):
+//   a = gamma rstd, A = -a rstd mean(dz xhat), B = a (rstd mean mean(dz xhat) - mean(dz))
 __global__ __launch_bounds__(256) void bn_bwd_finalize8_kernel(const float* __restrict__ part, int P, int C, double count,
-                                                              const float* gamma, const float* rstd, float* dgamma,
+                                                              const float* gamma, const float* mean, const float* rstd, float* dgamma,
                                                               float* dbeta, float* dalpha, float* coef) {
   __shared__ double tot[3][8];
   const int c0 = blockIdx.x * 8;
@@ -500,22 +531,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize8_kernel(const float* __re
     if (dgamma) dgamma[c] = (float)t2;
     if (dbeta) dbeta[c] = (float)t1;
     if (dalpha) dalpha[c] = (float)tot[2][threadIdx.x];
-    const float g = gamma ? gamma[c] : 1.f;
-    coef[c] = g * rstd[c];
-    coef[C + c] = (float)(t1 / count);
-    coef[2 * C + c] = (float)(t2 / count);
+    const double g = gamma ? (double)gamma[c] : 1.0, r = rstd ? (double)rstd[c] : 1.0, mu = mean ? (double)mean[c] : 0.0;
+    const double a = (double)(float)(g * r), cb = t1 / count, cc = t2 / count;
+    coef[c] = (float)a;
+    coef[C + c] = (float)(-a * cc * r);
+    coef[2 * C + c] = (float)(a * (cc * r * mu - cb));
   }
 }
 
-int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* rstd,
+int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* mean, const float* rstd,
                        float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st) {
-  FEDFR_REQUIRE(partials && P > 0 && C > 0 && rstd && coef, "bn_bwd_finalize: bad args");
-  if (EW_FIN8 && (C & 7) == 0)
-    hipLaunchKernelGGL(bn_bwd_finalize8_kernel, dim3(C / 8), dim3(256), 0, st, partials, P, C, count, gamma, rstd,
-                       dgamma, dbeta, dalpha, coef);
-  else
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partials, P, C, count, gamma, rstd,
-                       dgamma, dbeta, dalpha, coef);
+  FEDFR_REQUIRE(partials && P > 0 && C > 0 && (C & 7) == 0 && coef, "bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize8_kernel, dim3(C / 8), dim3(256), 0, st, partials, P, C, count, gamma, mean, rstd,
+                     dgamma, dbeta, dalpha, coef);
   FEDFR_LAUNCH_CHECK("bn_bwd_finalize");
   return FEDFR_OK;
 }
@@ -524,28 +552,31 @@ struct BnBwdDiv {
   FastDiv dHW, dW;
 };
 
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab) {
+template <bool ALPHA, bool NX>
+__global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 : 5) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab, int shfl) {
   const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
   const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   const bool active = rl < rpp;
-  if (!active && !p.nx) return;
-  extern __shared__ float red[];                    // [rpp][2 C] when the next BN's reduction rides along
+  if (!active && !NX) return;
+  extern __shared__ float red[];                    // next BN's reduction (NX)
   const int c0 = cl * 8;
-  float nmean[8], nrstd[8], n1[8], n2[8];
-  load8f(p.nx ? p.nmean : nullptr, c0, nmean, 0.f);
-  load8f(p.nx ? p.nrstd : nullptr, c0, nrstd, 1.f);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) n1[j] = n2[j] = 0.f;
-  float mean[8], rstd[8], ga[8], be[8], al[8], ca[8], cb[8], cc[8];
-  load8f(p.mean, c0, mean, 0.f);
-  load8f(p.rstd, c0, rstd, 1.f);
-  load8f(p.gamma, c0, ga, 1.f);
-  load8f(p.beta, c0, be, 0.f);
-  load8f(p.alpha, c0, al, 1.f);
+  float ca[8], cA[8], cB[8], G[8], H[8], al[8], nmean[8];
+  float nacc[2][8];                                  // sum dx | sum dx (x_next - mean_next), scaled by rstd_next at the end
   load8f(p.coef, c0, ca, 1.f);
-  load8f(p.coef + p.C, c0, cb, 0.f);
-  load8f(p.coef + 2 * p.C, c0, cc, 0.f);
-  const bool has_alpha = p.alpha != nullptr;
+  load8f(p.coef + p.C, c0, cA, 0.f);
+  load8f(p.coef + 2 * p.C, c0, cB, 0.f);
+  if (ALPHA) {
+    float mean[8], rstd[8];
+    load8f(p.sc ? nullptr : p.mean, c0, mean, 0.f);
+    load8f(p.sc ? nullptr : p.rstd, c0, rstd, 1.f);
+    ew_load_gh(p, c0, mean, rstd, G, H);
+    load8f(p.alpha, c0, al, 1.f);
+  }
+  if (NX) {
+    load8f(p.nmean, c0, nmean, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nacc[0][j] = nacc[1][j] = 0.f;
+  }
   const int bid = ew_block_id();
   const int mbeg = bid * slab, mend = min(p.M, mbeg + slab);
   auto one = [&](int m, const uint4& vd, const uint4& vx) {
@@ -555,13 +586,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
     unpack8(vx, x);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xh = (x[j] - mean[j]) * rstd[j];
       float dz = dy[j];
-      if (has_alpha) {
-        const float z = ga[j] * xh + be[j];
+      if (ALPHA) {
+        const float z = x[j] * G[j] + H[j];
         if (z <= 0.f) dz = dy[j] * al[j];
       }
-      o[j] = ca[j] * (dz - cb[j] - xh * cc[j]);
+      o[j] = ca[j] * dz + (cA[j] * x[j] + cB[j]);
     }
     if (p.add) {
       float a[8];
@@ -583,14 +613,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
     }
     const uint4 ov = pack8(o);
     *reinterpret_cast<uint4*>(p.dx + off) = ov;
-    if (p.nx) {                                      // the next BN sees the bf16-rounded dx, exactly as its own reduce pass would
+    if (NX) {                                        // the next BN sees the bf16-rounded dx, exactly as its own reduce pass would
       float dn[8], xn[8];
       unpack8(ov, dn);
       unpack8(*reinterpret_cast<const uint4*>(p.nx + off), xn);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        n1[j] += dn[j];
-        n2[j] += dn[j] * ((xn[j] - nmean[j]) * nrstd[j]);
+        nacc[0][j] += dn[j];
+        nacc[1][j] += dn[j] * (xn[j] - nmean[j]);
       }
     }
   };
@@ -604,28 +634,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(BnBwd p, BnBwd
       vx[u] = ew_ld16(p.x + off);
     }
 #pragma unroll
-    for (int u = 0; u < EW_UNROLL; ++u) one(m + u * rpp, vd[u], vx[u]);
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      one(m + u * rpp, vd[u], vx[u]);
+      __builtin_amdgcn_sched_barrier(0);            // see bn_bwd_reduce
+    }
   }
   for (; m < mend; m += rpp) {
     const size_t off = (size_t)m * p.C + c0;
     one(m, *reinterpret_cast<const uint4*>(p.dy + off), *reinterpret_cast<const uint4*>(p.x + off));
   }
-  if (p.nx) {
-    const int W2 = 2 * p.C;
-    if (active) {
+  if (NX) {
+    float nrstd[8];
+    load8f(p.nrstd, c0, nrstd, 1.f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        red[rl * W2 + c0 + j] = n1[j];
-        red[rl * W2 + p.C + c0 + j] = n2[j];
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < W2; i += EW_THREADS) {
-      float t = 0.f;
-      for (int r = 0; r < rpp; ++r) t += red[r * W2 + i];
-      p.npart[(size_t)bid * 3 * p.C + i] = t;
-    }
-    for (int i = threadIdx.x; i < p.C; i += EW_THREADS) p.npart[(size_t)bid * 3 * p.C + W2 + i] = 0.f;
+    for (int j = 0; j < 8; ++j) nacc[1][j] *= nrstd[j];
+    float* row = p.npart + (size_t)bid * 3 * p.C;
+    ew_block_colsum<2>(nacc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, row);
+    for (int i = threadIdx.x; i < p.C; i += EW_THREADS) row[2 * p.C + i] = 0.f;
   }
 }
 
@@ -634,6 +659,7 @@ int ew_bn_bwd_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 2048
 int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_apply"));
   FEDFR_REQUIRE(p.dy && p.x && p.coef && p.dx, "bn_bwd_apply: null tensor");
+  FEDFR_REQUIRE(!p.sc == !p.sh, "bn_bwd_apply: scale and shift come together");
   BnBwdDiv dv;
   dv.dHW = make_fastdiv(1);
   dv.dW = make_fastdiv(1);
@@ -644,8 +670,16 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   }
   if (p.nx) FEDFR_REQUIRE(p.nmean && p.nrstd && p.npart, "bn_bwd_apply: next-BN reduction needs mean / rstd / partials");
   const int slab = slab_rows(p.M, p.C, 2048);
-  const size_t lds = p.nx ? (size_t)rows_per_pass(p.C) * 2 * p.C * sizeof(float) : 0;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(p.M, slab)), dim3(EW_THREADS), lds, st, p, dv, slab);
+  const dim3 grid(ceil_div(p.M, slab));
+  const size_t lds = p.nx ? ew_colsum_lds(p.C, 2) : 0;
+  const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
+  if (p.alpha) {
+    if (p.nx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
+  } else {
+    if (p.nx) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
+  }
   FEDFR_LAUNCH_CHECK("bn_bwd_apply");
   return FEDFR_OK;
 }

@@ -381,9 +381,10 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
     *next_rows = ew_bn_bwd_apply_grid(M, b.C);
   }
   p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.beta = c.beta(b); p.alpha = alpha;
+  p.sc = c.save(b, 0); p.sh = c.save(b, 1);
   p.M = M; p.C = b.C; p.partials = c.part(); p.coef = c.coef(); p.add = add; p.add_up = add_up; p.H = H; p.W = H; p.dx = dx;
   if (fused_rows <= 0) FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));      // else: the producing dgrad kernel already wrote the partials
-  FEDFR_TRY(ew_bn_bwd_finalize(c.part(), fused_rows > 0 ? fused_rows : ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 3), c.grads + b.g_off,
+  FEDFR_TRY(ew_bn_bwd_finalize(c.part(), fused_rows > 0 ? fused_rows : ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 2), c.save(b, 3), c.grads + b.g_off,
                                c.grads + b.b_off, alpha ? c.grads + alpha_off : nullptr, c.coef(), c.st));
   return ew_bn_bwd_apply(p, c.st);
 }

@@ -43,6 +43,7 @@ SIGNATURES = {
     "fedfr_conv2d_dgrad_bnbwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp]),
     "fedfr_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "fedfr_conv2d_wgrad": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
+    "fedfr_conv2d_wgrad_pair": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_weight_shadows": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "fedfr_gemm_nt": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "fedfr_gemm_tn": (i32, [vp, vp, vp, i32, i32, i32, vp]),

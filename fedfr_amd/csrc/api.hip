@@ -19,6 +19,7 @@ extern int g_halo_waves;
 extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
 extern int g_tn_glds;
+extern int g_tn_pair;
 extern int g_dgrad_parity;
 extern int g_fuse_bnapply;
 extern int g_fuse_bnred_next;
@@ -80,6 +81,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "tn_glds")) {
     g_tn_glds = value;          // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "tn_pair")) {
+    g_tn_pair = value ? 1 : 0;  // same-shape weight-gradient GEMMs of a block in one launch, two blocks per CU
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "fuse_bnbwd")) {
@@ -259,6 +264,32 @@ int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* w
   p.out = (float*)ws;
   FEDFR_TRY(gemm_tn_launch(p, splits, ST(stream)));
   return ew_reduce_slabs(dw, (const float*)ws, splits, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream));
+}
+int fedfr_conv2d_wgrad_pair(const uint16_t* xa, const uint16_t* dya, float* dwa, const uint16_t* xb, const uint16_t* dyb, float* dwb,
+                            void* ws, size_t ws_bytes, int batch, int hin, int cin, int cout, int ksize, int stride, void* stream) {
+  FEDFR_TRY(conv_args_ok(batch, hin, cin, cout, ksize, stride));
+  FEDFR_REQUIRE(xa && dya && dwa && xb && dyb && dwb, "conv2d_wgrad_pair: null tensor");
+  const int hout = hin / stride;
+  GemmTN p{};
+  p.Kp = batch * hout * hout; p.NI = cout; p.NJ = ksize * ksize * cin;
+  p.mode = 1; p.H = hin; p.W = hin; p.C = cin; p.Ho = hout; p.Wo = hout; p.S = ksize; p.stride = stride;
+  p.pad = ksize == 3 ? 1 : 0; p.ldp = cout; p.use_tr = g_tn_use_tr;
+  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C);
+  const size_t one = (size_t)splits * p.NI * p.NJ * sizeof(float);
+  GemmTN a = p, b = p;
+  a.P = BF(dya); a.Q = BF(xa); b.P = BF(dyb); b.Q = BF(xb);
+  if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {      // shapes the paired kernel does not take: two ordinary launches
+    FEDFR_TRY(fedfr_conv2d_wgrad(xa, dya, dwa, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream));
+    return fedfr_conv2d_wgrad(xb, dyb, dwb, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream);
+  }
+  if (!ws || ws_bytes < 2 * one) {
+    fedfr_set_error("conv2d_wgrad_pair: workspace too small (%zu bytes, need %zu)", ws_bytes, 2 * one);
+    return FEDFR_ERR_WORKSPACE;
+  }
+  a.out = (float*)ws; b.out = (float*)((char*)ws + one);
+  FEDFR_TRY(gemm_tn_launch_pair(a, b, splits, ST(stream)));
+  FEDFR_TRY(ew_reduce_slabs(dwa, a.out, splits, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream)));
+  return ew_reduce_slabs(dwb, b.out, splits, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream));
 }
 int fedfr_weight_shadows(const float* w, uint16_t* wb, uint16_t* wdb, int cout, int ksize, int cin, void* stream) {
   FEDFR_REQUIRE(w, "weight_shadows: null");

@@ -66,6 +66,9 @@ bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride);
 int gemm_nt_pick_splits(int M, int N, int K);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st);
 int gemm_tn_launch(GemmTN p, int splits, hipStream_t st);
+// two same-shape conv weight-gradient problems in one launch (LDS-DMA kernel, two blocks per CU); check gemm_tn_pair_ok first
+bool gemm_tn_pair_ok(const GemmTN& a, const GemmTN& b, int splits);
+int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
 int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C_or_0);
 void gemm_tn_tiles(int NI, int NJ, int C_or_0, int* TI, int* TJ);
 

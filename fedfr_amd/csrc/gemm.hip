@@ -646,28 +646,50 @@ static int launch_tn(GemmTN p, int splits, hipStream_t st) {
   return FEDFR_OK;
 }
 
-int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
+// operand ranges and conv-gather dividers shared by the single and the paired launch
+static int tn_prepare(GemmTN& p) {
   FEDFR_REQUIRE(p.P && p.Q && p.out && p.Kp > 0 && p.NI > 0 && p.NJ > 0, "gemm_tn: null/empty operand");
   FEDFR_REQUIRE((p.NI & 7) == 0 && (p.NJ & 7) == 0 && (p.ldp & 7) == 0, "gemm_tn: NI, NJ, ldp must be multiples of 8");
-  int TI, TJ;
-  {
-    const unsigned long long pb = 2ull * (unsigned long long)p.Kp * p.ldp;
-    const unsigned long long qb = p.mode == 1 ? 2ull * ((unsigned long long)ceil_div(p.Kp, p.Ho * p.Wo)) * p.H * p.W * p.C
-                                              : 2ull * (unsigned long long)p.Kp * p.ldq;
-    FEDFR_REQUIRE(pb < (1ull << 32) - 64 && qb < (1ull << 32) - 64, "gemm_tn: operand larger than 4 GiB (32-bit buffer offsets)");
-    p.p_bytes = (unsigned)pb;
-    p.q_bytes = (unsigned)qb;
-  }
+  const unsigned long long pb = 2ull * (unsigned long long)p.Kp * p.ldp;
+  const unsigned long long qb = p.mode == 1 ? 2ull * ((unsigned long long)ceil_div(p.Kp, p.Ho * p.Wo)) * p.H * p.W * p.C
+                                            : 2ull * (unsigned long long)p.Kp * p.ldq;
+  FEDFR_REQUIRE(pb < (1ull << 32) - 64 && qb < (1ull << 32) - 64, "gemm_tn: operand larger than 4 GiB (32-bit buffer offsets)");
+  p.p_bytes = (unsigned)pb;
+  p.q_bytes = (unsigned)qb;
   if (p.mode == 1) {
     FEDFR_REQUIRE((p.C & 63) == 0 && p.NJ % p.C == 0, "gemm_tn: gather needs C%%64==0 and NJ=taps*C");
     p.dHoWo = make_fastdiv((unsigned)(p.Ho * p.Wo));
     p.dWo = make_fastdiv((unsigned)p.Wo);
     p.dHo = make_fastdiv((unsigned)p.Ho);
     FEDFR_REQUIRE((long long)p.Kp * (long long)(p.Ho * p.Wo) < (1ll << 40), "gemm_tn: fastdiv range");
+  } else {
+    FEDFR_REQUIRE((p.ldq & 7) == 0, "gemm_tn: ldq%%8");
+  }
+  return FEDFR_OK;
+}
+
+int g_tn_pair = 0;   // option "tn_pair": the two same-shape weight-gradient GEMMs of a residual block in ONE launch on the 64-KiB ring (two blocks
+                     // per CU).  Off: same box, the pair runs 15 % faster on its own (72.0 us vs 2 x 42.2 us, bit-identical slabs) but with four
+                     // waves per SIMD and 128 KB of LDS taken no BN-backward workgroup fits beside it any more: the main stream's streaming
+                     // kernels stretch (bn_bwd_reduce 16.9 -> 29.6 us) and the step gets slower, 20.65 -> 21.05 ms
+bool gemm_tn_pair_ok(const GemmTN& a, const GemmTN& b, int splits) {
+  return a.mode == 1 && b.mode == 1 && a.use_tr && b.use_tr && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C &&
+         gemm_tn_glds_pair_ok(a.Kp, a.NI, a.NJ, a.C, splits);
+}
+int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
+  FEDFR_REQUIRE(gemm_tn_pair_ok(a, b, splits), "gemm_tn_pair: problems cannot be paired");
+  FEDFR_TRY(tn_prepare(a));
+  FEDFR_TRY(tn_prepare(b));
+  return launch_tn_glds_pair(a, b, splits, st);
+}
+
+int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
+  FEDFR_TRY(tn_prepare(p));
+  int TI, TJ;
+  if (p.mode == 1) {
     if (p.use_tr && gemm_tn_glds_applies(p.NI, p.NJ, p.C, 1)) return launch_tn_glds(p, splits, st);
     gemm_tn_tiles(p.NI, p.NJ, p.C, &TI, &TJ);
   } else {
-    FEDFR_REQUIRE((p.ldq & 7) == 0, "gemm_tn: ldq%%8");
     gemm_tn_tiles(p.NI, p.NJ, 0, &TI, &TJ);
   }
 #define TN_CASE(a, b)                                                \

@@ -61,3 +61,6 @@ int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   //
 int launch_tn_glds(GemmTN p, int splits, hipStream_t st);   // gemm_tn_glds.hip  wgrad GEMM, LDS-DMA operand ring
 bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode);
 int gemm_tn_glds_pick_splits(int Kp, int NI, int NJ);
+int launch_tn_glds_pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
+bool gemm_tn_glds_pair_ok(int Kp, int NI, int NJ, int C, int splits);
+extern int g_tn_pair;

@@ -19,12 +19,15 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-constexpr int NS = 4;                       // ring stages
 constexpr int TILE_B = 64 * 256;            // one operand tile: 64 pixel rows x 128 channels bf16
 constexpr int STAGE_B = 2 * TILE_B;
 
-template <int WI, int WJ>   // wave grid: 2 x 2 (one wave per SIMD, 64 x 64 wave tiles) or 2 x 4 (two per SIMD, 64 x 32)
-__global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
+// Ring: NS stages, the tiles of K-step it + D are issued during the second half of K-step it.  NS = 4, D = 3 (128 KiB, one block per
+// CU) writes the slot K-step it - 1 released; NS = 2, D = 2 (64 KiB, TWO blocks per CU) writes the slot of K-step it itself, whose
+// fragments are all in registers once the mid-step barrier has been passed.
+template <int WI, int WJ, int NS>   // wave grid: 2 x 2 (one wave per SIMD, 64 x 64 wave tiles) or 2 x 4 (two per SIMD, 64 x 32)
+__device__ __forceinline__ void tn_glds_body(const GemmTN& p, const int bid, const int nblk) {
+  constexpr int D = NS == 2 ? 2 : NS - 1;
   constexpr int TI = 128, TJ = 128, RB = 256, NW = WI * WJ;
   constexpr int FI = TI / WI / 16, FJ = TJ / WJ / 16, NF = FI + FJ, NM = FI * FJ;   // fragments / MFMAs per k-half
   constexpr int RSTEP = 4 * NW, NROW = 64 / RSTEP;          // tile rows between a lane's rows; row steps per stage (4 or 2)
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WJ, wj = wave % WJ;
   // 1-D grid over (split, tile), split-major, XCD-remapped: an XCD owns whole K-splits (see gemm_tn_kernel)
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lid = xcd_remap(bid, nblk);
   const int split = lid / p.ntiles, tile = lid - split * p.ntiles;
   const int bj = tile % p.nbj, bi = tile / p.nbj;
   const int i0 = bi * TI, j0 = bj * TJ;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
   _Pragma("unroll") for (int tj = 0; tj < FJ; ++tj) {                                                       \
     _Pragma("unroll") for (int ti = 0; ti < FI; ++ti) {                                                     \
       const int m = tj * FI + ti;                                                                           \
-      if (m < NF) {                                                                                         \
+      if (m < NF) {                                                                     \
         const unsigned a = fo[m] + (stage_off);                                                             \
         TR_READ(oth[2 * m], a, (KS) * 32 * RB);                                                             \
         TR_READ(oth[2 * m + 1], a, (KS) * 32 * RB + 4 * RB);                                                \
@@ -154,11 +157,10 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
     }                                                                                                       \
   }
 
-  // prologue: three stages in flight, wait for the first, fetch its k-half-0 fragments
-  issue_stage(0, nsteps > 0);
-  issue_stage(1, nsteps > 1);
-  issue_stage(2, nsteps > 2);
-  wait_vmcnt<2 * DPS>();
+  // prologue: D stages in flight, wait for the first, fetch its k-half-0 fragments
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue_stage(s, nsteps > s);
+  wait_vmcnt<(D - 1) * DPS>();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -171,15 +173,16 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
 
   for (int it = 0; it < nsteps; ++it) {
     const unsigned cur_off = (unsigned)((it & (NS - 1)) * STAGE_B), nxt_off = (unsigned)(((it + 1) & (NS - 1)) * STAGE_B);
+    static_assert((NS & (NS - 1)) == 0, "ring size must be a power of two");
     // ---- first half: k-half 0 MFMAs; reads of this stage's k-half 1
     HALF(f0, f1, cur_off, 1, -1, false)
-    wait_vmcnt<DPS>();                                             // stage it+1 landed (it+2 may be in flight)
+    wait_vmcnt<(D - 2) * DPS>();                                   // stage it+1 landed (it+2 .. it+D-1 may be in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // f1 arrived
     __builtin_amdgcn_s_barrier();                                  // ... for every wave; everyone is done reading stage it-1
     __builtin_amdgcn_sched_barrier(0);
-    // ---- second half: k-half 1 MFMAs; reads of stage it+1's k-half 0 in front of the first eight, the DMA of stage it+3 (into
-    // the slot stage it-1 released) one row step behind every other one of the last eight
-    HALF(f1, f0, nxt_off, 0, (it + 3) & (NS - 1), it + 3 < nsteps)
+    // ---- second half: k-half 1 MFMAs; reads of stage it+1's k-half 0 in front of the first eight, the DMA of stage it+D one row
+    // step behind every other one of the last eight
+    HALF(f1, f0, nxt_off, 0, (it + D) & (NS - 1), it + D < nsteps)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -197,6 +200,21 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
       const int j = j0 + wj * (TJ / WJ) + tj * 16 + (lane >> 4) * 4;
       *reinterpret_cast<float4*>(slab + (size_t)i * p.NJ + j) = make_float4(acc[tj][ti][0], acc[tj][ti][1], acc[tj][ti][2], acc[tj][ti][3]);
     }
+}
+
+template <int WI, int WJ>
+__global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
+  tn_glds_body<WI, WJ, 4>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+// Two weight-gradient GEMMs of the same shape in one launch on the 64-KiB ring: blocks come in groups of eight (one per XCD under
+// round-robin placement) that alternate between the problems, so each CU gets a workgroup of either and the two interleave on its
+// SIMDs: four waves per SIMD instead of two hide each other's DMA issue, fragment reads and barrier waits.
+template <int WI, int WJ>
+__global__ __launch_bounds__(64 * WI * WJ, 2) void gemm_tn_glds_pair_kernel(GemmTN p0, GemmTN p1, int nblk) {
+  const int b = (int)blockIdx.x, second = (b >> 3) & 1;
+  const int local = ((b >> 4) << 3) | (b & 7);
+  if (local >= nblk) return;                       // padding of the last group of eight (whole workgroup, before any barrier)
+  tn_glds_body<WI, WJ, 2>(second ? p1 : p0, local, nblk);
 }
 }  // namespace
 
@@ -225,7 +243,7 @@ int launch_tn_glds(GemmTN p, int splits, hipStream_t st) {
   p.ksteps_total = ceil_div(p.Kp, 64);
   p.ksteps_per_split = ceil_div(p.ksteps_total, splits);
   FEDFR_REQUIRE(ceil_div(p.ksteps_total, p.ksteps_per_split) == splits, "gemm_tn_glds: splits=%d leaves an empty split", splits);
-  constexpr size_t lds = (size_t)NS * STAGE_B;
+  constexpr size_t lds = (size_t)4 * STAGE_B;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -237,4 +255,32 @@ int launch_tn_glds(GemmTN p, int splits, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 2>), dim3(p.ntiles * splits), dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_tn_glds");
   return FEDFR_OK;
+}
+
+// a and b: same NI, NJ, Kp (same tiling and K-split); each writes its own slab set
+int launch_tn_glds_pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
+  FEDFR_REQUIRE(gemm_tn_glds_applies(a.NI, a.NJ, a.C, a.mode) && gemm_tn_glds_applies(b.NI, b.NJ, b.C, b.mode) && a.use_tr && b.use_tr,
+                "gemm_tn_glds_pair: unsupported problem");
+  FEDFR_REQUIRE(a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp, "gemm_tn_glds_pair: the two problems differ in shape");
+  for (GemmTN* p : {&a, &b}) {
+    p->nbj = p->NJ / 128;
+    p->ntiles = (p->NI / 128) * p->nbj;
+    p->ksteps_total = ceil_div(p->Kp, 64);
+    p->ksteps_per_split = ceil_div(p->ksteps_total, splits);
+  }
+  FEDFR_REQUIRE(ceil_div(a.ksteps_total, a.ksteps_per_split) == splits, "gemm_tn_glds_pair: splits=%d leaves an empty split", splits);
+  const int nblk = a.ntiles * splits;
+  constexpr size_t lds = (size_t)2 * STAGE_B;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_pair_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  ProfScope prof(14, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
+  hipLaunchKernelGGL((gemm_tn_glds_pair_kernel<2, 4>), dim3(16 * ceil_div(nblk, 8)), dim3(512), lds, st, a, b, nblk);
+  FEDFR_LAUNCH_CHECK("gemm_tn_glds_pair");
+  return FEDFR_OK;
+}
+bool gemm_tn_glds_pair_ok(int Kp, int NI, int NJ, int C, int splits) {
+  return g_tn_glds >= 2 && g_tn_pair && gemm_tn_glds_applies(NI, NJ, C, 1);
 }

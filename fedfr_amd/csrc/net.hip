@@ -176,7 +176,7 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
   for (int i = 0; i < 6; ++i) n->ws_t[i] = wtake(n->g_elems * 2);
   for (int i = 0; i < 3; ++i) n->ws_t2[i] = wtake(n->g_elems * 2);
   n->ws_part = wtake(n->part_floats * 4);
-  n->ws_slab = wtake(n->slab_floats * 4);
+  n->ws_slab = wtake(n->slab_floats * 4 * 2);      // two regions: paired weight-gradient GEMMs write their slab sets side by side
   // small: coef[3*512] | finalize tmp [64*2*512] | dyfc f32 [B*F] | dyb bf16 [B*F] | dybt bf16 [F*Bp]
   n->ws_small = wtake((size_t)(3 * 512 + 64 * 2 * 512) * 4 + (size_t)Bq * num_features * 4 + (size_t)Bq * num_features * 2 +
                       (size_t)num_features * n->Bp * 2 + 1024);
@@ -191,7 +191,7 @@ struct Ctx {
   const float* params; float* bufs; const bf16_t* shadow; bf16_t* actb; float* actf; unsigned char* ws; float* grads;
   hipStream_t st;
   float* part() const { return reinterpret_cast<float*>(ws + n->ws_part); }
-  float* slab() const { return reinterpret_cast<float*>(ws + n->ws_slab); }
+  float* slab(int which = 0) const { return reinterpret_cast<float*>(ws + n->ws_slab) + (size_t)which * n->slab_floats; }
   float* coef() const { return reinterpret_cast<float*>(ws + n->ws_small); }
   float* ftmp() const { return coef() + 3 * 512; }
   float* dyfc() const { return ftmp() + 64 * 2 * 512; }
@@ -263,13 +263,17 @@ static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* d
   }
   return gemm_nt_launch(p, 1, c.st);
 }
-static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy, hipStream_t st) {
+static GemmTN wgrad_problem(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy) {
   GemmTN p{};
   p.P = dy; p.Q = in;
   p.Kp = c.n->B * cv.Hout * cv.Hout; p.NI = cv.Cout; p.NJ = cv.R * cv.R * cv.Cin;
   p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = cv.R;
   p.stride = cv.stride; p.pad = (cv.R == 3) ? 1 : 0;
   p.ldp = cv.Cout; p.ldq = 0; p.use_tr = g_tn_use_tr;
+  return p;
+}
+static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy, hipStream_t st) {
+  GemmTN p = wgrad_problem(c, cv, in, dy);
   const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C);
   float* dst = c.grads + cv.w_off;
   if (splits == 1) {
@@ -279,6 +283,20 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
   p.out = c.slab();
   FEDFR_TRY(gemm_tn_launch(p, splits, st));
   return ew_reduce_slabs(dst, c.slab(), splits, (size_t)p.NI * p.NJ, nullptr, 0, st);
+}
+// the two 3x3 weight gradients of a residual block; same shape (every block but a stage's first): one paired launch
+static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const bf16_t* dya, const ConvD& cvb, const bf16_t* inb,
+                       const bf16_t* dyb, hipStream_t st) {
+  GemmTN a = wgrad_problem(c, cva, ina, dya), b = wgrad_problem(c, cvb, inb, dyb);
+  const int splits = gemm_tn_pick_splits(a.Kp, a.NI, a.NJ, a.C);
+  if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {
+    FEDFR_TRY(conv_wgrad(c, cva, ina, dya, st));
+    return conv_wgrad(c, cvb, inb, dyb, st);
+  }
+  a.out = c.slab(0); b.out = c.slab(1);
+  FEDFR_TRY(gemm_tn_launch_pair(a, b, splits, st));
+  FEDFR_TRY(ew_reduce_slabs(c.grads + cva.w_off, c.slab(0), splits, (size_t)a.NI * a.NJ, nullptr, 0, st));
+  return ew_reduce_slabs(c.grads + cvb.w_off, c.slab(1), splits, (size_t)b.NI * b.NJ, nullptr, 0, st);
 }
 static int bn_coeffs(const Ctx& c, const BnD& b, int P, double count, bool training) {
   if (training)
@@ -481,8 +499,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     // ONE fork per block: every event record costs the main stream a ~8 us bubble (kernel trace), so the block's two or three
     // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
     fk.order(st, wst);
-    FEDFR_TRY(conv_wgrad(c, k.conv2, A + k.a2_off, dc2, wst));
-    FEDFR_TRY(conv_wgrad(c, k.conv1, A + k.a1_off, dc1, wst));
+    FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst));
     if (k.has_ds) {
       FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, dd, wst));
       FEDFR_TRY(conv_dgrad(c, k.ds, dd, dxd));

@@ -102,6 +102,11 @@ int fedfr_conv2d_dgrad_bnbwd(const uint16_t* dy, const uint16_t* wd, uint16_t* d
 size_t fedfr_conv2d_wgrad_ws_bytes(int batch, int hin, int cin, int cout, int ksize, int stride);
 int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* ws, size_t ws_bytes, int batch, int hin,
                        int cin, int cout, int ksize, int stride, void* stream);
+/* the two same-shape weight gradients of a residual block (conv1 / conv2, reference backbones/iresnet.py:38,41 through autograd) in one
+ * launch; ws holds 2 x fedfr_conv2d_wgrad_ws_bytes.  Shapes the paired kernel does not take run as two fedfr_conv2d_wgrad calls. */
+int fedfr_conv2d_wgrad_pair(const uint16_t* xa, const uint16_t* dya, float* dwa, const uint16_t* xb, const uint16_t* dyb,
+                            float* dwb, void* ws, size_t ws_bytes, int batch, int hin, int cin, int cout, int ksize,
+                            int stride, void* stream);
 int fedfr_weight_shadows(const float* w_krsc, uint16_t* w_bf16, uint16_t* wd_bf16, int cout, int ksize, int cin,
                          void* stream);
 /* plain GEMMs on the same kernels: C[m][n] = sum_k A[m][k] B[n][k] (fp32 out) and C[i][j] = sum_p P[p][i] Q[p][j] */

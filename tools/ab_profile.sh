@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B per-kernel comparison on ONE box: rocprofv3 kernel stats of bench.py with the default library and with libfedfr_hip_ab.so
+# A/B per-kernel comparison on ONE box: rocprofv3 kernel stats of bench.py, variant "new" = defaults, variant "ab" = libfedfr_hip_ab.so
+# or, when AB_OPTIONS is set (e.g. AB_OPTIONS=tn_pair=0), the default library with FEDFR_OPTIONS=$AB_OPTIONS
 # usage (on the GPU box): bash tools/ab_profile.sh [single|dual]   -> gpurun_out/ab_prof_{new,ab}.csv
 set -e
 mode=${1:-single}
@@ -7,7 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 [ "$mode" = single ] && export FEDFR_DUAL_STREAM=0
 for v in new ab; do
-  if [ $v = ab ]; then export FEDFR_HIP_LIB_NAME=libfedfr_hip_ab.so; else unset FEDFR_HIP_LIB_NAME; fi
+  unset FEDFR_HIP_LIB_NAME FEDFR_OPTIONS
+  if [ $v = ab ]; then if [ -n "$AB_OPTIONS" ]; then export FEDFR_OPTIONS=$AB_OPTIONS; else export FEDFR_HIP_LIB_NAME=libfedfr_hip_ab.so; fi; fi
   rm -rf /tmp/prof_$v
   timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile > /tmp/prof_$v.log 2>&1
   f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1)

@@ -36,7 +36,8 @@ PMC_TRAFFIC_MB = {"gemm_tn_glds_kernel<128,128>": {"fetch": 44.9, "write": 16.5,
 SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kernel<64,128>", "gemm_nt_kernel<64,64>",
               "gemm_tn_kernel<128,128>", "gemm_tn_kernel<128,64>", "gemm_tn_kernel<64,128>", "gemm_tn_kernel<64,64>",
               "conv3x3_halo2_kernel<128,14>", "conv3x3_halo2_kernel<128,28>", "conv3x3_halo2_kernel<64,*>", "conv3x3_halo_kernel<*>",
-              "conv3x3_glds_kernel<14,14>", "conv3x3_glds_kernel<28,7>", "gemm_tn_glds_kernel<128,128>", "conv3x3_glds_kernel<56,4>"]
+              "conv3x3_glds_kernel<14,14>", "conv3x3_glds_kernel<28,7>", "gemm_tn_glds_kernel<128,128>", "conv3x3_glds_kernel<56,4>",
+              "wgrad9_kernel<32x64x9>"]
 
 
 def cpu_baseline(arch, batch=16, steps=2):

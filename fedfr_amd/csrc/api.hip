@@ -20,6 +20,7 @@ extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_tn_pair;
+extern int g_wgrad9;
 extern int g_dgrad_parity;
 extern int g_fuse_bnapply;
 extern int g_fuse_bnred_next;
@@ -81,6 +82,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "tn_glds")) {
     g_tn_glds = value;          // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad9")) {
+    g_wgrad9 = value ? 1 : 0;   // nine-tap weight-gradient kernel for 3x3 / stride-1 layers on 14x14 and 28x28 maps
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "tn_pair")) {
@@ -241,7 +246,7 @@ int fedfr_conv2d_dgrad_bnbwd(const uint16_t* dy, const uint16_t* wd, uint16_t* d
 size_t fedfr_conv2d_wgrad_ws_bytes(int batch, int hin, int cin, int cout, int ksize, int stride) {
   const int hout = hin / (stride > 0 ? stride : 1);
   const int NJ = ksize * ksize * cin;
-  return (size_t)gemm_tn_pick_splits(batch * hout * hout, cout, NJ, cin) * cout * NJ * sizeof(float);
+  return (size_t)gemm_tn_max_splits(batch * hout * hout, cout, NJ, cin, hout, stride) * cout * NJ * sizeof(float);
 }
 int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* ws, size_t ws_bytes, int batch, int hin, int cin,
                        int cout, int ksize, int stride, void* stream) {
@@ -252,7 +257,7 @@ int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* w
   p.P = BF(dy); p.Q = BF(x); p.Kp = batch * hout * hout; p.NI = cout; p.NJ = ksize * ksize * cin;
   p.mode = 1; p.H = hin; p.W = hin; p.C = cin; p.Ho = hout; p.Wo = hout; p.S = ksize; p.stride = stride;
   p.pad = ksize == 3 ? 1 : 0; p.ldp = cout; p.use_tr = g_tn_use_tr;
-  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C);
+  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C, p.Wo, p.stride);
   if (splits == 1) {
     p.out = dw;
     return gemm_tn_launch(p, 1, ST(stream));
@@ -274,7 +279,7 @@ int fedfr_conv2d_wgrad_pair(const uint16_t* xa, const uint16_t* dya, float* dwa,
   p.Kp = batch * hout * hout; p.NI = cout; p.NJ = ksize * ksize * cin;
   p.mode = 1; p.H = hin; p.W = hin; p.C = cin; p.Ho = hout; p.Wo = hout; p.S = ksize; p.stride = stride;
   p.pad = ksize == 3 ? 1 : 0; p.ldp = cout; p.use_tr = g_tn_use_tr;
-  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C);
+  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C, p.Wo, p.stride);
   const size_t one = (size_t)splits * p.NI * p.NJ * sizeof(float);
   GemmTN a = p, b = p;
   a.P = BF(dya); a.Q = BF(xa); b.P = BF(dyb); b.Q = BF(xb);

@@ -69,7 +69,9 @@ int gemm_tn_launch(GemmTN p, int splits, hipStream_t st);
 // two same-shape conv weight-gradient problems in one launch (LDS-DMA kernel, two blocks per CU); check gemm_tn_pair_ok first
 bool gemm_tn_pair_ok(const GemmTN& a, const GemmTN& b, int splits);
 int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
-int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C_or_0);
+// Wo > 0: conv weight gradient on a Wo x Wo output map (lets the nine-tap kernel, wgrad9.hip, be chosen)
+int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C_or_0, int Wo = 0, int stride = 1);
+int gemm_tn_max_splits(int Kp, int NI, int NJ, int C_or_0, int Wo, int stride);
 void gemm_tn_tiles(int NI, int NJ, int C_or_0, int* TI, int* TJ);
 
 // optional HIP-event timing of every NT/TN launch (slots: see gemm.hip)

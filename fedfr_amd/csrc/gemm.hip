@@ -19,7 +19,7 @@ struct ProfSlot {
   long long launches = 0;
 };
 bool g_prof_on = false;
-ProfSlot g_prof[16];
+ProfSlot g_prof[20];
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
 }  // namespace
 
@@ -50,7 +50,7 @@ void gemm_profile_enable(int on) {
 }
 // caller must have synchronised the stream(s).  Returns 0 and fills totals for `slot`.
 int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
-  if (slot < 0 || slot >= 16) return -1;
+  if (slot < 0 || slot >= 20) return -1;
   ProfSlot& s = g_prof[slot];
   double ms = 0.0;
   for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
@@ -608,7 +608,8 @@ int g_tn_target_blocks = 416;   // option "tn_target_blocks"
 int g_tn_glds = 2;              // option "tn_glds": LDS-DMA wgrad kernel for 128-multiple conv shapes: 2 = 8 waves (two per SIMD: one wave's VALU / DMA issue hides
                                 // behind the other's MFMAs, +20 % over 1 = 4 waves), 0 = register-staged kernel
 
-int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C) {
+int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
+  if (Wo > 0 && wgrad9_applies_shape(Kp, NI, NJ, C, Wo, stride)) return wgrad9_pick_splits(Kp, NI, NJ, Wo);
   if (C > 0 && gemm_tn_glds_applies(NI, NJ, C, 1)) return gemm_tn_glds_pick_splits(Kp, NI, NJ);
   int TI, TJ;
   gemm_tn_tiles(NI, NJ, C, &TI, &TJ);
@@ -622,6 +623,19 @@ int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C) {
   // no empty trailing split
   const int per = ceil_div(ksteps, splits);
   return ceil_div(ksteps, per);
+}
+
+// slab count to size a workspace for: the largest any kernel choice (options can be toggled after a plan was created) would use
+int gemm_tn_max_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
+  const int w9 = g_wgrad9, gl = g_tn_glds;
+  int m = 1;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 3; ++b) {
+      g_wgrad9 = a; g_tn_glds = b;
+      m = std::max(m, gemm_tn_pick_splits(Kp, NI, NJ, C, Wo, stride));
+    }
+  g_wgrad9 = w9; g_tn_glds = gl;
+  return m;
 }
 
 template <int TI, int TJ, bool USE_TR>
@@ -673,7 +687,7 @@ int g_tn_pair = 0;   // option "tn_pair": the two same-shape weight-gradient GEM
                      // waves per SIMD and 128 KB of LDS taken no BN-backward workgroup fits beside it any more: the main stream's streaming
                      // kernels stretch (bn_bwd_reduce 16.9 -> 29.6 us) and the step gets slower, 20.65 -> 21.05 ms
 bool gemm_tn_pair_ok(const GemmTN& a, const GemmTN& b, int splits) {
-  return a.mode == 1 && b.mode == 1 && a.use_tr && b.use_tr && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C &&
+  return !wgrad9_applies(a) && a.mode == 1 && b.mode == 1 && a.use_tr && b.use_tr && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C &&
          gemm_tn_glds_pair_ok(a.Kp, a.NI, a.NJ, a.C, splits);
 }
 int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
@@ -687,6 +701,7 @@ int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
   FEDFR_TRY(tn_prepare(p));
   int TI, TJ;
   if (p.mode == 1) {
+    if (wgrad9_applies(p)) return launch_wgrad9(p, splits, st);
     if (p.use_tr && gemm_tn_glds_applies(p.NI, p.NJ, p.C, 1)) return launch_tn_glds(p, splits, st);
     gemm_tn_tiles(p.NI, p.NJ, p.C, &TI, &TJ);
   } else {

@@ -157,7 +157,7 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
     const long long Mo = Bq * c.Hout * c.Hout;
     part = std::max(part, (long long)gemm_nt_stat_rows((int)Mo, c.Cout) * 2 * c.Cout);
     const int NJ = c.R * c.R * c.Cin;
-    slab = std::max(slab, (long long)gemm_tn_pick_splits((int)Mo, c.Cout, NJ, c.Cin) * c.Cout * NJ);
+    slab = std::max(slab, (long long)gemm_tn_max_splits((int)Mo, c.Cout, NJ, c.Cin, c.Hout, c.stride) * c.Cout * NJ);
   };
   upd_part(M0, 64);
   for (auto& k : n->blocks) {
@@ -274,7 +274,7 @@ static GemmTN wgrad_problem(const Ctx& c, const ConvD& cv, const bf16_t* in, con
 }
 static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy, hipStream_t st) {
   GemmTN p = wgrad_problem(c, cv, in, dy);
-  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C);
+  const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C, p.Wo, p.stride);
   float* dst = c.grads + cv.w_off;
   if (splits == 1) {
     p.out = dst;
@@ -288,7 +288,7 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
 static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const bf16_t* dya, const ConvD& cvb, const bf16_t* inb,
                        const bf16_t* dyb, hipStream_t st) {
   GemmTN a = wgrad_problem(c, cva, ina, dya), b = wgrad_problem(c, cvb, inb, dyb);
-  const int splits = gemm_tn_pick_splits(a.Kp, a.NI, a.NJ, a.C);
+  const int splits = gemm_tn_pick_splits(a.Kp, a.NI, a.NJ, a.C, a.Wo, a.stride);
   if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {
     FEDFR_TRY(conv_wgrad(c, cva, ina, dya, st));
     return conv_wgrad(c, cvb, inb, dyb, st);

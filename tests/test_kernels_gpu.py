@@ -157,9 +157,12 @@ def test_conv_dgrad_fused_bn_bwd_reduction(B, H, Cin, Cout, prelu):
         assert float((got[i] - ref).abs().max()) < 2e-4 * scale + 1e-2, i
 
 
-@pytest.mark.parametrize("use_tr", [1, 0])
-@pytest.mark.parametrize("B,H,Cin,Cout,k,s", CONV_CASES)
-def test_conv_wgrad(B, H, Cin, Cout, k, s, use_tr):
+@pytest.mark.parametrize("variant", ["default", "no_wgrad9", "scalar_frags"])
+@pytest.mark.parametrize("B,H,Cin,Cout,k,s", CONV_CASES + [(128, 14, 256, 256, 3, 1), (19, 14, 256, 512, 3, 1), (33, 28, 128, 256, 3, 1)])
+def test_conv_wgrad(B, H, Cin, Cout, k, s, variant):
+    """default: the nine-tap kernel (wgrad9.hip) on 3x3/s1 14x14 and 28x28 layers, the LDS-DMA / register-staged TN GEMMs elsewhere;
+    no_wgrad9: the TN GEMMs everywhere; scalar_frags: their validation fallback without transpose reads."""
+    use_tr, w9 = (0 if variant == "scalar_frags" else 1), (0 if variant == "no_wgrad9" else 1)
     x, w = _conv_inputs(B, H, Cin, Cout, k, s)
     Ho = H // s
     dy = bf(rnd((B, Cout, Ho, Ho), 7)).float()
@@ -171,12 +174,14 @@ def test_conv_wgrad(B, H, Cin, Cout, k, s, use_tr):
     nbytes = _C.lib().fedfr_conv2d_wgrad_ws_bytes(B, H, Cin, Cout, k, s)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev())
     _C.call("fedfr_set_option", b"tn_use_tr", use_tr)
+    _C.call("fedfr_set_option", b"wgrad9", w9)
     try:
         _C.call("fedfr_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, B, H, Cin, Cout, k, s,
                 _C.stream())
         torch.cuda.synchronize()
     finally:
         _C.call("fedfr_set_option", b"tn_use_tr", 1)
+        _C.call("fedfr_set_option", b"wgrad9", 1)
     # bf16 operands are exact, fp32 accumulation: only summation order differs
     assert relerr(dw, ref) < 2e-4
 

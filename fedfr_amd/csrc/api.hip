@@ -21,6 +21,7 @@ extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_tn_pair;
 extern int g_wgrad9;
+extern int g_wgrad_depth;
 extern int g_dgrad_parity;
 extern int g_fuse_bnapply;
 extern int g_fuse_bnred_next;
@@ -82,6 +83,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "tn_glds")) {
     g_tn_glds = value;          // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad_depth")) {
+    g_wgrad_depth = value < 2 ? 2 : value > kWgradDepth ? kWgradDepth : value;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "wgrad9")) {

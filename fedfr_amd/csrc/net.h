@@ -42,6 +42,10 @@ struct BlockD {
   long long x_off, a1_off, c1_off, a2_off, c2_off, d_off, out_off;   // bf16 element offsets in act
 };
 
+// dual-stream backward: generations of (dc2, dc1, dd) the weight-gradient stream may lag behind the main stream.  With 2 the main
+// stream waited 1.4 ms per step for weight gradients of two blocks ago (mostly in the 7x7 / early 14x14 stages, whose weight GEMMs
+// are long and whose main-stream kernels are short); 4 generations cost 1.2 GB more workspace.
+constexpr int kWgradDepth = 4;
 struct FedfrNet {
   int layers[4];
   int B, Bp, HW, F;                     // batch, batch padded to 8, input side, feature dim
@@ -57,7 +61,7 @@ struct FedfrNet {
   long long act_bf16_count, act_float_off_bytes, act_bytes;
   // workspace layout (byte offsets)
   size_t ws_bytes;
-  size_t ws_g[2], ws_t[6], ws_t2[3], ws_part, ws_slab, ws_small, ws_fc;   // ws_t2: second copies of t0/t2/t4 (dual-stream backward)
+  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_slab, ws_small, ws_fc;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
   mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;

@@ -174,7 +174,7 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
   auto wtake = [&](size_t bytes) { const size_t o = w; w += align_up(bytes, 256); return o; };
   for (int i = 0; i < 2; ++i) n->ws_g[i] = wtake(n->g_elems * 2);
   for (int i = 0; i < 6; ++i) n->ws_t[i] = wtake(n->g_elems * 2);
-  for (int i = 0; i < 3; ++i) n->ws_t2[i] = wtake(n->g_elems * 2);
+  for (int i = 0; i < 3 * (kWgradDepth - 1); ++i) n->ws_t2[i] = wtake(n->g_elems * 2);
   n->ws_part = wtake(n->part_floats * 4);
   n->ws_slab = wtake(n->slab_floats * 4 * 2);      // two regions: paired weight-gradient GEMMs write their slab sets side by side
   // small: coef[3*512] | finalize tmp [64*2*512] | dyfc f32 [B*F] | dyb bf16 [B*F] | dybt bf16 [F*Bp]
@@ -200,7 +200,7 @@ struct Ctx {
   bf16_t* g(int i) const { return reinterpret_cast<bf16_t*>(ws + n->ws_g[i]); }
   bf16_t* t(int i) const { return reinterpret_cast<bf16_t*>(ws + n->ws_t[i]); }
   // tensors read by the weight-gradient GEMMs (dc2 = slot 0, dc1 = slot 1, dd = slot 2), double buffered per block parity
-  bf16_t* tw(int slot, int par) const { return reinterpret_cast<bf16_t*>(ws + (par ? n->ws_t2[slot] : n->ws_t[slot * 2])); }
+  bf16_t* tw(int slot, int par) const { return reinterpret_cast<bf16_t*>(ws + (par ? n->ws_t2[(par - 1) * 3 + slot] : n->ws_t[slot * 2])); }
   float* save(const BnD& b, int which) const { return actf + b.save_off + (long long)which * b.C; }   // 0 scale 1 shift 2 mean 3 rstd
   const float* gamma(const BnD& b) const { return params + b.g_off; }
   const float* beta(const BnD& b) const { return params + b.b_off; }
@@ -387,6 +387,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   return FEDFR_OK;
 }
 
+int g_wgrad_depth = kWgradDepth;   // option "wgrad_depth" (2..kWgradDepth): generations of weight-gradient operands in flight
 int g_fuse_bnred_next = 1;   // option "fuse_bnred_next": a BN-backward apply pass also reduces its output for the BN that consumes it
 static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
                   const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, int fused_rows = 0, const BnD* next_bn = nullptr,
@@ -475,15 +476,15 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   int pend_rows = 0;                               // partial rows of the next bn3 already reduced by the apply pass that produced its dy
   FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0, 0, &last.bn3, A + last.c2_off, &pend_rows));
   int cur = 1;
-  hipEvent_t wdone[2] = {nullptr, nullptr};        // "all weight GEMMs of the block with this parity have finished"
+  hipEvent_t wdone[kWgradDepth] = {};              // "all weight GEMMs of the block of this generation have finished"
   for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
     const BlockD& k = n->blocks[bi];
     const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
-    const int par = bi & 1;
+    const int par = bi % g_wgrad_depth;
     const bf16_t* g = c.g(cur);
     bf16_t* gin = c.g(cur ^ 1);
     bf16_t *dc2 = c.tw(0, par), *da2 = c.t(1), *dc1 = c.tw(1, par), *da1 = c.t(3), *dd = c.tw(2, par), *dxd = c.t(5);
-    fk.wait(st, wdone[par]);                         // the weight GEMMs two blocks ago were the last readers of dc2/dc1/dd[par]
+    fk.wait(st, wdone[par]);                         // the weight GEMMs kWgradDepth blocks ago were the last readers of dc2/dc1/dd[par]
     // out = bn3(c2) + identity
     FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0, pend_rows));
     pend_rows = 0;

@@ -782,10 +782,51 @@ __global__ void reduce_slabs_kernel(float* dst, const float* slabs, int nsplit, 
     reinterpret_cast<float4*>(dst)[i] = a;
   }
 }
+// many slabs of a small tensor (the 64-channel layers' weight gradients arrive as 128 slabs of 147 KB): one thread per output walking
+// all slabs is a serial chain of 128 loads on 9 K threads (93 us).  Here 8 lanes share an output (slab s goes to lane s % 8, four loads
+// in flight each) and meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(float* dst, const float* slabs, int nsplit, size_t n4, const float* bias, int bias_n) {
+  __shared__ float4 red[8][32];
+  const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + o;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* src = reinterpret_cast<const float4*>(slabs) + i;
+    int sidx = q;
+    for (; sidx + 24 < nsplit; sidx += 32) {
+      const float4 b0 = src[(size_t)sidx * n4], b1 = src[(size_t)(sidx + 8) * n4], b2 = src[(size_t)(sidx + 16) * n4], b3 = src[(size_t)(sidx + 24) * n4];
+      a.x += (b0.x + b1.x) + (b2.x + b3.x); a.y += (b0.y + b1.y) + (b2.y + b3.y);
+      a.z += (b0.z + b1.z) + (b2.z + b3.z); a.w += (b0.w + b1.w) + (b2.w + b3.w);
+    }
+    for (; sidx < nsplit; sidx += 8) {
+      const float4 b = src[(size_t)sidx * n4];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+  }
+  red[q][o] = a;
+  __syncthreads();
+  if (q == 0 && i < n4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float4 b = red[k][o];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias) {
+      const int c = (int)((i * 4) % (size_t)bias_n);
+      a.x += bias[c]; a.y += bias[c + 1]; a.z += bias[c + 2]; a.w += bias[c + 3];
+    }
+    reinterpret_cast<float4*>(dst)[i] = a;
+  }
+}
 int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n, hipStream_t st) {
   FEDFR_REQUIRE(dst && slabs && nsplit > 0 && n > 0 && (n & 3) == 0, "reduce_slabs: bad args (n%%4)");
   if (bias) FEDFR_REQUIRE((bias_n & 3) == 0 && bias_n > 0, "reduce_slabs: bias_n%%4");
   const size_t n4 = n / 4;
+  if (nsplit >= 16 && n4 <= 65536) {
+    hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n);
+    FEDFR_LAUNCH_CHECK("reduce_slabs_wide");
+    return FEDFR_OK;
+  }
   const int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n);
   FEDFR_LAUNCH_CHECK("reduce_slabs");

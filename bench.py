@@ -29,10 +29,11 @@ import torch.distributed as dist
 FWD_GFLOP_PER_IMG = {"iresnet100": 24.18, "iresnet50": 12.62}       # SURVEY.md §8(d), measured on the reference
 BF16_DENSE_PEAK_TFLOPS = 2500.0                                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 # HBM bytes per launch from the PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction, collected with
-# tools/pmc_traffic.sh on the 256->256 @14x14 layer = 58 of iresnet100's 103 convs; committed as profiles/r01_pmc_hbm_traffic_256x256_14_v8.txt).
+# tools/pmc_traffic.sh on the 256->256 @14x14 layer = 58 of iresnet100's 103 convs; committed under profiles/, file named per entry).
 # bench.py cannot run rocprofv3 on itself, so `roofline.traffic` quotes that measurement for the kernel it names.
-PMC_TRAFFIC_MB = {"gemm_tn_glds_kernel<128,128>": {"fetch": 44.9, "write": 16.5, "algorithmic": 25.7 + 16.5},
-                  "conv3x3_glds_kernel<14,14>": {"fetch": 22.5, "write": 13.2, "algorithmic": 14.0 + 12.9}}
+PMC_TRAFFIC_MB = {"gemm_tn_glds_kernel<128,128>": {"fetch": 44.9, "write": 16.5, "algorithmic": 25.7 + 16.5, "file": "profiles/r01_pmc_hbm_traffic_256x256_14_v8.txt"},
+                  "conv3x3_glds_kernel<14,14>": {"fetch": 22.5, "write": 13.2, "algorithmic": 14.0 + 12.9, "file": "profiles/r01_pmc_hbm_traffic_256x256_14_v13.txt"},
+                  "wgrad9_kernel<32x64x9>": {"fetch": 25.8, "write": 18.9, "algorithmic": 25.7 + 18.9, "file": "profiles/r01_pmc_hbm_traffic_256x256_14_v13.txt"}}
 SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kernel<64,128>", "gemm_nt_kernel<64,64>",
               "gemm_tn_kernel<128,128>", "gemm_tn_kernel<128,64>", "gemm_tn_kernel<64,128>", "gemm_tn_kernel<64,64>",
               "conv3x3_halo2_kernel<128,14>", "conv3x3_halo2_kernel<128,28>", "conv3x3_halo2_kernel<64,*>", "conv3x3_halo_kernel<*>",
@@ -173,7 +174,7 @@ def main():
                         "traffic": (round((PMC_TRAFFIC_MB[SLOT_NAMES[slot]]["fetch"] + PMC_TRAFFIC_MB[SLOT_NAMES[slot]]["write"]) * 1e6)
                                     if SLOT_NAMES[slot] in PMC_TRAFFIC_MB else None),
                         "traffic_note": ("HBM bytes per launch on the 256->256 @14x14 layer (fetch %(fetch).1f MB + write %(write).1f MB, algorithmic %(algorithmic).1f MB): "
-                                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_hbm_traffic_256x256_14_v8.txt" % PMC_TRAFFIC_MB[SLOT_NAMES[slot]]
+                                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %(file)s" % PMC_TRAFFIC_MB[SLOT_NAMES[slot]]
                                          if SLOT_NAMES[slot] in PMC_TRAFFIC_MB else None),
                         "timing": "HIP events around each launch, single-stream pass of %d steps" % psteps,
                         "launches_per_step": n // psteps, "avg_launch_us": round(ms * 1e3 / n, 2),

@@ -12,7 +12,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_traffic/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"][:64]
-        if "gemm" in k or "conv3x3" in k or "reduce_slabs" in k or "glds" in k:
+        if "gemm" in k or "conv3x3" in k or "reduce_slabs" in k or "glds" in k or "wgrad9" in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     f = d.get("FETCH_SIZE", [0]); w = d.get("WRITE_SIZE", [0])

@@ -33,7 +33,10 @@ __device__ __forceinline__ int ew_block_id() {
 #endif
 }
 #ifndef EW_UNROLL_ALPHA
-#define EW_UNROLL_ALPHA 3
+#define EW_UNROLL_ALPHA 2   // bn_bwd_reduce<PReLU>
+#endif
+#ifndef EW_UNROLL_HEAVY
+#define EW_UNROLL_HEAVY 2   // bn_bwd_apply with PReLU or with the next BN's reduction
 #endif
 #ifndef EW_UNROLL
 #define EW_UNROLL 4       // rows whose loads are issued together in the streaming BN kernels
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 :
   const bool active = rl < rpp;
   if (!active && !NX) return;
   extern __shared__ float red[];                    // next BN's reduction (NX)
+  constexpr int UNR = (ALPHA || NX) ? EW_UNROLL_HEAVY : EW_UNROLL;   // rows of loads in flight: the heavier variants trade one for registers (two waves beside wgrad9)
   const int c0 = cl * 8;
   float ca[8], cA[8], cB[8], G[8], H[8], al[8], nmean[8];
   float nacc[2][8];                                  // sum dx | sum dx (x_next - mean_next), scaled by rstd_next at the end
@@ -625,16 +629,16 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 :
     }
   };
   int m = active ? mbeg + rl : mend;
-  for (; m + (EW_UNROLL - 1) * rpp < mend; m += EW_UNROLL * rpp) {      // loads of EW_UNROLL rows first (see bn_bwd_reduce)
-    uint4 vd[EW_UNROLL], vx[EW_UNROLL];
+  for (; m + (UNR - 1) * rpp < mend; m += UNR * rpp) {      // loads of UNR rows first (see bn_bwd_reduce)
+    uint4 vd[UNR], vx[UNR];
 #pragma unroll
-    for (int u = 0; u < EW_UNROLL; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       const size_t off = (size_t)(m + u * rpp) * p.C + c0;
       vd[u] = ew_ld16(p.dy + off);
       vx[u] = ew_ld16(p.x + off);
     }
 #pragma unroll
-    for (int u = 0; u < EW_UNROLL; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       one(m + u * rpp, vd[u], vx[u]);
       __builtin_amdgcn_sched_barrier(0);            // see bn_bwd_reduce
     }

@@ -62,6 +62,11 @@ def cpu_baseline(arch, batch=16, steps=2):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: everything else that writes to file descriptor 1 during the run (the RCCL
+    # version banner librccl prints at communicator creation, warnings of native libraries) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -213,7 +218,7 @@ def main():
         if use_dist:
             out["fedavg_round_ms"] = round(dt * 1e3, 3)
             out["fedavg_exchange_ms"] = round((dt - t_local) * 1e3, 3)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

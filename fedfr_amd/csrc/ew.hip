@@ -555,14 +555,14 @@ struct BnBwdDiv {
   FastDiv dHW, dW;
 };
 
-template <bool ALPHA, bool NX>
-__global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 : 5) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab, int shfl) {
+template <bool ALPHA, bool NX, bool ADD>
+__global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX || ADD) ? 4 : 5) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab, int shfl) {
   const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
   const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   const bool active = rl < rpp;
   if (!active && !NX) return;
   extern __shared__ float red[];                    // next BN's reduction (NX)
-  constexpr int UNR = (ALPHA || NX) ? EW_UNROLL_HEAVY : EW_UNROLL;   // rows of loads in flight: the heavier variants trade one for registers (two waves beside wgrad9)
+  constexpr int UNR = (ALPHA || NX || ADD) ? EW_UNROLL_HEAVY : EW_UNROLL;   // rows of loads in flight: the heavier variants trade one for registers (two waves beside wgrad9)
   const int c0 = cl * 8;
   float ca[8], cA[8], cB[8], G[8], H[8], al[8], nmean[8];
   float nacc[2][8];                                  // sum dx | sum dx (x_next - mean_next), scaled by rstd_next at the end
@@ -583,7 +583,9 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 :
   }
   const int bid = ew_block_id();
   const int mbeg = bid * slab, mend = min(p.M, mbeg + slab);
-  auto one = [&](int m, const uint4& vd, const uint4& vx) {
+  // every tensor of a row (dy, x, the identity-path addend, the next BN's input) is fetched in the batch in front of the arithmetic:
+  // loads issued inside the per-row code wait out a full memory latency each
+  auto one = [&](int m, const uint4& vd, const uint4& vx, const uint4& va, const uint4& vn) {
     const size_t off = (size_t)m * p.C + c0;
     float dy[8], x[8], o[8];
     unpack8(vd, dy);
@@ -597,9 +599,9 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 :
       }
       o[j] = ca[j] * dz + (cA[j] * x[j] + cB[j]);
     }
-    if (p.add) {
+    if (ADD) {
       float a[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.add + off), a);
+      unpack8(va, a);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] += a[j];
     }
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 :
     if (NX) {                                        // the next BN sees the bf16-rounded dx, exactly as its own reduce pass would
       float dn[8], xn[8];
       unpack8(ov, dn);
-      unpack8(*reinterpret_cast<const uint4*>(p.nx + off), xn);
+      unpack8(vn, xn);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         nacc[0][j] += dn[j];
@@ -628,24 +630,28 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX) ? 4 :
       }
     }
   };
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
   int m = active ? mbeg + rl : mend;
   for (; m + (UNR - 1) * rpp < mend; m += UNR * rpp) {      // loads of UNR rows first (see bn_bwd_reduce)
-    uint4 vd[UNR], vx[UNR];
+    uint4 vd[UNR], vx[UNR], va[UNR], vn[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const size_t off = (size_t)(m + u * rpp) * p.C + c0;
       vd[u] = ew_ld16(p.dy + off);
       vx[u] = ew_ld16(p.x + off);
+      va[u] = ADD ? *reinterpret_cast<const uint4*>(p.add + off) : zero4;
+      vn[u] = NX ? *reinterpret_cast<const uint4*>(p.nx + off) : zero4;
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      one(m + u * rpp, vd[u], vx[u]);
+      one(m + u * rpp, vd[u], vx[u], va[u], vn[u]);
       __builtin_amdgcn_sched_barrier(0);            // see bn_bwd_reduce
     }
   }
   for (; m < mend; m += rpp) {
     const size_t off = (size_t)m * p.C + c0;
-    one(m, *reinterpret_cast<const uint4*>(p.dy + off), *reinterpret_cast<const uint4*>(p.x + off));
+    one(m, *reinterpret_cast<const uint4*>(p.dy + off), *reinterpret_cast<const uint4*>(p.x + off),
+        ADD ? *reinterpret_cast<const uint4*>(p.add + off) : zero4, NX ? *reinterpret_cast<const uint4*>(p.nx + off) : zero4);
   }
   if (NX) {
     float nrstd[8];
@@ -677,13 +683,19 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   const dim3 grid(ceil_div(p.M, slab));
   const size_t lds = p.nx ? ew_colsum_lds(p.C, 2) : 0;
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
-  if (p.alpha) {
-    if (p.nx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
-  } else {
-    if (p.nx) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl);
+#define BWD_APPLY(A, N, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, N, D>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl)
+  const int variant = (p.alpha ? 4 : 0) | (p.nx ? 2 : 0) | (p.add ? 1 : 0);
+  switch (variant) {
+    case 0: BWD_APPLY(false, false, false); break;
+    case 1: BWD_APPLY(false, false, true); break;
+    case 2: BWD_APPLY(false, true, false); break;
+    case 3: BWD_APPLY(false, true, true); break;
+    case 4: BWD_APPLY(true, false, false); break;
+    case 5: BWD_APPLY(true, false, true); break;
+    case 6: BWD_APPLY(true, true, false); break;
+    default: BWD_APPLY(true, true, true); break;
   }
+#undef BWD_APPLY
   FEDFR_LAUNCH_CHECK("bn_bwd_apply");
   return FEDFR_OK;
 }

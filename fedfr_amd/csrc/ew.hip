@@ -3,6 +3,7 @@
 // blocks stride over row slabs; per-channel partials are reduced through LDS and written as one row per
 // block (deterministic, no atomics), then finalised in fp64 by a tiny second kernel.
 #include "ew.h"
+#include "gemm_tn_dev.h"
 
 #define EW_THREADS 256
 // streaming 16-B load of data this pass is the last reader of for a long while (EW_NT=1: non-temporal, keeps L2 / MALL for the data
@@ -1184,7 +1185,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
   __shared__ double red[8][32];
   const int co = blockIdx.x, k = threadIdx.x & 31, g = threadIdx.x >> 5;
   double s = 0.0;
-  for (int b = g; b < nblk; b += 8) s += (double)tmp[(size_t)b * 2048 + co * 32 + k];
+  int b = g;
+  for (; b + 24 < nblk; b += 32) {                  // four independent loads per trip: the walk over ~1000 blocks is a latency chain
+    const float v0 = tmp[(size_t)b * 2048 + co * 32 + k], v1 = tmp[(size_t)(b + 8) * 2048 + co * 32 + k];
+    const float v2 = tmp[(size_t)(b + 16) * 2048 + co * 32 + k], v3 = tmp[(size_t)(b + 24) * 2048 + co * 32 + k];
+    s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+  }
+  for (; b < nblk; b += 8) s += (double)tmp[(size_t)b * 2048 + co * 32 + k];
   red[g][k] = s;
   __syncthreads();
   if (g == 0 && k < 27) {
@@ -1195,10 +1202,89 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// ---- stem wgrad on MFMA --------------------------------------------------------------------------------------------------
+// dw[co][k] = sum_px dy[px][co] * col[px][k] as a GEMM with the pixels as the reduction: A = dy^T (transpose reads of the [px][co] tile,
+// gemm_tn_dev.h), B = col kept TRANSPOSED in LDS ([k][px], built by the threads from the fp32 NCHW input), split into a bf16 high and
+// low part (x = hi + lo to 2^-17: two MFMAs per tile keep the fp32-input accuracy the VALU kernel had).  The VALU kernel above was
+// compute-bound (244 us for 224 MB of traffic at B = 128); this one streams.
+#ifndef STEM_WGRAD_MFMA
+#define STEM_WGRAD_MFMA 1
+#endif
+#ifndef STEM_WGRAD_PX
+#define STEM_WGRAD_PX 128
+#endif
+constexpr int SW_PX = STEM_WGRAD_PX;          // pixels per stage (256 threads: SW_PX pixels x 256 / SW_PX slices of the 32 im2col columns)
+constexpr int SW_CPITCH = 2 * SW_PX + 16;     // colT row pitch in bytes: +16 B keeps the 16 k-rows of a b128 fragment read on distinct banks
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                              float* __restrict__ tmp, int B, int H, int W, int px_per_block) {
+  __shared__ __attribute__((aligned(16))) unsigned char sdy[SW_PX * 128];          // [px][64 co] bf16, chunk-swizzled (tn_swz<128>)
+  __shared__ __attribute__((aligned(16))) unsigned char scol[2][32 * SW_CPITCH];   // hi / lo: [k 0..31][px] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = B * H * W;
+  const int mbeg = blockIdx.x * px_per_block, mend = min(M, mbeg + px_per_block);
+  f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};                  // wave = co block of 16; two k blocks of 16
+  const int foff = tn_frag_off<128>(wave * 16, lane);
+  const int kg = lane >> 4, kn = lane & 15;
+  for (int mc = mbeg; mc < mend; mc += SW_PX) {
+    // dy tile: 256 px x 8 chunks of 16 B
+#pragma unroll
+    for (int i = 0; i < SW_PX / 32; ++i) {
+      const int idx = tid + 256 * i;
+      const int px = idx >> 3, c = idx & 7;
+      const int m = mc + px;
+      const uint4 v = m < mend ? *reinterpret_cast<const uint4*>(dy + (size_t)m * 64 + c * 8) : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(sdy + px * 128 + ((c ^ tn_swz<128>(px)) << 4)) = v;
+    }
+    {   // im2col of this thread's pixel, transposed: colT[k][px], k = (tap, ci), rows 27..31 zero
+      constexpr int KSL = 32 * SW_PX / 256;                 // im2col columns per thread
+      const int pxl = tid % SW_PX, k0 = (tid / SW_PX) * KSL;
+      const int m = mc + pxl;
+      const bool okm = m < mend;
+      const int mm = okm ? m : 0;
+      const int img = mm / (H * W), rem = mm - img * H * W;
+      const int h = rem / W, wq = rem - h * W;
+#pragma unroll
+      for (int kk = 0; kk < KSL; ++kk) {
+        const int k = k0 + kk;
+        const int tap = k / 3, ci = k - tap * 3;
+        const int r = tap / 3, sx = tap - r * 3;
+        const int hp = h + r - 1, wp = wq + sx - 1;
+        float f = 0.f;
+        if (k < 27 && okm && (unsigned)hp < (unsigned)H && (unsigned)wp < (unsigned)W) f = x[(((size_t)img * 3 + ci) * H + hp) * W + wp];
+        const bf16_t hi = f2bf(f);
+        const bf16_t lo = f2bf(f - bf2f(hi));
+        *reinterpret_cast<bf16_t*>(scol[0] + k * SW_CPITCH + pxl * 2) = hi;
+        *reinterpret_cast<bf16_t*>(scol[1] + k * SW_CPITCH + pxl * 2) = lo;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < SW_PX / 32; ++ks) {
+      const bf16x8_t a = tn_frag_tr<128>(sdy + (ks >> 1) * 64 * 128, foff, ks & 1);      // dy^T fragment: 16 co x 32 px
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int boff = (kb * 16 + kn) * SW_CPITCH + (ks * 32 + kg * 8) * 2;            // colT[k][px .. px+7]
+        const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(scol[0] + boff);
+        const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(scol[1] + boff);
+        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc[kb], 0, 0, 0);
+        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc[kb], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D[m = co][n = k]: lane holds co = wave 16 + (lane >> 4) 4 + r, k = kb 16 + (lane & 15)
+  float* o = tmp + (size_t)blockIdx.x * 2048;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(wave * 16 + (lane >> 4) * 4 + r) * 32 + kb * 16 + (lane & 15)] = acc[kb][r];
+}
+
 static int stem_px_per_block(int M) {
   int ppb = ceil_div(M, 1024);
-  ppb = (ppb + 63) / 64 * 64;
-  if (ppb < 64) ppb = 64;
+  const int q = STEM_WGRAD_MFMA ? SW_PX : 64;           // whole stages
+  ppb = (ppb + q - 1) / q * q;
+  if (ppb < q) ppb = q;
   return ppb;
 }
 int ew_stem_wgrad_blocks(int B, int H, int W) {
@@ -1210,7 +1296,8 @@ int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B
   const int M = B * H * W;
   const int ppb = stem_px_per_block(M);
   const int nblk = ceil_div(M, ppb);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dy, tmp, B, H, W, ppb);
+  if (STEM_WGRAD_MFMA) hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nblk), dim3(256), 0, st, x, dy, tmp, B, H, W, ppb);
+  else hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dy, tmp, B, H, W, ppb);
   FEDFR_LAUNCH_CHECK("stem_wgrad");
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, tmp, nblk, dw);
   FEDFR_LAUNCH_CHECK("stem_wgrad_reduce");

@@ -1,5 +1,6 @@
 // conv3x3_glds_kernel + launcher template; one translation unit per instantiation (see gemm_dev.h).
 #pragma once
+#include <type_traits>
 #include <algorithm>
 #include "gemm_dev.h"
 
@@ -16,6 +17,9 @@
 #define GLDS_STAMP(i) do { } while (0)
 #endif
 // timing ablations for tools/stamp (results are WRONG with any bit set): 1 no in-loop DMA, 2 no barrier, 4 no fragment reads
+#ifndef GLDS_RASTER
+#define GLDS_RASTER 1      // padded-raster M index with fragment reuse across vertical taps (14x14 / 28x28 instantiations)
+#endif
 #ifndef GLDS_ABLATE
 #define GLDS_ABLATE 0
 #endif
@@ -66,6 +70,12 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   constexpr int NRD = TM + TN, MPR = (TM * TN) / NRD;    // fragment reads per k-half; MFMAs threaded per read
   constexpr int TPI = W_ / R_;                          // tiles per image
   constexpr int A_BYTES = NPA * 1024, B_BYTES = BN * 128, NB = 4;
+  // RST: the GEMM's M index is the position q = y * PWL + x in the padded raster of the LDS image (the PWL - W_ filler columns of a
+  // row are computed and thrown away: 224 positions either way), so the fragment of 16-position block rb for vertical tap dy IS the
+  // fragment of block rb + dy * PWL / 16 for dy = 0: taps run dx-major and every A fragment is read from LDS once per horizontal tap
+  // (9-11 row-block reads per k-step and dx instead of 21): 90 instead of 162 fragment reads per channel chunk and wave.
+  constexpr bool RST = GLDS_RASTER && (W_ == 14 || W_ == 28) && R_ * PWL == 2 * MW;
+  constexpr int VG = PWL / 16, NRB = TM + 2 * VG;
   static_assert(PT <= 2 * MW && PT > MW && W_ % R_ == 0 && (R_ + 2) * PWL <= NPA * 8 && NPA % NW == 0 && (BN / 8) % NW == 0 && MPR >= 1 &&
                     !(FUSED && ONECHUNK), "tile geometry");
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -122,18 +132,33 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   // ---- fragment addresses
   // A-fragment byte offsets inside an image buffer for the three horizontal taps (vertical taps and the buffer are immediates)
   int a_adr[3][TM];
+  int a_base[3];                                        // RST: row-block 0 of this wave for the three horizontal taps; block rb adds rb * 2048
   bool m_ok[TM];
+  int m_pix[TM];                                        // pixel inside the tile (row of the staged output tile)
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
-    const int t = wm * MW + mi * 16 + l15;              // pixel inside the tile
-    m_ok[mi] = t < PT;
-    const int tt = m_ok[mi] ? t : 0;
-    const int y = tt / W_, x = tt - y * W_;
+    if constexpr (RST) {
+      const int q = wm * MW + mi * 16 + l15;
+      const int y = q / PWL, x = q - y * PWL;
+      m_ok[mi] = x < W_;
+      m_pix[mi] = m_ok[mi] ? y * W_ + x : 0;
+    } else {
+      const int t = wm * MW + mi * 16 + l15;              // pixel inside the tile
+      m_ok[mi] = t < PT;
+      m_pix[mi] = t;
+      const int tt = m_ok[mi] ? t : 0;
+      const int y = tt / W_, x = tt - y * W_;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int r = y * PWL + x + dx;
-      a_adr[dx][mi] = r * 128 + ((lg ^ (r & 7)) << 4);  // k-step 1 flips chunk bit 2: XOR 64
+      for (int dx = 0; dx < 3; ++dx) {
+        const int r = y * PWL + x + dx;
+        a_adr[dx][mi] = r * 128 + ((lg ^ (r & 7)) << 4);  // k-step 1 flips chunk bit 2: XOR 64
+      }
     }
+  }
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int r = wm * MW + l15 + dx;
+    a_base[dx] = r * 128 + ((lg ^ (r & 7)) << 4);
   }
   int b_addr[TN];
 #pragma unroll
@@ -202,8 +227,8 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   // prologue: image of chunk 0, weight tiles of taps 0..2; wait for the image and tap 0, fetch tap 0's first fragments
   issue_a(0, 0, true);
   issue_b(0, 0, 0, true);
-  issue_b(1, 0, 1, true);
-  issue_b(2, 0, 2, true);
+  issue_b(RST ? 3 : 1, 0, 1, true);                      // RST walks the taps dx-major: (dy, dx) = (0,0), (1,0), (2,0), (0,1), ...
+  issue_b(RST ? 6 : 2, 0, 2, true);
   bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
   if constexpr (XFORM) {                               // coefficient staging overlaps the first DMA round trip
     for (int i = tid; i < p.C; i += NT) {
@@ -216,8 +241,104 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   glds_wait_vmcnt<2 * BP>();
   if constexpr (XFORM) transform(0, 0);
   __builtin_amdgcn_s_barrier();
-  read_frags(f0a, f0b, 0, 0, sB, 0);
   GLDS_STAMP(1);
+  if constexpr (RST) {
+    bf16x8_t fa[2][NRB], fb[2][TN];
+    auto rd_a = [&](int ks, int rb, int dx, int boff) {
+      fa[ks][rb] = *reinterpret_cast<const bf16x8_t*>(sA + ((a_base[dx] ^ (ks * 64)) + rb * 2048 + boff));
+    };
+    auto rd_b = [&](int ks, const unsigned char* cB) {
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) fb[ks][ni] = *reinterpret_cast<const bf16x8_t*>(cB + (b_addr[ni] ^ (ks * 64)));
+    };
+#pragma unroll
+    for (int rb = 0; rb < TM; ++rb) rd_a(0, rb, 0, 0);
+    rd_b(0, sB);
+    int bbuf = 0;                                          // ring slot of the current tap
+    for (int cc2 = 0; cc2 < cpt; cc2 += 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cc = cc2 + h;
+        if (ONECHUNK && h == 1) break;
+        const bool more_c = cc + 1 < cpt;
+        // one tap, iteration IT of the dx-major order (dx = IT / 3, dy = IT % 3; weight slice = tap dy * 3 + dx)
+        auto tap_body = [&](auto IT_) {
+          constexpr int it = decltype(IT_)::value;
+          constexpr int dx = it / 3, dy = it % 3;
+          constexpr int itn = it == 8 ? 0 : it + 1, dxn = itn / 3, dyn = itn % 3;
+          constexpr int lo1 = dy == 0 ? 0 : TM + (dy - 1) * VG, hi1 = dy == 0 ? TM : TM + dy * VG;       // new row blocks of this tap
+          constexpr int lo2 = dyn == 0 ? 0 : TM + (dyn - 1) * VG, hi2 = dyn == 0 ? TM : TM + dyn * VG;   // ... of the next tap
+          constexpr int NR1 = hi1 - lo1 + TN, NR2 = hi2 - lo2 + TN, NM = TM * TN;
+          const int boff = (ONECHUNK ? 0 : h) * A_BYTES;
+          const int boffn = (ONECHUNK ? 0 : (it == 8 ? (h ^ 1) : h)) * A_BYTES;
+          const unsigned char* cB = sB + bbuf * B_BYTES;
+          if constexpr (XFORM) {
+            if (it == 1) {
+              writeback(ONECHUNK ? 0 : h, cc);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!ONECHUNK && it == 8 && more_c) {
+              transform(h ^ 1, cc + 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          // ---- first half: k-step 0 MFMAs; this tap's NEW k-step 1 fragments are read between them
+          if (!(GLDS_ABLATE & 4)) {
+#pragma unroll
+            for (int rb = lo1; rb < hi1; ++rb) rd_a(1, rb, dx, boff);
+            rd_b(1, cB);
+          }
+          GLDS_PRIO(1);
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) acc[ni][mi] = MFMA16(fb[0][ni], fa[0][mi + dy * VG], acc[ni][mi]);
+          GLDS_PRIO(0);
+#pragma unroll
+          for (int i = 0; i < NR1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (NM / NR1) > 0 ? (NM / NR1) : 1, 0);   // MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               // 1 DS read
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(GLDS_ABLATE & 1)) { if (!ONECHUNK && (it == 1 || it == 2)) glds_wait_vmcnt<BP + AP>(); else glds_wait_vmcnt<BP>(); }
+          if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- second half: k-step 1 MFMAs; the next tap's new k-step 0 fragments and this tap's DMA issue between them
+          const int nb = (bbuf + 1) & (NB - 1);
+          if (!(GLDS_ABLATE & 4)) {
+#pragma unroll
+            for (int rb = lo2; rb < hi2; ++rb) rd_a(0, rb, dxn, boffn);
+            rd_b(0, sB + nb * B_BYTES);
+          }
+          if (!(GLDS_ABLATE & 1)) {
+            constexpr int i3 = it + 3, j3 = i3 >= 9 ? i3 - 9 : i3;
+            const int cc3 = i3 >= 9 ? cc + 1 : cc;
+            issue_b((j3 % 3) * 3 + j3 / 3, cc3, (bbuf + 3) & (NB - 1), cc3 < cpt);
+            if (!ONECHUNK && it == 0) issue_a(cc + 1, h ^ 1, more_c);
+          }
+          GLDS_PRIO(1);
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) acc[ni][mi] = MFMA16(fb[1][ni], fa[1][mi + dy * VG], acc[ni][mi]);
+          GLDS_PRIO(0);
+          constexpr int NE = NR2 > BP ? NR2 : BP, MP2 = (NM / NE) > 0 ? (NM / NE) : 1;
+#pragma unroll
+          for (int i = 0; i < NE; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MP2, 0);
+            if (i < NR2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < BP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // 1 VMEM (LDS-DMA piece)
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          bbuf = nb;
+        };
+        tap_body(std::integral_constant<int, 0>{}); tap_body(std::integral_constant<int, 1>{}); tap_body(std::integral_constant<int, 2>{});
+        tap_body(std::integral_constant<int, 3>{}); tap_body(std::integral_constant<int, 4>{}); tap_body(std::integral_constant<int, 5>{});
+        tap_body(std::integral_constant<int, 6>{}); tap_body(std::integral_constant<int, 7>{}); tap_body(std::integral_constant<int, 8>{});
+      }
+    }
+  } else {
+  read_frags(f0a, f0b, 0, 0, sB, 0);
 
   // Per tap (K = 64 = two MFMA k-steps): [28 MFMA k-step 0 | ds_read k-step 1] [vmcnt + barrier: tap+1's weights landed, everybody
   // is done with tap-1's slot] [28 MFMA k-step 1 | ds_read tap+1 k-step 0 | DMA: weights of tap+3, at tap 0 the next chunk's image].
@@ -290,6 +411,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       }
     }
   }
+  }
   // drain the (zero-writing) tail DMAs before the staging buffer is reused
   glds_wait_vmcnt<0>();
   __syncthreads();
@@ -321,7 +443,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-      const int ml = wm * MW + mi * 16 + l15;
+      const int ml = m_pix[mi];
       const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
       bf16_t h[4];
 #pragma unroll

@@ -41,6 +41,8 @@ SIGNATURES = {
     "fedfr_conv2d_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_conv2d_dgrad_bnbwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp]),
+    "fedfr_stream_create_low_priority": (i32, [vp]),
+    "fedfr_stream_destroy": (i32, [vp]),
     "fedfr_conv2d_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "fedfr_conv2d_wgrad": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_conv2d_wgrad_pair": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),

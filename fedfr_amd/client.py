@@ -176,6 +176,22 @@ class Sequential_model(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # fused train step
 # ------------------------------------------------------------------------------------------------
+def _make_aux_stream(device):
+    """Second HIP stream of the dual-stream backward (None with FEDFR_DUAL_STREAM=0): created at the LOWEST priority the device offers
+    (through the C ABI: torch clamps stream priorities to [-1, 0], HIP has +1), so that workgroups of the critical path on the caller's
+    stream are dispatched first whenever both streams have work.  FEDFR_AUX_PRIORITY=0 keeps a default-priority torch stream."""
+    import os
+    if os.environ.get("FEDFR_DUAL_STREAM", "1") == "0":
+        return None
+    if os.environ.get("FEDFR_AUX_PRIORITY", "1") != "0":
+        import ctypes
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _C.call("fedfr_stream_create_low_priority", ctypes.byref(h))
+        return torch.cuda.ExternalStream(h.value, device=device)
+    return torch.cuda.Stream(device=device)
+
+
 class FusedTrainer:
     """One optimiser lifetime (= one FL round for one client: the reference re-creates SGD every round, F8).
 
@@ -207,8 +223,7 @@ class FusedTrainer:
             self.fc_grad = torch.empty_like(self.fc)
         self.first = True
         # weight-gradient GEMMs run on a second HIP stream (fedfr_net_backward2) unless FEDFR_DUAL_STREAM=0
-        import os
-        self.aux_stream = torch.cuda.Stream(device=bb.device) if os.environ.get("FEDFR_DUAL_STREAM", "1") != "0" else None
+        self.aux_stream = _make_aux_stream(bb.device)
         bb.refresh_shadows(True)
 
     def set_lr(self, lr: float):
@@ -307,7 +322,7 @@ class FusedHeadTrainer:
         self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
         self.head_mom = {}
         self.first = True
-        self.aux_stream = torch.cuda.Stream(device=bb.device) if os.environ.get("FEDFR_DUAL_STREAM", "1") != "0" else None
+        self.aux_stream = _make_aux_stream(bb.device)
         self._shadows_pending = None
         bb.refresh_shadows(True)
 

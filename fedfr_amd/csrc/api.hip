@@ -338,6 +338,31 @@ int fedfr_stem_wgrad(const float* x, const uint16_t* dy, float* dw, void* ws, in
   return ew_stem_wgrad(x, BF(dy), dw, (float*)ws, batch, hw, hw, ST(stream));
 }
 
+// ---- streams -------------------------------------------------------------------------------------------------
+// A HIP stream of the LOWEST priority the device offers, for the weight-gradient stream of fedfr_net_backward2: workgroups of the
+// critical path (forward, dgrad -> BatchNorm-backward chain, on the caller's ordinary stream) are then dispatched first whenever
+// both streams have work.  (torch.cuda.Stream clamps priorities to [-1, 0]; HIP offers +1.)  Destroy with fedfr_stream_destroy.
+int fedfr_stream_create_low_priority(void** stream) {
+  FEDFR_REQUIRE(stream, "stream_create_low_priority: null");
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+  if (e != hipSuccess) {
+    fedfr_set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+    return FEDFR_ERR_HIP;
+  }
+  *stream = (void*)s;
+  return FEDFR_OK;
+}
+int fedfr_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    fedfr_set_error("hipStreamDestroy failed");
+    return FEDFR_ERR_HIP;
+  }
+  return FEDFR_OK;
+}
+
 // ---- BN ----------------------------------------------------------------------------------------------------
 int fedfr_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta, float* rm,
                       float* rv, float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd,

@@ -99,6 +99,10 @@ int fedfr_conv2d_dgrad_bnbwd(const uint16_t* dy, const uint16_t* wd, uint16_t* d
                              int ksize, int stride, const uint16_t* bn_x, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const float* alpha, float* partials, int* fused_rows,
                              void* stream);
+/* lowest-priority HIP stream for the aux_stream argument of fedfr_net_backward2 (no reference counterpart; the reference trains on
+ * one stream).  Destroy with fedfr_stream_destroy. */
+int fedfr_stream_create_low_priority(void** stream);
+int fedfr_stream_destroy(void* stream);
 size_t fedfr_conv2d_wgrad_ws_bytes(int batch, int hin, int cin, int cout, int ksize, int stride);
 int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* ws, size_t ws_bytes, int batch, int hin,
                        int cin, int cout, int ksize, int stride, void* stream);

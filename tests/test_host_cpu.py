@@ -124,3 +124,18 @@ def test_checkpoint_interchange_with_reference():
         ref2.load_state_dict(torch.load(p2))                    # strict
         for k, v in ref2.state_dict().items():
             assert torch.equal(v, sd_ref[k]), k
+
+
+def test_asm_read_hazard_checker(tmp_path):
+    """tools/check_asm_reads.py (static check of the hand-scheduled `ds_read_b64_tr_b16` reads in wgrad9.hip / gemm_tn_glds.hip):
+    a register delivered by an in-flight read may not be touched before the next `s_waitcnt lgkmcnt(0)`."""
+    import subprocess, sys, os
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_asm_reads.py")
+    good = tmp_path / "good.s"
+    good.write_text("kern:\n\tds_read_b64_tr_b16 v[10:11], v4 offset:0\n\tv_mfma_f32_16x16x32_bf16 v[20:23], v[0:3], v[4:7], v[20:23]\n"
+                    "\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v30, v10\n")
+    bad = tmp_path / "bad.s"
+    bad.write_text("kern:\n\tds_read_b64_tr_b16 v[10:11], v4 offset:0\n\tv_mov_b32_e32 v30, v10\n\ts_waitcnt lgkmcnt(0)\n")
+    assert subprocess.run([sys.executable, tool, str(good)], capture_output=True).returncode == 0
+    r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "pending" in r.stdout

@@ -91,3 +91,9 @@ constexpr int kMaxShadowEntries = 112;     // 112 x 32 B: the by-value table sta
 struct ShadowEntry { unsigned long long src, dst; unsigned short cout64, cin64, rs, pad; unsigned first_blk; };   // offsets in elements
 struct ShadowTable { int n; int pad; ShadowEntry e[kMaxShadowEntries]; };
 int ew_weight_dgrad_shadow_multi(const float* params, bf16_t* shadow, ShadowTable& t, hipStream_t st);
+// eval-mode (scale, shift) of many BatchNorms in one launch: offsets (fp32 elements) into the flat parameter / buffer / saved-statistics
+// tensors; g_off < 0: weight = 1 (by-value table, one launch per table-full)
+constexpr int kMaxBnEvalEntries = 160;      // 160 x 24 B stays under the 4 KiB kernel-argument limit
+struct BnEvalEntry { int C, g_off, b_off, rm_off, rv_off, save_off; };
+struct BnEvalTable { int n; float eps; BnEvalEntry e[kMaxBnEvalEntries]; };
+int ew_bn_eval_coeffs_multi(const float* params, const float* bufs, float* save, const BnEvalTable& t, hipStream_t st);

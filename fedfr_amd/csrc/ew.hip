@@ -249,6 +249,22 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
   scale[c] = g * rstd;
   shift[c] = b - rm[c] * g * rstd;
 }
+__global__ __launch_bounds__(256) void bn_eval_coeffs_multi_kernel(const float* __restrict__ params, const float* __restrict__ bufs,
+                                                                  float* __restrict__ save, BnEvalTable t) {
+  const BnEvalEntry e = t.e[blockIdx.x];
+  for (int c = blockIdx.y * 256 + threadIdx.x; c < e.C; c += gridDim.y * 256) {
+    const float rstd = 1.f / sqrtf(bufs[e.rv_off + c] + t.eps);
+    const float g = e.g_off >= 0 ? params[e.g_off + c] : 1.f, b = params[e.b_off + c];
+    save[e.save_off + c] = g * rstd;                                   // scale
+    save[e.save_off + e.C + c] = b - bufs[e.rm_off + c] * g * rstd;    // shift
+  }
+}
+int ew_bn_eval_coeffs_multi(const float* params, const float* bufs, float* save, const BnEvalTable& t, hipStream_t st) {
+  FEDFR_REQUIRE(params && bufs && save && t.n > 0 && t.n <= kMaxBnEvalEntries, "bn_eval_coeffs_multi: bad args");
+  hipLaunchKernelGGL(bn_eval_coeffs_multi_kernel, dim3(t.n, 2), dim3(256), 0, st, params, bufs, save, t);
+  FEDFR_LAUNCH_CHECK("bn_eval_coeffs_multi");
+  return FEDFR_OK;
+}
 int ew_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                       float* scale, float* shift, hipStream_t st) {
   FEDFR_REQUIRE(C > 0 && rm && rv && scale && shift, "bn_eval_coeffs: bad args");

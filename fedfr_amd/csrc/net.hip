@@ -302,7 +302,32 @@ static int bn_coeffs(const Ctx& c, const BnD& b, int P, double count, bool train
   if (training)
     return ew_bn_finalize(c.part(), P, b.C, count, c.gamma(b), c.beta(b), c.bufs + b.rm_off, c.bufs + b.rv_off, kBnMomentum,
                           kBnEps, c.save(b, 0), c.save(b, 1), c.save(b, 2), c.save(b, 3), c.ftmp(), c.st);
-  return ew_bn_eval_coeffs(b.C, c.gamma(b), c.beta(b), c.bufs + b.rm_off, c.bufs + b.rv_off, kBnEps, c.save(b, 0), c.save(b, 1), c.st);
+  return FEDFR_OK;      // eval mode: every BatchNorm's (scale, shift) was computed up front by eval_coeffs_all (one launch)
+}
+// eval-mode coefficients of all 2-D BatchNorms of the network in one launch (they depend on parameters and running statistics only;
+// one small kernel per BatchNorm cost 154 launches = 0.6 ms of a 5.7 ms forward at batch 128)
+static int eval_coeffs_all(const Ctx& c) {
+  BnEvalTable t{};
+  t.eps = kBnEps;
+  auto flush = [&]() -> int {
+    if (t.n == 0) return FEDFR_OK;
+    const int rc = ew_bn_eval_coeffs_multi(c.params, c.bufs, c.actf, t, c.st);
+    t.n = 0;
+    return rc;
+  };
+  auto add = [&](const BnD& b) -> int {
+    if (t.n == kMaxBnEvalEntries) FEDFR_TRY(flush());
+    BnEvalEntry& e = t.e[t.n++];
+    e.C = b.C; e.g_off = (int)b.g_off; e.b_off = (int)b.b_off; e.rm_off = (int)b.rm_off; e.rv_off = (int)b.rv_off; e.save_off = (int)b.save_off;
+    return FEDFR_OK;
+  };
+  FEDFR_TRY(add(c.n->stem_bn));
+  for (const auto& k : c.n->blocks) {
+    FEDFR_TRY(add(k.bn1)); FEDFR_TRY(add(k.bn2)); FEDFR_TRY(add(k.bn3));
+    if (k.has_ds) FEDFR_TRY(add(k.bnds));
+  }
+  FEDFR_TRY(add(c.n->bn2));
+  return flush();
 }
 static int apply(const Ctx& c, const bf16_t* x1, const BnD& b1, const float* alpha, const bf16_t* x2, const BnD* b2, bf16_t* y,
                  int M, bool stats, int nchw_hw = 0) {
@@ -345,6 +370,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   const int B = n->B, HW = n->HW;
   const int M0 = B * HW * HW;
   bf16_t* A = c.actb;
+  if (!tr) FEDFR_TRY(eval_coeffs_all(c));
   // stem: conv -> BN -> PReLU   (iresnet.py:160-162)
   FEDFR_TRY(ew_stem_fwd(x, params + n->stem.w_off, A + n->c0_off, tr ? c.part() : nullptr, B, HW, HW, st));
   FEDFR_TRY(bn_coeffs(c, n->stem_bn, ew_stem_stat_rows(B, HW, HW), (double)M0, tr));

@@ -21,6 +21,7 @@ extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_tn_pair;
 extern int g_wgrad9;
+extern int g_eval_fuse;
 extern int g_wgrad_depth;
 extern int g_dgrad_parity;
 extern int g_fuse_bnapply;
@@ -87,6 +88,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "wgrad_depth")) {
     g_wgrad_depth = value < 2 ? 2 : value > kWgradDepth ? kWgradDepth : value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "eval_fuse")) {
+    g_eval_fuse = value ? 1 : 0;   // eval-mode forward: BatchNorm (+PReLU, +identity, +next bn1) in the conv epilogues
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "wgrad9")) {

@@ -439,6 +439,16 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
     for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
+  float esc_[TN][4], esh_[TN][4], eal_[TN][4];
+  if (p.esc) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
+        esc_[ni][q] = p.esc[n]; esh_[ni][q] = p.esh[n]; eal_[ni][q] = p.ealpha ? p.ealpha[n] : 1.f;
+      }
+  }
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -448,7 +458,12 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       bf16_t h[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        h[q] = f2bf(acc[ni][mi][q]);
+        float a = acc[ni][mi][q];
+        if (p.esc) {                                         // eval-mode BatchNorm (+PReLU) of the output, on the fp32 accumulator
+          a = a * esc_[ni][q] + esh_[ni][q];
+          if (p.ealpha) a = a > 0.f ? a : eal_[ni][q] * a;
+        }
+        h[q] = f2bf(a);
         const float v = m_ok[mi] ? bf2f(h[q]) : 0.f;
         ssum[ni][q] += v;
         ssq[ni][q] += v * v;
@@ -485,7 +500,27 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   if constexpr (!FUSED) {
     for (int idx = tid; idx < PT * CPR; idx += NT) {
       const int row = idx / CPR, c = idx - row * CPR;
-      *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n0 + c * 8) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+      uint4 v = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+      const size_t go = (size_t)(m0 + row) * p.ldc + n0 + c * 8;
+      if (p.eadd || p.Cb2) {
+        float f[8];
+        unpack8(v, f);
+        if (p.eadd) {                                        // + identity path (one more bf16 rounding than the separate bn_apply pass)
+          float g[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.eadd + go), g);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) f[q] += g[q];
+          v = pack8(f);
+          unpack8(v, f);
+        }
+        if (p.Cb2) {                                         // the next block's bn1 of the (bf16) output
+          float y2[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) y2[q] = f[q] * p.esc2[n0 + c * 8 + q] + p.esh2[n0 + c * 8 + q];
+          *reinterpret_cast<uint4*>(p.Cb2 + go) = pack8(y2);
+        }
+      }
+      *reinterpret_cast<uint4*>(p.Cb + go) = v;
     }
   } else {
     // ---- fused BN-backward reduction (ew_bn_bwd_reduce on this tile): thread owns chunk column c (8 channels) of rows rg, rg + RG, ...
@@ -551,6 +586,8 @@ static int launch_glds(GemmNT p, hipStream_t st) {
                 "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
   FEDFR_REQUIRE(FUSED == (p.bpart != nullptr), "conv3x3_glds: fused / plain variant mismatch");
   FEDFR_REQUIRE(XFORM == (p.tsc != nullptr) && (!XFORM || (p.tsh && p.C <= 256)), "conv3x3_glds: input-transform variant mismatch");
+  FEDFR_REQUIRE(!(p.esc || p.eadd || p.Cb2) || (!FUSED && p.ldc == p.N && (!p.esc || p.esh) && (!p.Cb2 || (p.esc2 && p.esh2))),
+                "conv3x3_glds: output epilogue needs the plain variant, ldc == N and complete coefficient sets");
   if (FUSED) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");

@@ -41,6 +41,13 @@ struct GemmNT {
   // stride-2 dgrad by output-parity class (gemm.hip: nt_launch_parity): this launch computes the output pixels (2 h2 + par_h, 2 w2 + par_w)
   // of a [img][outH][outW] map with only the filter taps that reach a real (non-inserted-zero) input: 1, 2, 2 or 4 of the 9
   int par_on, par_h, par_w, outH, outW;
+  // optional OUTPUT epilogue of the LDS-DMA conv kernels (eval-mode forward, where the BatchNorm that follows a conv is a known
+  // per-channel affine): y = acc * esc[n] + esh[n] on the fp32 accumulators, PReLU with ealpha[n] if given, + eadd[m][n] (bf16, the
+  // identity path) if given; Cb2 (optional) receives y2 = y * esc2[n] + esh2[n] (the next block's bn1 of this block's output)
+  const float *esc, *esh, *ealpha;
+  const bf16_t* eadd;
+  const float *esc2, *esh2;
+  bf16_t* Cb2;
   unsigned long long* dbg;   // diagnostics builds only (tools/stamp_halo2.hip): per-block in-kernel clock stamps
 };
 
@@ -62,6 +69,8 @@ struct GemmTN {
 // rows of partial stats the NT kernel writes for a given M (needed to size / finalize)
 int gemm_nt_stat_rows(int M, int N);
 bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride);
+// shapes whose conv runs on an LDS-DMA kernel that implements the output epilogue (esc / eadd / Cb2)
+bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
 // number of splits / workspace helpers
 int gemm_nt_pick_splits(int M, int N, int K);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st);

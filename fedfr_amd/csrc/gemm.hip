@@ -357,6 +357,16 @@ int gemm_nt_stat_rows(int M, int N) {
 
 int g_dgrad_parity = 1;   // option "dgrad_parity": stride-2 3x3 dgrad as 4 output-parity classes (9/4 instead of 9 taps per output pixel)
 
+// shapes whose conv runs on a plain LDS-DMA kernel instantiation (mirrors the dispatch in gemm_nt_launch_one): those implement the
+// eval-mode output epilogue (GemmNT::esc / eadd / Cb2)
+bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride) {
+  if (g_conv_halo < 4 || ksize != 3 || stride != 1 || W <= 0 || M % (W * W) != 0 || nt_bm(M, N) != 128) return false;
+  if (W == 112) return C == 64 && N == 64;
+  if (W == 56) return (C == 64 && (N == 64 || N == 128)) || (C == 128 && N == 64);
+  if (W == 14 || W == 28) return N % 128 == 0 && C % 128 == 0;
+  return false;
+}
+
 // shapes whose forward conv can take its input's BatchNorm(+PReLU) as an LDS-image transform (conv_glds_x.hip)
 bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride) {
   if (g_conv_halo < 4 || ksize != 3 || stride != 1 || M % (W * W) != 0 || C > 256) return false;
@@ -405,6 +415,9 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
     p.a_bytes = (unsigned)ab;
     p.b_bytes = (unsigned)bb;
   }
+  if (p.esc || p.eadd || p.Cb2)
+    FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.pad == 1 && p.H == p.W && p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && !p.bpart && !p.tsc &&
+                  !p.stats && !p.par_on && gemm_nt_conv_epilogue_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: output epilogue is not available for this convolution");
   if (p.tsc) {
     FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.H == p.W && p.H == p.Ho && p.Cb && splits == 1 && !p.bpart &&
                   gemm_nt_conv_xform_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: input transform is not available for this convolution");

@@ -215,6 +215,24 @@ static int conv_fwd(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* out
   p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = stats ? c.part() : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
+// eval mode: the BatchNorm (+PReLU, + identity, + the next block's bn1 as a second output) that follows a conv applied in the conv
+// kernel's epilogue (GemmNT::esc ...), for the layers whose kernel implements it
+int g_eval_fuse = 1;   // option "eval_fuse"
+static bool conv_epilogue_ok(const Ctx& c, const ConvD& cv) {
+  return g_eval_fuse && gemm_nt_conv_epilogue_ok(cv.Hin, cv.Cin, cv.Cout, c.n->B * cv.Hout * cv.Hout, cv.R, cv.stride);
+}
+static int conv_fwd_ep(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* out, const BnD& bn, const float* alpha, const bf16_t* add,
+                       bf16_t* out2, const BnD* bn2) {
+  GemmNT p{};
+  p.A = in; p.B = c.shadow + cv.w_off;
+  p.M = c.n->B * cv.Hout * cv.Hout; p.N = cv.Cout; p.K = cv.R * cv.R * cv.Cin;
+  p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = cv.R;
+  p.stride = cv.stride; p.pad = 1; p.up = 1;
+  p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = nullptr;
+  p.esc = c.save(bn, 0); p.esh = c.save(bn, 1); p.ealpha = alpha; p.eadd = add;
+  if (out2) { p.Cb2 = out2; p.esc2 = c.save(*bn2, 0); p.esh2 = c.save(*bn2, 1); }
+  return gemm_nt_launch(p, 1, c.st);
+}
 // conv(act(bn(raw))): where the LDS-DMA kernel can normalise its input image itself the separate bn_apply pass disappears; the kernel
 // still leaves the normalised activation in `a` when training (the weight-gradient GEMM reads it), not in eval mode.
 int g_fuse_bnapply = 0;   // option "fuse_bnapply": BN(+PReLU) of a conv's input applied inside the LDS-DMA conv kernel (no bn_apply pass).  Off: measured
@@ -376,8 +394,38 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   FEDFR_TRY(bn_coeffs(c, n->stem_bn, ew_stem_stat_rows(B, HW, HW), (double)M0, tr));
   FEDFR_TRY(apply(c, A + n->c0_off, n->stem_bn, params + n->stem_alpha_off, nullptr, nullptr, A + n->a0_off, M0, tr));
   int Pprev = ew_bn_apply_grid(M0, 64);
-  for (const auto& k : n->blocks) {
+  bool a1_ready = false;                    // eval: the previous block's conv2 epilogue already wrote this block's bn1(x)
+  for (size_t bi = 0; bi < n->blocks.size(); ++bi) {
+    const BlockD& k = n->blocks[bi];
     const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
+    if (!tr && g_eval_fuse) {
+      // ---- eval mode: BatchNorms are known affines -> they ride in the conv epilogues where the kernel has one
+      if (!a1_ready) FEDFR_TRY(apply(c, A + k.x_off, k.bn1, nullptr, nullptr, nullptr, A + k.a1_off, Mi, false));
+      a1_ready = false;
+      if (conv_epilogue_ok(c, k.conv1)) {
+        FEDFR_TRY(conv_fwd_ep(c, k.conv1, A + k.a1_off, A + k.a2_off, k.bn2, params + k.alpha_off, nullptr, nullptr, nullptr));
+      } else {
+        FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, false));
+        FEDFR_TRY(apply(c, A + k.c1_off, k.bn2, params + k.alpha_off, nullptr, nullptr, A + k.a2_off, Mi, false));
+      }
+      if (k.has_ds) FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, false));
+      if (conv_epilogue_ok(c, k.conv2)) {
+        const bf16_t* idn = A + k.x_off;
+        if (k.has_ds) {                                                 // identity = bnds(ds(x)), materialised in the (unused) c2 slot
+          FEDFR_TRY(apply(c, A + k.d_off, k.bnds, nullptr, nullptr, nullptr, A + k.c2_off, Mo, false));
+          idn = A + k.c2_off;
+        }
+        const BlockD* nx = bi + 1 < n->blocks.size() ? &n->blocks[bi + 1] : nullptr;
+        FEDFR_TRY(conv_fwd_ep(c, k.conv2, A + k.a2_off, A + k.out_off, k.bn3, nullptr, idn, nx ? A + nx->a1_off : nullptr, nx ? &nx->bn1 : nullptr));
+        a1_ready = nx != nullptr;
+      } else {
+        FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, false));
+        if (k.has_ds) FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.d_off, &k.bnds, A + k.out_off, Mo, false));
+        else FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.x_off, nullptr, A + k.out_off, Mo, false));
+      }
+      Pprev = ew_bn_apply_grid(Mo, k.Cout);
+      continue;
+    }
     // bn1(x)
     FEDFR_TRY(bn_coeffs(c, k.bn1, Pprev, (double)Mi, tr));
     // a1 = bn1(x) -> conv1 -> bn2 -> a2 = prelu(bn2(c1)) -> conv2(stride) -> bn3

@@ -63,7 +63,8 @@ int fedfr_net_tensor_info(const fedfr_net_t* net, int i, char* name, int name_ca
 /* debug/inspection: where a saved activation lives inside `act` (bf16 element offset, [rows][channels] NHWC view).
  * block < 0: which = 0 stem conv output, 1 stem activation, 2 flattened bn2 output [B][fc_in] (NCHW order);
  * block >= 0: which = 0 block input, 1 bn1 out, 2 conv1 out, 3 prelu(bn2) out, 4 conv2 out, 5 downsample conv out
- * (offset -1 if the block has none), 6 block output. */
+ * (offset -1 if the block has none), 6 block output.  An eval-mode forward (training = 0) applies the BatchNorms in the conv epilogues
+ * where the kernel has one and then does not store the raw conv outputs (2, 4); fedfr_set_option("eval_fuse", 0) restores them. */
 int fedfr_net_act_info(const fedfr_net_t* net, int block, int which, long long* offset, int* rows, int* channels);
 /* refresh the bf16 weight shadows from fp32 params (after load_state_dict / an external optimizer step);
  * fwd_shadow_too = 0 when fedfr_sgd_step already wrote the mirror region. */

@@ -76,9 +76,13 @@ def test_forward_layerwise_vs_bf16_oracle(arch, batch, training):
     m, sd, layers = make_model(arch)
     x = R.closed_form_images(batch)
     m.train(training)
-    with torch.no_grad():
-        f = m._run_forward(x.to(DEV), training=training)
-    torch.cuda.synchronize()
+    _C.call("fedfr_set_option", b"eval_fuse", 0)       # every activation is inspected: the fused eval epilogues do not store c1 / c2
+    try:
+        with torch.no_grad():
+            f = m._run_forward(x.to(DEV), training=training)
+        torch.cuda.synchronize()
+    finally:
+        _C.call("fedfr_set_option", b"eval_fuse", 1)
     plan = m._plan(batch)
     nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])    # noqa: E731
     sdc = {k: v.clone() for k, v in sd.items()}
@@ -591,6 +595,35 @@ def test_full_size_step_invariants_r100_b128(monkeypatch):
     # (3)
     nbt = [v for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")]
     assert len(nbt) == 154 and len({int(v) for v in nbt}) == 1
+
+
+@pytest.mark.parametrize("arch,batch", [("iresnet18", 128), ("iresnet50", 64)])
+def test_eval_forward_fused_epilogues_match_separate_passes(arch, batch):
+    """Eval-mode forward at batches where the LDS-DMA conv kernels run: BatchNorm (+PReLU, + identity, + the next block's bn1) applied in
+    the conv epilogues (option eval_fuse, default) against the separate bn_apply passes.  The fused path keeps the conv output in fp32
+    until after the affine (one bf16 rounding fewer) and rounds once more after the identity add: agreement at the bf16-storage level, and both
+    against the fp32 oracle's embedding at the usual bf16-storage tolerance."""
+    m, sd, layers = make_model(arch, tag=5.0)
+    m.eval()
+    x = R.closed_form_images(batch).to(DEV)
+    outs = {}
+    for fuse in (1, 0):
+        _C.call("fedfr_set_option", b"eval_fuse", fuse)
+        try:
+            with torch.no_grad():
+                outs[fuse] = m(x).float().clone()
+            torch.cuda.synchronize()
+        finally:
+            _C.call("fedfr_set_option", b"eval_fuse", 1)
+    assert torch.isfinite(outs[1]).all()
+    # two bf16-storage pipelines with different rounding points: each sits ~1.2e-2 (iresnet50) from the fp32 embedding (DESIGN.md section 3)
+    assert rel(outs[1], outs[0]) < 3e-2, rel(outs[1], outs[0])
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = R.iresnet_forward(sd, R.closed_form_images(min(batch, 16)), layers, training=False)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert rel(outs[1][: ref.shape[0]], ref) < 4e-2, rel(outs[1][: ref.shape[0]], ref)
+    assert rel(outs[0][: ref.shape[0]], ref) < 4e-2
 
 
 def test_heads_vs_reference():

@@ -720,78 +720,102 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
 // =====================================================================================================
 // BatchNorm1d on fp32 [B][C]
 // =====================================================================================================
-__global__ void bn1d_fwd_kernel(const float* x, float* y, int B, int C, const float* gamma, const float* beta,
+// BatchNorm1d kernels: 64 channels x BN1D_RG row groups per workgroup (one thread per channel walking all B rows three times was a
+// 60 us latency chain for a 128 x 512 tensor); fp64 sums, the row groups meet in LDS.
+constexpr int BN1D_RG = 8;
+__device__ __forceinline__ double bn1d_rg_sum(double v, double (*red)[64], int rg, int cl) {
+  __syncthreads();                                   // previous use of red is over
+  red[rg][cl] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < BN1D_RG; ++i) t += red[i][cl];
+  return t;
+}
+__global__ __launch_bounds__(64 * BN1D_RG) void bn1d_fwd_kernel(const float* x, float* y, int B, int C, const float* gamma, const float* beta,
                                 float* rm, float* rv, float momentum, float eps, int training, float* save_mean,
                                 float* save_rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[BN1D_RG][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = min(blockIdx.x * 64 + cl, C - 1);
+  const bool own = blockIdx.x * 64 + cl < C && rg == 0;
   float mean, rstd;
   if (training) {
     double s = 0.0;
-    for (int b = 0; b < B; ++b) s += (double)x[(size_t)b * C + c];
-    const double mu = s / B;
+    for (int b = rg; b < B; b += BN1D_RG) s += (double)x[(size_t)b * C + c];
+    const double mu = bn1d_rg_sum(s, red, rg, cl) / B;
     double v = 0.0;
-    for (int b = 0; b < B; ++b) {
+    for (int b = rg; b < B; b += BN1D_RG) {
       const double d = (double)x[(size_t)b * C + c] - mu;
       v += d * d;
     }
+    v = bn1d_rg_sum(v, red, rg, cl);
     const double var = v / B;
     mean = (float)mu;
     rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const double unb = B > 1 ? v / (B - 1) : var;
-    rm[c] = (float)((1.0 - momentum) * (double)rm[c] + momentum * mu);
-    rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unb);
+    if (own) {
+      const double unb = B > 1 ? v / (B - 1) : var;
+      rm[c] = (float)((1.0 - momentum) * (double)rm[c] + momentum * mu);
+      rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unb);
+    }
   } else {
     mean = rm[c];
     rstd = 1.f / sqrtf(rv[c] + eps);
   }
-  if (save_mean) {
+  if (save_mean && own) {
     save_mean[c] = mean;
     save_rstd[c] = rstd;
   }
+  if (blockIdx.x * 64 + cl >= C) return;
   const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-  for (int b = 0; b < B; ++b) y[(size_t)b * C + c] = (x[(size_t)b * C + c] - mean) * rstd * g + bt;
+  for (int b = rg; b < B; b += BN1D_RG) y[(size_t)b * C + c] = (x[(size_t)b * C + c] - mean) * rstd * g + bt;
 }
 
 int ew_bn1d_fwd(const float* x, float* y, int B, int C, const float* gamma, const float* beta, float* rm, float* rv,
                 float momentum, float eps, int training, float* save_mean, float* save_rstd, hipStream_t st) {
   FEDFR_REQUIRE(x && y && B > 0 && C > 0 && rm && rv, "bn1d_fwd: bad args");
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, x, y, B, C, gamma, beta, rm, rv, momentum, eps,
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, x, y, B, C, gamma, beta, rm, rv, momentum, eps,
                      training, save_mean, save_rstd);
   FEDFR_LAUNCH_CHECK("bn1d_fwd");
   return FEDFR_OK;
 }
 
-__global__ void bn1d_bwd_kernel(const float* dy, const float* x, float* dx, int B, int C, const float* gamma,
+__global__ __launch_bounds__(64 * BN1D_RG) void bn1d_bwd_kernel(const float* dy, const float* x, float* dx, int B, int C, const float* gamma,
                                 const float* mean, const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb,
                                 bf16_t* dxbt, int ldt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[BN1D_RG][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = min(blockIdx.x * 64 + cl, C - 1);
+  const bool valid = blockIdx.x * 64 + cl < C, own = valid && rg == 0;
   const float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) {
+  for (int b = rg; b < B; b += BN1D_RG) {
     const float d = dy[(size_t)b * C + c];
     s1 += d;
     s2 += (double)d * (double)((x[(size_t)b * C + c] - mu) * rs);
   }
+  s1 = bn1d_rg_sum(s1, red, rg, cl);
+  s2 = bn1d_rg_sum(s2, red, rg, cl);
   const float m1 = (float)(s1 / B), m2 = (float)(s2 / B);
-  if (dbeta) dbeta[c] = (float)s1;
+  if (dbeta && own) dbeta[c] = (float)s1;
   double cs = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float xh = (x[(size_t)b * C + c] - mu) * rs;
-    const float v = g * rs * (dy[(size_t)b * C + c] - m1 - xh * m2);
-    dx[(size_t)b * C + c] = v;
-    cs += v;
-    if (dxb) dxb[(size_t)b * C + c] = f2bf(v);
-    if (dxbt) dxbt[(size_t)c * ldt + b] = f2bf(v);
-  }
-  if (dx_colsum) dx_colsum[c] = (float)cs;
+  if (valid)
+    for (int b = rg; b < B; b += BN1D_RG) {
+      const float xh = (x[(size_t)b * C + c] - mu) * rs;
+      const float v = g * rs * (dy[(size_t)b * C + c] - m1 - xh * m2);
+      dx[(size_t)b * C + c] = v;
+      cs += v;
+      if (dxb) dxb[(size_t)b * C + c] = f2bf(v);
+      if (dxbt) dxbt[(size_t)c * ldt + b] = f2bf(v);
+    }
+  cs = bn1d_rg_sum(cs, red, rg, cl);
+  if (dx_colsum && own) dx_colsum[c] = (float)cs;
 }
 
 int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const float* gamma, const float* mean,
                 const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb, bf16_t* dxbt, int ldt, hipStream_t st) {
   FEDFR_REQUIRE(dy && x && dx && B > 0 && C > 0 && mean && rstd, "bn1d_bwd: bad args");
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, dy, x, dx, B, C, gamma, mean, rstd, dbeta,
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, dy, x, dx, B, C, gamma, mean, rstd, dbeta,
                      dx_colsum, dxb, dxbt, ldt);
   FEDFR_LAUNCH_CHECK("bn1d_bwd");
   return FEDFR_OK;

@@ -55,6 +55,9 @@ int head_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn,
 // strided fp32 GEMM  C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ beta*C)
 // block tile 64x64, 4 waves (2x2) of 32x32, BK = 16, v_mfma_f32_16x16x4_f32
 // ---------------------------------------------------------------------------------------------------------
+#ifndef SGEMM_COLFLAG_BK
+#define SGEMM_COLFLAG_BK 16      // k depth of the hard-negative-mining GEMM (throughput-bound: measured per value below)
+#endif
 struct SgemmP {
   const float* A; const float* B; float* C;
   int M, N, K;
@@ -66,36 +69,37 @@ struct SgemmP {
   float thr;
 };
 
+template <int BK>      // k depth of a stage: 16, or 32 (half as many global-load round trips on the K loop: the head's 128 x 1000 x 512 GEMMs are a latency chain)
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
-  constexpr int BM = 64, BN = 64, BK = 16, LD = 80;   // k-major LDS rows; LD%32==16 + column XOR (k>>1)<<1: reads and writes conflict-free
+  constexpr int BM = 64, BN = 64, LD = 80, NL = BK / 4;   // k-major LDS rows; LD%32==16 + column XOR (k>>1)<<1: reads and writes conflict-free
   __shared__ float sA[2][BK][LD], sB[2][BK][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  float ra[4], rb[4];
+  float ra[NL], rb[NL];
   auto load = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int e = tid + 256 * i;
       int m, k;
-      if (p.sak == 1) { k = e & 15; m = e >> 4; } else { m = e & 63; k = e >> 6; }
+      if (p.sak == 1) { k = e & (BK - 1); m = e / BK; } else { m = e & 63; k = e >> 6; }
       const int gm = m0 + m, gk = k0 + k;
       ra[i] = (gm < p.M && gk < p.K) ? p.A[(long long)gm * p.sam + (long long)gk * p.sak] : 0.f;
       int n, kb;
-      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 15; n = e >> 4; }
+      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & (BK - 1); n = e / BK; }
       const int gn = n0 + n, gkb = k0 + kb;
       rb[i] = (gn < p.N && gkb < p.K) ? p.B[(long long)gkb * p.sbk + (long long)gn * p.sbn] : 0.f;
     }
   };
   auto store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int e = tid + 256 * i;
       int m, k;
-      if (p.sak == 1) { k = e & 15; m = e >> 4; } else { m = e & 63; k = e >> 6; }
+      if (p.sak == 1) { k = e & (BK - 1); m = e / BK; } else { m = e & 63; k = e >> 6; }
       sA[buf][k][m ^ ((k >> 1) << 1)] = ra[i];
       int n, kb;
-      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & 15; n = e >> 4; }
+      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & (BK - 1); n = e / BK; }
       sB[buf][kb][n ^ ((kb >> 1) << 1)] = rb[i];
     }
   };
@@ -167,7 +171,8 @@ int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, lo
                long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, hipStream_t st) {
   FEDFR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "sgemm: bad args");
   SgemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, nullptr, 0.f};
-  hipLaunchKernelGGL(sgemm_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  if (K >= 128) hipLaunchKernelGGL(sgemm_kernel<32>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(sgemm_kernel<16>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
   FEDFR_LAUNCH_CHECK("sgemm");
   return FEDFR_OK;
 }
@@ -175,7 +180,8 @@ int head_sgemm_colflag(const float* A, const float* B, int M, int N, int K, long
                        long long sbn, float alpha, float thr, unsigned char* flags, hipStream_t st) {
   FEDFR_REQUIRE(A && B && flags && M > 0 && N > 0 && K > 0, "sgemm_colflag: bad args");
   SgemmP p{A, B, nullptr, M, N, K, sam, sak, sbk, sbn, N, alpha, 0.f, nullptr, flags, thr};
-  hipLaunchKernelGGL(sgemm_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  if (SGEMM_COLFLAG_BK == 32) hipLaunchKernelGGL(sgemm_kernel<32>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(sgemm_kernel<16>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
   FEDFR_LAUNCH_CHECK("sgemm_colflag");
   return FEDFR_OK;
 }

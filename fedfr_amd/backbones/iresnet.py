@@ -23,7 +23,7 @@ from torch import nn
 
 from .. import _C
 
-__all__ = ["iresnet18", "iresnet34", "iresnet50", "iresnet100", "iresnet200", "IResNet", "IBasicBlock"]
+__all__ = ["iresnet18", "iresnet34", "iresnet50", "iresnet100", "iresnet200", "IResNet", "IBasicBlock", "BlockPlan"]
 
 KIND_CONV, KIND_BNW, KIND_BNB, KIND_PRELU, KIND_FCW, KIND_FCB, KIND_RM, KIND_RV, KIND_NBT = range(9)
 
@@ -110,6 +110,117 @@ class _Plan:
                 self.handle = None
         except Exception:
             pass
+
+
+def _read_table(h):
+    q = C.c_longlong()
+    counts = {}
+    for key in (_C.Q_PARAM_COUNT, _C.Q_TRAINABLE_COUNT, _C.Q_BUFFER_COUNT, _C.Q_NBT_COUNT, _C.Q_SHADOW_COUNT,
+                _C.Q_NUM_TENSORS, _C.Q_FC_IN, _C.Q_ACT_BYTES, _C.Q_WS_BYTES):
+        _C.call("fedfr_net_query", h, key, C.byref(q))
+        counts[key] = q.value
+    table = []
+    name = C.create_string_buffer(128)
+    kind, region, ndim = C.c_int(), C.c_int(), C.c_int()
+    off = C.c_longlong()
+    shape = (C.c_int * 4)()
+    for i in range(counts[_C.Q_NUM_TENSORS]):
+        _C.call("fedfr_net_tensor_info", h, i, name, 128, C.byref(kind), C.byref(region), C.byref(off), C.byref(ndim), shape)
+        table.append((name.value.decode(), kind.value, region.value, off.value, tuple(shape[: ndim.value])))
+    return counts, table
+
+
+class BlockPlan:
+    """A lone ``IBasicBlock(inplanes, planes, stride, downsample)`` (reference backbones/iresnet.py:28-57) on the GPU: the same C++
+    block code the whole-network plan runs, driven through ``fedfr_block_create``.  ``forward`` / ``backward`` exchange fp32 NCHW
+    tensors like the reference block; parameters use the reference block's state_dict keys.  Exists for block-level parity checks
+    (tests/golden/block.npz); networks run as one plan (``IResNet``)."""
+
+    def __init__(self, inplanes, planes, stride, hin, batch, device):
+        l = _C.lib()
+        self.handle = l.fedfr_block_create(inplanes, planes, stride, hin, batch)
+        if not self.handle:
+            raise RuntimeError("fedfr_block_create failed: " + _C.last_error())
+        self.cin, self.cout, self.stride, self.hin, self.hout, self.batch = inplanes, planes, stride, hin, hin // stride, batch
+        self.device = torch.device(device)
+        self.counts, self.table = _read_table(self.handle)
+        c = self.counts
+        self.params = torch.zeros(c[_C.Q_PARAM_COUNT], dtype=torch.float32, device=device)
+        self.grads = torch.zeros(c[_C.Q_PARAM_COUNT], dtype=torch.float32, device=device)
+        self.bufs = torch.zeros(c[_C.Q_BUFFER_COUNT], dtype=torch.float32, device=device)
+        self.nbt = torch.zeros(c[_C.Q_NBT_COUNT], dtype=torch.int64, device=device)
+        self.shadow = torch.empty(c[_C.Q_SHADOW_COUNT], dtype=torch.bfloat16, device=device)
+        self.act = torch.empty(c[_C.Q_ACT_BYTES], dtype=torch.uint8, device=device)
+        self.ws = torch.empty(c[_C.Q_WS_BYTES], dtype=torch.uint8, device=device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _C.lib().fedfr_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _view(self, flat, kind, off, shape):
+        if kind == KIND_CONV:
+            o, i, r, _ = shape
+            return flat[off: off + o * i * r * r].view(o, r, r, i).permute(0, 3, 1, 2)
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[off: off + n].view(shape)
+
+    def load_state_dict(self, sd):
+        for name, kind, region, off, shape in self.table:
+            v = sd[name].to(self.device)
+            if region == 0:
+                self._view(self.params, kind, off, shape).copy_(v)
+            elif region == 1:
+                self.bufs[off: off + shape[0]].copy_(v)
+            else:
+                self.nbt[off] = int(v)
+
+    def state_dict(self):
+        out = OrderedDict()
+        for name, kind, region, off, shape in self.table:
+            if region == 0:
+                out[name] = self._view(self.params, kind, off, shape).clone()
+            elif region == 1:
+                out[name] = self.bufs[off: off + shape[0]].clone()
+            else:
+                out[name] = self.nbt[off].clone()
+        return out
+
+    def grad_dict(self):
+        return OrderedDict((name, self._view(self.grads, kind, off, shape)) for name, kind, region, off, shape in self.table if region == 0)
+
+    def _act(self, which):
+        off, rows, ch = C.c_longlong(), C.c_int(), C.c_int()
+        _C.call("fedfr_net_act_info", self.handle, 0, which, C.byref(off), C.byref(rows), C.byref(ch))
+        a = self.act[off.value * 2: (off.value + rows.value * ch.value) * 2].view(torch.bfloat16).view(rows.value, ch.value)
+        h = int(round((rows.value // self.batch) ** 0.5))
+        return a.float().view(self.batch, h, h, ch.value).permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, x, training=True):
+        x = _C.require_gpu_tensor(x.contiguous(), torch.float32, "block input")
+        if tuple(x.shape) != (self.batch, self.cin, self.hin, self.hin):
+            raise RuntimeError("BlockPlan expects %s, got %s" % ((self.batch, self.cin, self.hin, self.hin), tuple(x.shape)))
+        st = _C.stream()
+        _C.call("fedfr_net_prepare_weights", self.handle, self.params.data_ptr(), self.shadow.data_ptr(), 1, st)
+        _C.call("fedfr_net_forward", self.handle, x.data_ptr(), self.params.data_ptr(), self.bufs.data_ptr(), self.shadow.data_ptr(),
+                self.act.data_ptr(), self.ws.data_ptr(), None, 1 if training else 0, st)
+        if training:
+            self.nbt += 1
+        return self._act(6)
+
+    def backward(self, dy, aux_stream=None):
+        dy = _C.require_gpu_tensor(dy.contiguous(), torch.float32, "block output gradient")
+        if tuple(dy.shape) != (self.batch, self.cout, self.hout, self.hout):
+            raise RuntimeError("BlockPlan.backward expects %s, got %s" % ((self.batch, self.cout, self.hout, self.hout), tuple(dy.shape)))
+        _C.call("fedfr_net_backward2", self.handle, None, dy.data_ptr(), self.params.data_ptr(), self.shadow.data_ptr(),
+                self.act.data_ptr(), self.ws.data_ptr(), self.grads.data_ptr(), _C.stream(),
+                aux_stream.cuda_stream if aux_stream is not None else None)
+        return self._act(7)
 
 
 def _tensor_table(layers, in_hw, nfeat):

@@ -133,6 +133,16 @@ fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_
   }
   return net_create(layers4, batch, in_hw, num_features);
 }
+fedfr_net_t* fedfr_block_create(int cin, int cout, int stride, int hin, int batch) {
+  return net_create_block(cin, cout, stride, hin, batch);
+}
+extern bf16_t* g_dbg_grads;
+extern size_t g_dbg_grads_elems;
+int fedfr_net_debug_capture(uint16_t* buf, size_t elems) {
+  g_dbg_grads = BFM(buf);
+  g_dbg_grads_elems = buf ? elems : 0;
+  return FEDFR_OK;
+}
 void fedfr_net_destroy(fedfr_net_t* net) {
   if (!net) return;
   for (auto e : net->events) (void)hipEventDestroy(e);
@@ -168,14 +178,19 @@ int fedfr_net_act_info(const fedfr_net_t* n, int block, int which, long long* of
   FEDFR_REQUIRE(n && offset && rows && channels, "net_act_info: null");
   const int B = n->B;
   if (block < 0) {          // which: 0 stem conv out (c0), 1 stem activation (a0), 2 flattened bn2 output t [B][fc_in]
-    FEDFR_REQUIRE(which >= 0 && which <= 2, "net_act_info: bad stem selector");
+    FEDFR_REQUIRE(which >= 0 && which <= 2 && !n->block_only, "net_act_info: bad stem selector");
     if (which == 2) { *offset = n->t_off; *rows = B; *channels = n->fc_in; return FEDFR_OK; }
     *offset = which == 0 ? n->c0_off : n->a0_off; *rows = B * n->HW * n->HW; *channels = 64;
     return FEDFR_OK;
   }
-  FEDFR_REQUIRE(block < (int)n->blocks.size() && which >= 0 && which <= 6, "net_act_info: bad selector");
+  FEDFR_REQUIRE(block < (int)n->blocks.size() && which >= 0 && which <= 7, "net_act_info: bad selector");
   const BlockD& k = n->blocks[block];
   const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
+  if (which == 7) {          // gradient wrt the input of a lone block (fedfr_block_create plans only)
+    FEDFR_REQUIRE(n->block_only, "net_act_info: selector 7 (dx) exists only for fedfr_block_create plans");
+    *offset = n->dx_off; *rows = Mi; *channels = k.Cin;
+    return FEDFR_OK;
+  }
   switch (which) {           // 0 x, 1 a1, 2 c1, 3 a2, 4 c2, 5 d, 6 out
     case 0: *offset = k.x_off; *rows = Mi; *channels = k.Cin; break;
     case 1: *offset = k.a1_off; *rows = Mi; *channels = k.Cin; break;

@@ -65,9 +65,14 @@ struct FedfrNet {
   mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;
+  bool block_only = false;              // plan of a lone IBasicBlock (net_create_block): no stem, no bn2/fc/features tail
+  long long dx_off = -1;                // block_only: bf16 arena offset of the gradient wrt the block input [B*Hin*Hin][Cin]
 };
 
 FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features);
+// lone IBasicBlock(cin, cout, stride) on a hin x hin map; with it net_forward takes x = fp32 NCHW [B][cin][hin][hin] (feats unused, may be
+// null) and net_backward takes dfeats = fp32 NCHW [B][cout][hout][hout]; y / dx are read from the arena (fedfr_net_act_info)
+FedfrNet* net_create_block(int cin, int cout, int stride, int hin, int batch);
 int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st);
 int net_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, const bf16_t* shadow,
                 unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st);

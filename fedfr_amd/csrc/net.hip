@@ -55,53 +55,28 @@ struct Builder {
     c.wd_off = -1;
     return c;
   }
+  // p: "layerL.i." inside a network, "" for a lone block (reference IBasicBlock attribute order, iresnet.py:37-43)
+  BlockD add_block(const std::string& p, int cin, int cout, int stride, int Hin, bool ds) {
+    BlockD k;
+    k.Cin = cin; k.Cout = cout; k.stride = stride; k.Hin = Hin; k.Hout = Hin / stride; k.has_ds = ds;
+    k.bn1 = add_bn(p + "bn1", k.Cin);
+    k.conv1 = add_conv(p + "conv1", k.Cin, k.Cout, 3, 1, k.Hin);
+    k.bn2 = add_bn(p + "bn2", k.Cout);
+    k.alpha_off = add_param(p + "prelu.weight", 3, {k.Cout});
+    k.conv2 = add_conv(p + "conv2", k.Cout, k.Cout, 3, k.stride, k.Hin);
+    k.bn3 = add_bn(p + "bn3", k.Cout);
+    if (k.has_ds) {
+      k.ds = add_conv(p + "downsample.0", k.Cin, k.Cout, 1, k.stride, k.Hin);
+      k.bnds = add_bn(p + "downsample.1", k.Cout);
+    }
+    return k;
+  }
 };
 }  // namespace
 
-FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features) {
-  if (batch <= 0 || in_hw <= 0 || (in_hw % 16) != 0 || num_features <= 0 || (num_features % 64) != 0) {
-    fedfr_set_error("net_create: need batch>0, in_hw%%16==0, num_features%%64==0 (got %d, %d, %d)", batch, in_hw, num_features);
-    return nullptr;
-  }
-  for (int i = 0; i < 4; ++i)
-    if (layers[i] <= 0) { fedfr_set_error("net_create: layers[%d]=%d", i, layers[i]); return nullptr; }
-  FedfrNet* n = new FedfrNet();
-  for (int i = 0; i < 4; ++i) n->layers[i] = layers[i];
-  n->B = batch; n->Bp = (batch + 7) / 8 * 8; n->HW = in_hw; n->F = num_features;
-  Builder b; b.n = n;
-  // ---- tensors in reference state_dict order (iresnet.py:76-98, :37-43) ----
-  n->stem = b.add_conv("conv1", 3, 64, 3, 1, in_hw);
-  n->stem_bn = b.add_bn("bn1", 64);
-  n->stem_alpha_off = b.add_param("prelu.weight", 3, {64});
-  int inpl = 64, H = in_hw;
-  for (int s = 0; s < 4; ++s) {
-    for (int i = 0; i < layers[s]; ++i) {
-      char pfx[64];
-      snprintf(pfx, sizeof pfx, "layer%d.%d", s + 1, i);
-      const std::string p(pfx);
-      BlockD k;
-      k.Cin = (i == 0) ? inpl : kPlanes[s]; k.Cout = kPlanes[s];
-      k.stride = (i == 0) ? 2 : 1; k.Hin = H; k.Hout = H / k.stride; k.has_ds = (i == 0);
-      k.bn1 = b.add_bn(p + ".bn1", k.Cin);
-      k.conv1 = b.add_conv(p + ".conv1", k.Cin, k.Cout, 3, 1, k.Hin);
-      k.bn2 = b.add_bn(p + ".bn2", k.Cout);
-      k.alpha_off = b.add_param(p + ".prelu.weight", 3, {k.Cout});
-      k.conv2 = b.add_conv(p + ".conv2", k.Cout, k.Cout, 3, k.stride, k.Hin);
-      k.bn3 = b.add_bn(p + ".bn3", k.Cout);
-      if (k.has_ds) {
-        k.ds = b.add_conv(p + ".downsample.0", k.Cin, k.Cout, 1, k.stride, k.Hin);
-        k.bnds = b.add_bn(p + ".downsample.1", k.Cout);
-      }
-      n->blocks.push_back(k);
-      H = k.Hout;
-    }
-    inpl = kPlanes[s];
-  }
-  n->bn2 = b.add_bn("bn2", 512);
-  n->final_hw = H; n->final_C = 512; n->fc_in = 512 * H * H;
-  n->fc_w_off = b.add_param("fc.weight", 4, {num_features, n->fc_in});
-  n->fc_b_off = b.add_param("fc.bias", 5, {num_features});
-  n->feat_bn = b.add_bn("features", num_features, /*frozen_weight=*/true);
+// shadow offsets, activation arena and workspace layout of a plan whose tensor list and block list are complete
+static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
+  const int batch = n->B, num_features = n->F;
   n->trainable_count = b.poff;
   for (auto& t : n->tensors)
     if (t.region == 0 && t.offset < 0) { t.offset = b.poff; n->feat_bn.g_off = b.poff; b.poff += (t.shape[0] + 3) / 4 * 4; }
@@ -121,10 +96,19 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
   long long aoff = 0;
   auto take = [&](long long elems) { const long long o = aoff; aoff += (elems + 7) / 8 * 8; return o; };
   const long long M0 = Bq * in_hw * in_hw;
-  n->c0_off = take(M0 * 64);
-  n->a0_off = take(M0 * 64);
-  long long prev = n->a0_off;
-  long long gmax = M0 * 64;
+  long long prev, gmax;
+  if (n->block_only) {                      // a lone IBasicBlock: its input tensor and the gradient wrt it live in the arena too
+    const BlockD& k0 = n->blocks.front();
+    prev = take(M0 * k0.Cin);
+    n->dx_off = take(M0 * k0.Cin);
+    n->c0_off = n->a0_off = -1;
+    gmax = M0 * k0.Cin;
+  } else {
+    n->c0_off = take(M0 * 64);
+    n->a0_off = take(M0 * 64);
+    prev = n->a0_off;
+    gmax = M0 * 64;
+  }
   for (auto& k : n->blocks) {
     const long long Mi = Bq * k.Hin * k.Hin, Mo = Bq * k.Hout * k.Hout;
     k.x_off = prev;
@@ -160,14 +144,17 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
     slab = std::max(slab, (long long)gemm_tn_max_splits((int)Mo, c.Cout, NJ, c.Cin, c.Hout, c.stride) * c.Cout * NJ);
   };
   upd_part(M0, 64);
+  int H = in_hw;
   for (auto& k : n->blocks) {
     const long long Mi = Bq * k.Hin * k.Hin, Mo = Bq * k.Hout * k.Hout;
     upd_part(Mi, k.Cin); upd_part(Mi, k.Cout); upd_part(Mo, k.Cout);
     upd_conv(k.conv1); upd_conv(k.conv2);
     if (k.has_ds) upd_conv(k.ds);
+    H = k.Hout;
   }
   upd_part(Bq * H * H, 512);
-  slab = std::max(slab, (long long)gemm_nt_pick_splits(batch, num_features, n->fc_in) * Bq * num_features);
+  if (n->fc_in > 0)
+    slab = std::max(slab, (long long)gemm_nt_pick_splits(batch, num_features, n->fc_in) * Bq * num_features);
   n->part_floats = (size_t)part;
   n->slab_floats = (size_t)slab;
   size_t w = 0;
@@ -182,6 +169,63 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
                       (size_t)num_features * n->Bp * 2 + 1024);
   n->ws_fc = wtake((size_t)n->Bp * n->fc_in * 4);
   n->ws_bytes = w;
+}
+
+FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features) {
+  if (batch <= 0 || in_hw <= 0 || (in_hw % 16) != 0 || num_features <= 0 || (num_features % 64) != 0) {
+    fedfr_set_error("net_create: need batch>0, in_hw%%16==0, num_features%%64==0 (got %d, %d, %d)", batch, in_hw, num_features);
+    return nullptr;
+  }
+  for (int i = 0; i < 4; ++i)
+    if (layers[i] <= 0) { fedfr_set_error("net_create: layers[%d]=%d", i, layers[i]); return nullptr; }
+  FedfrNet* n = new FedfrNet();
+  for (int i = 0; i < 4; ++i) n->layers[i] = layers[i];
+  n->B = batch; n->Bp = (batch + 7) / 8 * 8; n->HW = in_hw; n->F = num_features;
+  Builder b; b.n = n;
+  // ---- tensors in reference state_dict order (iresnet.py:76-98, :37-43) ----
+  n->stem = b.add_conv("conv1", 3, 64, 3, 1, in_hw);
+  n->stem_bn = b.add_bn("bn1", 64);
+  n->stem_alpha_off = b.add_param("prelu.weight", 3, {64});
+  int inpl = 64, H = in_hw;
+  for (int s = 0; s < 4; ++s) {
+    for (int i = 0; i < layers[s]; ++i) {
+      char pfx[64];
+      snprintf(pfx, sizeof pfx, "layer%d.%d.", s + 1, i);
+      BlockD k = b.add_block(pfx, (i == 0) ? inpl : kPlanes[s], kPlanes[s], (i == 0) ? 2 : 1, H, i == 0);
+      n->blocks.push_back(k);
+      H = k.Hout;
+    }
+    inpl = kPlanes[s];
+  }
+  n->bn2 = b.add_bn("bn2", 512);
+  n->final_hw = H; n->final_C = 512; n->fc_in = 512 * H * H;
+  n->fc_w_off = b.add_param("fc.weight", 4, {num_features, n->fc_in});
+  n->fc_b_off = b.add_param("fc.bias", 5, {num_features});
+  n->feat_bn = b.add_bn("features", num_features, /*frozen_weight=*/true);
+  plan_layout(n, b, in_hw);
+  return n;
+}
+
+// A lone IBasicBlock (reference backbones/iresnet.py:28-57) as a plan of its own: same block code as inside a network (net_forward /
+// net_backward run their block loop over this one block and skip stem and tail), tensors in the reference block's state_dict order.
+// Used by the block-level parity tests (tests/golden/block.npz) — x / dy / y / dx cross the ABI as fp32 NCHW like the reference's.
+FedfrNet* net_create_block(int cin, int cout, int stride, int hin, int batch) {
+  const bool ds = stride != 1;
+  if (batch <= 0 || hin <= 0 || (hin % (2 * stride)) != 0 || cin <= 0 || cout <= 0 || (cin % 64) || (cout % 64) || (stride != 1 && stride != 2) ||
+      (stride == 1 && cin != cout)) {
+    fedfr_set_error("block_create: need channels%%64==0, stride 1 (cin==cout) or 2 (with downsample), even map (got %d->%d s%d @%d)", cin, cout,
+                    stride, hin);
+    return nullptr;
+  }
+  FedfrNet* n = new FedfrNet();
+  for (int i = 0; i < 4; ++i) n->layers[i] = 0;
+  n->block_only = true;
+  n->B = batch; n->Bp = (batch + 7) / 8 * 8; n->HW = hin; n->F = 64;
+  Builder b; b.n = n;
+  n->blocks.push_back(b.add_block("", cin, cout, stride, hin, ds));
+  n->final_hw = n->blocks[0].Hout; n->final_C = cout; n->fc_in = 0;
+  n->fc_w_off = n->fc_b_off = -1;
+  plan_layout(n, b, hin);
   return n;
 }
 
@@ -298,6 +342,9 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
     p.out = dst;
     return gemm_tn_launch(p, 1, st);
   }
+  // the slab workspace was sized at plan creation (gemm_tn_max_splits); an option raised afterwards (tn_target_blocks) must not overrun it
+  FEDFR_REQUIRE((size_t)splits * p.NI * p.NJ <= c.n->slab_floats, "conv_wgrad: %d split-K slabs of %d x %d exceed the plan's slab workspace "
+                "(%zu floats): create the plan after changing tn_target_blocks", splits, p.NI, p.NJ, c.n->slab_floats);
   p.out = c.slab();
   FEDFR_TRY(gemm_tn_launch(p, splits, st));
   return ew_reduce_slabs(dst, c.slab(), splits, (size_t)p.NI * p.NJ, nullptr, 0, st);
@@ -311,6 +358,8 @@ static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const 
     FEDFR_TRY(conv_wgrad(c, cva, ina, dya, st));
     return conv_wgrad(c, cvb, inb, dyb, st);
   }
+  FEDFR_REQUIRE((size_t)splits * a.NI * a.NJ <= c.n->slab_floats, "conv_wgrad2: %d split-K slabs of %d x %d exceed the plan's slab workspace "
+                "(%zu floats): create the plan after changing tn_target_blocks", splits, a.NI, a.NJ, c.n->slab_floats);
   a.out = c.slab(0); b.out = c.slab(1);
   FEDFR_TRY(gemm_tn_launch_pair(a, b, splits, st));
   FEDFR_TRY(ew_reduce_slabs(c.grads + cva.w_off, c.slab(0), splits, (size_t)a.NI * a.NJ, nullptr, 0, st));
@@ -339,12 +388,12 @@ static int eval_coeffs_all(const Ctx& c) {
     e.C = b.C; e.g_off = (int)b.g_off; e.b_off = (int)b.b_off; e.rm_off = (int)b.rm_off; e.rv_off = (int)b.rv_off; e.save_off = (int)b.save_off;
     return FEDFR_OK;
   };
-  FEDFR_TRY(add(c.n->stem_bn));
+  if (!c.n->block_only) FEDFR_TRY(add(c.n->stem_bn));
   for (const auto& k : c.n->blocks) {
     FEDFR_TRY(add(k.bn1)); FEDFR_TRY(add(k.bn2)); FEDFR_TRY(add(k.bn3));
     if (k.has_ds) FEDFR_TRY(add(k.bnds));
   }
-  FEDFR_TRY(add(c.n->bn2));
+  if (!c.n->block_only) FEDFR_TRY(add(c.n->bn2));
   return flush();
 }
 static int apply(const Ctx& c, const bf16_t* x1, const BnD& b1, const float* alpha, const bf16_t* x2, const BnD* b2, bf16_t* y,
@@ -382,18 +431,30 @@ int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, 
 
 int net_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, const bf16_t* shadow,
                 unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st) {
-  FEDFR_REQUIRE(n && x && params && bufs && shadow && act && ws && feats, "net_forward: null buffer");
+  FEDFR_REQUIRE(n && x && params && bufs && shadow && act && ws && (feats || n->block_only), "net_forward: null buffer");
   Ctx c{n, params, bufs, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, nullptr, st};
   const bool tr = training != 0;
   const int B = n->B, HW = n->HW;
   const int M0 = B * HW * HW;
   bf16_t* A = c.actb;
   if (!tr) FEDFR_TRY(eval_coeffs_all(c));
-  // stem: conv -> BN -> PReLU   (iresnet.py:160-162)
-  FEDFR_TRY(ew_stem_fwd(x, params + n->stem.w_off, A + n->c0_off, tr ? c.part() : nullptr, B, HW, HW, st));
-  FEDFR_TRY(bn_coeffs(c, n->stem_bn, ew_stem_stat_rows(B, HW, HW), (double)M0, tr));
-  FEDFR_TRY(apply(c, A + n->c0_off, n->stem_bn, params + n->stem_alpha_off, nullptr, nullptr, A + n->a0_off, M0, tr));
-  int Pprev = ew_bn_apply_grid(M0, 64);
+  int Pprev;
+  if (n->block_only) {
+    // lone block: x (fp32 NCHW) -> NHWC bf16 block input; an identity "apply" pass leaves the column statistics bn1 needs, exactly
+    // where the previous block's output pass leaves them inside a network
+    const BlockD& k0 = n->blocks.front();
+    FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(x, c.g(0), B, k0.Cin, HW * HW, st));
+    BnApply a{};
+    a.x1 = c.g(0); a.y = A + k0.x_off; a.M = M0; a.C = k0.Cin; a.stats = tr ? c.part() : nullptr;
+    FEDFR_TRY(ew_bn_apply(a, st));
+    Pprev = ew_bn_apply_grid(M0, k0.Cin);
+  } else {
+    // stem: conv -> BN -> PReLU   (iresnet.py:160-162)
+    FEDFR_TRY(ew_stem_fwd(x, params + n->stem.w_off, A + n->c0_off, tr ? c.part() : nullptr, B, HW, HW, st));
+    FEDFR_TRY(bn_coeffs(c, n->stem_bn, ew_stem_stat_rows(B, HW, HW), (double)M0, tr));
+    FEDFR_TRY(apply(c, A + n->c0_off, n->stem_bn, params + n->stem_alpha_off, nullptr, nullptr, A + n->a0_off, M0, tr));
+    Pprev = ew_bn_apply_grid(M0, 64);
+  }
   bool a1_ready = false;                    // eval: the previous block's conv2 epilogue already wrote this block's bn1(x)
   for (size_t bi = 0; bi < n->blocks.size(); ++bi) {
     const BlockD& k = n->blocks[bi];
@@ -442,6 +503,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     }
     Pprev = ew_bn_apply_grid(Mo, k.Cout);
   }
+  if (n->block_only) return FEDFR_OK;
   // bn2 -> flatten (NCHW order) -> fc -> features   (iresnet.py:167-171)
   const BlockD& last = n->blocks.back();
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
@@ -452,6 +514,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     p.A = A + n->t_off; p.B = shadow + n->fc_w_off; p.M = B; p.N = n->F; p.K = n->fc_in; p.mode = 0; p.lda = n->fc_in;
     p.Cb = nullptr; p.Cf = c.slab(); p.stats = nullptr;
     const int splits = gemm_nt_pick_splits(B, n->F, n->fc_in);
+    FEDFR_REQUIRE((size_t)splits * B * n->F <= n->slab_floats, "net_forward: fc split-K slabs exceed the plan's slab workspace");
     FEDFR_TRY(gemm_nt_launch(p, splits, st));
     FEDFR_TRY(ew_reduce_slabs(c.actf + n->yfc_off, c.slab(), splits, (size_t)B * n->F, params + n->fc_b_off, n->F, st));
   }
@@ -461,6 +524,21 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   return FEDFR_OK;
 }
 
+// debug capture (tests): when set, net_backward copies the gradient entering every block (bf16 NHWC [B*Hout*Hout][Cout], last block first)
+// and finally the gradient wrt the first block's input, back to back into this caller-owned device buffer
+bf16_t* g_dbg_grads = nullptr;
+size_t g_dbg_grads_elems = 0;
+static int dbg_capture(const bf16_t* src, size_t elems, size_t* off, hipStream_t st) {
+  if (!g_dbg_grads) return FEDFR_OK;
+  FEDFR_REQUIRE(*off + elems <= g_dbg_grads_elems, "net_backward: debug gradient buffer too small (%zu + %zu > %zu elements)", *off, elems,
+                g_dbg_grads_elems);
+  if (hipMemcpyAsync(g_dbg_grads + *off, src, elems * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    fedfr_set_error("net_backward: debug capture copy failed");
+    return FEDFR_ERR_HIP;
+  }
+  *off += elems;
+  return FEDFR_OK;
+}
 int g_wgrad_depth = kWgradDepth;   // option "wgrad_depth" (2..kWgradDepth): generations of weight-gradient operands in flight
 int g_fuse_bnred_next = 1;   // option "fuse_bnred_next": a BN-backward apply pass also reduces its output for the BN that consumes it
 static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
@@ -517,13 +595,18 @@ struct Fork {
 
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
                  unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux) {
-  FEDFR_REQUIRE(n && x && dfeats && params && shadow && act && ws && grads, "net_backward: null buffer");
+  FEDFR_REQUIRE(n && (x || n->block_only) && dfeats && params && shadow && act && ws && grads, "net_backward: null buffer");
   Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
   const int B = n->B, F = n->F, HW = n->HW;
   bf16_t* A = c.actb;
   Fork fk{n, st, aux};
   const hipStream_t wst = aux ? aux : st;          // stream of the weight-gradient GEMMs
   fk.order(st, wst);                                // aux starts after everything already queued on main (forward pass)
+  int pend_rows = 0;                               // partial rows of the next bn3 already reduced by the apply pass that produced its dy
+  if (n->block_only) {
+    const BlockD& k0 = n->blocks.front();
+    FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dfeats, c.g(1), B, k0.Cout, k0.Hout * k0.Hout, st));      // dy of the block, fp32 NCHW like the reference's
+  } else {
   // ---- features (BN1d) backward; fc.bias grad = colsum(d y_fc) ----
   if (hipMemsetAsync(c.dybt(), 0, (size_t)F * n->Bp * 2, st) != hipSuccess) {
     fedfr_set_error("net_backward: hipMemsetAsync failed");
@@ -547,9 +630,10 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   const BlockD& last = n->blocks.back();
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
   FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dxfc, c.g(0), B, n->final_C, hw, st));
-  int pend_rows = 0;                               // partial rows of the next bn3 already reduced by the apply pass that produced its dy
   FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0, 0, &last.bn3, A + last.c2_off, &pend_rows));
+  }
   int cur = 1;
+  size_t dbg_off = 0;
   hipEvent_t wdone[kWgradDepth] = {};              // "all weight GEMMs of the block of this generation have finished"
   for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
     const BlockD& k = n->blocks[bi];
@@ -557,6 +641,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     const int par = bi % g_wgrad_depth;
     const bf16_t* g = c.g(cur);
     bf16_t* gin = c.g(cur ^ 1);
+    FEDFR_TRY(dbg_capture(g, (size_t)Mo * k.Cout, &dbg_off, st));
     bf16_t *dc2 = c.tw(0, par), *da2 = c.t(1), *dc1 = c.tw(1, par), *da1 = c.t(3), *dd = c.tw(2, par), *dxd = c.t(5);
     fk.wait(st, wdone[par]);                         // the weight GEMMs kWgradDepth blocks ago were the last readers of dc2/dc1/dd[par]
     // out = bn3(c2) + identity
@@ -593,10 +678,18 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     cur ^= 1;
   }
   fk.order(wst, st);                                 // join: the stem wgrad below reuses the slab workspace; callers see all grads
-  // ---- stem: a0 = prelu(bn1(conv1(x))) ----
   const int M0 = B * HW * HW;
+  FEDFR_TRY(dbg_capture(c.g(cur), (size_t)M0 * n->blocks.front().Cin, &dbg_off, st));
+  if (n->block_only) {                               // the gradient wrt the block input stays readable in the arena
+    if (hipMemcpyAsync(A + n->dx_off, c.g(cur), (size_t)M0 * n->blocks.front().Cin * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      fedfr_set_error("net_backward: hipMemcpyAsync failed");
+      return FEDFR_ERR_HIP;
+    }
+  } else {
+  // ---- stem: a0 = prelu(bn1(conv1(x))) ----
   FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, c.t(0), n->stem_alpha_off));
   FEDFR_TRY(ew_stem_wgrad(x, c.t(0), grads + n->stem.w_off, c.slab(), B, HW, HW, st));
+  }
   if (!fk.ok) {
     fedfr_set_error("net_backward: HIP event record/wait failed");
     return FEDFR_ERR_HIP;

@@ -43,7 +43,17 @@ int fedfr_profile_read(int slot, double* total_ms, long long* launches, double* 
  * ------------------------------------------------------------------------------------------------ */
 typedef struct FedfrNet fedfr_net_t;
 fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_features);
+/* A lone IBasicBlock(cin, cout, stride) on a hin x hin map (reference backbones/iresnet.py:28-57) as a plan of its own, driven by the
+ * same query / tensor_info / prepare_weights / forward / backward entry points (tensors in the reference block's state_dict order:
+ * bn1.*, conv1.weight, bn2.*, prelu.weight, conv2.weight, bn3.*, downsample.0.weight, downsample.1.*).  With such a plan
+ * fedfr_net_forward takes x = fp32 NCHW [B][cin][hin][hin] (feats may be NULL; y = act selector 6) and fedfr_net_backward takes
+ * dfeats = fp32 NCHW [B][cout][hout][hout] (dx = act selector 7).  stride 1 needs cin == cout; stride 2 adds the 1x1 downsample. */
+fedfr_net_t* fedfr_block_create(int cin, int cout, int stride, int hin, int batch);
 void fedfr_net_destroy(fedfr_net_t* net);
+/* debug (tests): while buf != NULL, fedfr_net_backward* copies the gradient entering every block (bf16 NHWC, last block first) and then
+ * the gradient wrt the first block's input back to back into buf (caller-owned, `elems` bf16 elements); NULL turns it off.  The one
+ * exception to "no pointer is retained": clear it before freeing the buffer. */
+int fedfr_net_debug_capture(uint16_t* buf, size_t elems);
 enum {
   FEDFR_Q_PARAM_COUNT = 0,      /* fp32 elements: trainable region + frozen features.weight */
   FEDFR_Q_TRAINABLE_COUNT = 1,
@@ -63,7 +73,7 @@ int fedfr_net_tensor_info(const fedfr_net_t* net, int i, char* name, int name_ca
 /* debug/inspection: where a saved activation lives inside `act` (bf16 element offset, [rows][channels] NHWC view).
  * block < 0: which = 0 stem conv output, 1 stem activation, 2 flattened bn2 output [B][fc_in] (NCHW order);
  * block >= 0: which = 0 block input, 1 bn1 out, 2 conv1 out, 3 prelu(bn2) out, 4 conv2 out, 5 downsample conv out
- * (offset -1 if the block has none), 6 block output.  An eval-mode forward (training = 0) applies the BatchNorms in the conv epilogues
+ * (offset -1 if the block has none), 6 block output, 7 gradient wrt the block input (fedfr_block_create plans only, after a backward).  An eval-mode forward (training = 0) applies the BatchNorms in the conv epilogues
  * where the kernel has one and then does not store the raw conv outputs (2, 4); fedfr_set_option("eval_fuse", 0) restores them. */
 int fedfr_net_act_info(const fedfr_net_t* net, int block, int which, long long* offset, int* rows, int* channels);
 /* refresh the bf16 weight shadows from fp32 params (after load_state_dict / an external optimizer step);

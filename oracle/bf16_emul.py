@@ -22,18 +22,38 @@ def q(x: torch.Tensor) -> torch.Tensor:
     return x + (x.detach().to(torch.bfloat16).float() - x.detach())
 
 
+class _RoundGrad(torch.autograd.Function):
+    """identity forward; the gradient flowing back through this point is rounded to bf16 — where the HIP backward stores a bf16 tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def qg(x: torch.Tensor) -> torch.Tensor:
+    return _RoundGrad.apply(x)
+
+
 def _bn(sd, prefix, x, training):
     return R._bn(sd, prefix, x, training)
 
 
-def block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: int, training: bool) -> torch.Tensor:
-    a1 = q(_bn(sd, p + ".bn1", x, training))
-    c1 = q(F.conv2d(a1, q(sd[p + ".conv1.weight"]), None, 1, 1))
-    a2 = q(F.prelu(_bn(sd, p + ".bn2", c1, training), sd[p + ".prelu.weight"]))
-    c2 = q(F.conv2d(a2, q(sd[p + ".conv2.weight"]), None, stride, 1))
+def block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: int, training: bool, grad_round: bool = False) -> torch.Tensor:
+    """``grad_round``: also round the gradients at the points where the HIP backward stores them in bf16 (the gradient wrt the block
+    input, bn1 / bn2 outputs, conv outputs and the compact down-sample-path gradient: net.hip gin, da1, dc1, da2, dc2, dd, dxd)."""
+    r = qg if grad_round else (lambda t: t)
+    x = r(x)
+    a1 = r(q(_bn(sd, p + ".bn1", x, training)))
+    c1 = r(q(F.conv2d(a1, q(sd[p + ".conv1.weight"]), None, 1, 1)))
+    a2 = r(q(F.prelu(_bn(sd, p + ".bn2", c1, training), sd[p + ".prelu.weight"])))
+    c2 = r(q(F.conv2d(a2, q(sd[p + ".conv2.weight"]), None, stride, 1)))
     out = _bn(sd, p + ".bn3", c2, training)
     if (p + ".downsample.0.weight") in sd:
-        d = q(F.conv2d(x, q(sd[p + ".downsample.0.weight"]), None, stride, 0))
+        d = r(q(F.conv2d(r(x), q(sd[p + ".downsample.0.weight"]), None, stride, 0)))
         idn = _bn(sd, p + ".downsample.1", d, training)
     else:
         idn = x

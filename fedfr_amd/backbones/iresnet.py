@@ -289,9 +289,11 @@ class IResNet(nn.Module):
         self.dropout_p = float(dropout)
         counts, table = _tensor_table(self.layers_cfg, self.in_hw, num_features)
         self._counts, self._table = counts, table
-        # flat storage (CPU until .to(device), like any nn.Module)
-        self._flat_params = torch.zeros(counts[_C.Q_PARAM_COUNT], dtype=torch.float32)
-        self._flat_bufs = torch.zeros(counts[_C.Q_BUFFER_COUNT], dtype=torch.float32)
+        # flat storage (CPU until .to(device), like any nn.Module).  Parameters and BN running statistics are slices of ONE fp32
+        # tensor, followed by a float image of the num_batches_tracked counters: the FedAvg exchange of a round is then a single
+        # in-place all-reduce of `_flat_state` (server.fedavg_all_reduce), with no packing copies
+        self._flat_state = torch.zeros(self._state_len(counts), dtype=torch.float32)
+        self._slice_state()
         self._flat_nbt = torch.zeros(counts[_C.Q_NBT_COUNT], dtype=torch.int64)
         self._flat_grads: Optional[torch.Tensor] = None
         self._shadow: Optional[torch.Tensor] = None
@@ -321,6 +323,16 @@ class IResNet(nn.Module):
         self._init_weights(zero_init_residual)
 
     # ------------------------------------------------------------------ storage plumbing
+    @staticmethod
+    def _state_len(counts):
+        return counts[_C.Q_PARAM_COUNT] + counts[_C.Q_BUFFER_COUNT] + (counts[_C.Q_NBT_COUNT] + 3) // 4 * 4
+
+    def _slice_state(self):
+        P, Bc, N = self._counts[_C.Q_PARAM_COUNT], self._counts[_C.Q_BUFFER_COUNT], self._counts[_C.Q_NBT_COUNT]
+        self._flat_params = self._flat_state[:P]
+        self._flat_bufs = self._flat_state[P: P + Bc]
+        self._nbt_f32 = self._flat_state[P + Bc: P + Bc + N]          # scratch: float image of num_batches_tracked during an exchange
+
     def _views(self):
         """yield (owner module, attr, view tensor, is_param, kind) for every state_dict entry."""
         mods = dict(self.named_modules())
@@ -377,12 +389,12 @@ class IResNet(nn.Module):
                         m.bn2.weight.zero_()          # bn2, as the reference does (iresnet.py:109-112)
 
     def _apply(self, fn, recurse=True):
-        new = fn(self._flat_params)
+        new = fn(self._flat_state)
         if new.dtype != torch.float32:
             raise RuntimeError("fedfr_amd.IResNet keeps fp32 master weights (bf16 compute copies are internal); "
                                "dtype conversion to %s is not supported" % new.dtype)
-        self._flat_params = new
-        self._flat_bufs = fn(self._flat_bufs)
+        self._flat_state = new
+        self._slice_state()
         self._flat_nbt = fn(self._flat_nbt) if not self._flat_nbt.is_floating_point() else self._flat_nbt
         if self._flat_nbt.device != self._flat_params.device:
             self._flat_nbt = self._flat_nbt.to(self._flat_params.device)
@@ -397,6 +409,8 @@ class IResNet(nn.Module):
 
     def __getstate__(self):
         st = self.__dict__.copy()
+        for k in ("_flat_params", "_flat_bufs", "_nbt_f32"):      # slices of _flat_state: rebuilt, never copied on their own
+            st.pop(k, None)
         st["_plans"] = {}
         st["_shadow"] = None
         st["_flat_grads"] = None
@@ -412,13 +426,31 @@ class IResNet(nn.Module):
         memo[id(self)] = new
         for k, v in self.__getstate__().items():
             new.__dict__[k] = copy.deepcopy(v, memo)
+        new._slice_state()
         new._bind(create=False)
         return new
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._slice_state()
+        self._bind(create=False)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._shadow_dirty = True
         return out
+
+    def release_workspace(self):
+        """Drop everything but the weights: activation arenas / workspaces of every batch size, bf16 shadows, the flat gradient buffer
+        (GBs for iresnet100); they are rebuilt on the next forward.  For models that stay resident but idle between rounds."""
+        self._plans = {}
+        self._shadow = None
+        self._flat_grads = None
+        self._grad_views = None
+        self._shadow_dirty = True
+        self._grads_live = False
+        for p in self.parameters():
+            p.grad = None
 
     def mark_weights_dirty(self):
         """Call after modifying parameters in place outside of this package's optimiser while in eval mode."""
@@ -470,6 +502,7 @@ class IResNet(nn.Module):
             self._flat_grads = torch.zeros(self._counts[_C.Q_PARAM_COUNT], dtype=torch.float32, device=self.device)
             self._grad_views = None
 
+    @_C.on_device(lambda self: self._flat_params.device)
     def refresh_shadows(self, fwd_shadow_too=True):
         self._ensure_device_state()
         plan = next(iter(self._plans.values())) if self._plans else self._plan(8)
@@ -484,6 +517,7 @@ class IResNet(nn.Module):
         if x.device != self.device:
             raise RuntimeError("input on %s but model on %s" % (x.device, self.device))
 
+    @_C.on_device(lambda self: self._flat_params.device)
     def _run_forward(self, x, training: bool):
         self._ensure_device_state()
         plan = self._plan(x.shape[0])
@@ -520,6 +554,7 @@ class IResNet(nn.Module):
             self._grad_views = views
         return self._grad_views
 
+    @_C.on_device(lambda self: self._flat_params.device)
     def _run_backward(self, plan, x, dfeats):
         """Writes parameter gradients into the flat grad buffer and exposes them as ``p.grad`` views
         (accumulating if the caller did not zero them — torch.optim semantics)."""
@@ -537,6 +572,7 @@ class IResNet(nn.Module):
                 p.grad = g
         self._grads_live = True
 
+    @_C.on_device(lambda self: self._flat_params.device)
     def forward(self, x):
         self._check_input(x)
         x = x.contiguous()
@@ -552,6 +588,11 @@ class IResNet(nn.Module):
     # flat accessors used by the fused trainer / FedAvg
     def flat_state(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         return self._flat_params, self._flat_bufs, self._flat_nbt
+
+    def exchange_buffer(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(whole fp32 state [params | running stats | float image of num_batches_tracked (+pad)], that float image, the int64
+        counters): the one tensor a FedAvg round all-reduces in place."""
+        return self._flat_state, self._nbt_f32, self._flat_nbt
 
     def trainable_count(self) -> int:
         return self._counts[_C.Q_TRAINABLE_COUNT]

@@ -176,20 +176,39 @@ class Sequential_model(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # fused train step
 # ------------------------------------------------------------------------------------------------
+_AUX_STREAMS = {}      # device index -> the one auxiliary stream every trainer on that device shares (created once, lives with the process)
+_AUX_LOCK = __import__("threading").Lock()
+
+
 def _make_aux_stream(device):
     """Second HIP stream of the dual-stream backward (None with FEDFR_DUAL_STREAM=0): created at the LOWEST priority the device offers
     (through the C ABI: torch clamps stream priorities to [-1, 0], HIP has +1), so that workgroups of the critical path on the caller's
-    stream are dispatched first whenever both streams have work.  FEDFR_AUX_PRIORITY=0 keeps a default-priority torch stream."""
+    stream are dispatched first whenever both streams have work.  FEDFR_AUX_PRIORITY=0 keeps a default-priority torch stream.
+    ONE stream per device for the life of the process: trainers are re-created every FL round for every client (the reference
+    re-creates its optimiser the same way), a stream per trainer would leak a HIP stream each time."""
     import os
     if os.environ.get("FEDFR_DUAL_STREAM", "1") == "0":
         return None
-    if os.environ.get("FEDFR_AUX_PRIORITY", "1") != "0":
-        import ctypes
-        h = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            _C.call("fedfr_stream_create_low_priority", ctypes.byref(h))
-        return torch.cuda.ExternalStream(h.value, device=device)
-    return torch.cuda.Stream(device=device)
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _AUX_LOCK:
+        return _aux_stream_locked(idx)
+
+
+def _aux_stream_locked(idx):
+    import os
+    s = _AUX_STREAMS.get(idx)
+    if s is None:
+        if os.environ.get("FEDFR_AUX_PRIORITY", "1") != "0":
+            import ctypes
+            h = ctypes.c_void_p()
+            with torch.cuda.device(idx):
+                _C.call("fedfr_stream_create_low_priority", ctypes.byref(h))
+            s = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+        else:
+            s = torch.cuda.Stream(device=torch.device("cuda", idx))
+        _AUX_STREAMS[idx] = s
+    return s
 
 
 class FusedTrainer:
@@ -224,11 +243,22 @@ class FusedTrainer:
         self.first = True
         # weight-gradient GEMMs run on a second HIP stream (fedfr_net_backward2) unless FEDFR_DUAL_STREAM=0
         self.aux_stream = _make_aux_stream(bb.device)
+        self._shadows_pending = None
+        if self.aux_stream is not None:       # the shared aux stream may still carry the previous trainer's shadow rebuild of this backbone
+            torch.cuda.current_stream().wait_stream(self.aux_stream)
         bb.refresh_shadows(True)
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
 
+    def finish(self):
+        """Order the aux-stream shadow rebuild of the last step before anything the caller does next on the current stream
+        (state_dict snapshot, load_state_dict of the next round, a new trainer)."""
+        if self._shadows_pending is not None:
+            torch.cuda.current_stream().wait_stream(self._shadows_pending)
+            self._shadows_pending = None
+
+    @_C.on_device(lambda self: self.bb.device)
     def forward_backward(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         bb = self.bb
         bb._check_input(imgs)
@@ -264,13 +294,14 @@ class FusedTrainer:
 
     def _backward(self, plan, imgs, dfeats, st):
         bb = self.bb
-        if getattr(self, "_shadows_pending", None) is not None:
+        if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)   # dgrad shadows rebuilt on aux after the last SGD step
             self._shadows_pending = None
         _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
                 self.aux_stream.cuda_stream if self.aux_stream is not None else None)
 
+    @_C.on_device(lambda self: self.bb.device)
     def optimizer_step(self):
         bb = self.bb
         st = _C.stream()
@@ -324,32 +355,29 @@ class FusedHeadTrainer:
         self.first = True
         self.aux_stream = _make_aux_stream(bb.device)
         self._shadows_pending = None
+        if self.aux_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.aux_stream)
         bb.refresh_shadows(True)
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
 
-    def step(self, imgs: torch.Tensor, labels: torch.Tensor, head_loss):
-        """``head_loss(feats, labels) -> (loss, *extras)``; returns that tuple (loss detached)."""
+    def _forward(self, imgs, labels):
         bb = self.bb
         bb._check_input(imgs)
         labels = _C.require_gpu_tensor(labels, torch.int64, "labels")
-        B = imgs.shape[0]
-        plan = bb._plan(B)
-        st = _C.stream()
-        feats = torch.empty(B, bb.num_features, dtype=f32, device=bb.device)
+        plan = bb._plan(imgs.shape[0])
+        feats = torch.empty(imgs.shape[0], bb.num_features, dtype=f32, device=bb.device)
         _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
-                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1, st)
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1, _C.stream())
         bb._flat_nbt += 1
         bb._fwd_generation += 1
-        for hp in self.head_params:                                   # opt.zero_grad()
-            hp.grad = None
-        feats.requires_grad_(True)
-        with torch.enable_grad():
-            out = head_loss(feats, labels)
-            loss = out[0] if isinstance(out, tuple) else out
-            loss.backward()
-        dfeats = _C.require_gpu_tensor(feats.grad.contiguous(), f32, "d(loss)/d(features)")
+        return plan, feats, labels
+
+    def _backward_and_update(self, plan, imgs, dfeats):
+        """backbone backward from d(loss)/d(features), then opt.step() for the backbone (flat) and every head parameter with a grad."""
+        bb, st = self.bb, _C.stream()
+        dfeats = _C.require_gpu_tensor(dfeats.contiguous(), f32, "d(loss)/d(features)")
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
@@ -379,6 +407,19 @@ class FusedHeadTrainer:
         else:
             bb.refresh_shadows(False)
         self.first = False
+
+    @_C.on_device(lambda self: self.bb.device)
+    def step(self, imgs: torch.Tensor, labels: torch.Tensor, head_loss):
+        """``head_loss(feats, labels) -> (loss, *extras)``; returns that tuple (loss detached)."""
+        plan, feats, labels = self._forward(imgs, labels)
+        for hp in self.head_params:                                   # opt.zero_grad()
+            hp.grad = None
+        feats.requires_grad_(True)
+        with torch.enable_grad():
+            out = head_loss(feats, labels)
+            loss = out[0] if isinstance(out, tuple) else out
+            loss.backward()
+        self._backward_and_update(plan, imgs, feats.grad)
         if isinstance(out, tuple):
             return tuple(o.detach() if torch.is_tensor(o) else o for o in out)
         return loss.detach()
@@ -388,6 +429,67 @@ class FusedHeadTrainer:
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
+
+
+class ShardedHeadTrainer(FusedHeadTrainer):
+    """BASELINE config 5 — "iresnet100 + CosFace + personalized transform head, 8 clients = 8 MI355X, PartialFC class-sharded across
+    GPUs".  The reference never runs this combination (its clients own private dense heads, client.py:149; its PartialFC is dead
+    code), so the definition is this build's:
+
+    * every rank is one FL client with its OWN backbone (weights diverge during the round, no gradient all-reduce) and its own data
+      shard: identities [id_base, id_base + n_local_ids) of the global label space;
+    * the identity head is ONE ``PartialFC(world_size=W)`` shared by all ranks: per step the normalised embeddings and labels of all
+      W clients are all-gathered (global batch B*W), every rank computes the logits of its class shard against all of them, the
+      softmax statistics are all-reduced, and d(embedding) comes back by reduce-scatter (partial_fc.py:118-176, four packed
+      collectives per step) — this couples the clients step by step, unlike pure FL;
+    * each client also trains its private ``BCE_module`` (client.py:25-60) on its own embeddings with local labels
+      ``label - id_base`` (rows of other clients' identities are all-negative, client.py:48-52), weight 10 (client.py:383);
+    * loss_i = CosFace-PartialFC loss (identical on all ranks) + 10 * BCE_i; backbone + BCE parameters + the rank's PartialFC rows
+      get momentum-SGD (coupled weight decay); at round end the backbones are averaged with ``server.fedavg_all_reduce``.
+    """
+
+    def __init__(self, backbone, pfc, bce_module=None, id_base: int = 0, lr: float = 0.1, momentum: float = 0.9,
+                 weight_decay: float = 5e-4, bce_weight: float = 10.0):
+        super().__init__(backbone, list(bce_module.parameters()) if bce_module is not None else [], lr, momentum, weight_decay)
+        self.pfc, self.bce_module, self.id_base, self.bce_weight = pfc, bce_module, int(id_base), float(bce_weight)
+        self.bce_loss = losses.BCE_loss() if bce_module is not None else None
+        if bce_module is not None:
+            bce_module.train()
+
+    @_C.on_device(lambda self: self.bb.device)
+    def step(self, imgs: torch.Tensor, labels: torch.Tensor, perm=None):
+        """labels: GLOBAL identity ids.  Returns (loss, cos_loss, bce_loss or None) as device scalars."""
+        plan, feats, labels = self._forward(imgs, labels)
+        # ---- shared class-sharded head (the step's collectives live in here)
+        fn, finv = ops.normalize_rows(feats)
+        x_grad, cos_loss = self.pfc.forward_backward(labels, fn, None, perm=perm)
+        dfeats = ops.normalize_rows_bwd(fn, finv, x_grad.contiguous())
+        # ---- private personalised head on this client's own embeddings
+        bce = None
+        if self.bce_module is not None:
+            for hp in self.head_params:
+                hp.grad = None
+            leaf = feats.detach().requires_grad_(True)
+            with torch.enable_grad():
+                lab = labels - self.id_base                   # local identity index; other clients' identities -> n_class = the
+                lab = torch.where((lab < 0) | (lab >= self.bce_module.n_class), torch.full_like(lab, self.bce_module.n_class), lab)
+                z, gt = self.bce_module(leaf, lab)            # all-negative row of client.py:48-52
+                bce = self.bce_loss(z, gt)
+                (self.bce_weight * bce).backward()
+            ops.axpy_(dfeats, leaf.grad, 1.0)
+            bce = bce.detach()
+        self._backward_and_update(plan, imgs, dfeats)
+        self.pfc.fused_sgd_update(self.lr, self.mu, self.wd)
+        loss = cos_loss if bce is None else ops.axpy_(ops.scale(bce.reshape(1), self.bce_weight), cos_loss.reshape(1), 1.0).reshape(())
+        return loss, cos_loss, bce
+
+    def end_round(self, data_size: float, total_size: float):
+        """FedAvg of the backbones over the ranks (ONE all-reduce of the flat state)."""
+        from .server import fedavg_all_reduce
+        self.finish()
+        w = fedavg_all_reduce(self.bb, data_size, total_size, self.pfc.comm)
+        self.bb.refresh_shadows(True)
+        return w
 
 
 # ------------------------------------------------------------------------------------------------
@@ -493,6 +595,21 @@ def to_device_batch(imgs, labels, device, train: bool):
     return imgs.to(device, non_blocking=True).contiguous(), labels
 
 
+_BACKBONE_POOL = {}     # (network, device, dropout) -> the one resident backbone (+ activation arenas) all Clients of this process share
+
+
+def shared_backbone(network: str, device, dropout=0):
+    """The reference builds a client's backbone inside ``train()`` and deletes it afterwards (client.py:513, :568-570), so 40 clients
+    fit one GPU.  Here a backbone owns GBs of activation arena + workspace per batch size (iresnet100 at B=128: 5.8 + 3 GB), so all
+    Clients of a process train through ONE resident instance per (arch, device): each call loads its own state_dict into it."""
+    device = torch.device(device)
+    key = (network, str(device), float(dropout))
+    bb = _BACKBONE_POOL.get(key)
+    if bb is None:
+        bb = _BACKBONE_POOL[key] = getattr(backbones, network)(False, dropout=dropout, fp16=cfg.fp16).to(device)
+    return bb
+
+
 class Client(object):
     """Local trainer of one FL participant (reference client.py:116-157, :511-582).
 
@@ -530,15 +647,13 @@ class Client(object):
         if hasattr(data, "test_loaders"):
             self.test_loaders = data.test_loaders[self.cid]                      # client.py:128-129
         self.logger = logging.getLogger("FL_face.client")
-        self._backbone = None
         self.loss_meter = AverageMeter()
         self.sync_every = getattr(args, "loss_sync_every", 1)      # reference syncs (loss.item()) every step
 
     def _get_backbone(self):
-        if self._backbone is None:
-            self._backbone = getattr(backbones, self.args.network)(False, dropout=self.dropout, fp16=cfg.fp16).to(self.device)
-        return self._backbone
+        return shared_backbone(self.args.network, self.device, self.dropout)
 
+    @_C.on_device(lambda self: self.device)
     def train(self, start_epoch=0, callback_verification=None):
         """reference client.py:511-571."""
         backbone = self._get_backbone()
@@ -563,10 +678,12 @@ class Client(object):
                     pending = []
         for l in pending:
             loss_meter.update(l.item(), 1)
+        trainer.finish()
         self.loss_meter = loss_meter
         self.backbone_state_dict = flat_state_dict(backbone)
         self.fc_module.cpu()
 
+    @_C.on_device(lambda self: self.device)
     def data_update_fc(self, fed_model_state_dict, norm_before_avg, fc_name="center_features", save_to_disk=False):
         """reference client.py:159-188: class centres of the client's own identities under the incoming global model become the
         local rows of the cosine head."""
@@ -579,6 +696,7 @@ class Client(object):
             torch.save(init_fc, os.path.join(getattr(self, "client_output", "."), fc_name + ".pth"))
         self.fc_module.update_from_tensor(init_fc)
 
+    @_C.on_device(lambda self: self.device)
     def choose_hard_negative_2(self, public_train_loader, pretrained_label, pretrained_feats, threshold=0.2):
         """reference client.py:191-236 (feature-based hard negatives): embed the local images with the current backbone, keep
         every public image whose normalised embedding has cosine similarity > threshold with ANY local embedding.  The
@@ -612,6 +730,7 @@ class Client(object):
             logits = torch.cat([logits, tmp], dim=1)
         return logits
 
+    @_C.on_device(lambda self: self.device)
     def train_with_public_data(self, start_epoch=0, callback_verification=None, public_train_loader=None, pretrained_fc=None,
                                choose_hard_negative=False, pretrained_label=None, pretrained_feats=None, combine_loader=None):
         """reference client.py:287-508 — local + public identities, CosFace over [local | public] class centres, optional
@@ -709,6 +828,7 @@ class Client(object):
             self.bce_module.cpu()
         if use_con:
             self.last_model.load_state_dict(self.backbone_state_dict)               # client.py:499-501
+            self.last_model.release_workspace()      # keep only its 260 MB of weights resident between rounds, not its arenas
             del global_model
 
     def get_train_loss(self):

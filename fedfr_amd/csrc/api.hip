@@ -434,6 +434,12 @@ int fedfr_softmax_grad(float* z, const long long* label, int R, int C, int ldz, 
 int fedfr_margin_bwd(const float* dlogits, const long long* label, const float* dmul, float s, int R, int C, float* dcos, void* stream) {
   return head_margin_bwd(dlogits, label, dmul, s, R, C, dcos, ST(stream));
 }
+int fedfr_exp_rowsum_target(float* z, const long long* label, int R, int C, int ldz, const float* row_max, float* sums2, void* stream) {
+  return head_exp_rowsum_target(z, label, R, C, ldz, row_max, sums2, ST(stream));
+}
+int fedfr_nll_mean_ratio(const float* num, const float* den, int R, float floor_, float* loss, void* stream) {
+  return head_nll_mean_ratio(num, den, R, floor_, loss, ST(stream));
+}
 int fedfr_nll_mean(const float* prob_t, int R, float floor_, float* loss, void* stream) {
   return head_nll_mean(prob_t, R, floor_, loss, ST(stream));
 }

@@ -15,6 +15,8 @@ int head_softmax_grad(float* z, const long long* label, int R, int C, int ldz, c
 int head_margin_bwd(const float* dlogits, const long long* label, const float* dmul, float s, int R, int C, float* dcos,
                     hipStream_t st);
 int head_nll_mean(const float* prob_t, int R, float floor_, float* loss, hipStream_t st);
+int head_exp_rowsum_target(float* z, const long long* label, int R, int C, int ldz, const float* row_max, float* sums2, hipStream_t st);
+int head_nll_mean_ratio(const float* num, const float* den, int R, float floor_, float* loss, hipStream_t st);
 int head_bce_logits(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
                     float* z, unsigned char* gt, float* dzdcos, hipStream_t st);
 int head_bce_loss(const float* z, const unsigned char* gt, const float* dzdcos, int B, int C, float r, float lam, float loss_scale,

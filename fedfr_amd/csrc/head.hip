@@ -297,6 +297,39 @@ __global__ __launch_bounds__(256) void exp_rowsum_kernel(float* __restrict__ z, 
   if (threadIdx.x == 0) row_sum[row] = sum;
 }
 
+// step 2 of the class-sharded softmax (PartialFC): as exp_rowsum, and the target's numerator rides along — sums2[row] = sum_c e,
+// sums2[R + row] = e[label] (0 when this shard does not hold the row's class), so that ONE sum all-reduce of the [2][R] tensor replaces
+// the reference's two (partial_fc.py:147 sum of exponentials, :161 target probability)
+__global__ __launch_bounds__(256) void exp_rowsum_target_kernel(float* __restrict__ z, const long long* __restrict__ label, int R, int C, int ldz,
+                                                                const float* __restrict__ row_max, float* __restrict__ sums2) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  float* zr = z + (size_t)row * ldz;
+  const float mx = row_max[row];
+  const long long y = label[row];
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float e = expf(zr[c] - mx);
+    zr[c] = e;
+    sum += e;
+    if (c == y) sums2[R + row] = e;
+  }
+  sum = block_sum(sum, sh);
+  if (threadIdx.x == 0) {
+    sums2[row] = sum;
+    if (y < 0 || y >= C) sums2[R + row] = 0.f;
+  }
+}
+// loss = -mean_r log(max(num[r] / den[r], floor))
+__global__ __launch_bounds__(256) void nll_mean_ratio_kernel(const float* __restrict__ num, const float* __restrict__ den, int R, float floor_,
+                                                             float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) s += -logf(fmaxf(num[r] / den[r], floor_));
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *loss = s / R;
+}
+
 // step 3: p = z / sum; prob_t[row] = p[label] (0 when label == -1); grad wrt cos in place:
 //   g[c] = (p[c] - [c == y]) * inv_batch * (c == y ? dmul[row] : s)
 __global__ __launch_bounds__(256) void softmax_grad_kernel(float* __restrict__ z, const long long* __restrict__ label, int C, int ldz,
@@ -340,6 +373,18 @@ int head_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float
   FEDFR_REQUIRE(z && row_max && row_sum && R > 0 && C > 0, "exp_rowsum: bad args");
   hipLaunchKernelGGL(exp_rowsum_kernel, dim3(R), dim3(256), 0, st, z, C, ldz, row_max, row_sum);
   FEDFR_LAUNCH_CHECK("exp_rowsum");
+  return FEDFR_OK;
+}
+int head_exp_rowsum_target(float* z, const long long* label, int R, int C, int ldz, const float* row_max, float* sums2, hipStream_t st) {
+  FEDFR_REQUIRE(z && label && row_max && sums2 && R > 0 && C > 0, "exp_rowsum_target: bad args");
+  hipLaunchKernelGGL(exp_rowsum_target_kernel, dim3(R), dim3(256), 0, st, z, label, R, C, ldz, row_max, sums2);
+  FEDFR_LAUNCH_CHECK("exp_rowsum_target");
+  return FEDFR_OK;
+}
+int head_nll_mean_ratio(const float* num, const float* den, int R, float floor_, float* loss, hipStream_t st) {
+  FEDFR_REQUIRE(num && den && loss && R > 0, "nll_mean_ratio: bad args");
+  hipLaunchKernelGGL(nll_mean_ratio_kernel, dim3(1), dim3(256), 0, st, num, den, R, floor_, loss);
+  FEDFR_LAUNCH_CHECK("nll_mean_ratio");
   return FEDFR_OK;
 }
 int head_softmax_grad(float* z, const long long* label, int R, int C, int ldz, const float* row_sum, const float* dmul, float s,

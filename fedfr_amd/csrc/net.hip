@@ -211,7 +211,7 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
 // Used by the block-level parity tests (tests/golden/block.npz) — x / dy / y / dx cross the ABI as fp32 NCHW like the reference's.
 FedfrNet* net_create_block(int cin, int cout, int stride, int hin, int batch) {
   const bool ds = stride != 1;
-  if (batch <= 0 || hin <= 0 || (hin % (2 * stride)) != 0 || cin <= 0 || cout <= 0 || (cin % 64) || (cout % 64) || (stride != 1 && stride != 2) ||
+  if (batch <= 0 || hin <= 0 || (hin % stride) != 0 || cin <= 0 || cout <= 0 || (cin % 64) || (cout % 64) || (stride != 1 && stride != 2) ||
       (stride == 1 && cin != cout)) {
     fedfr_set_error("block_create: need channels%%64==0, stride 1 (cin==cout) or 2 (with downsample), even map (got %d->%d s%d @%d)", cin, cout,
                     stride, hin);

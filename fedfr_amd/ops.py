@@ -92,6 +92,50 @@ def softmax_ce_grad(cosine: torch.Tensor, label: torch.Tensor, s: float, m: floa
     return prob_t, cosine
 
 
+def sharded_softmax_ce_grad(cosine: torch.Tensor, label: torch.Tensor, s: float, m: float, arcface: bool, inv_batch: float,
+                            all_reduce, floor: float = 1e-30):
+    """The class-sharded form (PartialFC, partial_fc.py:138-166) with its three reductions packed into two collectives: in place on
+    this rank's ``cosine`` [R, C_local] (labels already localised, -1 = class lives elsewhere): margin -> global row max (MAX
+    all-reduce) -> exponentials; ONE SUM all-reduce of [row sums | target numerators]; gradient wrt the cosine matrix.
+    Returns (loss_v scalar = -mean log max(p_target, floor), grad == cosine storage)."""
+    cosine = _chk(cosine, "cosine")
+    label = _chk(label, "label", torch.int64)
+    R, Cc = cosine.shape
+    dev = cosine.device
+    row_max = torch.empty(R, dtype=f32, device=dev)
+    sums2 = torch.empty(2, R, dtype=f32, device=dev)
+    dmul = torch.empty(R, dtype=f32, device=dev)
+    prob_t = torch.empty(R, dtype=f32, device=dev)
+    loss = torch.empty((), dtype=f32, device=dev)
+    st = _C.stream()
+    _C.call("fedfr_margin_rowmax", cosine.data_ptr(), label.data_ptr(), R, Cc, Cc, s, m, 1 if arcface else 0,
+            row_max.data_ptr(), dmul.data_ptr(), st)
+    all_reduce(row_max, "max")                                                                     # partial_fc.py:142
+    _C.call("fedfr_exp_rowsum_target", cosine.data_ptr(), label.data_ptr(), R, Cc, Cc, row_max.data_ptr(), sums2.data_ptr(), st)
+    all_reduce(sums2, "sum")                                                                       # partial_fc.py:147 + :161
+    _C.call("fedfr_softmax_grad", cosine.data_ptr(), label.data_ptr(), R, Cc, Cc, sums2.data_ptr(), dmul.data_ptr(), s,
+            inv_batch, prob_t.data_ptr(), st)
+    _C.call("fedfr_nll_mean_ratio", sums2[1].data_ptr(), sums2[0].data_ptr(), R, floor, loss.data_ptr(), st)
+    return loss, cosine
+
+
+def scale(x: torch.Tensor, w: float) -> torch.Tensor:
+    """w * x (fp32) as a HIP kernel."""
+    x = _chk(x, "x")
+    out = torch.empty_like(x)
+    _C.call("fedfr_fedavg_axpy", out.data_ptr(), x.data_ptr(), float(w), x.numel(), 0, _C.stream())
+    return out
+
+
+def axpy_(dst: torch.Tensor, src: torch.Tensor, w: float) -> torch.Tensor:
+    """dst += w * src in place (fp32, HIP kernel)."""
+    dst, src = _chk(dst, "dst"), _chk(src, "src")
+    if dst.numel() != src.numel():
+        raise RuntimeError("axpy_: size mismatch")
+    _C.call("fedfr_fedavg_axpy", dst.data_ptr(), src.data_ptr(), float(w), dst.numel(), 1, _C.stream())
+    return dst
+
+
 def nll_mean(prob_t: torch.Tensor, floor: float = 0.0) -> torch.Tensor:
     loss = torch.empty((), dtype=f32, device=prob_t.device)
     _C.call("fedfr_nll_mean", prob_t.data_ptr(), prob_t.numel(), floor, loss.data_ptr(), _C.stream())

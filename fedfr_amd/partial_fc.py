@@ -13,24 +13,26 @@ import os
 from typing import Optional
 
 import torch
-import torch.distributed as dist
 from torch.nn import Module
 from torch.nn.parameter import Parameter
 
 from . import _C, ops
+from .comm import default_comm
 
 f32 = torch.float32
-
-
-def _is_dist(world_size: int) -> bool:
-    return world_size > 1 and dist.is_available() and dist.is_initialized()
 
 
 class PartialFC(Module):
     @torch.no_grad()
     def __init__(self, rank, local_rank, world_size, batch_size, resume, margin_softmax, num_classes, sample_rate=1.0,
-                 embedding_size=512, prefix="./", seed: int = 100):
+                 embedding_size=512, prefix="./", seed: int = 100, comm=None):
+        """Reference signature (partial_fc.py:20-23) + two build extensions: ``seed`` of the counter-based sampling RNG and ``comm``
+        (fedfr_amd.comm: the exchange layer; default = the torch.distributed process group when world_size > 1)."""
         super().__init__()
+        self.comm = comm if comm is not None else default_comm(world_size)
+        if self.comm.world_size != world_size or self.comm.rank != rank:
+            raise ValueError("PartialFC: rank/world_size (%d/%d) disagree with the communicator (%d/%d)"
+                             % (rank, world_size, self.comm.rank, self.comm.world_size))
         self.num_classes: int = num_classes
         self.rank: int = rank
         self.local_rank: int = local_rank
@@ -122,8 +124,10 @@ class PartialFC(Module):
             return
         index = torch.empty(self.num_sample, dtype=torch.int64, device=self.device)
         _C.call("fedfr_pfc_topk", self._perm.data_ptr(), self.num_local, self.num_sample, index.data_ptr(), self._npos.data_ptr(), st)
-        npos = int(self._npos.item())                       # host sync, as torch.unique in the reference
-        if npos > self.num_sample:                          # more positives than samples: index = positives (:101-102)
+        # more positives than samples -> index = the positives (:101-102), a data-dependent SHAPE.  It cannot happen while the global
+        # batch is no larger than num_sample (npos <= B*W), which is every BASELINE config: then no host sync at all
+        npos = int(self._npos.item()) if n > self.num_sample else 0
+        if npos > self.num_sample:
             index = torch.empty(npos, dtype=torch.int64, device=self.device)
             _C.call("fedfr_pfc_positive", self._perm.data_ptr(), self.num_local, index.data_ptr(), self._npos.data_ptr(), st)
         self.index = index
@@ -140,6 +144,7 @@ class PartialFC(Module):
         return ops.sgemm(total_features, norm_weight, trans_b=True)
 
     @torch.no_grad()
+    @_C.on_device(lambda self: self.device)
     def update(self):
         """scatter the sampled rows back (partial_fc.py:113-116)."""
         st = _C.stream()
@@ -150,34 +155,30 @@ class PartialFC(Module):
         _C.call("fedfr_rows_scatter", self.weight.data_ptr(), sw.data_ptr(), self.index.data_ptr(), k, self.embedding_size,
                 self.num_local, st)
 
-    # ------------------------------------------------------------------ collectives
-    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
-        if not _is_dist(self.world_size):
-            return t.clone()
-        if dist.get_backend() == "gloo":      # gloo moves device tensors only through broadcast / all_reduce (debug + test path)
-            out = torch.zeros((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            out[self.rank] = t
-            dist.all_reduce(out)
-        else:
-            out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t.contiguous())
-        return out.view((-1,) + tuple(t.shape[1:]))
+    # ------------------------------------------------------------------ exchange points
+    # The reference has six (partial_fc.py:122,134,142,147,161,173); packed here into four collectives per step:
+    #   G  all-gather of [features | label bits]            (C1 + C2: one [B, D+2] fp32 tensor, the int64 label bit-cast into 2 lanes)
+    #   M  max all-reduce of the row maxima                 (C3)
+    #   S  sum all-reduce of [row sums | target numerators] (C4 + C5: one [2, B*W] tensor)
+    #   R  reduce-scatter of d(total_features)              (C6)
+    def _gather_inputs(self, label, features):
+        W = self.world_size
+        if W == 1:
+            return label.to(torch.int64).clone(), features
+        if not getattr(self.comm, "bitwise_gather", True):       # gloo debug path: its device "all-gather" is an arithmetic all-reduce
+            return self.comm.all_gather(label.to(torch.int64).contiguous()), self.comm.all_gather(features)
+        B, D = features.shape
+        packed = torch.empty(B, D + 2, dtype=f32, device=features.device)
+        packed[:, :D] = features
+        packed[:, D:] = label.to(torch.int64).contiguous().view(torch.int32).view(B, 2).view(f32)    # exact bit copy
+        tot = self.comm.all_gather(packed)                                                    # G
+        total_label = tot[:, D:].contiguous().view(torch.int32).view(-1).view(torch.int64).clone()
+        return total_label, tot[:, :D].contiguous()
 
-    def _reduce_scatter(self, full: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
-        if dist.get_backend() == "gloo":
-            dist.all_reduce(full)
-            return full.view((self.world_size,) + tuple(like.shape))[self.rank].clone()
-        out = torch.empty_like(like)
-        dist.reduce_scatter_tensor(out, full)
-        return out
-
-    def _all_reduce(self, t: torch.Tensor, op: str):
-        if _is_dist(self.world_size):
-            dist.all_reduce(t, dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
-
-    def prepare(self, label, optimizer, perm=None):
+    def prepare(self, label, optimizer, perm=None, total_label=None):
         """partial_fc.py:118-128: gather labels, sample, alias the sampled rows into the optimiser's last group."""
-        total_label = self._all_gather(label.to(torch.int64).contiguous())       # C1
+        if total_label is None:
+            total_label = self.comm.all_gather(label.to(torch.int64).contiguous())           # C1 alone (callers without features)
         self.sample(total_label, perm)
         if optimizer is not None:
             optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
@@ -186,28 +187,34 @@ class PartialFC(Module):
         norm_weight, winv = ops.normalize_rows(self.sub_weight.data)
         return total_label, norm_weight, winv
 
+    @_C.on_device(lambda self: self.device)
     def forward_backward(self, label, features, optimizer, perm=None):
         """partial_fc.py:130-176.  Returns (x_grad [B, D], loss_v scalar); ``self.sub_weight.grad`` is set."""
         features = _C.require_gpu_tensor(features.detach().contiguous(), f32, "features")
-        total_label, norm_weight, winv = self.prepare(label, optimizer, perm)
-        total_features = self._all_gather(features)                                        # C2
+        W = self.world_size
+        total_label, total_features = self._gather_inputs(label, features)                  # G
+        total_label, norm_weight, winv = self.prepare(label, optimizer, perm, total_label)
         logits = self.forward(total_features, norm_weight)
-        inv_batch = 1.0 / (self.batch_size * self.world_size)
-        prob_t, grad = ops.softmax_ce_grad(logits, total_label, self._s, self._m, self._arc, inv_batch,
-                                           all_reduce=self._all_reduce if _is_dist(self.world_size) else None)   # C3-C5
-        loss_v = ops.nll_mean(prob_t, 1e-30)
+        inv_batch = 1.0 / (self.batch_size * W)
+        if W > 1:
+            loss_v, grad = ops.sharded_softmax_ce_grad(logits, total_label, self._s, self._m, self._arc, inv_batch,
+                                                       self.comm.all_reduce, 1e-30)                  # M, S
+        else:
+            prob_t, grad = ops.softmax_ce_grad(logits, total_label, self._s, self._m, self._arc, inv_batch)
+            loss_v = ops.nll_mean(prob_t, 1e-30)
         # logits.backward(grad): d total_features = grad @ norm_weight ; d norm_weight = grad^T @ total_features
         dfeat = ops.sgemm(grad, norm_weight)
         dwn = ops.sgemm(grad, total_features, trans_a=True)
         self.sub_weight.grad = ops.normalize_rows_bwd(norm_weight, winv, dwn)
-        if _is_dist(self.world_size):                                                        # C6
-            x_grad = self._reduce_scatter(dfeat, features)
+        if W > 1:
+            x_grad = self.comm.reduce_scatter(dfeat)                                          # R
+            x_grad = ops.scale(x_grad, float(W))                                              # partial_fc.py:174
         else:
             x_grad = dfeat
-        x_grad = x_grad * self.world_size                                                    # partial_fc.py:174
         return x_grad, loss_v
 
     @torch.no_grad()
+    @_C.on_device(lambda self: self.device)
     def fused_sgd_update(self, lr, momentum=0.9, weight_decay=5e-4):
         """Caller-side ``opt.step(); pfc.update()`` for the sampled rows as two HIP calls (momentum rows already
         exist, so this is never a 'first' step — partial_fc.py:124-126)."""

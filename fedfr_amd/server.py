@@ -103,24 +103,40 @@ def _i64_scale(acc: torch.Tensor, src: torch.Tensor, w: float):
     _C.call("fedfr_fedavg_i64", acc.data_ptr(), src.data_ptr(), float(np.float32(w)), src.numel(), 0, None, _C.stream())
 
 
-def fedavg_all_reduce(backbone, data_size: float, group=None, _axpy=_axpy, _i64=_i64_scale):
-    """One client per rank: scale the local flat state by n_i/Σn and SUM all-reduce it over RCCL/xGMI
-    (replaces the CPU loop of server.py:25-34 + the state_dict hand-offs of server.py:286,311).  In place.
-    ``_axpy`` / ``_i64`` are the HIP scale kernels (injectable only so the collective plumbing can be exercised
-    by the 2-rank gloo CPU test)."""
-    import torch.distributed as dist
-    p, b, n = backbone.flat_state()
-    tot = torch.tensor([float(data_size)], dtype=torch.float64, device=p.device)
-    dist.all_reduce(tot, group=group)
-    w = float(data_size) / float(tot.item())
-    _axpy(p, p, w, False)
-    _axpy(b, b, w, False)
-    nf = torch.empty(n.numel(), dtype=f32, device=p.device)
-    _i64(nf, n, w)
-    dist.all_reduce(p, group=group)
-    dist.all_reduce(b, group=group)
-    dist.all_reduce(nf, group=group)
-    n.copy_(nf.to(torch.int64))          # load_state_dict's float -> int64 truncation (F9)
+def _i64_trunc(acc: torch.Tensor, dst: torch.Tensor):
+    """dst (int64) = trunc(acc) — load_state_dict's float -> int64 copy of the averaged num_batches_tracked (F9)."""
+    _C.call("fedfr_fedavg_i64", acc.data_ptr(), dst.data_ptr(), 0.0, dst.numel(), 1, dst.data_ptr(), _C.stream())
+
+
+def exchange_data_sizes(data_size: float, comm) -> float:
+    """Σ n_j over the ranks (one tiny all-reduce + host read).  Run it when the sizes become known — at round start, off the exchange
+    path — and hand the result to ``fedavg_all_reduce``; ranks that know every client's size in advance skip it."""
+    t = torch.tensor([float(data_size)], dtype=torch.float64)
+    t = comm.all_reduce(t, "sum")
+    return float(t.item())
+
+
+def fedavg_all_reduce(backbone, data_size: float, total_size: float, comm=None, _axpy=_axpy, _i64=_i64_scale, _trunc=_i64_trunc):
+    """One client per rank: the FedAvg of a round as ONE collective (replaces the CPU loop of server.py:25-34 and the state_dict
+    hand-offs of server.py:286,311).  The local state — parameters, BN running statistics and a float image of the
+    ``num_batches_tracked`` counters, which are slices of one fp32 tensor (``IResNet.exchange_buffer``) — is scaled in place by the
+    pre-agreed weight n_i / Σn (the reference's ``weights[i] / sum(weights)``, server.py:27) and SUM-all-reduced in place over
+    RCCL/xGMI: 261 MB for iresnet100, no packing copies, no host synchronisation.  The counters are truncated back to int64 as
+    ``load_state_dict`` does (F9).  The summation ORDER is the collective's (a ring), not the reference's ascending client index: results
+    agree with ``FedPavg`` to fp32 rounding, not bit for bit.
+    ``comm``: fedfr_amd.comm communicator (default: the torch.distributed world).  ``_axpy`` / ``_i64`` / ``_trunc`` are the HIP
+    kernels (injectable only so the plumbing can be exercised by the gloo CPU test)."""
+    from .comm import TorchDistComm
+    if comm is None:
+        comm = TorchDistComm()
+    state, nbt_f, nbt = backbone.exchange_buffer()
+    w = float(data_size) / float(total_size)
+    n_float = (nbt_f.data_ptr() - state.data_ptr()) // 4          # params + running stats: everything in front of the counter image
+    fl = state[:n_float]
+    _axpy(fl, fl, w, False)
+    _i64(nbt_f, nbt, w)
+    comm.all_reduce(state, "sum")                  # THE exchange of the round
+    _trunc(nbt_f, nbt)
     backbone.mark_weights_dirty()
     return w
 
@@ -150,16 +166,17 @@ class Server(object):
         self.pretrained_label = None                 # [N_public] identity of every public image
         self.pretrained_feats = None                 # [N_public, 512] normalised embeddings (hard-negative mining)
         self.pretrained_fc = None                    # [n_public, 512] class centres of the public identities (server.py:182-240)
+        self.pretrain_fc = None                      # where the reference stores the FedAvg'd public centres (server.py:325, see train())
 
     # ---- public-set inference sweeps (reference server.py:182-263)
     def _eval_backbone(self):
-        bb = getattr(self, "_sweep_backbone", None)
-        if bb is None:
-            bb = self._sweep_backbone = getattr(backbones, self.args.network)(False, dropout=0, fp16=True).to(self.device)
+        from .client import shared_backbone
+        bb = shared_backbone(self.args.network, self.device, 0)       # the process-wide resident instance (one set of arenas)
         bb.load_state_dict(flat_state_dict(self.federated_model))
         return bb.eval()
 
     @torch.no_grad()
+    @_C.on_device(lambda self: self.device)
     def Generate_pretrain_feats(self):
         """normalised embeddings of the whole public set under the current global model (server.py:242-263); stays on the GPU."""
         from .client import embed_dataset
@@ -167,6 +184,7 @@ class Server(object):
         return feats
 
     @torch.no_grad()
+    @_C.on_device(lambda self: self.device)
     def Initialize_pretrain_FC(self, only_labels=False):
         """(init_matrix [n_public_ID, 512], raw_labels [N]) — per-identity mean embedding of the public set (server.py:182-240).
         The reference's optional .pth cache (load_pth / save_pth) is checkpoint I/O, outside this path."""
@@ -178,6 +196,7 @@ class Server(object):
                                                 getattr(self, "norm_before_avg", getattr(self.args, "norm_before_avg", True)))
         return init_matrix, raw_labels.cpu()
 
+    @_C.on_device(lambda self: self.device)
     def train(self):
         from .config import config as cfg
         models, models_fc, losses_, data_sizes = [], [], [], []
@@ -209,10 +228,19 @@ class Server(object):
             data_sizes.append(self.clients[i].get_data_size())
         self.avg_loss = sum(losses_) / len(losses_)
         if return_all:                                                                           # server.py:316-327
-            self.pretrained_fc = FedAvg_on_FC(self.pretrained_fc, models_fc, data_sizes, p=1.0)
+            # Reference quirk kept: the averaged public centres are assigned to `self.pretrain_fc` — a misspelling of
+            # `self.pretrained_fc` (server.py:325 vs :121-124, :295) — so the clients of the NEXT round still receive the initial
+            # centres.  `args.feedback_public_fc = True` (a build extension, off by default) feeds the average back.
+            self.pretrain_fc = FedAvg_on_FC(self.pretrained_fc, models_fc, data_sizes, p=1.0)
+            if getattr(self.args, "feedback_public_fc", False):
+                self.pretrained_fc = self.pretrain_fc
         if getattr(self.args, "aggr_alg", "FedAvg") in ("FedAvg", "FedProx"):
             aggr_state_dict = FedPavg(models, data_sizes)
             self.federated_model.load_state_dict(aggr_state_dict)
-        self.global_round += 1
-        self.global_epoch += self.local_epoch
+        # the round / epoch counters belong to the driver, as in the reference (train.py:87-88): call step_round() after train()
         return self.avg_loss
+
+    def step_round(self):
+        """What the reference driver does after every ``server.train()`` (train.py:87-88)."""
+        self.global_epoch += self.local_epoch
+        self.global_round += 1

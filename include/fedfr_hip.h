@@ -171,6 +171,11 @@ int fedfr_softmax_grad(float* z, const long long* label, int R, int C, int ldz, 
 int fedfr_margin_bwd(const float* dlogits, const long long* label, const float* dmul, float s, int R, int C, float* dcos,
                      void* stream);
 int fedfr_nll_mean(const float* prob_t, int R, float floor_, float* loss, void* stream);
+/* class-sharded softmax (PartialFC): fedfr_exp_rowsum that also emits the target's numerator — sums2 [2][R] = (sum_c e, e[label] or 0) —
+ * so ONE sum all-reduce replaces partial_fc.py:147 and :161; fedfr_nll_mean_ratio: loss = -mean log(max(num/den, floor)) */
+int fedfr_exp_rowsum_target(float* z, const long long* label, int R, int C, int ldz, const float* row_max, float* sums2,
+                            void* stream);
+int fedfr_nll_mean_ratio(const float* num, const float* den, int R, float floor_, float* loss, void* stream);
 /* BCE personalised head: z = r*(g(cos) -/+ m) + bias, g(x) = 2((x+1)/2)^t - 1; gt[b][c] = (label[b] == c) */
 int fedfr_bce_logits(const float* cosv, const long long* label, const float* bias, int B, int C, float m, float r, float t,
                      float* z, unsigned char* gt, float* dzdcos, void* stream);

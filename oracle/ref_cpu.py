@@ -860,3 +860,59 @@ def pfc_sgd_update(weight: torch.Tensor, weight_mom: torch.Tensor, index: Option
         else:
             weight[index] = sw
             weight_mom[index] = sm
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config 5 — build-defined hybrid, composed from the restated reference pieces:
+# per-client backbone (iresnet.py) + ONE class-sharded PartialFC over all ranks (partial_fc.py:118-176) + a private BCE_module per
+# client (client.py:25-60, weight 10 as client.py:383), momentum-SGD on everything, FedPavg of the backbones at round end.
+# --------------------------------------------------------------------------------------
+def config5_client_steps(sd: Dict[str, torch.Tensor], pfc_weight: torch.Tensor, pfc_mom: torch.Tensor, bce: Dict[str, torch.Tensor],
+                         batches, layers: Sequence[int], comm, batch_size: int, num_classes: int, sample_rate: float, id_base: int,
+                         lr: float, perms=None, margin_name: str = "CosFace", s: float = 30.0, m: float = 0.4, momentum: float = 0.9,
+                         weight_decay: float = 5e-4, bce_weight: float = 10.0):
+    """One rank's local steps.  ``batches``: [(imgs, GLOBAL labels)]; ``bce``: {conv_w, conv_b, weight, bias}; all state updated in place.
+    Returns per-step (loss, cos_loss, bce_loss)."""
+    keys = trainable_keys(sd)
+    params = [sd[k] for k in keys]
+    bufs: List[Optional[torch.Tensor]] = [None] * len(params)
+    bkeys = ["conv_w", "conv_b", "weight", "bias"]
+    bbufs: List[Optional[torch.Tensor]] = [None] * len(bkeys)
+    n_local_ids = bce["weight"].shape[0]
+    out = []
+    for st, (imgs, labels) in enumerate(batches):
+        for p in params:
+            p.requires_grad_(True)
+            p.grad = None
+        feats = iresnet_forward(sd, imgs, layers, training=True)
+        fdet = feats.detach()
+        # shared sharded head on the normalised embeddings (upstream PartialFC protocol)
+        fn_in = fdet.clone().requires_grad_(True)
+        fn = F.normalize(fn_in)
+        r = pfc_forward_backward(labels, fn.detach(), pfc_weight, pfc_mom, comm, batch_size, num_classes, sample_rate, margin_name, s, m,
+                                 None if perms is None else perms[st])
+        fn.backward(r["x_grad"])
+        dfeats = fn_in.grad.clone()
+        # private personalised head
+        bp = [bce[k].requires_grad_(True) for k in bkeys]
+        for p in bp:
+            p.grad = None
+        leaf = fdet.clone().requires_grad_(True)
+        lab = labels - id_base
+        lab = torch.where((lab < 0) | (lab >= n_local_ids), torch.full_like(lab, n_local_ids), lab)
+        z, gt = bce_module_forward(leaf, lab, *bp)
+        bl = bce_loss(z, gt)
+        (bce_weight * bl).backward()
+        dfeats = dfeats + leaf.grad
+        feats.backward(dfeats)
+        grads = [p.grad for p in params]
+        bgrads = [p.grad for p in bp]
+        for p in params + bp:
+            p.requires_grad_(False)
+        sgd_step(params, grads, bufs, lr, momentum, weight_decay)
+        sgd_step(bp, bgrads, bbufs, lr, momentum, weight_decay)
+        pfc_sgd_update(pfc_weight, pfc_mom, r["index"], r["sub_weight_grad"], lr, momentum, weight_decay)
+        for p in params + bp:
+            p.grad = None
+        out.append((float(r["loss_v"]) + bce_weight * float(bl.detach()), float(r["loss_v"]), float(bl.detach())))
+    return out

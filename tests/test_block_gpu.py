@@ -80,7 +80,12 @@ def test_block_vs_reference(name, dual_stream):
     print("block %s dual=%d front %.2e %s behind %.2e %s" % (name, dual_stream, max(front.values()), max(front, key=front.get),
                                                             max(behind.values()), max(behind, key=behind.get)))
     assert max(front.values()) < 1e-2, front
-    assert max(behind.values()) < (1e-2 if lin else 8e-2), behind
+    # bn1.bias / bn2.bias gradients are column sums of a tensor whose channel means the BatchNorm behind it has just removed: the exact
+    # value is a border effect of the 3x3 window, i.e. a nearly cancelling sum of bf16-rounded terms (measured 1.0e-2 on the slope-1 blocks)
+    sums = {k: e for k, e in behind.items() if k in ("g_bn1.bias", "g_bn2.bias")}
+    rest = {k: e for k, e in behind.items() if k not in sums}
+    assert max(rest.values()) < (1e-2 if lin else 4e-2), rest
+    assert max(sums.values()) < (2e-2 if lin else 8e-2), sums
     # BN buffers after one training forward (momentum 0.1, unbiased running variance) and the batch counters
     out = plan.state_dict()
     for k, v in out.items():
@@ -94,8 +99,11 @@ def test_block_vs_reference(name, dual_stream):
     for k, v in grads.items():
         if float(g[name + "_gn_" + k]) > 1e-6 * gmax:
             emu["g_" + k] = rel(v, ge[k])
-    print("   vs bf16 oracle: worst %.2e %s" % (max(emu.values()), max(emu, key=emu.get)))
-    assert max(emu.values()) < 1.5e-2, emu
+    esum = {k: e for k, e in emu.items() if k in ("g_bn1.bias", "g_bn2.bias")}       # the nearly cancelling column sums (see above)
+    erest = {k: e for k, e in emu.items() if k not in esum}
+    print("   vs bf16 oracle: worst %.2e %s; cancelling sums %.2e" % (max(erest.values()), max(erest, key=erest.get), max(esum.values())))
+    assert max(erest.values()) < 1e-2, erest
+    assert max(esum.values()) < 2.5e-2, esum
     assert float(np.median(list(emu.values()))) < 4e-3, emu
 
 
@@ -169,8 +177,14 @@ def test_backward_layerwise_vs_bf16_oracle(arch, batch):
             if float(bsd[k].grad.norm()) < 1e-4 * scale:                 # biases in front of a BatchNorm: analytically zero
                 continue
             errs.append((k, rel(params[k].grad, bsd[k].grad)))
-    worst = max(errs, key=lambda e: e[1])
+    # bn1.bias / bn2.bias gradients are column sums of tensors whose channel means a BatchNorm backward has just removed (the exact
+    # value is a border effect of the 3x3 window): nearly cancelling sums of bf16-rounded terms, held to a looser bar
+    sums = [e for e in errs if e[0].endswith(("bn1.bias", "bn2.bias"))]
+    rest = [e for e in errs if not e[0].endswith(("bn1.bias", "bn2.bias"))]
+    worst, worst_sum = max(rest, key=lambda e: e[1]), max(sums, key=lambda e: e[1])
     vals = np.array([e for _, e in errs])
-    print("layerwise bwd %s: worst %.2e (%s) median %.2e p90 %.2e" % (arch, worst[1], worst[0], np.median(vals), np.percentile(vals, 90)))
-    assert worst[1] < 3e-2, worst
-    assert np.median(vals) < 4e-3, np.median(vals)
+    print("layerwise bwd %s: worst %.2e (%s) cancelling sums %.2e (%s) median %.2e p90 %.2e" %
+          (arch, worst[1], worst[0], worst_sum[1], worst_sum[0], np.median(vals), np.percentile(vals, 90)))
+    assert worst[1] < 1e-2, worst
+    assert worst_sum[1] < 3e-2, worst_sum
+    assert np.median(vals) < 2e-3, np.median(vals)

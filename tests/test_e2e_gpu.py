@@ -513,7 +513,12 @@ def test_public_data_server_round():
     assert srv.pretrained_feats.shape == (8, 512) and all(len(c.HN_index) == 8 for c in clients)
     assert [c.get_data_size() for c in clients] == [16, 12]                    # combined dataset sizes drive FedAvg (client.py:302)
     assert all(c.fc_module.fc.shape[0] == nl for c in clients)                 # remove_pretrain() after the round
-    assert srv.pretrained_fc.shape == (npub, 512) and not torch.equal(srv.pretrained_fc, pre)
+    # reference quirk (server.py:325): the averaged centres land in `pretrain_fc`; `pretrained_fc` (what clients receive) is unchanged
+    assert srv.pretrain_fc.shape == (npub, 512) and not torch.equal(srv.pretrain_fc, pre)
+    assert torch.equal(srv.pretrained_fc, pre)
+    assert srv.global_round == 0 and srv.global_epoch == 0            # counters belong to the driver (train.py:87-88)
+    srv.step_round()
+    assert srv.global_round == 1 and srv.global_epoch == srv.local_epoch
     m0, m1 = clients[0].get_model(), clients[1].get_model()
     w0, w1 = np.float32(16 / 28), np.float32(12 / 28)
     agg = srv.federated_model.state_dict()

@@ -62,8 +62,18 @@ def _fedavg_worker(rank, port, tmp):
         def cpu_scale(dst, src, w, accumulate):      # test double for the HIP axpy: the collective plumbing is under test
             assert not accumulate
             dst.copy_(src * np.float32(w))
-        w = server.fedavg_all_reduce(m, sizes[rank], _axpy=cpu_scale, _i64=lambda acc, src, w_: acc.copy_(src.float() * np.float32(w_)))
+        from fedfr_amd.comm import TorchDistComm
+        comm = TorchDistComm()
+        total = server.exchange_data_sizes(sizes[rank], comm)          # round start: Σ n_j becomes known to every rank
+        assert total == 400.0
+        calls = []
+        real_all_reduce = comm.all_reduce
+        comm.all_reduce = lambda t, op="sum": (calls.append(t.numel()), real_all_reduce(t, op))[1]
+        w = server.fedavg_all_reduce(m, sizes[rank], total, comm, _axpy=cpu_scale,
+                                     _i64=lambda acc, src, w_: acc.copy_(src.float() * np.float32(w_)),
+                                     _trunc=lambda acc, dst: dst.copy_(acc.to(torch.int64)))
         assert abs(w - sizes[rank] / 400.0) < 1e-12
+        assert calls == [m._flat_state.numel()]                        # ONE collective: the whole flat state, in place
         torch.save({k: v.clone() for k, v in m.state_dict().items()}, os.path.join(tmp, "r%d.pt" % rank))
     finally:
         dist.barrier()

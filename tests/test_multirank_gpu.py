@@ -1,0 +1,348 @@
+"""Multi-rank paths on ONE GPU: W simulated ranks as threads (fedfr_amd.comm.ThreadComm) or as processes sharing cuda:0 over gloo.
+
+* class-sharded PartialFC at world_size 4 and 8 (BASELINE config 5's shard geometry) against the reference captured over gloo;
+* the stock-optimizer contract of PartialFC (partial_fc.py:124-126);
+* the FedAvg exchange (ONE all-reduce of the flat state, real HIP scale kernels) against FedPavg;
+* BASELINE config 5 (per-client backbones + global sharded PartialFC + private BCE heads + FedAvg) against the oracle's composition;
+* BASELINE config 3 at full size as a property test; client memory stays flat across many clients.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from oracle import ref_cpu as R  # noqa: E402
+
+from fedfr_amd import backbones, losses, client, server, ops, _C  # noqa: E402
+from fedfr_amd.comm import ThreadComm, TorchDistComm  # noqa: E402
+from fedfr_amd.partial_fc import PartialFC  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), (T(b) if not isinstance(b, torch.Tensor) else b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def maxrel(a, b):
+    a, b = a.detach().double().cpu(), (T(b) if not isinstance(b, torch.Tensor) else b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _pfc_inputs(B, C, rank, st, num_local):
+    feats = F.normalize(R.closed_form((B, 512), 0.113 + 0.01 * rank + 0.001 * st, 0.2 + st, 1.0))
+    lab = (R.closed_form_labels(B, C, tag=st + 3 * rank) * 31 + rank) % C
+    perm = R.closed_form((num_local,), 0.77 + 0.1 * st, 0.3 + rank, 0.5, 0.5)
+    return feats, lab, perm
+
+
+def _pfc_rank(g, comm, world, optimizer_factory=None):
+    """one rank of the golden protocol of tools/make_golden.py:_pfc_run through the product PartialFC."""
+    rank = comm.rank
+    B, C, rate = int(g["B"]), int(g["C"]), float(g["rate"])
+    s, m, steps, mn = float(g["s"]), float(g["m"]), int(g["steps"]), str(g["margin"])
+    gr = int(g["grad_rows"]) if "grad_rows" in g.files else 48
+    wr = int(g["w_rows"]) if "w_rows" in g.files else 64
+    pfc = PartialFC(rank=rank, local_rank=0, world_size=world, batch_size=B, resume=False, margin_softmax=getattr(losses, mn)(s=s, m=m),
+                    num_classes=C, sample_rate=rate, embedding_size=512, prefix="/tmp", comm=comm)
+    num_local, class_start = R.pfc_shard(C, world, rank)
+    assert (pfc.num_local, pfc.class_start) == (num_local, class_start)
+    pfc.weight.copy_(R.closed_form((num_local, 512), 0.071 + 0.003 * rank, 1.1, 0.01).to(DEV))
+    pfc.weight_mom.zero_()
+    opt = optimizer_factory(pfc) if optimizer_factory else None
+    for st in range(steps):
+        feats, lab, perm = _pfc_inputs(B, C, rank, st, num_local)
+        if opt is not None:
+            opt.zero_grad()
+        x_grad, loss_v = pfc.forward_backward(lab.to(DEV), feats.to(DEV), opt, perm=perm.to(DEV))
+        pre = "r%d_s%d_" % (rank, st)
+        if (pre + "index") in g.files:
+            assert torch.equal(pfc.index.cpu(), T(g[pre + "index"])), "sampled class set differs"
+        assert maxrel(x_grad, g[pre + "x_grad"]) < 1e-4
+        assert abs(float(loss_v) - float(g[pre + "loss_v"])) < 1e-4 * max(1.0, abs(float(g[pre + "loss_v"])))
+        swg = pfc.sub_weight.grad
+        assert maxrel(swg[:: max(1, swg.shape[0] // gr)][:gr], g[pre + "sub_weight_grad_rows"]) < 1e-4
+        assert maxrel(swg.norm(dim=1), g[pre + "sub_weight_grad_rownorm"]) < 1e-4
+        if opt is not None:
+            opt.step()                     # stock torch.optim.SGD on the aliased sampled rows + momentum rows ...
+            pfc.update()                   # ... then scatter back (the caller protocol of partial_fc.py:113-116, :124-126)
+        else:
+            pfc.fused_sgd_update(0.1, 0.9, 5e-4)
+        assert maxrel(pfc.weight[:: max(1, num_local // wr)][:wr], g[pre + "weight_rows"]) < 1e-5
+        assert maxrel(pfc.weight_mom[:: max(1, num_local // wr)][:wr], g[pre + "mom_rows"]) < 1e-4
+        assert abs(float(pfc.weight.double().sum()) - float(g[pre + "weight_sum"])) < 1e-3
+    return "ok"
+
+
+@pytest.mark.parametrize("name,world", [("pfc_w4", 4), ("pfc_w8", 8)])
+def test_partial_fc_w4_w8_vs_reference(name, world):
+    """world_size 4 (uneven shards 501/501/501/500, ArcFace) and world_size 8 at BASELINE config 5's shard geometry (85 003 classes:
+    10 626 / 10 625 per rank, sample_rate 0.1 -> 1 062 sampled rows, CosFace) — the product's HIP path on every rank, the four packed
+    collectives through the in-process communicator, against the reference captured with 4 / 8 gloo processes."""
+    g = load_golden(name)
+    assert ThreadComm.run(world, lambda c: _pfc_rank(g, c, world), device=DEV) == ["ok"] * world
+
+
+@pytest.mark.parametrize("name", ["pfc_w1_arc_r01", "pfc_w1_cos_r1", "pfc_w1_cos_r03"])
+def test_partial_fc_stock_optimizer_contract(name):
+    """partial_fc.py:124-126: ``prepare`` aliases the sampled rows and their momentum rows into the LAST param group of a stock
+    torch.optim.SGD; ``opt.step(); pfc.update()`` then equals the reference's update (same goldens as the fused route)."""
+    g = load_golden(name)
+
+    def make_opt(pfc):
+        dummy = torch.nn.Parameter(torch.zeros(1, device=DEV))
+        return torch.optim.SGD([{"params": [dummy]}, {"params": [pfc.sub_weight]}], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    from fedfr_amd.comm import SingleComm
+    assert _pfc_rank(g, SingleComm(), 1, make_opt) == "ok"
+
+
+def _closed_form_backbone(tag):
+    m = backbones.iresnet18(False, dropout=0, fp16=True)
+    m.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet18"], tag=tag))
+    return m.to(DEV)
+
+
+def test_fedavg_all_reduce_real_kernels_four_ranks():
+    """The round's exchange with the REAL HIP scale kernels under a 4-rank group: every rank ends with the same model, and it is
+    FedPavg of the four local models — bit for bit here, because the in-process communicator adds in ascending rank order like
+    server.py:27-33 (RCCL's ring order would differ in the last bit)."""
+    sizes = [300.0, 100.0, 250.0, 50.0]
+    models = [_closed_form_backbone(float(r + 1)) for r in range(4)]
+    for r, m in enumerate(models):
+        m._flat_nbt += 3 * r                                        # different counters per client (F9 path)
+    expect = server.FedPavg([client.flat_state_dict(m) for m in models], sizes)
+
+    def run(c):
+        calls = []
+        real = c.all_reduce
+        c.all_reduce = lambda t, op="sum": (calls.append(t.numel()), real(t, op))[1]
+        w = server.fedavg_all_reduce(models[c.rank], sizes[c.rank], sum(sizes), c)
+        assert calls == [models[c.rank]._flat_state.numel()]        # ONE collective, the whole state in place
+        return w
+    ws = ThreadComm.run(4, run, device=DEV)
+    assert ws == [s / sum(sizes) for s in sizes]
+    torch.cuda.synchronize()
+    for m in models:
+        out = m.state_dict()
+        for k, v in expect.items():
+            if v.is_floating_point() and out[k].is_floating_point():
+                assert torch.equal(out[k], v), k
+            else:
+                assert int(out[k]) == int(float(v)), k                # float average truncated to int64 (F9)
+
+
+def _fedavg_gloo_worker(rank, port, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        m = _closed_form_backbone(float(rank + 1))
+        sizes = [300.0, 100.0]
+        comm = TorchDistComm()
+        total = server.exchange_data_sizes(sizes[rank], comm)
+        server.fedavg_all_reduce(m, sizes[rank], total, comm)
+        torch.cuda.synchronize()
+        torch.save({k: v.cpu() for k, v in m.state_dict().items()}, os.path.join(tmp, "r%d.pt" % rank))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_fedavg_all_reduce_two_processes_shared_gpu(tmp_path):
+    """Two PROCESSES sharing cuda:0, torch.distributed over gloo (RCCL refuses two ranks on one device), real HIP kernels."""
+    import torch.multiprocessing as mp
+    mp.spawn(_fedavg_gloo_worker, args=(29671, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    expect = server.FedPavg([client.flat_state_dict(_closed_form_backbone(1.0)), client.flat_state_dict(_closed_form_backbone(2.0))], [300, 100])
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        if a[k].is_floating_point():
+            assert torch.equal(a[k], expect[k].cpu()), k              # two addends: a + b == b + a in fp32
+        else:
+            assert int(a[k]) == int(float(expect[k]))
+
+
+# ---- BASELINE config 5 ------------------------------------------------------------------------------------------------------------
+def _config5_inputs(rank, W, B, n_ids, steps):
+    """rank's data shard: identities [rank * n_ids, (rank + 1) * n_ids)."""
+    return [(R.closed_form_images(B, tag=float(rank * 3 + s)), R.closed_form_labels(B, n_ids, tag=s + rank) + rank * n_ids) for s in range(steps)]
+
+
+def test_config5_hybrid_vs_oracle():
+    """4 clients (threads) on one GPU: per-client iresnet18 + ONE PartialFC sharded over the 4 ranks (uneven shards, sample_rate 0.5,
+    injected draws) + a private BCE head each, 2 local steps, then the FedAvg exchange.  Against the oracle's composition of the
+    restated reference pieces (oracle/ref_cpu.py:config5_client_steps) run on the CPU with the same communicator pattern."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_golden import _OracleThreadComm
+    W, B, n_ids, steps, lr, rate = 4, 4, 10, 2, 0.01, 0.5
+    C = W * n_ids + 3                                           # 43 classes -> shards 11/11/11/10: PartialFC shards != client id ranges
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sizes = [40.0, 30.0, 20.0, 10.0]
+
+    def state(rank):
+        nl, _ = R.pfc_shard(C, W, rank)
+        return (R.closed_form_state_dict(layers, tag=float(rank + 1)), R.closed_form((nl, 512), 0.071 + 0.003 * rank, 1.1, 0.01),
+                {"conv_w": torch.eye(512), "conv_b": torch.zeros(512), "weight": R.head_fc(n_ids, seed=20 + rank), "bias": torch.zeros(n_ids)},
+                [R.closed_form((nl,), 0.77 + 0.1 * st, 0.3 + rank, 0.5, 0.5) for st in range(steps)])
+
+    # ---- oracle on the CPU
+    def oracle_rank(c):
+        torch.set_num_threads(2)
+        sd, w, bce, perms = state(c.rank)
+        mom = torch.zeros_like(w)
+        out = R.config5_client_steps(sd, w, mom, bce, _config5_inputs(c.rank, W, B, n_ids, steps), layers, _OracleThreadComm(c), B, C, rate,
+                                     c.rank * n_ids, lr, perms)
+        return out, sd, w, bce
+    ref = ThreadComm.run(W, oracle_rank)
+    ref_avg = R.fedpavg([r[1] for r in ref], sizes)
+
+    # ---- product path, 4 ranks on cuda:0
+    def hip_rank(c):
+        rank = c.rank
+        sd, w, bce, perms = state(rank)
+        bb = backbones.iresnet18(False, dropout=0, fp16=True)
+        bb.load_state_dict(sd)
+        bb = bb.to(DEV)
+        pfc = PartialFC(rank=rank, local_rank=0, world_size=W, batch_size=B, resume=False, margin_softmax=losses.CosFace(s=30, m=0.4),
+                        num_classes=C, sample_rate=rate, embedding_size=512, prefix="/tmp", comm=c)
+        pfc.weight.copy_(w.to(DEV))
+        pfc.weight_mom.zero_()
+        bm = client.BCE_module(512, n_ids, 1).to(DEV)
+        bm.weight.data = bce["weight"].to(DEV)
+        tr = client.ShardedHeadTrainer(bb, pfc, bm, id_base=rank * n_ids, lr=lr)
+        ls = []
+        for st, (imgs, lab) in enumerate(_config5_inputs(rank, W, B, n_ids, steps)):
+            loss, cos, b = tr.step(imgs.to(DEV), lab.to(DEV), perm=perms[st].to(DEV))
+            ls.append((float(loss), float(cos), float(b)))
+        local = {k: v.clone() for k, v in bb.state_dict().items()}
+        tr.end_round(sizes[rank], sum(sizes))
+        torch.cuda.synchronize()
+        return ls, local, bb.state_dict(), pfc.weight.clone(), bm
+    out = ThreadComm.run(W, hip_rank, device=DEV)
+    for rank in range(W):
+        ls, local, avg, pw, bm = out[rank]
+        rls, rsd, rw, rbce = ref[rank]
+        for (l, c_, b), (rl, rc, rb) in zip(ls, rls):
+            assert abs(c_ - rc) < 1e-2 * abs(rc), (rank, c_, rc)              # bf16 backbone: 1e-2-class embeddings -> loss
+            assert abs(b - rb) < 1e-2 * abs(rb), (rank, b, rb)
+            assert abs(l - rl) < 1e-2 * abs(rl)
+        assert ls[0][1] == out[0][0][0][1]                                       # the sharded-head loss is the same number on every rank
+        for k in ("conv1.weight", "layer2.0.downsample.0.weight", "bn1.weight", "prelu.weight", "fc.bias"):
+            assert rel(local[k], rsd[k]) < 1e-2, (rank, k, rel(local[k], rsd[k]))
+        for k in ("bn1.running_mean", "layer4.1.bn3.running_var"):
+            assert rel(local[k], rsd[k]) < 3e-2, (rank, k)
+        assert rel(pw, rw) < 1e-3, (rank, rel(pw, rw))                           # this rank's PartialFC shard after 2 sampled updates
+        assert rel(bm.weight.data, rbce["weight"]) < 2e-2 and rel(bm.converter[0].weight.data, rbce["conv_w"]) < 1e-3
+        # round end: every rank holds the same averaged backbone == FedPavg of the four local models
+        for k in ("conv1.weight", "layer3.1.conv2.weight", "bn2.running_var", "fc.bias"):
+            assert torch.equal(avg[k], out[0][2][k]), k
+            assert rel(avg[k], ref_avg[k]) < 1e-2, (k, rel(avg[k], ref_avg[k]))
+        assert int(avg["bn1.num_batches_tracked"]) == int(float(ref_avg["bn1.num_batches_tracked"]))
+    exp = server.FedPavg([_fsd(out[r][1]) for r in range(W)], sizes)
+    for k in ("conv1.weight", "layer3.1.conv2.weight", "bn2.running_var"):
+        assert torch.equal(out[0][2][k], exp[k]), k                                # exact vs FedPavg of the HIP-side local models
+
+
+def _fsd(sd):
+    return {k: v.to(DEV) for k, v in sd.items()}
+
+
+def test_config5_scale_properties():
+    """Config 5's real head geometry on one GPU: 8 ranks (threads), 85 000 classes sharded 10 625 per rank, sample_rate 0.1 -> 1 062
+    sampled rows, global batch 8 x 16 (iresnet18 backbones keep it light): size-independent properties of the hybrid step."""
+    W, B, C = 8, 16, 85000
+    n_ids = C // W
+
+    def run(c):
+        rank = c.rank
+        bb = _closed_form_backbone(float(rank + 1))
+        pfc = PartialFC(rank=rank, local_rank=0, world_size=W, batch_size=B, resume=False, margin_softmax=losses.CosFace(s=30, m=0.4),
+                        num_classes=C, sample_rate=0.1, embedding_size=512, prefix="/tmp", comm=c)
+        assert (pfc.num_local, pfc.num_sample) == (10625, 1062)
+        w0 = pfc.weight.clone()
+        bm = client.BCE_module(512, 64, 1).to(DEV)
+        tr = client.ShardedHeadTrainer(bb, pfc, bm, id_base=rank * n_ids, lr=0.01)
+        lab = (R.closed_form_labels(B, 64, tag=rank) + rank * n_ids).to(DEV)
+        out = [tr.step(R.closed_form_images(B, tag=float(rank + st)).to(DEV), lab) for st in range(2)]
+        torch.cuda.synchronize()
+        idx = pfc.index
+        assert idx.numel() == 1062 and bool((idx[1:] > idx[:-1]).all())
+        mine = lab[(lab >= pfc.class_start) & (lab < pfc.class_start + pfc.num_local)] - pfc.class_start
+        assert bool(torch.isin(mine, idx).all())                                  # this shard's positives are always sampled
+        changed = (pfc.weight != w0).any(dim=1)
+        assert 1062 <= int(changed.sum()) <= 2 * 1062                            # two steps, two sampled sets, nothing else touched
+        tr.end_round(100.0 + rank, sum(100.0 + r for r in range(W)))
+        torch.cuda.synchronize()
+        return [float(o[1]) for o in out], bb._flat_state.clone()
+    res = ThreadComm.run(W, run, device=DEV)
+    for r in range(1, W):
+        assert res[r][0] == res[0][0]                                             # one global softmax: same loss everywhere
+        assert torch.equal(res[r][1], res[0][1])                                  # one averaged model after the exchange
+    assert all(np.isfinite(v) and 5.0 < v < 40.0 for v in res[0][0])             # ~ ln(8 * 1062) + s * m for random weights
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 once at full size: iresnet100 + ArcFace + PartialFC sample_rate 0.1 over 85 000 identities, B = 128."""
+    C, B = 85000, 128
+    m = backbones.iresnet100(False, dropout=0, fp16=True)
+    m.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet100"]))
+    m = m.to(DEV)
+    pfc = PartialFC(rank=0, local_rank=0, world_size=1, batch_size=B, resume=False, margin_softmax=losses.ArcFace(s=30, m=0.4),
+                    num_classes=C, sample_rate=0.1, embedding_size=512, prefix="/tmp")
+    w0 = pfc.weight.clone()
+    p0 = m._flat_params.clone()
+    tr = client.FusedTrainer(m, pfc, "ArcFace", 30.0, 0.4, lr=0.01)
+    lab = ((R.closed_form_labels(B, C, tag=1) * 977) % C).to(DEV)
+    ls = [float(tr.step(R.closed_form_images(B, tag=float(st)).to(DEV), lab)) for st in range(3)]
+    tr.finish()
+    torch.cuda.synchronize()
+    assert pfc.index.numel() == 8500 and bool((pfc.index[1:] > pfc.index[:-1]).all()) and bool(torch.isin(lab, pfc.index).all())
+    assert all(np.isfinite(v) and 5.0 < v < 45.0 for v in ls), ls
+    changed = (pfc.weight != w0).any(dim=1)
+    assert 8500 <= int(changed.sum()) <= 3 * 8500
+    assert bool(torch.isfinite(m._flat_params).all()) and not torch.equal(m._flat_params, p0)
+    assert int(m.state_dict()["bn1.num_batches_tracked"]) == 3 + 3            # closed-form state starts at 3 + (idx % 5) = 3 for bn1 ... +3 steps
+
+
+def test_many_clients_share_one_backbone_memory_flat():
+    """Server.train trains clients one after another in one process (server.py:283); every Client must not keep its own
+    backbone + activation arenas resident.  8 clients: allocated memory after client 2..8 equals that after client 1."""
+    class Args:
+        network, loss, local_epoch, output_dir, BCE_local, aggr_alg = "iresnet18", "CosFace", 1, "/tmp", False, "FedAvg"
+
+    class DS:
+        ID_base = 0
+
+    class Loader(list):
+        dataset = DS()
+    n = 8
+
+    class Data:
+        train_class_sizes = [10] * n
+        train_dataset_sizes = [8] * n
+        train_loaders = [Loader([(R.closed_form_images(4, tag=float(c)), R.closed_form_labels(4, 10, tag=c))]) for c in range(n)]
+    from fedfr_amd.config import config as cfg
+    cfg.lr = 0.01
+    clients = [client.Client(c, Args, Data, device=DEV) for c in range(n)]
+    sd = R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet18"], tag=2.0)
+    mem = []
+    for c in clients:
+        c.backbone_state_dict = sd
+        c.train(0)
+        c.backbone_state_dict = {k: v.cpu() for k, v in c.backbone_state_dict.items()}      # what a driver keeps per client
+        torch.cuda.synchronize()
+        mem.append(torch.cuda.memory_allocated(DEV))
+    assert max(mem[1:]) - mem[0] < 8 << 20, mem                 # < 8 MB drift over 7 more clients (one backbone's arenas are ~GBs)
+    assert len({id(c._get_backbone()) for c in clients}) == 1
+    assert len(client._AUX_STREAMS) <= 1                         # one auxiliary stream per device, not one per trainer

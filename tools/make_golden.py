@@ -289,12 +289,13 @@ def _cpu_cuda_shims():
         torch.cuda.Stream, torch.cuda.current_stream, torch.cuda.stream, torch.Tensor.cuda = saved
 
 
-def _pfc_run(rank, world, B, C, rate, margin_name, s, m, steps, seed_base, q=None):
+def _pfc_run(rank, world, B, C, rate, margin_name, s, m, steps, seed_base, q=None, port=29611, grad_rows=48, w_rows=64):
     import torch.distributed as dist
     import partial_fc
+    torch.set_num_threads(max(1, 8 // world))
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = "29611"
+        os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
         def _rs(out, lst, *a, **k):   # gloo lacks reduce_scatter
@@ -341,12 +342,12 @@ def _pfc_run(rank, world, B, C, rate, margin_name, s, m, steps, seed_base, q=Non
             pre = "r%d_s%d_" % (rank, st)
             res[pre + "x_grad"] = x_grad.detach().clone()
             res[pre + "loss_v"] = loss_v.detach().clone()
-            res[pre + "sub_weight_grad_rows"] = sw_grad[:: max(1, sw_grad.shape[0] // 48)][:48].clone()
+            res[pre + "sub_weight_grad_rows"] = sw_grad[:: max(1, sw_grad.shape[0] // grad_rows)][:grad_rows].clone()
             res[pre + "sub_weight_grad_rownorm"] = sw_grad.norm(dim=1)
             if pfc.index is not None:
                 res[pre + "index"] = pfc.index.clone()
-            res[pre + "weight_rows"] = pfc.weight[:: max(1, num_local // 64)][:64].clone()
-            res[pre + "mom_rows"] = pfc.weight_mom[:: max(1, num_local // 64)][:64].clone()
+            res[pre + "weight_rows"] = pfc.weight[:: max(1, num_local // w_rows)][:w_rows].clone()
+            res[pre + "mom_rows"] = pfc.weight_mom[:: max(1, num_local // w_rows)][:w_rows].clone()
             res[pre + "weight_sum"] = pfc.weight.double().sum()
             res[pre + "mom_sum"] = pfc.weight_mom.double().sum()
     if world > 1:
@@ -382,6 +383,20 @@ def gen_pfc():
     for p in procs:
         p.join()
     save("pfc_w2", B=B, C=C, rate=rate, s=s, m=m, steps=steps, margin=np.array(mn), **res)
+    # W = 4 (2003 classes -> shards 501/501/501/500) and W = 8 at BASELINE config 5's shard geometry (85 003 classes -> 10 626 x 3 +
+    # 10 625 x 5 per rank, sample_rate 0.1 -> 1 062 sampled rows, CosFace): fewer sampled rows are kept per rank to bound the fixture
+    for name, W, B, C, rate, mn, s, m, steps, port, gr, wr in (("pfc_w4", 4, 4, 2003, 0.2, "ArcFace", 30.0, 0.4, 2, 29613, 16, 16),
+                                                                ("pfc_w8", 8, 4, 85003, 0.1, "CosFace", 30.0, 0.4, 2, 29615, 6, 6)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_pfc_run, args=(r, W, B, C, rate, mn, s, m, steps, 0, q, port, gr, wr)) for r in range(W)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in procs:
+            res.update(q.get())
+        for p in procs:
+            p.join()
+        save(name, B=B, C=C, rate=rate, s=s, m=m, steps=steps, margin=np.array(mn), grad_rows=gr, w_rows=wr, **res)
 
 
 def _pfc_single_entry(q, B, C, rate, mn, s, m, steps):

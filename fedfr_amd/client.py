@@ -180,24 +180,26 @@ _AUX_STREAMS = {}      # device index -> the one auxiliary stream every trainer 
 _AUX_LOCK = __import__("threading").Lock()
 
 
-def _make_aux_stream(device):
+def _make_aux_stream(device, slot: int = 0):
     """Second HIP stream of the dual-stream backward (None with FEDFR_DUAL_STREAM=0): created at the LOWEST priority the device offers
     (through the C ABI: torch clamps stream priorities to [-1, 0], HIP has +1), so that workgroups of the critical path on the caller's
     stream are dispatched first whenever both streams have work.  FEDFR_AUX_PRIORITY=0 keeps a default-priority torch stream.
-    ONE stream per device for the life of the process: trainers are re-created every FL round for every client (the reference
-    re-creates its optimiser the same way), a stream per trainer would leak a HIP stream each time."""
+    ONE stream per (device, slot) for the life of the process: trainers are re-created every FL round for every client (the reference
+    re-creates its optimiser the same way), a stream per trainer would leak a HIP stream each time.  ``slot`` > 0: further streams
+    for clients that train CONCURRENTLY on one device (one slot per concurrent client)."""
     import os
     if os.environ.get("FEDFR_DUAL_STREAM", "1") == "0":
         return None
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     with _AUX_LOCK:
-        return _aux_stream_locked(idx)
+        return _aux_stream_locked(idx, int(slot))
 
 
-def _aux_stream_locked(idx):
+def _aux_stream_locked(idx, slot):
     import os
-    s = _AUX_STREAMS.get(idx)
+    key = idx if slot == 0 else (idx, slot)
+    s = _AUX_STREAMS.get(key)
     if s is None:
         if os.environ.get("FEDFR_AUX_PRIORITY", "1") != "0":
             import ctypes
@@ -207,7 +209,7 @@ def _aux_stream_locked(idx):
             s = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
         else:
             s = torch.cuda.Stream(device=torch.device("cuda", idx))
-        _AUX_STREAMS[idx] = s
+        _AUX_STREAMS[key] = s
     return s
 
 
@@ -219,7 +221,7 @@ class FusedTrainer:
     """
 
     def __init__(self, backbone: "backbones.IResNet", fc, loss_name: str = "CosFace", s: float = 30.0,
-                 m: float = 0.4, lr: float = 0.1, momentum: float = 0.9, weight_decay: float = 5e-4):
+                 m: float = 0.4, lr: float = 0.1, momentum: float = 0.9, weight_decay: float = 5e-4, aux_slot: int = 0):
         """``fc``: a dense class-weight tensor [C, 512] (FC_module.fc.data), or a ``PartialFC`` instance — then the head is the
         sampled / class-sharded softmax (its margin comes from the PartialFC's own ``margin_softmax``)."""
         from .partial_fc import PartialFC
@@ -242,7 +244,7 @@ class FusedTrainer:
             self.fc_grad = torch.empty_like(self.fc)
         self.first = True
         # weight-gradient GEMMs run on a second HIP stream (fedfr_net_backward2) unless FEDFR_DUAL_STREAM=0
-        self.aux_stream = _make_aux_stream(bb.device)
+        self.aux_stream = _make_aux_stream(bb.device, aux_slot)
         self._shadows_pending = None
         if self.aux_stream is not None:       # the shared aux stream may still carry the previous trainer's shadow rebuild of this backbone
             torch.cuda.current_stream().wait_stream(self.aux_stream)

@@ -4,6 +4,7 @@
 // block (deterministic, no atomics), then finalised in fp64 by a tiny second kernel.
 #include "ew.h"
 #include "gemm_tn_dev.h"
+#include "gemm_dev.h"   // ProfScope: HIP-event timing of a launch on its stream (bench.py roofline leg); slots 20.. carry algorithmic bytes
 
 #define EW_THREADS 256
 // streaming 16-B load of data this pass is the last reader of for a long while (EW_NT=1: non-temporal, keeps L2 / MALL for the data
@@ -221,6 +222,7 @@ int ew_bn_finalize(const float* partials, int P, int C, double count, const floa
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* save_mean, float* save_rstd, float* tmp, hipStream_t st) {
   FEDFR_REQUIRE(partials && P > 0 && C > 0 && scale && shift && save_mean && save_rstd, "bn_finalize: bad args");
+  ProfScope prof(23, (double)P * 2 * C * 4, st);
   const float* src = partials;
   if (P > 1024) {
     FEDFR_REQUIRE(tmp != nullptr, "bn_finalize: P=%d needs a tmp buffer", P);
@@ -384,6 +386,7 @@ int ew_bn_apply(const BnApply& p, hipStream_t st) {
   const int slab = slab_rows(p.M, p.C, 1024);
   const int grid = ceil_div(p.M, slab);
   const size_t lds = p.stats ? (size_t)rows_per_pass(p.C) * 2 * p.C * sizeof(float) : 0;
+  ProfScope prof(20, (double)p.M * p.C * 2 * (p.x2 ? 3 : 2), st);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
   FEDFR_LAUNCH_CHECK("bn_apply");
   return FEDFR_OK;
@@ -531,6 +534,7 @@ int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st) {
   const int grid = ceil_div(p.M, slab);
   const size_t lds = ew_colsum_lds(p.C, 3);
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
+  ProfScope prof(21, (double)p.M * p.C * 2 * 2, st);
   if (p.alpha) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
   FEDFR_LAUNCH_CHECK("bn_bwd_reduce");
@@ -562,6 +566,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize8_kernel(const float* __re
 int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* mean, const float* rstd,
                        float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st) {
   FEDFR_REQUIRE(partials && P > 0 && C > 0 && (C & 7) == 0 && coef, "bn_bwd_finalize: bad args");
+  ProfScope prof(24, (double)P * 3 * C * 4, st);
   hipLaunchKernelGGL(bn_bwd_finalize8_kernel, dim3(C / 8), dim3(256), 0, st, partials, P, C, count, gamma, mean, rstd,
                      dgamma, dbeta, dalpha, coef);
   FEDFR_LAUNCH_CHECK("bn_bwd_finalize");
@@ -702,6 +707,8 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
 #define BWD_APPLY(A, N, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, N, D>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl)
   const int variant = (p.alpha ? 4 : 0) | (p.nx ? 2 : 0) | (p.add ? 1 : 0);
+  // algorithmic bytes: dy + x read, dx written, + the identity addend (compact when up-sampled), + the next BN's input when its reduction rides along
+  ProfScope prof(22, (double)p.M * p.C * 2 * (3.0 + (p.add ? 1.0 : 0.0) + (p.add_up ? 0.25 : 0.0) + (p.nx ? 1.0 : 0.0)), st);
   switch (variant) {
     case 0: BWD_APPLY(false, false, false); break;
     case 1: BWD_APPLY(false, false, true); break;
@@ -879,6 +886,7 @@ int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const 
   FEDFR_REQUIRE(dst && slabs && nsplit > 0 && n > 0 && (n & 3) == 0, "reduce_slabs: bad args (n%%4)");
   if (bias) FEDFR_REQUIRE((bias_n & 3) == 0 && bias_n > 0, "reduce_slabs: bias_n%%4");
   const size_t n4 = n / 4;
+  ProfScope prof(25, (double)n * 4 * (nsplit + 1), st);
   if (nsplit >= 16 && n4 <= 65536) {
     hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n);
     FEDFR_LAUNCH_CHECK("reduce_slabs_wide");

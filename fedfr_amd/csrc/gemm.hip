@@ -19,7 +19,7 @@ struct ProfSlot {
   long long launches = 0;
 };
 bool g_prof_on = false;
-ProfSlot g_prof[20];
+ProfSlot g_prof[32];   // 0..16: MFMA GEMM kernels (slot = flops); 20..27: HBM-bound kernels (slot 'flops' = algorithmic BYTES)
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
 }  // namespace
 
@@ -50,7 +50,7 @@ void gemm_profile_enable(int on) {
 }
 // caller must have synchronised the stream(s).  Returns 0 and fills totals for `slot`.
 int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
-  if (slot < 0 || slot >= 20) return -1;
+  if (slot < 0 || slot >= 32) return -1;
   ProfSlot& s = g_prof[slot];
   double ms = 0.0;
   for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {

@@ -2,6 +2,7 @@
 // PartialFC sampling (counter-based RNG, radix top-k select, ordered compaction), row gather/scatter.
 // Reference semantics: torch.optim.SGD as used in client.py:335,527-529; server.py:25-46; partial_fc.py:89-116.
 #include "optim.h"
+#include "gemm_dev.h"   // ProfScope
 
 // ---------------------------------------------------------------------------------------------------------
 // SGD: g += wd*p ; buf = first ? g : mu*buf + g ; p -= lr*buf ; optional bf16 shadow of the new p.
@@ -50,6 +51,7 @@ int optim_sgd(float* p, const float* g, float* buf, bf16_t* shadow, size_t n, fl
   FEDFR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd: buffers must be 16-byte aligned");
   const size_t work = n / 4 + 1;
   const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+  ProfScope prof(26, (double)n * (first ? 16.0 : 20.0) + (shadow ? 2.0 * n : 0.0), st);      // p, g (, buf) read; p, buf (, bf16 mirror) written
   hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first);
   FEDFR_LAUNCH_CHECK("sgd");
   return FEDFR_OK;

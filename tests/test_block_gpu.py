@@ -77,15 +77,15 @@ def test_block_vs_reference(name, dual_stream):
             assert float(v.abs().max()) < 1e-3 * gmax, k
     front = {k: e for k, e in errs.items() if k not in POST_MASK}
     behind = {k: e for k, e in errs.items() if k in POST_MASK}
-    print("block %s dual=%d front %.2e %s behind %.2e %s" % (name, dual_stream, max(front.values()), max(front, key=front.get),
-                                                            max(behind.values()), max(behind, key=behind.get)))
-    assert max(front.values()) < 1e-2, front
+    assert max(front.values()) < 7.5e-3, front                   # measured <= 5.95e-3 on all seven fixtures; north_star: 1e-2
     # bn1.bias / bn2.bias gradients are column sums of a tensor whose channel means the BatchNorm behind it has just removed: the exact
     # value is a border effect of the 3x3 window, i.e. a nearly cancelling sum of bf16-rounded terms (measured 1.0e-2 on the slope-1 blocks)
     sums = {k: e for k, e in behind.items() if k in ("g_bn1.bias", "g_bn2.bias")}
     rest = {k: e for k, e in behind.items() if k not in sums}
-    assert max(rest.values()) < (1e-2 if lin else 4e-2), rest
-    assert max(sums.values()) < (2e-2 if lin else 8e-2), sums
+    print("block %s dual=%d: front %.2e (%s); behind the PReLU kink %.2e (%s), cancelling sums %.2e" %
+          (name, dual_stream, max(front.values()), max(front, key=front.get), max(rest.values()), max(rest, key=rest.get), max(sums.values())))
+    assert max(rest.values()) < (7.5e-3 if lin else 4e-2), rest              # slope 1: inside north_star's 1e-2 like everything else
+    assert max(sums.values()) < (1.35e-2 if lin else 7.5e-2), sums           # measured 1.06e-2 / 5.9e-2
     # BN buffers after one training forward (momentum 0.1, unbiased running variance) and the batch counters
     out = plan.state_dict()
     for k, v in out.items():
@@ -102,8 +102,8 @@ def test_block_vs_reference(name, dual_stream):
     esum = {k: e for k, e in emu.items() if k in ("g_bn1.bias", "g_bn2.bias")}       # the nearly cancelling column sums (see above)
     erest = {k: e for k, e in emu.items() if k not in esum}
     print("   vs bf16 oracle: worst %.2e %s; cancelling sums %.2e" % (max(erest.values()), max(erest, key=erest.get), max(esum.values())))
-    assert max(erest.values()) < 1e-2, erest
-    assert max(esum.values()) < 2.5e-2, esum
+    assert max(erest.values()) < 6e-3, erest                     # measured <= 4.6e-3
+    assert max(esum.values()) < 1.9e-2, esum                     # measured <= 1.5e-2
     assert float(np.median(list(emu.values()))) < 4e-3, emu
 
 
@@ -185,6 +185,6 @@ def test_backward_layerwise_vs_bf16_oracle(arch, batch):
     vals = np.array([e for _, e in errs])
     print("layerwise bwd %s: worst %.2e (%s) cancelling sums %.2e (%s) median %.2e p90 %.2e" %
           (arch, worst[1], worst[0], worst_sum[1], worst_sum[0], np.median(vals), np.percentile(vals, 90)))
-    assert worst[1] < 1e-2, worst
-    assert worst_sum[1] < 3e-2, worst_sum
-    assert np.median(vals) < 2e-3, np.median(vals)
+    assert worst[1] < 5.5e-3, worst                     # measured 2.3e-3 / 2.7e-3 / 4.3e-3 (iresnet18 / 50 / 100)
+    assert worst_sum[1] < 2.5e-2, worst_sum             # measured <= 1.9e-2
+    assert np.median(vals) < 1.3e-3, np.median(vals)    # measured 0.5e-3 / 1.0e-3 / 0.9e-3

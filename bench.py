@@ -328,6 +328,52 @@ def main():
                       "note": "pinned uint8 HWC host batches (4.8 MB/step) -> H2D on a copy stream -> fedfr_preprocess_u8 -> train step; "
                               "`value` above excludes this input path (inputs resident in HBM)"}
 
+    # ---- two independent clients training concurrently on this GPU (Server.train with args.parallel_clients = 2): the clients of an FL
+    # round are independent, and a second client's kernel chain fills the CUs one chain leaves idle between its ~1250 dependent launches
+    concurrent = None
+    if rank == 0 and world == 1 and not args.no_profile and args.head == "dense":
+        import threading
+        tr.finish()
+        torch.cuda.synchronize()
+        torch.manual_seed(101)
+        model2 = getattr(backbones, args.arch)(False, dropout=0, fp16=True).to(dev)
+        fc2 = (torch.randn(NC, 512) * 0.01).to(dev)
+        lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        st2 = torch.cuda.Stream(device=dev, priority=hi_p)
+        with torch.cuda.stream(st2):
+            tr2 = client.FusedTrainer(model2, fc2, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4, aux_slot=1)
+        pairs = [(tr, torch.cuda.current_stream()), (tr2, st2)]
+        csteps = max(5, min(args.steps, 20))
+        bar = threading.Barrier(3)
+
+        def worker(k):
+            t_, s_ = pairs[k]
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(s_):
+                for i in range(3):
+                    t_.step(imgs[(i + k) % nbuf], labs[(i + k) % nbuf])
+                s_.synchronize()
+                bar.wait()
+                for i in range(csteps):
+                    t_.step(imgs[(i + k) % nbuf], labs[(i + k) % nbuf])
+                t_.finish()
+                s_.synchronize()
+                bar.wait()
+        ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(2)]
+        for t_ in ths:
+            t_.start()
+        bar.wait()
+        tc = time.perf_counter()
+        bar.wait()
+        dtc = time.perf_counter() - tc
+        for t_ in ths:
+            t_.join()
+        concurrent = {"clients_on_this_gpu": 2, "value": round(2 * B * csteps / dtc, 1), "unit": "images/sec",
+                      "ms_per_step_per_client": round(dtc * 1e3 / csteps, 3), "steps": csteps,
+                      "note": "two independent clients (own backbone, optimiser, HIP stream pair), each running the same bs=%d train step; "
+                              "aggregate over both.  `value` above is ONE client alone" % B}
+        del tr2, model2
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
         cpu = cpu_baseline(args.arch)
@@ -355,6 +401,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": end_to_end,
+            "concurrent_clients": concurrent,
         }
         if use_dist:
             out["fedavg_round_ms"] = round(dt * 1e3, 3)

@@ -341,7 +341,7 @@ class FusedHeadTrainer:
     ``fedfr_sgd_step`` (torch.optim.SGD semantics: coupled weight decay, momentum buffer created on first use)."""
 
     def __init__(self, backbone: "backbones.IResNet", head_params: Iterable[nn.Parameter], lr: float = 0.1,
-                 momentum: float = 0.9, weight_decay: float = 5e-4):
+                 momentum: float = 0.9, weight_decay: float = 5e-4, aux_slot: int = 0):
         import os
         self.bb = backbone
         self.head_params = list(head_params)
@@ -355,7 +355,7 @@ class FusedHeadTrainer:
         self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
         self.head_mom = {}
         self.first = True
-        self.aux_stream = _make_aux_stream(bb.device)
+        self.aux_stream = _make_aux_stream(bb.device, aux_slot)
         self._shadows_pending = None
         if self.aux_stream is not None:
             torch.cuda.current_stream().wait_stream(self.aux_stream)
@@ -600,15 +600,17 @@ def to_device_batch(imgs, labels, device, train: bool):
 _BACKBONE_POOL = {}     # (network, device, dropout) -> the one resident backbone (+ activation arenas) all Clients of this process share
 
 
-def shared_backbone(network: str, device, dropout=0):
+def shared_backbone(network: str, device, dropout=0, slot: int = 0):
     """The reference builds a client's backbone inside ``train()`` and deletes it afterwards (client.py:513, :568-570), so 40 clients
     fit one GPU.  Here a backbone owns GBs of activation arena + workspace per batch size (iresnet100 at B=128: 5.8 + 3 GB), so all
-    Clients of a process train through ONE resident instance per (arch, device): each call loads its own state_dict into it."""
+    Clients of a process train through ONE resident instance per (arch, device, slot): each call loads its own state_dict into it.
+    ``slot`` > 0: the instances of clients that train concurrently on one device (``Server.train`` with ``args.parallel_clients``)."""
     device = torch.device(device)
-    key = (network, str(device), float(dropout))
-    bb = _BACKBONE_POOL.get(key)
-    if bb is None:
-        bb = _BACKBONE_POOL[key] = getattr(backbones, network)(False, dropout=dropout, fp16=cfg.fp16).to(device)
+    key = (network, str(device), float(dropout), int(slot))
+    with _AUX_LOCK:
+        bb = _BACKBONE_POOL.get(key)
+        if bb is None:
+            bb = _BACKBONE_POOL[key] = getattr(backbones, network)(False, dropout=dropout, fp16=cfg.fp16).to(device)
     return bb
 
 
@@ -653,7 +655,7 @@ class Client(object):
         self.sync_every = getattr(args, "loss_sync_every", 1)      # reference syncs (loss.item()) every step
 
     def _get_backbone(self):
-        return shared_backbone(self.args.network, self.device, self.dropout)
+        return shared_backbone(self.args.network, self.device, self.dropout, getattr(self, "slot", 0))
 
     @_C.on_device(lambda self: self.device)
     def train(self, start_epoch=0, callback_verification=None):
@@ -664,7 +666,8 @@ class Client(object):
         self.fc_module.to(self.device)
         self.fc_module.train()
         trainer = FusedTrainer(backbone, self.fc_module.fc.data, self.loss_name, 30.0, 0.4,
-                               lr=cfg.lr_func(start_epoch) * cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+                               lr=cfg.lr_func(start_epoch) * cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
+                               aux_slot=getattr(self, "slot", 0))
         loss_meter = AverageMeter()
         pending = []
         for epoch in range(start_epoch, start_epoch + self.local_epoch):
@@ -776,7 +779,8 @@ class Client(object):
             import copy
             global_model = copy.deepcopy(backbone).eval()                          # frozen copy of the incoming global model
             self.last_model = self.last_model.to(self.device).eval()
-        trainer = FusedHeadTrainer(backbone, head_params, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+        trainer = FusedHeadTrainer(backbone, head_params, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
+                                   aux_slot=getattr(self, "slot", 0))
         margin, fc_module = self.margin_softmax, self.fc_module
         state = {}
 

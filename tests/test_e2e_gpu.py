@@ -127,28 +127,55 @@ def test_forward_layerwise_vs_bf16_oracle(arch, batch, training):
     assert dict(errs)["feats"] < 2e-3, dict(errs)["feats"]
 
 
+# measured x 1.25 (north_star's 1e-2 is not reachable for whole-network embeddings with bf16 MFMA operands:
+# tools/precision_study.py): (eval, train) embeddings per architecture; running statistics of early / last layers
+# measured (eval, train): iresnet50 1.17e-2 / 1.71e-2 (the bf16-storage oracle: 1.7e-2 train), iresnet100 1.55e-2 / 2.59e-2;
+# running statistics: 1.7e-3 (early layers), 1.5e-2 (bn2 / features)
+EMB_TOL = {"iresnet50": (1.5e-2, 2.2e-2), "iresnet100": (2e-2, 3.3e-2)}
+STAT_TOL_EARLY, STAT_TOL_LATE = 2.5e-3, 2e-2
+
+
 @pytest.mark.parametrize("arch,batch,fname", [("iresnet50", 8, "r50_b8"), ("iresnet100", 6, "r100_b6")])
 def test_backbone_forward_vs_reference(arch, batch, fname):
     """Embeddings against the imported fp32 reference.  bf16 activation/weight STORAGE alone moves the embeddings of
     these 50/100-layer train-mode-BN nets by 1.2e-2 / 1.6e-2 (oracle/bf16_emul.py vs the fp32 oracle, same inputs);
-    the HIP path sits at exactly that level (measured 1.2e-2 / 1.6e-2), asserted with 2x headroom."""
+    the HIP path sits at exactly that level; asserted at measured x 1.25 (EMB_TOL)."""
     g = load_golden(fname)
     m, sd, layers = make_model(arch)
     x = R.closed_form_images(batch).to(DEV)
     m.eval()
     with torch.no_grad():
         fe = m(x)
-    assert rel(fe, g["feat_eval"]) < 3e-2, rel(fe, g["feat_eval"])
     m.train()
     ft = m(x)
-    assert rel(ft, g["feat_train"]) < 4e-2, rel(ft, g["feat_train"])
+    print("MEASURED %s embeddings: eval %.3e train %.3e" % (arch, rel(fe, g["feat_eval"]), rel(ft, g["feat_train"])))
+    lim_e, lim_t = EMB_TOL[arch]
+    assert rel(fe, g["feat_eval"]) < lim_e, rel(fe, g["feat_eval"])
+    assert rel(ft, g["feat_train"]) < lim_t, rel(ft, g["feat_train"])
     # running stats: reference momentum / unbiased-variance rule (fp32 statistics of bf16 tensors)
     sd_out = m.state_dict()
+    worst_early, worst_late = 0.0, 0.0
     for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer4.2.bn3", "bn2", "features"):
-        tol = 3e-2 if k in ("bn2", "features") else 1e-2     # late layers carry the accumulated bf16 storage noise
+        e = max(rel(sd_out[k + ".running_mean"], g["rm_" + k]), rel(sd_out[k + ".running_var"], g["rv_" + k]))
+        if k in ("bn2", "features"):
+            worst_late = max(worst_late, e)
+        else:
+            worst_early = max(worst_early, e)
+    print("MEASURED %s running stats: early layers %.3e, bn2/features %.3e" % (arch, worst_early, worst_late))
+    for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer4.2.bn3", "bn2", "features"):
+        tol = STAT_TOL_LATE if k in ("bn2", "features") else STAT_TOL_EARLY     # late layers carry the accumulated bf16 storage noise
         assert rel(sd_out[k + ".running_mean"], g["rm_" + k]) < tol, (k, rel(sd_out[k + ".running_mean"], g["rm_" + k]))
         assert rel(sd_out[k + ".running_var"], g["rv_" + k]) < tol, (k, rel(sd_out[k + ".running_var"], g["rv_" + k]))
         assert int(sd_out[k + ".num_batches_tracked"]) == int(g["nbt_" + k])
+
+
+# whole-network gradients against the fp32 reference: measured x 1.25.  These are NOT kernel-error bounds — per block the backward pass
+# is within 4.3e-3 of the bf16-storage oracle (test_block_gpu.py) — they bound what 50-100 layers of bf16 storage, PReLU derivative flips
+# and BatchNorm-backward mean subtractions do to a gradient (the bf16 oracle shows the same numbers: oracle/bf16_emul.py)
+# measured: cosines 1.7e-2 / 2.6e-2; gradient norms median 3.2e-3 / 4.2e-3, max 6.7e-2 / 4.7e-2; directions median 8.5e-2 / 1.18e-1,
+# max 0.175 / 0.33 (the maxima are bn1.bias-type gradients: nearly cancelling column sums, see test_block_gpu.py)
+GRAD_TOL = {"iresnet50": {"cosine": 2.2e-2, "norm_median": 4.5e-3, "norm_max": 8.5e-2, "dir_median": 0.11, "dir_max": 0.22},
+            "iresnet100": {"cosine": 3.3e-2, "norm_median": 5.5e-3, "norm_max": 6e-2, "dir_median": 0.15, "dir_max": 0.42}}
 
 
 @pytest.mark.parametrize("arch,batch,fname", [("iresnet50", 8, "r50_b8"), ("iresnet100", 6, "r100_b6")])
@@ -170,7 +197,8 @@ def test_train_step_grads_vs_reference(arch, batch, fname):
     logits = losses.CosFace(s=30, m=0.4)(cosine, lab)
     loss = ops.cross_entropy(logits, lab)
     loss.backward()
-    assert rel(cosine, g["cosine"]) < 5e-2, rel(cosine, g["cosine"])
+    print("MEASURED %s cosine %.3e loss %.3e" % (arch, rel(cosine, g["cosine"]), abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))))
+    assert rel(cosine, g["cosine"]) < GRAD_TOL[arch]["cosine"], rel(cosine, g["cosine"])
     assert abs(float(loss) - float(g["loss"])) < 5e-3 * abs(float(g["loss"]))
     names = [str(n) for n in g["grad_names"]]
     params = dict(m.named_parameters())
@@ -178,8 +206,9 @@ def test_train_step_grads_vs_reference(arch, batch, fname):
     ref = g["grad_norms"]
     big = ref > 1e-6 * ref.max()
     relerr = np.abs(norms[big] - ref[big]) / ref[big]
-    assert np.median(relerr) < 1e-2, np.median(relerr)
-    assert relerr.max() < 0.15, (relerr.max(), names[int(np.argmax(relerr))])
+    print("MEASURED %s grad norms: median %.3e max %.3e (%s)" % (arch, np.median(relerr), relerr.max(), names[int(np.argmax(relerr))]))
+    assert np.median(relerr) < GRAD_TOL[arch]["norm_median"], np.median(relerr)
+    assert relerr.max() < GRAD_TOL[arch]["norm_max"], (relerr.max(), names[int(np.argmax(relerr))])
     dirs = []
     gmax = max(float(T(g[k]).double().norm()) for k in g.files if k.startswith("g_") and k[2:] in params)
     for k in g.files:
@@ -192,8 +221,9 @@ def test_train_step_grads_vs_reference(arch, batch, fname):
     dirs.append(("fc.weight[:4,:2048]", rel(params["fc.weight"].grad[:4, :2048], g["g_fc.weight_slice"])))
     dirs.append(("head fc[:8]", rel(fcm.fc.grad[:8], g["g_fc_head_rows"])))
     vals = np.array([d for _, d in dirs])
-    assert np.median(vals) < 0.2, np.median(vals)
-    assert vals.max() < 0.6, max(dirs, key=lambda d: d[1])
+    print("MEASURED %s grad directions: median %.3e max %.3e (%s)" % (arch, np.median(vals), vals.max(), max(dirs, key=lambda d: d[1])[0]))
+    assert np.median(vals) < GRAD_TOL[arch]["dir_median"], np.median(vals)
+    assert vals.max() < GRAD_TOL[arch]["dir_max"], max(dirs, key=lambda d: d[1])
 
 
 def test_fused_client_loop_vs_reference():
@@ -538,6 +568,10 @@ def test_large_batch_train_step_vs_oracle(fuse_bnbwd):
         _C.call("fedfr_set_option", b"fuse_bnbwd", 0)
 
 
+# measured x 1.25 (cosine 1.17e-2, norms 2.0e-3 / 9.3e-2, directions 4.2e-2 / 0.34, head gradient 1.2e-2)
+LB_TOL = {"cosine": 1.5e-2, "norm_median": 2.5e-3, "norm_max": 0.12, "dir_median": 5.5e-2, "dir_max": 0.43, "head": 1.6e-2}
+
+
 def _large_batch_step():
     layers = R.IRESNET_LAYERS["iresnet18"]
     B, C = 128, 100
@@ -552,15 +586,18 @@ def _large_batch_step():
     loss.backward()
     torch.set_num_threads(min(64, torch.get_num_threads()))
     f_ref, c_ref, l_ref, g_ref, fcg_ref = R.train_step_grads(sd, fc0.clone(), x, lab, layers)
-    assert rel(cosine, c_ref) < 5e-2, rel(cosine, c_ref)
+    print("MEASURED r18 b128 cosine %.3e loss %.3e" % (rel(cosine, c_ref), abs(float(loss) - l_ref) / abs(l_ref)))
+    assert rel(cosine, c_ref) < LB_TOL["cosine"], rel(cosine, c_ref)
     assert abs(float(loss) - l_ref) < 5e-3 * abs(l_ref)
     params = dict(m.named_parameters())
     names = [k for k in R.trainable_keys(sd) if float(g_ref[k].norm()) > 1e-6 * max(float(v.norm()) for v in g_ref.values())]
     nerr = np.array([abs(float(params[k].grad.norm()) - float(g_ref[k].norm())) / float(g_ref[k].norm()) for k in names])
     derr = np.array([rel(params[k].grad, g_ref[k]) for k in names])
-    assert np.median(nerr) < 1e-2 and nerr.max() < 0.15, (np.median(nerr), nerr.max(), names[int(np.argmax(nerr))])
-    assert np.median(derr) < 0.15 and derr.max() < 0.6, (np.median(derr), derr.max(), names[int(np.argmax(derr))])
-    assert rel(fcm.fc.grad, fcg_ref) < 5e-2
+    print("MEASURED r18 b128 grad norms median %.3e max %.3e; directions median %.3e max %.3e (%s); head grad %.3e" %
+          (np.median(nerr), nerr.max(), np.median(derr), derr.max(), names[int(np.argmax(derr))], rel(fcm.fc.grad, fcg_ref)))
+    assert np.median(nerr) < LB_TOL["norm_median"] and nerr.max() < LB_TOL["norm_max"], (np.median(nerr), nerr.max(), names[int(np.argmax(nerr))])
+    assert np.median(derr) < LB_TOL["dir_median"] and derr.max() < LB_TOL["dir_max"], (np.median(derr), derr.max(), names[int(np.argmax(derr))])
+    assert rel(fcm.fc.grad, fcg_ref) < LB_TOL["head"]
 
 
 def test_full_size_step_invariants_r100_b128(monkeypatch):

@@ -348,3 +348,39 @@ def test_many_clients_share_one_backbone_memory_flat():
     assert max(mem[1:]) - mem[0] < 8 << 20, mem                 # < 8 MB drift over 7 more clients (one backbone's arenas are ~GBs)
     assert len({id(c._get_backbone()) for c in clients}) == 1
     assert len(client._AUX_STREAMS) <= 1                         # one auxiliary stream per device, not one per trainer
+
+
+def test_parallel_clients_round_equals_sequential():
+    """``args.parallel_clients = 2``: two clients of a round train CONCURRENTLY on the GPU (own stream pair + resident backbone each).
+    Clients are independent and every kernel is deterministic, so the round's aggregate is bit-identical to the sequential round."""
+    class DS:
+        ID_base = 0
+
+    class Loader(list):
+        dataset = DS()
+    n = 4
+
+    class Data:
+        train_class_sizes = [10] * n
+        train_dataset_sizes = [300, 100, 200, 50]
+        train_loaders = [Loader([(R.closed_form_images(4, tag=float(c * 2 + s_)), R.closed_form_labels(4, 10, tag=c + s_)) for s_ in range(2)])
+                         for c in range(n)]
+    from fedfr_amd.config import config as cfg
+    cfg.lr = 0.01
+    outs = []
+    for par in (1, 2):
+        class Args:
+            network, loss, local_epoch, output_dir, BCE_local, aggr_alg = "iresnet18", "CosFace", 1, "/tmp", False, "FedAvg"
+            parallel_clients = par
+        clients = [client.Client(c, Args, Data, device=DEV) for c in range(n)]
+        for c in clients:
+            c.fc_module.fc.data = R.head_fc(10, seed=30 + c.cid)
+        srv = server.Server(clients, Data, Args, device=DEV)
+        srv.federated_model.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet18"], tag=2.0))
+        loss = srv.train()
+        torch.cuda.synchronize()
+        outs.append((loss, {k: v.clone() for k, v in srv.federated_model.state_dict().items()}, [c.get_train_loss() for c in clients]))
+    assert outs[0][2] == outs[1][2]                                   # per-client mean losses
+    assert outs[0][0] == outs[1][0]
+    for k, v in outs[0][1].items():
+        assert torch.equal(v, outs[1][1][k]), k

@@ -30,6 +30,7 @@ SIGNATURES = {
     "fedfr_net_create": (vp, [C.POINTER(i32), i32, i32, i32]),
     "fedfr_block_create": (vp, [i32, i32, i32, i32, i32]),
     "fedfr_net_debug_capture": (i32, [vp, sz]),
+    "fedfr_net_set_dropout": (i32, [vp, f32, u64, C.POINTER(i64)]),
     "fedfr_net_destroy": (None, [vp]),
     "fedfr_net_query": (i32, [vp, i32, C.POINTER(i64)]),
     "fedfr_net_tensor_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),

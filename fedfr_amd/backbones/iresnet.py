@@ -287,6 +287,7 @@ class IResNet(nn.Module):
         self.num_features = num_features
         self.in_hw = 112
         self.dropout_p = float(dropout)
+        self.dropout_seed = 100                     # seed of the counter-based dropout mask (reference RNG seed, train.py:35)
         counts, table = _tensor_table(self.layers_cfg, self.in_hw, num_features)
         self._counts, self._table = counts, table
         # flat storage (CPU until .to(device), like any nn.Module).  Parameters and BN running statistics are slices of ONE fp32
@@ -488,6 +489,10 @@ class IResNet(nn.Module):
             if len(self._plans) >= 2:       # arenas are GBs: keep at most two batch sizes alive
                 self._plans.pop(next(iter(self._plans)))
             p = _Plan(self.layers_cfg, batch, self.in_hw, self.num_features, self.device)
+            if self.dropout_p > 0:
+                off = C.c_longlong()
+                _C.call("fedfr_net_set_dropout", p.handle, self.dropout_p, self.dropout_seed, C.byref(off))
+                p.mask_off = off.value
             self._plans[batch] = p
         return p
 
@@ -576,9 +581,6 @@ class IResNet(nn.Module):
     def forward(self, x):
         self._check_input(x)
         x = x.contiguous()
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("fedfr_amd: dropout>0 is outside the accelerated hot path "
-                                      "(the FL configs use dropout=0, reference client.py:142)")
         if self.training and torch.is_grad_enabled():
             if self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, device=x.device, requires_grad=True)

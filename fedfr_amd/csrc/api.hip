@@ -143,6 +143,15 @@ int fedfr_net_debug_capture(uint16_t* buf, size_t elems) {
   g_dbg_grads_elems = buf ? elems : 0;
   return FEDFR_OK;
 }
+int fedfr_net_set_dropout(fedfr_net_t* n, float p, unsigned long long seed, long long* mask_offset_bytes) {
+  FEDFR_REQUIRE(n && !n->block_only && p >= 0.f && p < 1.f, "net_set_dropout: need a network plan and 0 <= p < 1");
+  FEDFR_REQUIRE(((size_t)n->B * n->fc_in) % 8 == 0, "net_set_dropout: batch * fc_in must be a multiple of 8");
+  n->dropout_p = p;
+  n->dropout_seed = seed;
+  n->dropout_step = 0;
+  if (mask_offset_bytes) *mask_offset_bytes = n->mask_off_bytes;
+  return FEDFR_OK;
+}
 void fedfr_net_destroy(fedfr_net_t* net) {
   if (!net) return;
   for (auto e : net->events) (void)hipEventDestroy(e);

@@ -97,3 +97,8 @@ constexpr int kMaxBnEvalEntries = 160;      // 160 x 24 B stays under the 4 KiB 
 struct BnEvalEntry { int C, g_off, b_off, rm_off, rv_off, save_off; };
 struct BnEvalTable { int n; float eps; BnEvalEntry e[kMaxBnEvalEntries]; };
 int ew_bn_eval_coeffs_multi(const float* params, const float* bufs, float* save, const BnEvalTable& t, hipStream_t st);
+
+// nn.Dropout(p, inplace=True) on the flattened bn2 output (iresnet.py:96,169): counter-based mask (seed, step, index), kept values scaled by
+// 1 / (1 - p); mask: one byte per element, kept for the backward pass (dx: fp32, same element order)
+int ew_dropout_fwd(bf16_t* t, unsigned char* mask, size_t n, float p, unsigned long long seed, unsigned long long step, hipStream_t st);
+int ew_dropout_bwd(float* dx, const unsigned char* mask, size_t n, float p, hipStream_t st);

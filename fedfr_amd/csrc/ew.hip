@@ -1437,3 +1437,67 @@ int ew_pad_input_nhwc(const float* src, bf16_t* dst, int B, int C, int HW, int C
   FEDFR_LAUNCH_CHECK("pad_input_nhwc");
   return FEDFR_OK;
 }
+
+
+// =====================================================================================================
+// Dropout on the flattened bn2 output (reference backbones/iresnet.py:96,169: nn.Dropout(p, inplace=True) between bn2 and fc)
+// =====================================================================================================
+// Counter-based mask: element i of training step `step` is kept iff a 16-bit hash of (seed, step, i) >= p * 65536, so the mask is a pure
+// function of (seed, step, index) — reproducible, no RNG state on the device.  Kept values are scaled by 1 / (1 - p) (torch semantics).
+__device__ __forceinline__ unsigned long long dropout_hash(unsigned long long x) {   // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(bf16_t* __restrict__ t, unsigned char* __restrict__ mask, size_t n8, unsigned thr,
+                                                          float inv_keep, unsigned long long seed, unsigned long long step) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const unsigned long long key = seed * 0x100000001B3ull + step * 0x9E3779B1ull;
+    const unsigned long long h0 = dropout_hash(key ^ (2 * i)), h1 = dropout_hash(key ^ (2 * i + 1));
+    uint4 v = reinterpret_cast<uint4*>(t)[i];
+    float f[8];
+    unpack8(v, f);
+    unsigned char m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned r = (unsigned)(((j < 4 ? h0 : h1) >> (16 * (j & 3))) & 0xffffu);
+      m[j] = r >= thr ? 1 : 0;
+      f[j] = m[j] ? f[j] * inv_keep : 0.f;
+    }
+    reinterpret_cast<uint4*>(t)[i] = pack8(f);
+    uint2 mk;
+    mk.x = (unsigned)m[0] | ((unsigned)m[1] << 8) | ((unsigned)m[2] << 16) | ((unsigned)m[3] << 24);
+    mk.y = (unsigned)m[4] | ((unsigned)m[5] << 8) | ((unsigned)m[6] << 16) | ((unsigned)m[7] << 24);
+    reinterpret_cast<uint2*>(mask)[i] = mk;
+  }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(float* __restrict__ dx, const unsigned char* __restrict__ mask, size_t n4, float inv_keep) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const unsigned mk = reinterpret_cast<const unsigned*>(mask)[i];
+    float4 d = reinterpret_cast<float4*>(dx)[i];
+    d.x = (mk & 0xffu) ? d.x * inv_keep : 0.f;
+    d.y = (mk & 0xff00u) ? d.y * inv_keep : 0.f;
+    d.z = (mk & 0xff0000u) ? d.z * inv_keep : 0.f;
+    d.w = (mk & 0xff000000u) ? d.w * inv_keep : 0.f;
+    reinterpret_cast<float4*>(dx)[i] = d;
+  }
+}
+int ew_dropout_fwd(bf16_t* t, unsigned char* mask, size_t n, float p, unsigned long long seed, unsigned long long step, hipStream_t st) {
+  FEDFR_REQUIRE(t && mask && n > 0 && (n & 7) == 0 && p > 0.f && p < 1.f, "dropout_fwd: bad args (n%%8, 0 < p < 1)");
+  const size_t n8 = n / 8;
+  const int grid = (int)std::min<size_t>((n8 + 255) / 256, 4096);
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid), dim3(256), 0, st, t, mask, n8, (unsigned)(p * 65536.f), 1.f / (1.f - p), seed, step);
+  FEDFR_LAUNCH_CHECK("dropout_fwd");
+  return FEDFR_OK;
+}
+int ew_dropout_bwd(float* dx, const unsigned char* mask, size_t n, float p, hipStream_t st) {
+  FEDFR_REQUIRE(dx && mask && n > 0 && (n & 3) == 0 && p > 0.f && p < 1.f, "dropout_bwd: bad args (n%%4, 0 < p < 1)");
+  const size_t n4 = n / 4;
+  const int grid = (int)std::min<size_t>((n4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid), dim3(256), 0, st, dx, mask, n4, 1.f / (1.f - p));
+  FEDFR_LAUNCH_CHECK("dropout_bwd");
+  return FEDFR_OK;
+}

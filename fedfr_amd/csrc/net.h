@@ -65,6 +65,11 @@ struct FedfrNet {
   mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;
+  // nn.Dropout between bn2 and fc (iresnet.py:96,169): p = 0 off; the mask of the last training forward lives in the arena
+  float dropout_p = 0.f;
+  unsigned long long dropout_seed = 100;
+  mutable unsigned long long dropout_step = 0;      // counts training forwards (the mask is a function of (seed, step, index))
+  long long mask_off_bytes = -1;                    // byte offset of the mask [B * fc_in] inside `act`
   bool block_only = false;              // plan of a lone IBasicBlock (net_create_block): no stem, no bn2/fc/features tail
   long long dx_off = -1;                // block_only: bf16 arena offset of the gradient wrt the block input [B*Hin*Hin][Cin]
 };

@@ -127,7 +127,8 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
   long long foff = b.saveoff;                 // bnsave floats first
   n->yfc_off = foff; foff += Bq * num_features;
   n->feat_save_off = foff; foff += 2 * (long long)num_features;
-  n->act_bytes = n->act_float_off_bytes + (long long)align_up((size_t)foff * 4, 256);
+  n->mask_off_bytes = n->act_float_off_bytes + (long long)align_up((size_t)foff * 4, 256);
+  n->act_bytes = n->mask_off_bytes + (long long)align_up((size_t)Bq * n->fc_in, 256);
   // ---- workspace ----
   n->g_elems = (size_t)gmax;
   long long part = (long long)ew_stem_stat_rows(batch, in_hw, in_hw) * 128;
@@ -509,6 +510,8 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
   FEDFR_TRY(bn_coeffs(c, n->bn2, Pprev, (double)Mf, tr));
   FEDFR_TRY(apply(c, A + last.out_off, n->bn2, nullptr, nullptr, nullptr, A + n->t_off, Mf, false, hw));
+  if (tr && n->dropout_p > 0.f)            // nn.Dropout(p, inplace=True) on the flattened bn2 output (iresnet.py:169); identity in eval mode
+    FEDFR_TRY(ew_dropout_fwd(A + n->t_off, act + n->mask_off_bytes, (size_t)B * n->fc_in, n->dropout_p, n->dropout_seed, n->dropout_step++, st));
   {
     GemmNT p{};
     p.A = A + n->t_off; p.B = shadow + n->fc_w_off; p.M = B; p.N = n->F; p.K = n->fc_in; p.mode = 0; p.lda = n->fc_in;
@@ -629,6 +632,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   }
   const BlockD& last = n->blocks.back();
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
+  if (n->dropout_p > 0.f) FEDFR_TRY(ew_dropout_bwd(dxfc, act + n->mask_off_bytes, (size_t)B * n->fc_in, n->dropout_p, st));
   FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dxfc, c.g(0), B, n->final_C, hw, st));
   FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0, 0, &last.bn3, A + last.c2_off, &pend_rows));
   }

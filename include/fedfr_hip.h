@@ -50,6 +50,11 @@ fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_
  * dfeats = fp32 NCHW [B][cout][hout][hout] (dx = act selector 7).  stride 1 needs cin == cout; stride 2 adds the 1x1 downsample. */
 fedfr_net_t* fedfr_block_create(int cin, int cout, int stride, int hin, int batch);
 void fedfr_net_destroy(fedfr_net_t* net);
+/* nn.Dropout(p, inplace=True) between bn2 and fc (backbones/iresnet.py:96,169; the reference uses p = 0.4 for its webface configuration,
+ * client.py:142): training forwards then zero a counter-based random subset of the flattened bn2 output (element i of the k-th training
+ * forward is kept iff hash16(seed, k, i) >= p * 65536) and scale the rest by 1 / (1 - p); the backward applies the same mask.  p = 0 turns it
+ * off; the call resets the forward counter.  *mask_offset_bytes (optional): where the last mask ([batch * fc_in] bytes, 0/1) lives in `act`. */
+int fedfr_net_set_dropout(fedfr_net_t* net, float p, unsigned long long seed, long long* mask_offset_bytes);
 /* debug (tests): while buf != NULL, fedfr_net_backward* copies the gradient entering every block (bf16 NHWC, last block first) and then
  * the gradient wrt the first block's input back to back into buf (caller-owned, `elems` bf16 elements); NULL turns it off.  The one
  * exception to "no pointer is retained": clear it before freeing the buffer. */

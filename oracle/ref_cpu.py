@@ -306,8 +306,11 @@ def ibasic_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: i
 
 
 def iresnet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, layers: Sequence[int],
-                    training: bool = True, return_taps: bool = False):
-    """iresnet.py:158-172 with fp16=False (CPU path) and dropout p=0 (client.py:142)."""
+                    training: bool = True, return_taps: bool = False, dropout_p: float = 0.0,
+                    dropout_mask: Optional[torch.Tensor] = None):
+    """iresnet.py:158-172 with fp16=False (CPU path).  ``dropout_p`` > 0 with an injected keep-``dropout_mask`` [B, 25088] (0/1): the
+    nn.Dropout(p, inplace=True) of iresnet.py:169 with that mask (torch's RNG stream is not part of the contract; FL configs use p = 0,
+    client.py:142)."""
     taps = {}
     h = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
     h = _bn(sd, "bn1", h, training)
@@ -319,6 +322,8 @@ def iresnet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, layers: Sequen
         taps["layer%d" % (si + 1)] = h
     h = _bn(sd, "bn2", h, training)
     h = torch.flatten(h, 1)
+    if training and dropout_p > 0.0:
+        h = h * dropout_mask.to(h.dtype) / (1.0 - dropout_p)
     h = F.linear(h, sd["fc.weight"], sd["fc.bias"])
     h = _bn(sd, "features", h, training)
     return (h, taps) if return_taps else h

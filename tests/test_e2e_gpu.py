@@ -873,3 +873,60 @@ def test_cpu_tensor_is_rejected_loudly():
     m = backbones.iresnet18()
     with pytest.raises(RuntimeError, match="MI355X"):
         m(torch.zeros(2, 3, 112, 112))
+
+
+def test_dropout_matches_oracle_with_same_mask():
+    """dropout > 0 (reference iresnet.py:96,169; 0.4 for the webface configuration, client.py:142): nn.Dropout between bn2 and fc.
+    The mask is counter-based (seed, step, index) — torch's RNG stream is not part of the contract — so parity = the oracle run with
+    the HIP path's own mask injected: embeddings and gradients as close as without dropout; plus the mask's statistics and its
+    determinism, eval-mode identity and the backward's use of the same mask."""
+    import ctypes as C
+    p, B, NC = 0.4, 8, 20
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sd = R.closed_form_state_dict(layers, tag=1.0)
+
+    def run(seed):
+        m = backbones.iresnet18(False, dropout=p, fp16=True)
+        m.dropout_seed = seed
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        x = R.closed_form_images(B).to(DEV)
+        f = m(x)
+        plan = m._plan(B)
+        mask = plan.act[plan.mask_off: plan.mask_off + B * 25088].clone().view(B, 25088)
+        (f * R.closed_form((B, 512), 0.37, 0.9, 1.0).to(DEV)).sum().backward()
+        grads = {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+        f2 = m(x)                                                 # second training forward: step 1 -> another mask
+        mask2 = plan.act[plan.mask_off: plan.mask_off + B * 25088].clone().view(B, 25088)
+        m.eval()
+        with torch.no_grad():
+            fe = m(x)
+        return m, f.detach(), mask, grads, mask2, fe, f2.detach()
+    m, f, mask, grads, mask2, fe, f2 = run(100)
+    keep = float(mask.float().mean())
+    assert set(mask.unique().tolist()) <= {0, 1} and abs(keep - (1 - p)) < 4 * (p * (1 - p) / mask.numel()) ** 0.5 + 1e-3, keep
+    assert not torch.equal(mask, mask2) and abs(float(mask2.float().mean()) - (1 - p)) < 5e-3
+    _, f_b, mask_b, _, _, _, _ = run(100)
+    assert torch.equal(mask, mask_b) and torch.equal(f, f_b)       # same seed, same step -> same mask, same result
+    _, _, mask_c, _, _, _, _ = run(101)
+    assert not torch.equal(mask, mask_c)
+    # oracle with the same mask (fp32) — forward and backward
+    sdo = {k: v.clone() for k, v in sd.items()}
+    keys = R.trainable_keys(sdo)
+    for k in keys:
+        sdo[k].requires_grad_(True)
+    fo = R.iresnet_forward(sdo, R.closed_form_images(B), layers, True, dropout_p=p, dropout_mask=mask.cpu())
+    (fo * R.closed_form((B, 512), 0.37, 0.9, 1.0)).sum().backward()
+    assert rel(f, fo) < 2e-2, rel(f, fo)                              # bf16 backbone: the no-dropout level on this net is ~1e-2
+    for k in ("fc.weight", "layer4.1.conv2.weight", "bn2.weight", "conv1.weight"):
+        assert rel(grads[k], sdo[k].grad) < 0.1, (k, rel(grads[k], sdo[k].grad))
+    # fc.weight's gradient is exactly zero in the dropped input columns of every image where they are dropped in all images
+    dead = (mask.sum(dim=0) == 0).nonzero().flatten()
+    if dead.numel():
+        assert float(grads["fc.weight"][:, dead].abs().max()) == 0.0
+    # eval mode: dropout is the identity (embeddings equal a dropout-free model's)
+    m0 = backbones.iresnet18(False, dropout=0, fp16=True)
+    m0.load_state_dict({k: v for k, v in m.state_dict().items()})
+    m0 = m0.to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(fe, m0(R.closed_form_images(B).to(DEV)))

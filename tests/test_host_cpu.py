@@ -149,3 +149,14 @@ def test_asm_read_hazard_checker(tmp_path):
     assert subprocess.run([sys.executable, tool, str(good)], capture_output=True).returncode == 0
     r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
     assert r.returncode == 1 and "pending" in r.stdout
+
+
+def test_oracle_dropout_is_torch_dropout_with_injected_mask():
+    """the oracle's masked dropout (iresnet_forward(dropout_mask=...)) == nn.Dropout(p) as the reference applies it (iresnet.py:169) when
+    torch draws that same mask."""
+    p = 0.4
+    x = R.closed_form((4, 25088), 0.013, 0.2, 1.0)
+    torch.manual_seed(5)
+    y = torch.nn.functional.dropout(x.clone(), p=p, training=True)
+    mask = (y != 0).float()
+    assert torch.allclose(x * mask / (1 - p), y)

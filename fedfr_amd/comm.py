@@ -58,8 +58,8 @@ class TorchDistComm:
             out = torch.zeros((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
             out[self.rank] = t
             self.dist.all_reduce(out, group=self.group)
-        else:
-            out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        else:                             # concatenated along dim 0: the output form every backend accepts
+            out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             self.dist.all_gather_into_tensor(out, t, group=self.group)
         return out.view((-1,) + tuple(t.shape[1:]))
 

@@ -160,3 +160,58 @@ def test_oracle_dropout_is_torch_dropout_with_injected_mask():
     y = torch.nn.functional.dropout(x.clone(), p=p, training=True)
     mask = (y != 0).float()
     assert torch.allclose(x * mask / (1 - p), y)
+
+
+# ---- exchange layer (fedfr_amd/comm.py) on CPU tensors ----------------------------------------------------------------------------
+def _comm_script(c):
+    """the four verbs against their definitions; returns per-rank results for cross-rank checks."""
+    W, r = c.world_size, c.rank
+    g = c.all_gather(torch.full((2, 3), float(r)))
+    assert g.shape == (2 * W, 3) and all(float(g[2 * i, 0]) == i for i in range(W))
+    s = c.all_reduce(torch.arange(4, dtype=torch.float32) * (r + 1), "sum")
+    assert torch.equal(s, torch.arange(4, dtype=torch.float32) * (W * (W + 1) / 2))
+    m = c.all_reduce(torch.tensor([float(r), -float(r)]), "max")
+    assert torch.equal(m, torch.tensor([float(W - 1), 0.0]))
+    full = torch.arange(W * 2 * 3, dtype=torch.float32).view(W * 2, 3) + r
+    rs = c.reduce_scatter(full)
+    exp = (torch.arange(W * 2 * 3, dtype=torch.float32).view(W * 2, 3) * W + W * (W - 1) / 2)[2 * r: 2 * r + 2]
+    assert torch.equal(rs, exp)
+    # int64 labels bit-cast into float lanes survive an all_gather (PartialFC's packed gather)
+    lab = torch.tensor([2 ** 40 + r, 7 * r, -1], dtype=torch.int64)
+    packed = torch.cat([torch.ones(3, 2), lab.view(torch.int32).view(3, 2).view(torch.float32)], dim=1)
+    back = c.all_gather(packed)[:, 2:].contiguous().view(torch.int32).view(-1).view(torch.int64).view(W, 3)
+    assert torch.equal(back[r], lab) and int(back[(r + 1) % W][0]) == 2 ** 40 + (r + 1) % W
+    c.barrier()
+    return r
+
+
+def test_thread_comm_verbs():
+    from fedfr_amd.comm import ThreadComm, SingleComm
+    assert ThreadComm.run(3, _comm_script) == [0, 1, 2]
+    assert ThreadComm.run(8, _comm_script) == list(range(8))
+    assert _comm_script(SingleComm()) == 0
+    with pytest.raises(ZeroDivisionError):                       # a failing rank surfaces, the others are released (no hang)
+        ThreadComm.run(4, lambda c: 1 / 0 if c.rank == 2 else c.barrier())
+
+
+def _dist_comm_worker(rank, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        from fedfr_amd.comm import TorchDistComm, default_comm
+        c = default_comm(2)
+        assert isinstance(c, TorchDistComm) and (c.rank, c.world_size) == (rank, 2)
+        _comm_script(c)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_torch_dist_comm_verbs_gloo():
+    import torch.multiprocessing as mp
+    mp.spawn(_dist_comm_worker, args=(29681,), nprocs=2, join=True)
+    from fedfr_amd.comm import default_comm, SingleComm
+    assert isinstance(default_comm(1), SingleComm)
+    with pytest.raises(RuntimeError):
+        default_comm(2)                                          # world_size 2 without a process group: loud, not silent

@@ -384,3 +384,37 @@ def test_parallel_clients_round_equals_sequential():
     assert outs[0][0] == outs[1][0]
     for k, v in outs[0][1].items():
         assert torch.equal(v, outs[1][1][k]), k
+
+
+def _rccl_world1_worker(rank, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        c = TorchDistComm()
+        assert c.bitwise_gather and (c.rank, c.world_size) == (0, 1)
+        t = torch.arange(12, dtype=torch.float32, device=DEV).view(4, 3)
+        assert torch.equal(c.all_gather(t), t)                                   # all_gather_into_tensor
+        assert torch.equal(c.all_reduce(t.clone(), "sum"), t) and torch.equal(c.all_reduce(t.clone(), "max"), t)
+        assert torch.equal(c.reduce_scatter(t.clone()), t)                       # reduce_scatter_tensor
+        lab = torch.tensor([2 ** 40 + 3, 7, -1], dtype=torch.int64, device=DEV)
+        packed = torch.cat([torch.ones(3, 2, device=DEV), lab.view(torch.int32).view(3, 2).view(torch.float32)], dim=1)
+        assert torch.equal(c.all_gather(packed)[:, 2:].contiguous().view(torch.int32).view(-1).view(torch.int64), lab)
+        m = _closed_form_backbone(1.0)
+        before = m._flat_state.clone()
+        nbt = m._flat_nbt.clone()
+        assert server.fedavg_all_reduce(m, 5.0, server.exchange_data_sizes(5.0, c), c) == 1.0
+        torch.cuda.synchronize()
+        P = m._flat_params.numel() + m._flat_bufs.numel()
+        assert torch.equal(m._flat_state[:P], before[:P]) and torch.equal(m._flat_nbt, nbt)      # weight 1.0: the exchange is the identity
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_torch_dist_comm_over_rccl_world1():
+    """The RCCL code paths of the exchange layer (all_gather_into_tensor, reduce_scatter_tensor, in-place all_reduce of the model state) at
+    world size 1 — what one GPU can run of them; multi-rank semantics are covered by the gloo / thread tests above."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_world1_worker, args=(29683,), nprocs=1, join=True)

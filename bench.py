@@ -228,155 +228,180 @@ def main():
 
     # ---- roofline leg: HIP-event timing of every MFMA GEMM launch and of the HBM-bound BatchNorm / SGD kernels, in a separate short
     # pass over the same workload
+    leg_errors = {}
     roofline = None
     if rank == 0 and not args.no_profile:
-        psteps = 3
-        # kernels are timed one at a time: the weight-gradient GEMMs normally share the GPU with the dgrad/BN chain on a
-        # second stream, which stretches every kernel's wall time; for a per-kernel roofline the pass runs single-stream
-        # (rocprof summary of the matching command: FEDFR_DUAL_STREAM=0 python bench.py ..., profiles/*_single_stream*)
-        saved_aux = tr.aux_stream
-        tr.finish()
-        torch.cuda.synchronize()
-        tr.aux_stream = None
-        _C.call("fedfr_profile_enable", 1)
-        for i in range(psteps):
-            tr.step(imgs[i % nbuf], labs[i % nbuf])
-        torch.cuda.synchronize()
-        tr.aux_stream = saved_aux
+        try:
+            psteps = 3
+            # kernels are timed one at a time: the weight-gradient GEMMs normally share the GPU with the dgrad/BN chain on a
+            # second stream, which stretches every kernel's wall time; for a per-kernel roofline the pass runs single-stream
+            # (rocprof summary of the matching command: FEDFR_DUAL_STREAM=0 python bench.py ..., profiles/*_single_stream*)
+            saved_aux = tr.aux_stream
+            tr.finish()
+            torch.cuda.synchronize()
+            tr.aux_stream = None
+            _C.call("fedfr_profile_enable", 1)
+            for i in range(psteps):
+                tr.step(imgs[i % nbuf], labs[i % nbuf])
+            torch.cuda.synchronize()
+            tr.aux_stream = saved_aux
 
-        def read(slot):
-            ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
-            _C.call("fedfr_profile_read", slot, C.byref(ms), C.byref(n), C.byref(fl))
-            return ms.value, n.value, fl.value
-        rows = []
-        for slot in range(len(SLOT_NAMES)):
-            ms, n, fl = read(slot)
-            if n:
-                rows.append((ms, n, fl, slot))
-        hbm_rows = {name: read(slot) for slot, name in HBM_SLOTS.items()}
-        _C.call("fedfr_profile_enable", 0)
-        rows.sort(reverse=True)
-        traffic = pmc_traffic()
+            def read(slot):
+                ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
+                _C.call("fedfr_profile_read", slot, C.byref(ms), C.byref(n), C.byref(fl))
+                return ms.value, n.value, fl.value
+            rows = []
+            for slot in range(len(SLOT_NAMES)):
+                ms, n, fl = read(slot)
+                if n:
+                    rows.append((ms, n, fl, slot))
+            hbm_rows = {name: read(slot) for slot, name in HBM_SLOTS.items()}
+            _C.call("fedfr_profile_enable", 0)
+            rows.sort(reverse=True)
+            traffic = pmc_traffic()
 
-        def entry(ms, n, fl, slot):
-            name = SLOT_NAMES[slot]
-            ach = fl / (ms * 1e-3) / 1e12
-            tr_bytes, tr_file, tr_detail = traffic.get(name, (None, None, None))
-            e = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": tr_bytes,
-                 "launches_per_step": n // psteps, "avg_launch_us": round(ms * 1e3 / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3)}
-            if tr_bytes is not None:
-                e["traffic_note"] = ("HBM bytes per launch on the 256->256 @14x14 layer, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
-                                     "FETCH x2 gfx950 correction), %s: %s; algorithmic %.1f MB" % (tr_file, tr_detail, ALGORITHMIC_MB.get(name, float("nan"))))
-                e["algorithmic_bytes"] = int(ALGORITHMIC_MB[name] * 1e6) if name in ALGORITHMIC_MB else None
-            return e
-        if rows:
-            roofline = entry(*rows[0])
-            roofline["timing"] = "HIP events around each launch on its stream, single-stream pass of %d steps" % psteps
-            if len(rows) > 1:                      # the two 3x3 kernels (forward/dgrad and weight gradient) tie for the largest time share
-                roofline["second"] = entry(*rows[1])
-            roofline["all_gemm_kernels"] = [{"kernel": SLOT_NAMES[s_], "ms_per_step": round(m_ / psteps, 3), "launches_per_step": k // psteps,
-                                             "tflops": round(f / (m_ * 1e-3) / 1e12, 1)} for m_, k, f, s_ in rows]
-            # the HBM-bound third of the step: BatchNorm forward / backward streaming passes (algorithmic bytes = tensors read + written once)
-            fam = [hbm_rows[k] for k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply") if hbm_rows[k][1]]
-            if fam:
-                fms, fb = sum(r[0] for r in fam), sum(r[2] for r in fam)
-                roofline["hbm"] = {"bound": "hbm", "kernel": "bn_apply + bn_bwd_reduce + bn_bwd_apply", "achieved": round(fb / (fms * 1e-3) / 1e9, 1),
-                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                   "traffic": None, "ms_per_step": round(fms / psteps, 3), "launches_per_step": sum(r[1] for r in fam) // psteps,
-                                   "algorithmic_gb_per_step": round(fb / psteps / 1e9, 2)}
-            roofline["hbm_kernels"] = [{"kernel": k, "ms_per_step": round(v[0] / psteps, 3), "launches_per_step": v[1] // psteps,
-                                        "gbps": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] else None} for k, v in hbm_rows.items() if v[1]]
+            def entry(ms, n, fl, slot):
+                name = SLOT_NAMES[slot]
+                ach = fl / (ms * 1e-3) / 1e12
+                tr_bytes, tr_file, tr_detail = traffic.get(name, (None, None, None))
+                e = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": tr_bytes,
+                     "launches_per_step": n // psteps, "avg_launch_us": round(ms * 1e3 / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3)}
+                if tr_bytes is not None:
+                    e["traffic_note"] = ("HBM bytes per launch on the 256->256 @14x14 layer, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                                         "FETCH x2 gfx950 correction), %s: %s; algorithmic %.1f MB" % (tr_file, tr_detail, ALGORITHMIC_MB.get(name, float("nan"))))
+                    e["algorithmic_bytes"] = int(ALGORITHMIC_MB[name] * 1e6) if name in ALGORITHMIC_MB else None
+                return e
+            if rows:
+                roofline = entry(*rows[0])
+                roofline["timing"] = "HIP events around each launch on its stream, single-stream pass of %d steps" % psteps
+                if len(rows) > 1:                      # the two 3x3 kernels (forward/dgrad and weight gradient) tie for the largest time share
+                    roofline["second"] = entry(*rows[1])
+                roofline["all_gemm_kernels"] = [{"kernel": SLOT_NAMES[s_], "ms_per_step": round(m_ / psteps, 3), "launches_per_step": k // psteps,
+                                                 "tflops": round(f / (m_ * 1e-3) / 1e12, 1)} for m_, k, f, s_ in rows]
+                # the HBM-bound third of the step: BatchNorm forward / backward streaming passes (algorithmic bytes = tensors read + written once)
+                fam = [hbm_rows[k] for k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply") if hbm_rows[k][1]]
+                if fam:
+                    fms, fb = sum(r[0] for r in fam), sum(r[2] for r in fam)
+                    roofline["hbm"] = {"bound": "hbm", "kernel": "bn_apply + bn_bwd_reduce + bn_bwd_apply", "achieved": round(fb / (fms * 1e-3) / 1e9, 1),
+                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                       "traffic": None, "ms_per_step": round(fms / psteps, 3), "launches_per_step": sum(r[1] for r in fam) // psteps,
+                                       "algorithmic_gb_per_step": round(fb / psteps / 1e9, 2)}
+                roofline["hbm_kernels"] = [{"kernel": k, "ms_per_step": round(v[0] / psteps, 3), "launches_per_step": v[1] // psteps,
+                                            "gbps": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] else None} for k, v in hbm_rows.items() if v[1]]
+        except Exception as e:      # an auxiliary leg must never cost the headline number
+            leg_errors['roofline'] = "%s: %s" % (type(e).__name__, e)
+            print("bench.py: the roofline leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
     # ---- end to end with the input path in the loop: the host hands over uint8 HWC batches (1 byte per pixel-channel, pinned memory);
     # upload on a copy stream + on-device ToTensor/Normalize/flip (fedfr_preprocess_u8, dataset.py:81-92) overlap the previous step
     end_to_end = None
     if rank == 0 and world == 1 and not args.no_profile:
-        from fedfr_amd import ops
-        tr.finish()
-        gh = torch.Generator().manual_seed(7)
-        host = [torch.randint(0, 256, (B, 112, 112, 3), dtype=torch.uint8, generator=gh).pin_memory() for _ in range(2)]
-        flips = [(torch.rand(B, generator=gh) < 0.5).to(torch.uint8).pin_memory() for _ in range(2)]
-        copy_stream = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream()
-        staged = [None, None]
+        try:
+            from fedfr_amd import ops
+            tr.finish()
+            gh = torch.Generator().manual_seed(7)
+            host = [torch.randint(0, 256, (B, 112, 112, 3), dtype=torch.uint8, generator=gh).pin_memory() for _ in range(2)]
+            flips = [(torch.rand(B, generator=gh) < 0.5).to(torch.uint8).pin_memory() for _ in range(2)]
+            copy_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream()
+            staged = [None, None]
 
-        def stage(i):
-            with torch.cuda.stream(copy_stream):
-                u8 = host[i % 2].to(dev, non_blocking=True)
-                fl = flips[i % 2].to(dev, non_blocking=True)
-                staged[i % 2] = (ops.preprocess_u8(u8, fl), u8, fl)
-        esteps = max(5, min(args.steps, 20))
-        stage(0)
-        for i in range(2):                                             # warm-up of the staging path
-            main.wait_stream(copy_stream)
-            x = staged[i % 2][0]
-            stage(i + 1)
-            tr.step(x, labs[i % nbuf])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(2, 2 + esteps):
-            main.wait_stream(copy_stream)
-            x = staged[i % 2][0]
-            x.record_stream(main)
-            stage(i + 1)
-            tr.step(x, labs[i % nbuf])
-        tr.finish()
-        torch.cuda.synchronize()
-        dte = time.perf_counter() - t1
-        end_to_end = {"value": round(B * esteps / dte, 1), "unit": "images/sec", "ms_per_step": round(dte * 1e3 / esteps, 3), "steps": esteps,
-                      "note": "pinned uint8 HWC host batches (4.8 MB/step) -> H2D on a copy stream -> fedfr_preprocess_u8 -> train step; "
-                              "`value` above excludes this input path (inputs resident in HBM)"}
+            def stage(i):
+                with torch.cuda.stream(copy_stream):
+                    u8 = host[i % 2].to(dev, non_blocking=True)
+                    fl = flips[i % 2].to(dev, non_blocking=True)
+                    staged[i % 2] = (ops.preprocess_u8(u8, fl), u8, fl)
+            esteps = max(5, min(args.steps, 20))
+            stage(0)
+            for i in range(2):                                             # warm-up of the staging path
+                main.wait_stream(copy_stream)
+                x = staged[i % 2][0]
+                stage(i + 1)
+                tr.step(x, labs[i % nbuf])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(2, 2 + esteps):
+                main.wait_stream(copy_stream)
+                x = staged[i % 2][0]
+                x.record_stream(main)
+                stage(i + 1)
+                tr.step(x, labs[i % nbuf])
+            tr.finish()
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t1
+            end_to_end = {"value": round(B * esteps / dte, 1), "unit": "images/sec", "ms_per_step": round(dte * 1e3 / esteps, 3), "steps": esteps,
+                          "note": "pinned uint8 HWC host batches (4.8 MB/step) -> H2D on a copy stream -> fedfr_preprocess_u8 -> train step; "
+                                  "`value` above excludes this input path (inputs resident in HBM)"}
+        except Exception as e:      # an auxiliary leg must never cost the headline number
+            leg_errors['end_to_end'] = "%s: %s" % (type(e).__name__, e)
+            print("bench.py: the end_to_end leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
     # ---- two independent clients training concurrently on this GPU (Server.train with args.parallel_clients = 2): the clients of an FL
     # round are independent, and a second client's kernel chain fills the CUs one chain leaves idle between its ~1250 dependent launches
     concurrent = None
     if rank == 0 and world == 1 and not args.no_profile and args.head == "dense":
-        import threading
-        tr.finish()
-        torch.cuda.synchronize()
-        torch.manual_seed(101)
-        model2 = getattr(backbones, args.arch)(False, dropout=0, fp16=True).to(dev)
-        fc2 = (torch.randn(NC, 512) * 0.01).to(dev)
-        lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-        st2 = torch.cuda.Stream(device=dev, priority=hi_p)
-        with torch.cuda.stream(st2):
-            tr2 = client.FusedTrainer(model2, fc2, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4, aux_slot=1)
-        pairs = [(tr, torch.cuda.current_stream()), (tr2, st2)]
-        csteps = max(5, min(args.steps, 20))
-        bar = threading.Barrier(3)
+        try:
+            import threading
+            tr.finish()
+            torch.cuda.synchronize()
+            torch.manual_seed(101)
+            model2 = getattr(backbones, args.arch)(False, dropout=0, fp16=True).to(dev)
+            fc2 = (torch.randn(NC, 512) * 0.01).to(dev)
+            lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            st2 = torch.cuda.Stream(device=dev, priority=hi_p)
+            with torch.cuda.stream(st2):
+                tr2 = client.FusedTrainer(model2, fc2, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4, aux_slot=1)
+            pairs = [(tr, torch.cuda.current_stream()), (tr2, st2)]
+            csteps = max(5, min(args.steps, 20))
+            bar = threading.Barrier(3)
 
-        def worker(k):
-            t_, s_ = pairs[k]
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(s_):
-                for i in range(3):
-                    t_.step(imgs[(i + k) % nbuf], labs[(i + k) % nbuf])
-                s_.synchronize()
-                bar.wait()
-                for i in range(csteps):
-                    t_.step(imgs[(i + k) % nbuf], labs[(i + k) % nbuf])
-                t_.finish()
-                s_.synchronize()
-                bar.wait()
-        ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(2)]
-        for t_ in ths:
-            t_.start()
-        bar.wait()
-        tc = time.perf_counter()
-        bar.wait()
-        dtc = time.perf_counter() - tc
-        for t_ in ths:
-            t_.join()
-        concurrent = {"clients_on_this_gpu": 2, "value": round(2 * B * csteps / dtc, 1), "unit": "images/sec",
-                      "ms_per_step_per_client": round(dtc * 1e3 / csteps, 3), "steps": csteps,
-                      "note": "two independent clients (own backbone, optimiser, HIP stream pair), each running the same bs=%d train step; "
-                              "aggregate over both.  `value` above is ONE client alone" % B}
-        del tr2, model2
+            werr = []
+
+            def worker(k):
+                t_, s_ = pairs[k]
+                try:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(s_):
+                        for i in range(3):
+                            t_.step(imgs[(i + k) % nbuf], labs[(i + k) % nbuf])
+                        s_.synchronize()
+                        bar.wait(timeout=300)
+                        for i in range(csteps):
+                            t_.step(imgs[(i + k) % nbuf], labs[(i + k) % nbuf])
+                        t_.finish()
+                        s_.synchronize()
+                        bar.wait(timeout=300)
+                except BaseException as e:      # noqa: BLE001 — a failing client must release the others, never hang the bench
+                    werr.append(e)
+                    bar.abort()
+            ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(2)]
+            for t_ in ths:
+                t_.start()
+            bar.wait(timeout=300)
+            tc = time.perf_counter()
+            bar.wait(timeout=300)
+            dtc = time.perf_counter() - tc
+            for t_ in ths:
+                t_.join(60)
+            if werr:
+                raise werr[0]
+            concurrent = {"clients_on_this_gpu": 2, "value": round(2 * B * csteps / dtc, 1), "unit": "images/sec",
+                          "ms_per_step_per_client": round(dtc * 1e3 / csteps, 3), "steps": csteps,
+                          "note": "two independent clients (own backbone, optimiser, HIP stream pair), each running the same bs=%d train step; "
+                                  "aggregate over both.  `value` above is ONE client alone" % B}
+            del tr2, model2
+        except Exception as e:      # an auxiliary leg must never cost the headline number
+            leg_errors['concurrent'] = "%s: %s" % (type(e).__name__, e)
+            print("bench.py: the concurrent leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
-        cpu = cpu_baseline(args.arch)
+        try:
+            cpu = cpu_baseline(args.arch)
+        except Exception as e:      # an auxiliary leg must never cost the headline number
+            leg_errors['cpu'] = "%s: %s" % (type(e).__name__, e)
+            print("bench.py: the cpu leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
     if rank == 0:
         ms_step = dt * 1e3 / args.steps
@@ -403,6 +428,8 @@ def main():
             "end_to_end": end_to_end,
             "concurrent_clients": concurrent,
         }
+        if leg_errors:
+            out["leg_errors"] = leg_errors
         if use_dist:
             out["fedavg_round_ms"] = round(dt * 1e3, 3)
             out["fedavg_exchange_ms"] = round((dt - t_local) * 1e3, 3)

@@ -51,6 +51,7 @@ class TorchDistComm:
         self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
         self.bitwise_gather = not self._gloo       # all_gather is a pure byte copy (callers may pack bit-cast integers into float lanes)
+        self.needs_device_tensors = not self._gloo  # RCCL moves device memory only
 
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()

@@ -111,7 +111,8 @@ def _i64_trunc(acc: torch.Tensor, dst: torch.Tensor):
 def exchange_data_sizes(data_size: float, comm) -> float:
     """Σ n_j over the ranks (one tiny all-reduce + host read).  Run it when the sizes become known — at round start, off the exchange
     path — and hand the result to ``fedavg_all_reduce``; ranks that know every client's size in advance skip it."""
-    t = torch.tensor([float(data_size)], dtype=torch.float64)
+    dev = torch.device("cuda", torch.cuda.current_device()) if getattr(comm, "needs_device_tensors", False) else torch.device("cpu")
+    t = torch.tensor([float(data_size)], dtype=torch.float64, device=dev)
     t = comm.all_reduce(t, "sum")
     return float(t.item())
 

@@ -150,8 +150,10 @@ def main():
     ap.add_argument("--arch", default="iresnet100", choices=["iresnet100", "iresnet50"])
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--classes", type=int, default=1000)
-    ap.add_argument("--head", default="dense", choices=["dense", "pfc"],
-                    help="dense: CosFace + dense cosine head (headline); pfc: ArcFace + PartialFC sample_rate 0.1 (BASELINE config 3; use --classes 85000)")
+    ap.add_argument("--head", default="dense", choices=["dense", "pfc", "pfc-sharded"],
+                    help="dense: CosFace + dense cosine head (headline); pfc: ArcFace + PartialFC sample_rate 0.1 (BASELINE config 3; use --classes 85000); "
+                         "pfc-sharded: BASELINE config 5 = per-client backbone + ONE CosFace PartialFC class-sharded over all ranks (sample_rate 0.1) + "
+                         "a private BCE head per client (use --classes 85000 under torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -179,13 +181,26 @@ def main():
         fc = PartialFC(rank=0, local_rank=local_rank, world_size=1, batch_size=B, resume=False,
                        margin_softmax=losses.ArcFace(s=30, m=0.4), num_classes=NC, sample_rate=0.1, embedding_size=512, prefix="/tmp")
         tr = client.FusedTrainer(model, fc, "ArcFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    elif args.head == "pfc-sharded":
+        from fedfr_amd import losses
+        from fedfr_amd.comm import SingleComm, TorchDistComm
+        from fedfr_amd.partial_fc import PartialFC
+        comm = TorchDistComm() if (use_dist and world > 1) else SingleComm()
+        pfc = PartialFC(rank=rank if world > 1 else 0, local_rank=local_rank, world_size=world, batch_size=B, resume=False,
+                        margin_softmax=losses.CosFace(s=30, m=0.4), num_classes=NC, sample_rate=0.1, embedding_size=512, prefix="/tmp", comm=comm)
+        n_ids = NC // world                                                       # this client's identities: [rank * n_ids, (rank + 1) * n_ids)
+        bce = client.BCE_module(512, n_ids, 1).to(dev)
+        tr = client.ShardedHeadTrainer(model, pfc, bce, id_base=rank * n_ids, lr=1e-3, momentum=0.9, weight_decay=5e-4)
     else:
         fc = (torch.randn(NC, 512) * 0.01).to(dev)                                # client.py:66
         tr = client.FusedTrainer(model, fc, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4)
     g = torch.Generator().manual_seed(100 + rank)
     nbuf = 4
     imgs = [(torch.rand(B, 3, 112, 112, generator=g) * 2 - 1).to(dev) for _ in range(nbuf)]   # already resident in HBM
-    labs = [torch.randint(0, NC, (B,), generator=g).to(dev) for _ in range(nbuf)]
+    if args.head == "pfc-sharded":
+        labs = [(torch.randint(0, NC // world, (B,), generator=g) + rank * (NC // world)).to(dev) for _ in range(nbuf)]
+    else:
+        labs = [torch.randint(0, NC, (B,), generator=g).to(dev) for _ in range(nbuf)]
 
     def barrier():
         if use_dist:
@@ -211,6 +226,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = tr.step(imgs[i % nbuf], labs[i % nbuf])
+    if isinstance(loss, tuple):
+        loss = loss[0]
     t_local = None
     if use_dist:
         tr.finish()
@@ -408,7 +425,8 @@ def main():
         value = world * B * args.steps / dt
         step_tflop = 3 * FWD_GFLOP_PER_IMG[args.arch] * B / 1e3
         out = {
-            "metric": "images/sec (%s+%s train step, bs=%d/GPU, 112x112)" % (args.arch, "CosFace" if args.head == "dense" else "ArcFace+PartialFC", B),
+            "metric": "images/sec (%s+%s train step, bs=%d/GPU, 112x112)" % (args.arch, {"dense": "CosFace", "pfc": "ArcFace+PartialFC",
+                                                                                 "pfc-sharded": "CosFace+sharded PartialFC+BCE head"}[args.head], B),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -416,7 +434,9 @@ def main():
                                    "(fwd+bwd+momentum-SGD), batch %d/GPU, 112x112 synthetic faces, random-init weights, "
                                    "bf16 activations/weights with fp32 accumulate + fp32 master weights, fp32 head"
                                    % (args.arch, ("CosFace(s=30,m=0.4) + dense %d-class cosine head" % NC) if args.head == "dense"
-                                      else ("ArcFace(s=30,m=0.4) + PartialFC sample_rate 0.1 over %d classes" % NC), B),
+                                      else ("ArcFace(s=30,m=0.4) + PartialFC sample_rate 0.1 over %d classes" % NC) if args.head == "pfc"
+                                      else ("CosFace(s=30,m=0.4) PartialFC sample_rate 0.1 over %d classes class-sharded over %d rank(s) + private "
+                                            "BCE head over %d identities per client (BASELINE config 5)" % (NC, world, NC // world)), B),
                        "global_batch": world * B, "parallelism": "1 client per GPU (FedAvg), dp%d" % world,
                        "clients": world},
             "images_per_sec_per_gpu": round(value / world, 1),

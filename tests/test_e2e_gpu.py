@@ -930,3 +930,48 @@ def test_dropout_matches_oracle_with_same_mask():
     m0 = m0.to(DEV).eval()
     with torch.no_grad():
         assert torch.equal(fe, m0(R.closed_form_images(B).to(DEV)))
+
+
+def test_client_train_ragged_and_single_image_batches_vs_oracle():
+    """Edge cases of the reference hot loop (client.py:536-551): a ragged last batch (a DataLoader without drop_last) and a batch of ONE
+    image, which the reference duplicates before the forward pass (client.py:538-540: BatchNorm needs two samples) — through Client.train
+    (batches of 5, 3 and 1 images: three plan sizes, the 2-plan cache evicts one) against the oracle's loop on the same data."""
+    class Args:
+        network, loss, local_epoch, output_dir, BCE_local, aggr_alg = "iresnet18", "CosFace", 1, "/tmp", False, "FedAvg"
+
+    class DS:
+        ID_base = 0
+
+    class Loader(list):
+        dataset = DS()
+    C = 10
+    batches = [(R.closed_form_images(n, tag=float(i)), R.closed_form_labels(n, C, tag=i)) for i, n in enumerate((5, 3, 1))]
+
+    class Data:
+        train_class_sizes, train_dataset_sizes, train_loaders = [C], [9], [Loader(batches)]
+    from fedfr_amd.config import config as cfg
+    saved = cfg.lr
+    cfg.lr = 0.01
+    try:
+        cl = client.Client(0, Args, Data, device=DEV)
+        layers = R.IRESNET_LAYERS["iresnet18"]
+        cl.backbone_state_dict = R.closed_form_state_dict(layers, tag=2.0)
+        cl.fc_module.fc.data = R.head_fc(C, seed=5)
+        cl.train(0)
+        lr_eff = cfg.lr_func(0) * cfg.lr
+    finally:
+        cfg.lr = saved
+    sd = R.closed_form_state_dict(layers, tag=2.0)
+    fc = R.head_fc(C, seed=5)
+    losses_ref, sd, fc = R.client_train(sd, fc, batches, layers, "CosFace", 30.0, 0.4, lr_eff, 0.9, 5e-4)
+    assert abs(cl.get_train_loss() - float(np.mean(losses_ref))) < 1e-2 * abs(float(np.mean(losses_ref))), (cl.get_train_loss(), losses_ref)
+    out = cl.get_model()
+    assert int(out["bn1.num_batches_tracked"]) == int(sd["bn1.num_batches_tracked"])        # three forward passes
+    errs = {k: rel(out[k], sd[k]) for k in ("conv1.weight", "bn1.weight", "prelu.weight", "layer2.0.downsample.0.weight", "fc.bias",
+                                            "bn1.running_mean", "bn1.running_var")}
+    errs["head"] = rel(cl.fc_module.fc.data, fc)
+    print("MEASURED ragged client loop:", {k: "%.2e" % v for k, v in errs.items()})
+    # batches of 5 / 3 / 2 images: BatchNorm statistics over so few samples are ill-conditioned, the bf16 gradient noise is several times that
+    # of the batch-8 client fixture (test_fused_client_loop_vs_reference: 1e-2) — measured 1.6e-2 on conv1.weight
+    for k, v in errs.items():
+        assert v < (3.3e-2 if k == "head" else 2.1e-2), (k, v)          # measured 2.6e-2 / 1.6e-2

@@ -33,46 +33,29 @@ class PartialFC(Module):
         if self.comm.world_size != world_size or self.comm.rank != rank:
             raise ValueError("PartialFC: rank/world_size (%d/%d) disagree with the communicator (%d/%d)"
                              % (rank, world_size, self.comm.rank, self.comm.world_size))
-        self.num_classes: int = num_classes
-        self.rank: int = rank
-        self.local_rank: int = local_rank
-        self.device = torch.device("cuda:{}".format(self.local_rank))
-        self.world_size: int = world_size
-        self.batch_size: int = batch_size
-        self.margin_softmax = margin_softmax
-        self.sample_rate: float = sample_rate
-        self.embedding_size: int = embedding_size
-        self.prefix: str = prefix
-        self.num_local: int = num_classes // world_size + int(rank < num_classes % world_size)         # partial_fc.py:34
-        self.class_start: int = num_classes // world_size * rank + min(rank, num_classes % world_size)  # :35
-        self.num_sample: int = int(self.sample_rate * self.num_local)
-        self.weight_name = os.path.join(self.prefix, "rank:{}_softmax_weight.pt".format(self.rank))
-        self.weight_mom_name = os.path.join(self.prefix, "rank:{}_softmax_weight_mom.pt".format(self.rank))
-        logger = logging.getLogger("FL_face.partial")
-        self.weight = None
-        if resume:
-            try:
-                self.weight = torch.load(self.weight_name).to(self.device)
-                logger.info("softmax weight resume successfully!")
-            except (FileNotFoundError, KeyError, IndexError):
-                logger.info("softmax weight resume fail!")
-            try:
-                self.weight_mom = torch.load(self.weight_mom_name).to(self.device)
-                logger.info("softmax weight mom resume successfully!")
-            except (FileNotFoundError, KeyError, IndexError):
-                self.weight_mom = None
-                logger.info("softmax weight mom resume fail!")
+        # public attributes of the reference object (partial_fc.py:24-39,63-69): callers and checkpoints rely on these names
+        self.rank, self.local_rank, self.world_size = int(rank), int(local_rank), int(world_size)
+        self.num_classes, self.batch_size, self.embedding_size = int(num_classes), int(batch_size), int(embedding_size)
+        self.margin_softmax, self.sample_rate, self.prefix = margin_softmax, float(sample_rate), str(prefix)
+        self.device = torch.device("cuda", self.local_rank)
+        base, extra = divmod(self.num_classes, self.world_size)          # class c lives on the rank whose [class_start, +num_local) holds it:
+        self.num_local = base + (1 if self.rank < extra else 0)           # the first `extra` ranks hold one class more (partial_fc.py:34-35)
+        self.class_start = base * self.rank + min(self.rank, extra)
+        self.num_sample = int(self.sample_rate * self.num_local)
+        self.weight_name, self.weight_mom_name = (os.path.join(self.prefix, "rank:%d_softmax_weight%s.pt" % (self.rank, sfx)) for sfx in ("", "_mom"))
+        log = logging.getLogger("FL_face.partial")
+        self.weight = self._restore(self.weight_name, "softmax weight", log) if resume else None
         if self.weight is None:
-            self.weight = torch.normal(0, 0.01, (self.num_local, self.embedding_size), device=self.device)
-            self.weight_mom = None
-        if getattr(self, "weight_mom", None) is None:
+            self.weight = torch.normal(0, 0.01, (self.num_local, self.embedding_size), device=self.device)          # partial_fc.py:45,56
+        self.weight_mom = self._restore(self.weight_mom_name, "softmax weight mom", log) if resume else None
+        if self.weight_mom is None or self.weight_mom.shape != self.weight.shape:
             self.weight_mom = torch.zeros_like(self.weight)
         # The reference overlaps label gather + sampling on a side stream (partial_fc.py:61,119).  Here sampling is ~30 us of
         # kernels, and side-stream allocations consumed by main-stream kernels would need record_stream() bookkeeping, so
         # everything is enqueued on the caller's current stream; the attribute is kept for API compatibility.
         self.stream = torch.cuda.current_stream(self.device)
         self.index = None
-        self._seed, self._step = int(seed) * 1000003 + rank, 0
+        self._seed, self._step = int(seed) * 1000003 + self.rank, 0
         self._perm = torch.empty(self.num_local, dtype=f32, device=self.device)
         self._npos = torch.zeros(1, dtype=torch.int32, device=self.device)
         # margin parameters for the fused softmax kernels
@@ -80,29 +63,44 @@ class PartialFC(Module):
         if name not in ("CosFace", "ArcFace"):
             raise ValueError("margin_softmax must be a fedfr_amd.losses.CosFace/ArcFace instance")
         self._arc, self._s, self._m = name == "ArcFace", float(margin_softmax.s), float(margin_softmax.m)
-        if int(self.sample_rate) == 1:
-            self.update = lambda: 0
-            self.sub_weight = Parameter(self.weight)
-            self.sub_weight_mom = self.weight_mom
-        else:
-            self.sub_weight = Parameter(torch.empty((0, 0), device=self.device))
+        self._sampling = int(self.sample_rate) != 1
+        if self._sampling:
+            self.sub_weight = Parameter(torch.empty((0, 0), device=self.device))          # filled by sample() every step
+        else:                                                                            # sample_rate 1: the whole shard is the "sample"
+            self._alias_all_rows()
+            self.update = lambda: 0                                                       # nothing to scatter back (partial_fc.py:64-67)
 
-    # ------------------------------------------------------------------ persistence (partial_fc.py:71-87)
+    def _restore(self, path, what, log):
+        """one tensor of a resumed run (partial_fc.py:41-53), or None when the file is missing / unreadable."""
+        try:
+            t = torch.load(path).to(self.device)
+        except (FileNotFoundError, KeyError, IndexError):
+            log.info("%s resume fail!", what)
+            return None
+        log.info("%s resume successfully!", what)
+        return t
+
+    def _alias_all_rows(self):
+        self.sub_weight = Parameter(self.weight)
+        self.sub_weight_mom = self.weight_mom
+
+    # ------------------------------------------------------------------ persistence: the reference's file names (partial_fc.py:71-87)
+    def _fc_path(self):
+        return os.path.join(self.prefix, "FC_rank_%d.pth" % self.local_rank)
+
     def save_params(self):
-        torch.save(self.weight.data, self.weight_name)
-        torch.save(self.weight_mom, self.weight_mom_name)
+        for t, path in ((self.weight.data, self.weight_name), (self.weight_mom, self.weight_mom_name)):
+            torch.save(t, path)
 
     def save_FC(self):
-        torch.save(self.weight.data, os.path.join(self.prefix, "FC_rank_%d.pth" % (self.local_rank)))
-
-    def update_FC(self):
-        model_path = os.path.join(self.prefix, "FC_rank_%d.pth" % (self.local_rank))
-        self.weight.data = torch.load(model_path).to(self.device)
-        self.sub_weight = Parameter(self.weight)
+        torch.save(self.weight.data, self._fc_path())
 
     def update_from_tensor(self, tensor):
         self.weight.data = tensor.to(self.device)
         self.sub_weight = Parameter(self.weight)
+
+    def update_FC(self):
+        self.update_from_tensor(torch.load(self._fc_path()))
 
     # ------------------------------------------------------------------ sampling (partial_fc.py:89-106)
     @torch.no_grad()
@@ -111,7 +109,7 @@ class PartialFC(Module):
         ``perm`` injects the uniform draw (parity tests); by default a counter-based HIP RNG fills it."""
         st = _C.stream()
         n = total_label.numel()
-        sampling = int(self.sample_rate) != 1
+        sampling = self._sampling
         if sampling:
             if perm is not None:
                 self._perm.copy_(perm)

@@ -163,13 +163,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal switches (NOT for measurements): FEDFR_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and FEDFR_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device), so that the N > 1 code path can be run end to end on a one-GPU box
+    share = os.environ.get("FEDFR_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("FEDFR_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("FEDFR_FORCE_DIST") == "1"      # FORCE_DIST: exercise the RCCL path on 1 GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fedfr_amd import _C, backbones, client, server
     torch.manual_seed(100 + rank)                                  # reference seed 100 (train.py:35)
@@ -178,7 +186,7 @@ def main():
     if args.head == "pfc":
         from fedfr_amd import losses
         from fedfr_amd.partial_fc import PartialFC
-        fc = PartialFC(rank=0, local_rank=local_rank, world_size=1, batch_size=B, resume=False,
+        fc = PartialFC(rank=0, local_rank=dev_index, world_size=1, batch_size=B, resume=False,
                        margin_softmax=losses.ArcFace(s=30, m=0.4), num_classes=NC, sample_rate=0.1, embedding_size=512, prefix="/tmp")
         tr = client.FusedTrainer(model, fc, "ArcFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4)
     elif args.head == "pfc-sharded":
@@ -186,7 +194,7 @@ def main():
         from fedfr_amd.comm import SingleComm, TorchDistComm
         from fedfr_amd.partial_fc import PartialFC
         comm = TorchDistComm() if (use_dist and world > 1) else SingleComm()
-        pfc = PartialFC(rank=rank if world > 1 else 0, local_rank=local_rank, world_size=world, batch_size=B, resume=False,
+        pfc = PartialFC(rank=rank if world > 1 else 0, local_rank=dev_index, world_size=world, batch_size=B, resume=False,
                         margin_softmax=losses.CosFace(s=30, m=0.4), num_classes=NC, sample_rate=0.1, embedding_size=512, prefix="/tmp", comm=comm)
         n_ids = NC // world                                                       # this client's identities: [rank * n_ids, (rank + 1) * n_ids)
         bce = client.BCE_module(512, n_ids, 1).to(dev)
@@ -247,7 +255,10 @@ def main():
     # pass over the same workload
     leg_errors = {}
     roofline = None
-    if rank == 0 and not args.no_profile:
+    # rank-0-only legs re-run tr.step(): with a step that contains collectives (the sharded head at world > 1) the other ranks would have to
+    # join in, so those configurations report the timed region only
+    collective_step = args.head == "pfc-sharded" and world > 1
+    if rank == 0 and not args.no_profile and not collective_step:
         try:
             psteps = 3
             # kernels are timed one at a time: the weight-gradient GEMMs normally share the GPU with the dgrad/BN chain on a
@@ -429,7 +440,7 @@ def main():
                                                                                  "pfc-sharded": "CosFace+sharded PartialFC+BCE head"}[args.head], B),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic" if backend == "nccl" and not share else "synthetic (REHEARSAL: ranks share one GPU / gloo — not a measurement)",
             "config": {"workload": "%s + %s, full train step "
                                    "(fwd+bwd+momentum-SGD), batch %d/GPU, 112x112 synthetic faces, random-init weights, "
                                    "bf16 activations/weights with fp32 accumulate + fp32 master weights, fp32 head"

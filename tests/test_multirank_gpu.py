@@ -418,3 +418,69 @@ def test_torch_dist_comm_over_rccl_world1():
     world size 1 — what one GPU can run of them; multi-rank semantics are covered by the gloo / thread tests above."""
     import torch.multiprocessing as mp
     mp.spawn(_rccl_world1_worker, args=(29683,), nprocs=1, join=True)
+
+
+def _config5_gloo_worker(rank, port):
+    """rank of a 2-PROCESS config-5 run (torch.distributed over gloo, both ranks on cuda:0): product path, then the oracle's composition
+    over the same process group on the CPU."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        W, B, n_ids, steps, lr, rate = 2, 4, 10, 2, 0.01, 0.5
+        C = W * n_ids + 1                                              # 21 classes -> shards 11 / 10
+        layers = R.IRESNET_LAYERS["iresnet18"]
+        sizes = [30.0, 10.0]
+        nl, _ = R.pfc_shard(C, W, rank)
+        sd0 = R.closed_form_state_dict(layers, tag=float(rank + 1))
+        w0 = R.closed_form((nl, 512), 0.071 + 0.003 * rank, 1.1, 0.01)
+        bce0 = R.head_fc(n_ids, seed=20 + rank)
+        perms = [R.closed_form((nl,), 0.77 + 0.1 * st, 0.3 + rank, 0.5, 0.5) for st in range(steps)]
+        batches = _config5_inputs(rank, W, B, n_ids, steps)
+        # ---- product path
+        comm = TorchDistComm()
+        bb = backbones.iresnet18(False, dropout=0, fp16=True)
+        bb.load_state_dict(sd0)
+        bb = bb.to(DEV)
+        pfc = PartialFC(rank=rank, local_rank=0, world_size=W, batch_size=B, resume=False, margin_softmax=losses.CosFace(s=30, m=0.4),
+                        num_classes=C, sample_rate=rate, embedding_size=512, prefix="/tmp")          # default comm = the process group
+        assert isinstance(pfc.comm, TorchDistComm)
+        pfc.weight.copy_(w0.to(DEV))
+        pfc.weight_mom.zero_()
+        bm = client.BCE_module(512, n_ids, 1).to(DEV)
+        bm.weight.data = bce0.clone().to(DEV)
+        tr = client.ShardedHeadTrainer(bb, pfc, bm, id_base=rank * n_ids, lr=lr)
+        ls = []
+        for st, (imgs, lab) in enumerate(batches):
+            loss, cos, b = tr.step(imgs.to(DEV), lab.to(DEV), perm=perms[st].to(DEV))
+            ls.append((float(loss), float(cos), float(b)))
+        local = {k: v.clone() for k, v in bb.state_dict().items()}
+        tr.end_round(sizes[rank], server.exchange_data_sizes(sizes[rank], comm))
+        torch.cuda.synchronize()
+        avg = bb.state_dict()
+        # ---- oracle over the same group (CPU tensors)
+        sd = {k: v.clone() for k, v in sd0.items()}
+        w, mom = w0.clone(), torch.zeros_like(w0)
+        bce = {"conv_w": torch.eye(512), "conv_b": torch.zeros(512), "weight": bce0.clone(), "bias": torch.zeros(n_ids)}
+        ref = R.config5_client_steps(sd, w, mom, bce, batches, layers, R.DistComm(), B, C, rate, rank * n_ids, lr, perms)
+        for (l, c_, b), (rl, rc, rb) in zip(ls, ref):
+            assert abs(c_ - rc) < 1e-2 * abs(rc) and abs(b - rb) < 1e-2 * abs(rb) and abs(l - rl) < 1e-2 * abs(rl), (ls, ref)
+        for k in ("conv1.weight", "bn1.weight", "layer2.0.downsample.0.weight", "fc.bias"):
+            assert rel(local[k], sd[k]) < 1e-2, (k, rel(local[k], sd[k]))
+        assert rel(pfc.weight, w) < 3e-2
+        # FedAvg of the two local models, gathered through the group for the check
+        mine = local["conv1.weight"].contiguous().cpu()
+        both = [torch.zeros_like(mine) for _ in range(W)]
+        dist.all_gather(both, mine)
+        exp = np.float32(sizes[0] / 40.0) * both[0] + np.float32(sizes[1] / 40.0) * both[1]
+        assert torch.equal(avg["conv1.weight"].cpu(), exp)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_config5_two_processes_gloo_vs_oracle():
+    """Config 5 as two PROCESSES (ranks share cuda:0; exchange through torch.distributed / gloo, i.e. TorchDistComm inside PartialFC
+    and fedavg_all_reduce) against the oracle's composition run over the same process group."""
+    import torch.multiprocessing as mp
+    mp.spawn(_config5_gloo_worker, args=(29691,), nprocs=2, join=True)

@@ -32,7 +32,7 @@ HBM_PEAK_GBPS = 8000.0                                                # MI355X_M
 SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kernel<64,128>", "gemm_nt_kernel<64,64>",
               "gemm_tn_kernel<128,128>", "gemm_tn_kernel<128,64>", "gemm_tn_kernel<64,128>", "gemm_tn_kernel<64,64>",
               "conv3x3_halo2_kernel<128,14>", "conv3x3_halo2_kernel<128,28>", "conv3x3_halo2_kernel<64,*>", "conv3x3_halo_kernel<*>",
-              "conv3x3_glds_kernel<14,14>", "conv3x3_glds_kernel<28,7>", "gemm_tn_glds_kernel<128,128>", "conv3x3_glds_kernel<56,4>",
+              "conv3x3_glds_kernel<14,14>", "conv3x3_glds_kernel<28,7>", "gemm_tn_glds_kernel<128,128>", "conv3x3 64-channel layers (c64p / glds<56,4>)",
               "wgrad9_kernel<32x64x9>"]
 HBM_SLOTS = {20: "bn_apply", 21: "bn_bwd_reduce", 22: "bn_bwd_apply", 23: "bn_finalize", 24: "bn_bwd_finalize", 25: "reduce_slabs", 26: "sgd"}
 # ALGORITHMIC HBM bytes per launch on the 256->256 @14x14 layer (58 of iresnet100's 103 convs; B = 128): conv fwd/dgrad = input 12.85 MB

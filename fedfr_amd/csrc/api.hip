@@ -21,6 +21,7 @@ extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_tn_pair;
 extern int g_wgrad9;
+extern int g_conv_c64p;
 extern int g_eval_fuse;
 extern int g_wgrad_depth;
 extern int g_dgrad_parity;
@@ -104,6 +105,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "fuse_bnbwd")) {
     g_fuse_bnbwd = value ? 1 : 0;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "conv_c64p")) {
+    g_conv_c64p = value ? 1 : 0;   // persistent register-resident-weights kernel for the 64 -> 64 channel 3x3 layers (112x112 / 56x56)
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "nt_nbuf")) {

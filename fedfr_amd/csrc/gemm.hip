@@ -423,6 +423,7 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
                   gemm_nt_conv_xform_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: input transform is not available for this convolution");
     return launch_conv_glds_x(p, st);
   }
+  if (splits == 1 && conv_c64p_applies(p)) return launch_conv_c64p(p, st);
   const int BM = nt_bm(p.M, p.N);
   if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {

@@ -54,6 +54,10 @@ CONV_CASES = [
     (131, 28, 128, 256, 3, 1),
     (9, 56, 64, 128, 3, 1),      # LDS-DMA kernel, single input chunk -> 128-wide tile (fwd) / two chunks -> 64-wide tile (dgrad)
     (3, 56, 128, 64, 3, 1),
+    # 64 -> 64 channel layers: persistent kernel with the filter bank in registers (conv_c64p.hip): 1, 2 and 5 tiles per workgroup
+    (1, 56, 64, 64, 3, 1),
+    (20, 112, 64, 64, 3, 1),
+    (37, 56, 64, 64, 3, 1),
 ]
 
 

@@ -22,6 +22,7 @@ extern int g_tn_glds;
 extern int g_tn_pair;
 extern int g_wgrad9;
 extern int g_conv_c64p;
+extern int g_bn_sliced, g_bn_sliced_pre;
 extern int g_eval_fuse;
 extern int g_wgrad_depth;
 extern int g_dgrad_parity;
@@ -109,6 +110,14 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "conv_c64p")) {
     g_conv_c64p = value ? 1 : 0;   // persistent register-resident-weights kernel for the 64 -> 64 channel 3x3 layers (112x112 / 56x56)
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "bn_sliced")) {
+    g_bn_sliced = value ? 1 : 0;   // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "bn_sliced_pre")) {
+    g_bn_sliced_pre = value;       // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "nt_nbuf")) {
@@ -421,6 +430,34 @@ int fedfr_bn_bwd(const uint16_t* dy, const uint16_t* x, const float* mean, const
   FEDFR_TRY(ew_bn_bwd_reduce(p, ST(stream)));
   FEDFR_TRY(ew_bn_bwd_finalize(partials, ew_bn_bwd_grid(M, C), C, (double)M, gamma, mean, rstd, dgamma, dbeta, dalpha, coef, ST(stream)));
   return ew_bn_bwd_apply(p, ST(stream));
+}
+
+int fedfr_bn_sliced_rows(int M, int C) { return ew_bn_sliced_rows(M, C); }
+int fedfr_bn_sliced_ok(int M, int C, int rows_in, int backward) { return ew_bn_sliced_ok(M, C, rows_in, backward != 0) ? 1 : 0; }
+int fedfr_bn_apply_sliced(const float* partials, int P, double count, const float* gamma, const float* beta, float* rm, float* rv,
+                          float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd, const uint16_t* x1,
+                          const float* alpha, const uint16_t* x2, uint16_t* y, int M, int C, float* stats, void* stream) {
+  FEDFR_REQUIRE(ew_bn_sliced_ok(M, C, P, false), "bn_apply_sliced: shape M=%d C=%d with %d partial rows is not served (fedfr_bn_sliced_ok)", M, C, P);
+  BnApplyS a{};
+  a.part = partials; a.P = P; a.count = count; a.gamma = gamma; a.beta = beta; a.rm = rm; a.rv = rv; a.momentum = momentum; a.eps = eps;
+  a.scale = scale; a.shift = shift; a.mean = save_mean; a.rstd = save_rstd; a.x1 = BF(x1); a.alpha = alpha; a.x2 = BF(x2); a.y = BFM(y);
+  a.M = M; a.C = C; a.stats = stats;
+  return ew_bn_apply_sliced(a, ST(stream));
+}
+int fedfr_bn_bwd_sliced(const uint16_t* dy, const uint16_t* x, const float* mean, const float* rstd, const float* gamma, const float* alpha,
+                        const float* sc, const float* sh, int M, int C, float* partials, int rows_in, float* dgamma, float* dbeta,
+                        float* dalpha, const uint16_t* add, uint16_t* dx, const uint16_t* nx, const float* nmean, const float* nrstd,
+                        float* npart, void* stream) {
+  FEDFR_REQUIRE(partials && ew_bn_sliced_ok(M, C, rows_in > 0 ? rows_in : ew_bn_sliced_rows(M, C), true),
+                "bn_bwd_sliced: shape M=%d C=%d (%d rows) is not served (fedfr_bn_sliced_ok)", M, C, rows_in);
+  BnBwdS p{};
+  p.dy = BF(dy); p.x = BF(x); p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.alpha = alpha; p.sc = sc; p.sh = sh; p.M = M; p.C = C;
+  p.count = (double)M; p.partials = partials;
+  if (rows_in <= 0) FEDFR_TRY(ew_bn_bwd_reduce_sliced(p, ST(stream)));
+  p.part_in = partials; p.P = rows_in > 0 ? rows_in : ew_bn_sliced_rows(M, C);
+  p.dgamma = dgamma; p.dbeta = dbeta; p.dalpha = dalpha; p.add = BF(add); p.dx = BFM(dx);
+  p.nx = BF(nx); p.nmean = nmean; p.nrstd = nrstd; p.npart = npart;
+  return ew_bn_bwd_apply_sliced(p, ST(stream));
 }
 
 // ---- head ------------------------------------------------------------------------------------------------------

@@ -52,6 +52,39 @@ int ew_bn_bwd_finalize(const float* partials, int P, int C, double count, const 
                        float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st);
 int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st);
 
+// ---- channel-sliced BatchNorm passes that reduce their partial rows themselves: no finalize launch (bn_sliced.hip) -------------
+// partial rows everywhere: [row][statistic][C] fp32, the layout the kernels above and the conv epilogues write
+struct BnApplyS {
+  const float* part; int P;                       // statistics of x1: P rows [2][C] (sum, sumsq)
+  double count; const float *gamma, *beta; float *rm, *rv; float momentum, eps;
+  float *scale, *shift, *mean, *rstd;             // [C] each, written (what ew_bn_finalize leaves)
+  const bf16_t* x1; const float* alpha;           // y = prelu?(bn(x1)) ...
+  const bf16_t* x2;                               // ... + x2 (identity path), or null
+  bf16_t* y;
+  int M, C;
+  float* stats;                                   // statistics of y: ew_bn_sliced_rows(M, C) rows [2][C], or null; must not alias `part`
+  int G, ppg;                                     // set by the launcher
+};
+struct BnBwdS {
+  const bf16_t *dy, *x;
+  const float *mean, *rstd, *gamma, *alpha;       // alpha non-null => PReLU after the BN
+  const float *sc, *sh;                           // the forward's (scale, shift): required with alpha (PReLU mask = sign(x sc + sh))
+  int M, C;
+  float* partials;                                // reduce pass: ew_bn_sliced_rows(M, C) rows [3][C] written
+  const float* part_in; int P; double count;      // apply pass: the P rows [3][C] to reduce
+  float *dgamma, *dbeta, *dalpha;                 // apply pass: parameter gradients written (null: skipped)
+  const bf16_t* add;                              // optional same-shape addend (identity-path gradient)
+  bf16_t* dx;
+  const bf16_t* nx; const float *nmean, *nrstd;   // optional: dx reduced as the dy of the BatchNorm that consumes it ...
+  float* npart;                                   // ... into ew_bn_sliced_rows(M, C) rows [3][C]; must not alias `part_in`
+  int G, ppg;
+};
+int ew_bn_sliced_rows(int M, int C);
+bool ew_bn_sliced_ok(int M, int C, int P_in, bool backward);
+int ew_bn_apply_sliced(BnApplyS p, hipStream_t st);
+int ew_bn_bwd_reduce_sliced(BnBwdS p, hipStream_t st);
+int ew_bn_bwd_apply_sliced(BnBwdS p, hipStream_t st);
+
 // ---- BatchNorm1d on fp32 [B][C] (the `features` layer) ------------------------------------------------
 int ew_bn1d_fwd(const float* x, float* y, int B, int C, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, float momentum, float eps, int training,

@@ -355,6 +355,14 @@ int gemm_nt_stat_rows(int M, int N) {
   return ceil_div(M, BM) * WM;
 }
 
+// rows of gemm_nt_stat_rows that carry data for a conv with BatchNorm statistics in its epilogue (the rest are zero rows the kernel
+// writes so that a finalize over the 128-pixel-tile row count stays right): the 196-pixel-tile LDS-DMA kernels leave 2 per tile
+bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
+int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride) {
+  if ((W == 14 || W == 28) && gemm_nt_conv_epilogue_ok(W, C, N, M, ksize, stride)) return M / 196 * 2;
+  return gemm_nt_stat_rows(M, N);
+}
+
 int g_dgrad_parity = 1;   // option "dgrad_parity": stride-2 3x3 dgrad as 4 output-parity classes (9/4 instead of 9 taps per output pixel)
 
 // shapes whose conv runs on a plain LDS-DMA kernel instantiation (mirrors the dispatch in gemm_nt_launch_one): those implement the

@@ -46,6 +46,7 @@ struct BlockD {
 // stream waited 1.4 ms per step for weight gradients of two blocks ago (mostly in the 7x7 / early 14x14 stages, whose weight GEMMs
 // are long and whose main-stream kernels are short); 4 generations cost 1.2 GB more workspace.
 constexpr int kWgradDepth = 4;
+constexpr int kSlicedRowsMax = 256;     // partial rows a channel-sliced BatchNorm pass writes at most (ew_bn_sliced_rows)
 struct FedfrNet {
   int layers[4];
   int B, Bp, HW, F;                     // batch, batch padded to 8, input side, feature dim
@@ -61,7 +62,7 @@ struct FedfrNet {
   long long act_bf16_count, act_float_off_bytes, act_bytes;
   // workspace layout (byte offsets)
   size_t ws_bytes;
-  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_slab, ws_small, ws_fc;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
+  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_part2, ws_slab, ws_small, ws_fc;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
   mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;

@@ -164,6 +164,7 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
   for (int i = 0; i < 6; ++i) n->ws_t[i] = wtake(n->g_elems * 2);
   for (int i = 0; i < 3 * (kWgradDepth - 1); ++i) n->ws_t2[i] = wtake(n->g_elems * 2);
   n->ws_part = wtake(n->part_floats * 4);
+  n->ws_part2 = wtake((size_t)kSlicedRowsMax * 3 * 1024 * 4);   // rows written by the channel-sliced BatchNorm passes (bn_sliced.hip)
   n->ws_slab = wtake(n->slab_floats * 4 * 2);      // two regions: paired weight-gradient GEMMs write their slab sets side by side
   // small: coef[3*512] | finalize tmp [64*2*512] | dyfc f32 [B*F] | dyb bf16 [B*F] | dybt bf16 [F*Bp]
   n->ws_small = wtake((size_t)(3 * 512 + 64 * 2 * 512) * 4 + (size_t)Bq * num_features * 4 + (size_t)Bq * num_features * 2 +
@@ -236,6 +237,10 @@ struct Ctx {
   const float* params; float* bufs; const bf16_t* shadow; bf16_t* actb; float* actf; unsigned char* ws; float* grads;
   hipStream_t st;
   float* part() const { return reinterpret_cast<float*>(ws + n->ws_part); }
+  // second partial-row buffer: a channel-sliced pass reduces the rows it is handed while (other workgroups of the same launch) write the
+  // rows of its own output, so those go to whichever buffer it does not read
+  float* part2() const { return reinterpret_cast<float*>(ws + n->ws_part2); }
+  float* part_other(const float* in) const { return in == part2() ? part() : part2(); }
   float* slab(int which = 0) const { return reinterpret_cast<float*>(ws + n->ws_slab) + (size_t)which * n->slab_floats; }
   float* coef() const { return reinterpret_cast<float*>(ws + n->ws_small); }
   float* ftmp() const { return coef() + 3 * 512; }
@@ -366,9 +371,10 @@ static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const 
   FEDFR_TRY(ew_reduce_slabs(c.grads + cva.w_off, c.slab(0), splits, (size_t)a.NI * a.NJ, nullptr, 0, st));
   return ew_reduce_slabs(c.grads + cvb.w_off, c.slab(1), splits, (size_t)b.NI * b.NJ, nullptr, 0, st);
 }
-static int bn_coeffs(const Ctx& c, const BnD& b, int P, double count, bool training) {
+struct Rows { const float* ptr; int P; };     // where a BatchNorm's partial statistics rows are
+static int bn_coeffs(const Ctx& c, const BnD& b, Rows r, double count, bool training) {
   if (training)
-    return ew_bn_finalize(c.part(), P, b.C, count, c.gamma(b), c.beta(b), c.bufs + b.rm_off, c.bufs + b.rv_off, kBnMomentum,
+    return ew_bn_finalize(r.ptr, r.P, b.C, count, c.gamma(b), c.beta(b), c.bufs + b.rm_off, c.bufs + b.rv_off, kBnMomentum,
                           kBnEps, c.save(b, 0), c.save(b, 1), c.save(b, 2), c.save(b, 3), c.ftmp(), c.st);
   return FEDFR_OK;      // eval mode: every BatchNorm's (scale, shift) was computed up front by eval_coeffs_all (one launch)
 }
@@ -406,6 +412,26 @@ static int apply(const Ctx& c, const bf16_t* x1, const BnD& b1, const float* alp
   return ew_bn_apply(a, c.st);
 }
 
+// train-mode BatchNorm whose statistics are the partial rows `r`, applied: y = prelu?(bn(x1)) (+ x2).  One channel-sliced launch that reduces
+// the rows itself where the shape allows (bn_sliced.hip), else finalize + the row-slab pass.  *out (optional) = where the statistics of y are.
+static int bn_apply_train(const Ctx& c, const BnD& b, Rows r, const bf16_t* x1, const float* alpha, const bf16_t* x2, bf16_t* y, int M,
+                          Rows* out) {
+  if (ew_bn_sliced_ok(M, b.C, r.P, false)) {
+    BnApplyS a{};
+    a.part = r.ptr; a.P = r.P; a.count = (double)M; a.gamma = c.gamma(b); a.beta = c.beta(b);
+    a.rm = c.bufs + b.rm_off; a.rv = c.bufs + b.rv_off; a.momentum = kBnMomentum; a.eps = kBnEps;
+    a.scale = c.save(b, 0); a.shift = c.save(b, 1); a.mean = c.save(b, 2); a.rstd = c.save(b, 3);
+    a.x1 = x1; a.alpha = alpha; a.x2 = x2; a.y = y; a.M = M; a.C = b.C;
+    a.stats = out ? c.part_other(r.ptr) : nullptr;
+    if (out) *out = Rows{a.stats, ew_bn_sliced_rows(M, b.C)};
+    return ew_bn_apply_sliced(a, c.st);
+  }
+  FEDFR_TRY(bn_coeffs(c, b, r, (double)M, true));
+  FEDFR_TRY(apply(c, x1, b, alpha, x2, nullptr, y, M, out != nullptr));
+  if (out) *out = Rows{c.part(), ew_bn_apply_grid(M, b.C)};
+  return FEDFR_OK;
+}
+
 int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st) {
   FEDFR_REQUIRE(n && params && shadow, "prepare_weights: null");
   if (fwd_shadow_too) FEDFR_TRY(ew_cast_f32_bf16(params, shadow, (size_t)n->trainable_count, st));
@@ -439,7 +465,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   const int M0 = B * HW * HW;
   bf16_t* A = c.actb;
   if (!tr) FEDFR_TRY(eval_coeffs_all(c));
-  int Pprev;
+  Rows prev{c.part(), 0};                  // statistics of the tensor the next BatchNorm normalises
   if (n->block_only) {
     // lone block: x (fp32 NCHW) -> NHWC bf16 block input; an identity "apply" pass leaves the column statistics bn1 needs, exactly
     // where the previous block's output pass leaves them inside a network
@@ -448,13 +474,13 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     BnApply a{};
     a.x1 = c.g(0); a.y = A + k0.x_off; a.M = M0; a.C = k0.Cin; a.stats = tr ? c.part() : nullptr;
     FEDFR_TRY(ew_bn_apply(a, st));
-    Pprev = ew_bn_apply_grid(M0, k0.Cin);
+    prev.P = ew_bn_apply_grid(M0, k0.Cin);
   } else {
     // stem: conv -> BN -> PReLU   (iresnet.py:160-162)
     FEDFR_TRY(ew_stem_fwd(x, params + n->stem.w_off, A + n->c0_off, tr ? c.part() : nullptr, B, HW, HW, st));
-    FEDFR_TRY(bn_coeffs(c, n->stem_bn, ew_stem_stat_rows(B, HW, HW), (double)M0, tr));
+    FEDFR_TRY(bn_coeffs(c, n->stem_bn, Rows{c.part(), ew_stem_stat_rows(B, HW, HW)}, (double)M0, tr));
     FEDFR_TRY(apply(c, A + n->c0_off, n->stem_bn, params + n->stem_alpha_off, nullptr, nullptr, A + n->a0_off, M0, tr));
-    Pprev = ew_bn_apply_grid(M0, 64);
+    prev.P = ew_bn_apply_grid(M0, 64);
   }
   bool a1_ready = false;                    // eval: the previous block's conv2 epilogue already wrote this block's bn1(x)
   for (size_t bi = 0; bi < n->blocks.size(); ++bi) {
@@ -485,30 +511,54 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
         if (k.has_ds) FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.d_off, &k.bnds, A + k.out_off, Mo, false));
         else FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.x_off, nullptr, A + k.out_off, Mo, false));
       }
-      Pprev = ew_bn_apply_grid(Mo, k.Cout);
       continue;
     }
-    // bn1(x)
-    FEDFR_TRY(bn_coeffs(c, k.bn1, Pprev, (double)Mi, tr));
-    // a1 = bn1(x) -> conv1 -> bn2 -> a2 = prelu(bn2(c1)) -> conv2(stride) -> bn3
-    FEDFR_TRY(conv_fwd_bn(c, k.conv1, A + k.x_off, k.bn1, nullptr, A + k.a1_off, A + k.c1_off, tr));
-    FEDFR_TRY(bn_coeffs(c, k.bn2, gemm_nt_stat_rows(Mi, k.Cout), (double)Mi, tr));
-    FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, tr));
-    FEDFR_TRY(bn_coeffs(c, k.bn3, gemm_nt_stat_rows(Mo, k.Cout), (double)Mo, tr));
-    if (k.has_ds) {
-      FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, tr));
-      FEDFR_TRY(bn_coeffs(c, k.bnds, gemm_nt_stat_rows(Mo, k.Cout), (double)Mo, tr));
-      FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.d_off, &k.bnds, A + k.out_off, Mo, tr));
-    } else {
-      FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.x_off, nullptr, A + k.out_off, Mo, tr));
+    if (!tr) {                                // eval mode without the fused epilogues: known affines, plain passes
+      FEDFR_TRY(conv_fwd_bn(c, k.conv1, A + k.x_off, k.bn1, nullptr, A + k.a1_off, A + k.c1_off, false));
+      FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, false));
+      if (k.has_ds) {
+        FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, false));
+        FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.d_off, &k.bnds, A + k.out_off, Mo, false));
+      } else {
+        FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.x_off, nullptr, A + k.out_off, Mo, false));
+      }
+      continue;
     }
-    Pprev = ew_bn_apply_grid(Mo, k.Cout);
+    // a1 = bn1(x) -> conv1 -> a2 = prelu(bn2(c1)) -> conv2(stride) -> bn3(c2) + identity.  Statistics: the pass that produced x left
+    // them in `prev`; a conv's epilogue leaves its output's in c.part()
+    const bool xf1 = g_fuse_bnapply && gemm_nt_conv_xform_ok(k.conv1.Hin, k.conv1.Cin, k.conv1.Cout, Mi, k.conv1.R, k.conv1.stride);
+    const bool xf2 = g_fuse_bnapply && gemm_nt_conv_xform_ok(k.conv2.Hin, k.conv2.Cin, k.conv2.Cout, Mo, k.conv2.R, k.conv2.stride);
+    if (xf1) {
+      FEDFR_TRY(bn_coeffs(c, k.bn1, prev, (double)Mi, true));
+      FEDFR_TRY(conv_fwd_bn(c, k.conv1, A + k.x_off, k.bn1, nullptr, A + k.a1_off, A + k.c1_off, true));
+    } else {
+      FEDFR_TRY(bn_apply_train(c, k.bn1, prev, A + k.x_off, nullptr, nullptr, A + k.a1_off, Mi, nullptr));
+      FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, true));
+    }
+    const Rows r1{c.part(), gemm_nt_stat_rows_live(Mi, k.Cout, k.conv1.Cin, k.conv1.Hin, k.conv1.R, k.conv1.stride)};
+    if (xf2) {
+      FEDFR_TRY(bn_coeffs(c, k.bn2, r1, (double)Mi, true));
+      FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, true));
+    } else {
+      FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
+      FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, true));
+    }
+    const Rows r2{c.part(), gemm_nt_stat_rows_live(Mo, k.Cout, k.conv2.Cin, k.conv2.Hin, k.conv2.R, k.conv2.stride)};
+    if (k.has_ds) {
+      FEDFR_TRY(bn_coeffs(c, k.bn3, r2, (double)Mo, true));
+      FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, true));
+      FEDFR_TRY(bn_coeffs(c, k.bnds, Rows{c.part(), gemm_nt_stat_rows(Mo, k.Cout)}, (double)Mo, true));
+      FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.d_off, &k.bnds, A + k.out_off, Mo, true));
+      prev = Rows{c.part(), ew_bn_apply_grid(Mo, k.Cout)};
+    } else {
+      FEDFR_TRY(bn_apply_train(c, k.bn3, r2, A + k.c2_off, nullptr, A + k.x_off, A + k.out_off, Mo, &prev));
+    }
   }
   if (n->block_only) return FEDFR_OK;
   // bn2 -> flatten (NCHW order) -> fc -> features   (iresnet.py:167-171)
   const BlockD& last = n->blocks.back();
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
-  FEDFR_TRY(bn_coeffs(c, n->bn2, Pprev, (double)Mf, tr));
+  FEDFR_TRY(bn_coeffs(c, n->bn2, prev, (double)Mf, tr));
   FEDFR_TRY(apply(c, A + last.out_off, n->bn2, nullptr, nullptr, nullptr, A + n->t_off, Mf, false, hw));
   if (tr && n->dropout_p > 0.f)            // nn.Dropout(p, inplace=True) on the flattened bn2 output (iresnet.py:169); identity in eval mode
     FEDFR_TRY(ew_dropout_fwd(A + n->t_off, act + n->mask_off_bytes, (size_t)B * n->fc_in, n->dropout_p, n->dropout_seed, n->dropout_step++, st));
@@ -544,22 +594,45 @@ static int dbg_capture(const bf16_t* src, size_t elems, size_t* off, hipStream_t
 }
 int g_wgrad_depth = kWgradDepth;   // option "wgrad_depth" (2..kWgradDepth): generations of weight-gradient operands in flight
 int g_fuse_bnred_next = 1;   // option "fuse_bnred_next": a BN-backward apply pass also reduces its output for the BN that consumes it
+// BatchNorm (+PReLU) backward: dx = a dz + A x + B (+ addend).  `have`: partial rows that already exist (left by the pass that produced
+// dy); else a reduce pass runs first.  With next_bn, dx is also reduced as the dy of that BatchNorm's backward -> *next_rows.
+// Channel-sliced passes without a finalize launch where the shape allows (bn_sliced.hip), else reduce / finalize / apply of ew.hip.
 static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
-                  const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, int fused_rows = 0, const BnD* next_bn = nullptr,
-                  const bf16_t* next_x = nullptr, int* next_rows = nullptr) {
+                  const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, Rows have = Rows{nullptr, 0}, const BnD* next_bn = nullptr,
+                  const bf16_t* next_x = nullptr, Rows* next_rows = nullptr) {
+  const bool nxt = next_bn && next_x && next_rows && g_fuse_bnred_next && next_bn->C == b.C;
+  if (!add_up && ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C), true)) {
+    BnBwdS p{};
+    p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.alpha = alpha;
+    p.sc = c.save(b, 0); p.sh = c.save(b, 1); p.M = M; p.C = b.C; p.count = (double)M;
+    if (have.P > 0) {
+      p.part_in = have.ptr; p.P = have.P;
+    } else {
+      p.partials = c.part();
+      FEDFR_TRY(ew_bn_bwd_reduce_sliced(p, c.st));
+      p.part_in = c.part(); p.P = ew_bn_sliced_rows(M, b.C);
+    }
+    p.dgamma = c.grads + b.g_off; p.dbeta = c.grads + b.b_off; p.dalpha = alpha ? c.grads + alpha_off : nullptr;
+    p.add = add; p.dx = dx;
+    if (nxt) {
+      p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part_other(p.part_in);
+      *next_rows = Rows{p.npart, ew_bn_sliced_rows(M, b.C)};
+    }
+    return ew_bn_bwd_apply_sliced(p, c.st);
+  }
   BnBwd p{};
-  if (next_bn && next_x && next_rows && g_fuse_bnred_next && next_bn->C == b.C) {
+  if (nxt) {
     // dx is the dy of next_bn's backward: its (sum, sum * xhat) partials ride along in this apply pass (one tensor read instead of
     // a separate two-tensor reduce kernel); they land in the shared partial buffer, which this BN's finalize has finished reading
     p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part();
-    *next_rows = ew_bn_bwd_apply_grid(M, b.C);
+    *next_rows = Rows{c.part(), ew_bn_bwd_apply_grid(M, b.C)};
   }
   p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.beta = c.beta(b); p.alpha = alpha;
   p.sc = c.save(b, 0); p.sh = c.save(b, 1);
   p.M = M; p.C = b.C; p.partials = c.part(); p.coef = c.coef(); p.add = add; p.add_up = add_up; p.H = H; p.W = H; p.dx = dx;
-  if (fused_rows <= 0) FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));      // else: the producing dgrad kernel already wrote the partials
-  FEDFR_TRY(ew_bn_bwd_finalize(c.part(), fused_rows > 0 ? fused_rows : ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 2), c.save(b, 3), c.grads + b.g_off,
-                               c.grads + b.b_off, alpha ? c.grads + alpha_off : nullptr, c.coef(), c.st));
+  if (have.P <= 0) FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));      // else: the producing pass already wrote the partials
+  FEDFR_TRY(ew_bn_bwd_finalize(have.P > 0 ? have.ptr : c.part(), have.P > 0 ? have.P : ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 2),
+                               c.save(b, 3), c.grads + b.g_off, c.grads + b.b_off, alpha ? c.grads + alpha_off : nullptr, c.coef(), c.st));
   return ew_bn_bwd_apply(p, c.st);
 }
 
@@ -605,7 +678,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   Fork fk{n, st, aux};
   const hipStream_t wst = aux ? aux : st;          // stream of the weight-gradient GEMMs
   fk.order(st, wst);                                // aux starts after everything already queued on main (forward pass)
-  int pend_rows = 0;                               // partial rows of the next bn3 already reduced by the apply pass that produced its dy
+  Rows pend{nullptr, 0};                           // partial rows of the next bn3 already reduced by the apply pass that produced its dy
   if (n->block_only) {
     const BlockD& k0 = n->blocks.front();
     FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dfeats, c.g(1), B, k0.Cout, k0.Hout * k0.Hout, st));      // dy of the block, fp32 NCHW like the reference's
@@ -634,7 +707,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
   if (n->dropout_p > 0.f) FEDFR_TRY(ew_dropout_bwd(dxfc, act + n->mask_off_bytes, (size_t)B * n->fc_in, n->dropout_p, st));
   FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dxfc, c.g(0), B, n->final_C, hw, st));
-  FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0, 0, &last.bn3, A + last.c2_off, &pend_rows));
+  FEDFR_TRY(bn_bwd(c, n->bn2, nullptr, c.g(0), A + last.out_off, Mf, nullptr, nullptr, 0, c.g(1), 0, Rows{nullptr, 0}, &last.bn3, A + last.c2_off, &pend));
   }
   int cur = 1;
   size_t dbg_off = 0;
@@ -649,12 +722,12 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     bf16_t *dc2 = c.tw(0, par), *da2 = c.t(1), *dc1 = c.tw(1, par), *da1 = c.t(3), *dd = c.tw(2, par), *dxd = c.t(5);
     fk.wait(st, wdone[par]);                         // the weight GEMMs kWgradDepth blocks ago were the last readers of dc2/dc1/dd[par]
     // out = bn3(c2) + identity
-    FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0, pend_rows));
-    pend_rows = 0;
+    FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0, pend));
+    pend = Rows{nullptr, 0};
     int f2 = 0, f1 = 0;
     FEDFR_TRY(conv_dgrad(c, k.conv2, dc2, da2, &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
     // a2 = prelu(bn2(c1))
-    FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, da2, A + k.c1_off, Mi, nullptr, nullptr, 0, dc1, k.alpha_off, f2));
+    FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, da2, A + k.c1_off, Mi, nullptr, nullptr, 0, dc1, k.alpha_off, Rows{c.part(), f2}));
     // identity path first (its BN reduction uses the shared partial buffer), then conv1's dgrad whose epilogue may
     // leave bn1's partial sums there for the bn_bwd that follows immediately
     if (k.has_ds) {
@@ -673,11 +746,11 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     // a1 = bn1(x)
     const BlockD* prev = bi > 0 ? &n->blocks[bi - 1] : nullptr;      // its bn3 consumes gin next
     if (k.has_ds) {
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, nullptr, dxd, k.Hin, gin, 0, f1, prev ? &prev->bn3 : nullptr,
-                       prev ? A + prev->c2_off : nullptr, &pend_rows));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, nullptr, dxd, k.Hin, gin, 0, Rows{c.part(), f1}, prev ? &prev->bn3 : nullptr,
+                       prev ? A + prev->c2_off : nullptr, &pend));
     } else {
-      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, g, nullptr, 0, gin, 0, f1, prev ? &prev->bn3 : nullptr,
-                       prev ? A + prev->c2_off : nullptr, &pend_rows));
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, g, nullptr, 0, gin, 0, Rows{c.part(), f1}, prev ? &prev->bn3 : nullptr,
+                       prev ? A + prev->c2_off : nullptr, &pend));
     }
     cur ^= 1;
   }

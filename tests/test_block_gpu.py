@@ -185,6 +185,11 @@ def test_backward_layerwise_vs_bf16_oracle(arch, batch):
     vals = np.array([e for _, e in errs])
     print("layerwise bwd %s: worst %.2e (%s) cancelling sums %.2e (%s) median %.2e p90 %.2e" %
           (arch, worst[1], worst[0], worst_sum[1], worst_sum[0], np.median(vals), np.percentile(vals, 90)))
-    assert worst[1] < 5.5e-3, worst                     # measured 2.3e-3 / 2.7e-3 / 4.3e-3 (iresnet18 / 50 / 100)
+    print("   top: " + ", ".join("%s %.2e" % e for e in sorted(rest, key=lambda e: -e[1])[:6]))
+    # measured 2.4e-3 / 5.7e-3 / 3.7e-3 (iresnet18 / 50 / 100; 2.3e-3 / 2.7e-3 / 4.3e-3 with option bn_sliced=0).  The outliers come in pairs
+    # (bn1.weight, conv1.weight) of ONE block: both read the gradient behind that block's PReLU, where a bf16 rounding that lands on the
+    # other side of the kink changes the derivative of an element by (1 - slope); which block draws the outlier moves with the last
+    # fp32 bits of the BatchNorm coefficients (summation order), its size does not
+    assert worst[1] < 7.2e-3, worst
     assert worst_sum[1] < 2.5e-2, worst_sum             # measured <= 1.9e-2
     assert np.median(vals) < 1.3e-3, np.median(vals)    # measured 0.5e-3 / 1.0e-3 / 0.9e-3

@@ -492,8 +492,23 @@ def test_bn_backward_next_reduction_fusion_equivalence():
             outs.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
         finally:
             _C.call("fedfr_set_option", b"fuse_bnred_next", 1)
-    worst = max(rel(outs[1][k], outs[0][k]) for k in outs[0] if float(outs[0][k].norm()) > 1e-6 * max(float(v.norm()) for v in outs[0].values()))
-    assert worst < 2e-2, worst       # bf16 activations downstream of a differently-ordered fp32 sum: last-bit flips propagate
+    # biases in front of a BatchNorm (bn3 / downsample BN feed the next bn1 through the residual sum) have an analytically zero gradient:
+    # what is computed is the rounding noise of a cancelling column sum, different for every summation order -> those are held to an
+    # ABSOLUTE bar (a fraction of the same layer's weight gradient), everything else to a relative one
+    def zero_mean_bias(k):
+        return k.endswith(("bn3.bias", "downsample.1.bias"))
+    errs = {k: rel(outs[1][k], outs[0][k]) for k in outs[0] if not zero_mean_bias(k) and float(outs[0][k].norm()) > 0}
+    # bn1.bias / bn2.bias: a conv and a BatchNorm follow, only the zero-padded border keeps the sum from cancelling (tests/test_block_gpu.py)
+    sums = {k: e for k, e in errs.items() if k.endswith(("bn1.bias", "bn2.bias"))}
+    rest = {k: e for k, e in errs.items() if k not in sums}
+    print("fuse_bnred_next on vs off: worst %.2e (%s); border sums %.2e (%s)" % (max(rest.values()), max(rest, key=rest.get), max(sums.values()),
+                                                                                 max(sums, key=sums.get)))
+    assert max(rest.values()) < 2e-2, max(rest, key=rest.get)       # bf16 activations downstream of a differently-ordered fp32 sum: last-bit flips propagate
+    assert max(sums.values()) < 6e-2, max(sums, key=sums.get)
+    for k in outs[0]:
+        if zero_mean_bias(k):
+            wn = float(outs[0][k[:-4] + "weight"].norm())
+            assert float((outs[1][k] - outs[0][k]).norm()) < 2e-2 * wn, (k, float(outs[0][k].norm()), wn)
 
 
 def test_public_data_server_round():

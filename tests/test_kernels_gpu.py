@@ -370,6 +370,125 @@ def test_bn_backward(M, C, prelu, addmode):
         torch.testing.assert_close(da.cpu(), aa.grad, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("M,C,prelu,second,rows_in", [(25088, 256, False, 1, 256), (6272, 512, True, 0, 98), (3001, 64, True, 1, 7),
+                                                      (100352, 128, False, 0, 64), (1000, 256, False, 1, 1), (784, 256, True, 1, 8)])
+def test_bn_apply_sliced(M, C, prelu, second, rows_in):
+    """channel-sliced apply pass that reduces the partial rows itself vs F.batch_norm (+PReLU, + identity) on the same bf16 tensor; the
+    statistics of its OUTPUT (rows for the next BatchNorm) vs the output's column sums; ragged M and a single partial row included."""
+    assert _C.lib().fedfr_bn_sliced_ok(M, C, rows_in, 0) == 1
+    x = bf(rnd((M, C), 1) * 2 + 0.3)
+    gamma, beta = rnd((C,), 2) * 0.2 + 1, rnd((C,), 3) * 0.1
+    rm, rv = rnd((C,), 4) * 0.1, rnd((C,), 5) * 0.1 + 1
+    alpha = rnd((C,), 6) * 0.1 + 0.25
+    x2 = bf(rnd((M, C), 7))
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(x.float(), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    if prelu:
+        ref = F.prelu(ref, alpha)
+    if second:
+        ref = ref + x2.float()
+    d = dev()
+    # partial rows as a producer would leave them: rows_in slabs of the pixels, (sum, sumsq) per channel
+    xf = x.float()
+    bounds = np.linspace(0, M, rows_in + 1).astype(int)
+    part = torch.stack([torch.stack([xf[a:b].sum(0), (xf[a:b] ** 2).sum(0)]) for a, b in zip(bounds[:-1], bounds[1:])]).to(d)
+    xd, g_, b_, rm_, rv_ = x.to(d), gamma.to(d), beta.to(d), rm.to(d), rv.to(d)
+    scale, shift, mean, rstd = (torch.full((C,), float("nan"), device=d) for _ in range(4))
+    rows = _C.lib().fedfr_bn_sliced_rows(M, C)
+    stats = torch.full((rows, 2, C), float("nan"), device=d)
+    y = torch.empty_like(xd)
+    al = alpha.to(d) if prelu else None
+    x2d = x2.to(d) if second else None
+    _C.call("fedfr_bn_apply_sliced", part.data_ptr(), rows_in, float(M), g_.data_ptr(), b_.data_ptr(), rm_.data_ptr(), rv_.data_ptr(), 0.1, 1e-5,
+            scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), xd.data_ptr(), _C.ptr(al), _C.ptr(x2d), y.data_ptr(), M, C,
+            stats.data_ptr(), _C.stream())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(mean.cpu(), xf.mean(0), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rstd.cpu(), 1 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(scale.cpu(), gamma * rstd.cpu(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(shift.cpu(), beta - mean.cpu() * gamma * rstd.cpu(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm_.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv_.cpu(), rv_ref, rtol=1e-4, atol=1e-5)
+    assert relerr(y.float(), ref) < 6e-3
+    yf = y.float().cpu()
+    torch.testing.assert_close(stats[:, 0].sum(0).cpu(), yf.sum(0), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(stats[:, 1].sum(0).cpu(), (yf ** 2).sum(0), rtol=1e-4, atol=2e-2)
+    # an error, not a wrong answer, for the shapes the sliced passes do not serve
+    assert _C.lib().fedfr_bn_sliced_ok(128 * 112 * 112, 64, 64, 0) == 0 and _C.lib().fedfr_bn_sliced_ok(M, C, 4096, 0) == 0
+    with pytest.raises(RuntimeError):
+        _C.call("fedfr_bn_apply_sliced", part.data_ptr(), 4096, float(M), g_.data_ptr(), b_.data_ptr(), None, None, 0.1, 1e-5, scale.data_ptr(),
+                shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), xd.data_ptr(), None, None, y.data_ptr(), M, C, None, _C.stream())
+
+
+@pytest.mark.parametrize("M,C,prelu,with_add,with_next", [(25088, 256, True, False, False), (25088, 256, False, True, True),
+                                                          (6272, 512, False, False, True), (3001, 64, True, True, True),
+                                                          (100352, 128, False, True, False), (784, 256, False, True, True),
+                                                          (784, 256, True, False, False), (1176, 512, False, True, True), (12544, 256, False, True, False),
+                                                          (50176, 128, False, True, False), (3136, 512, False, True, False),
+                                                          (12544, 256, False, False, False)])
+def test_bn_bwd_sliced(M, C, prelu, with_add, with_next):
+    """channel-sliced BatchNorm(+PReLU) backward (reduce pass + apply pass that reduces the rows itself) vs autograd; the rows it leaves for
+    the NEXT BatchNorm backward (sum dx, sum dx * xhat_next) vs the same sums of its bf16 output; and vs the row-slab path (fedfr_bn_bwd)."""
+    x = bf(rnd((M, C), 1) * 2 + 0.3)
+    dy = bf(rnd((M, C), 2))
+    gamma, beta = rnd((C,), 3) * 0.2 + 1, rnd((C,), 4) * 0.1
+    alpha = rnd((C,), 5) * 0.1 + 0.25
+    xg = x.float().requires_grad_(True)
+    gg, bb, aa = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    out = F.batch_norm(xg, None, None, gg, bb, True, 0.1, 1e-5)
+    if prelu:
+        out = F.prelu(out, aa)
+    out.backward(dy.float())
+    ref = xg.grad.clone()
+    add = bf(rnd((M, C), 6)) if with_add else None
+    if with_add:
+        ref = ref + add.float()
+    d = dev()
+    mean = x.float().mean(0)
+    rstd = 1.0 / torch.sqrt(x.float().var(0, unbiased=False) + 1e-5)
+    sc, sh = gamma * rstd, beta - mean * gamma * rstd
+    nx = bf(rnd((M, C), 8) * 1.5 - 0.2) if with_next else None
+    nmean = nx.float().mean(0) if with_next else None
+    nrstd = 1.0 / torch.sqrt(nx.float().var(0, unbiased=False) + 1e-5) if with_next else None
+    rows = _C.lib().fedfr_bn_sliced_rows(M, C)
+    part = torch.full((rows, 3, C), float("nan"), device=d)
+    npart = torch.full((rows, 3, C), float("nan"), device=d)
+    dg, db, da = (torch.full((C,), float("nan"), device=d) for _ in range(3))
+    dx = torch.empty(M, C, dtype=torch.bfloat16, device=d)
+    t = lambda v: None if v is None else v.to(d)   # noqa: E731
+    k = dict(dy=t(dy), x=t(x), mean=t(mean), rstd=t(rstd), gamma=t(gamma), alpha=t(alpha) if prelu else None, sc=t(sc), sh=t(sh), add=t(add),
+             nx=t(nx), nmean=t(nmean), nrstd=t(nrstd))
+    _C.call("fedfr_bn_bwd_sliced", k["dy"].data_ptr(), k["x"].data_ptr(), k["mean"].data_ptr(), k["rstd"].data_ptr(), k["gamma"].data_ptr(),
+            _C.ptr(k["alpha"]), k["sc"].data_ptr(), k["sh"].data_ptr(), M, C, part.data_ptr(), 0, dg.data_ptr(), db.data_ptr(),
+            da.data_ptr() if prelu else None, _C.ptr(k["add"]), dx.data_ptr(), _C.ptr(k["nx"]), _C.ptr(k["nmean"]), _C.ptr(k["nrstd"]),
+            npart.data_ptr() if with_next else None, _C.stream())
+    torch.cuda.synchronize()
+    assert relerr(dx.float(), ref) < 8e-3
+    torch.testing.assert_close(dg.cpu(), gg.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(db.cpu(), bb.grad, rtol=2e-3, atol=2e-3)
+    if prelu:
+        torch.testing.assert_close(da.cpu(), aa.grad, rtol=2e-3, atol=2e-3)
+    if with_next:
+        dxf = dx.float().cpu()
+        torch.testing.assert_close(npart[:, 0].sum(0).cpu(), dxf.sum(0), rtol=1e-3, atol=2e-2)
+        torch.testing.assert_close(npart[:, 1].sum(0).cpu(), (dxf * (nx.float() - nmean) * nrstd).sum(0), rtol=1e-3, atol=5e-2)
+        assert float(npart[:, 2].abs().max()) == 0.0
+    # same numbers as the row-slab kernels (reduce / finalize / apply), up to the summation order
+    rows_o = _C.lib().fedfr_bn_bwd_rows(M, C)
+    part_o = torch.empty(rows_o, 3, C, device=d)
+    coef = torch.empty(3, C, device=d)
+    dg2, db2, da2 = (torch.empty(C, device=d) for _ in range(3))
+    dx2 = torch.empty_like(dx)
+    beta_d = t(beta)
+    _C.call("fedfr_bn_bwd", k["dy"].data_ptr(), k["x"].data_ptr(), k["mean"].data_ptr(), k["rstd"].data_ptr(), k["gamma"].data_ptr(),
+            beta_d.data_ptr(), _C.ptr(k["alpha"]), M, C, part_o.data_ptr(), coef.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
+            da2.data_ptr() if prelu else None, _C.ptr(k["add"]), None, 0, dx2.data_ptr(), _C.stream())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dg.cpu(), dg2.cpu(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), db2.cpu(), rtol=1e-4, atol=1e-3)
+    assert relerr(dx.float(), dx2.float()) < 4e-3      # bf16 outputs of coefficients that differ in the last fp32 bits
+
+
 @pytest.mark.parametrize("M,N,K,ta,tb", [(128, 1000, 512, False, True), (128, 512, 1000, False, False), (1000, 512, 128, True, False),
                                         (7, 33, 19, False, True), (65, 130, 40, True, False)])
 def test_sgemm(M, N, K, ta, tb):

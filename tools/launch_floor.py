@@ -60,6 +60,20 @@ def main():
         out[key] = {"finalize_us": timed(fin), "bn_apply_us": timed(app, 200, 20), "finalize_then_apply_us": timed(both, 200, 20),
                     "apply_GBps": None}
         out[key]["apply_GBps"] = round(2 * M * Cc * 2 / out[key]["bn_apply_us"] / 1e3, 1)
+        # the channel-sliced pass that reduces the P rows itself (one launch instead of the two above), with and without output statistics
+        for Pin in (P, 2 * P, 32):
+            if not _C.lib().fedfr_bn_sliced_ok(M, Cc, Pin, 0):
+                continue
+            part_s = torch.randn(Pin, 2, Cc, device=dev).abs()
+            srows = _C.lib().fedfr_bn_sliced_rows(M, Cc)
+            sstats = torch.empty(srows, 2, Cc, device=dev)
+
+            def sliced(with_stats):
+                _C.call("fedfr_bn_apply_sliced", part_s.data_ptr(), Pin, float(M), g.data_ptr(), b.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                        0.1, 1e-5, sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), xa.data_ptr(), None, None, ya.data_ptr(),
+                        M, Cc, sstats.data_ptr() if with_stats else None, st)
+            out[key]["sliced_P%d_us" % Pin] = timed(lambda: sliced(False), 200, 20)
+            out[key]["sliced_P%d_stats_us" % Pin] = timed(lambda: sliced(True), 200, 20)
     print(json.dumps(out))
 
 

@@ -381,6 +381,7 @@ def main():
             with torch.cuda.stream(st2):
                 tr2 = client.FusedTrainer(model2, fc2, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4, aux_slot=1)
             pairs = [(tr, torch.cuda.current_stream()), (tr2, st2)]
+            _C.call("fedfr_set_option", b"wgrad9p", 1)          # what Server.train selects when clients share the GPU (csrc/wgrad9p.hip)
             csteps = max(5, min(args.steps, 20))
             bar = threading.Barrier(3)
 
@@ -417,11 +418,14 @@ def main():
             concurrent = {"clients_on_this_gpu": 2, "value": round(2 * B * csteps / dtc, 1), "unit": "images/sec",
                           "ms_per_step_per_client": round(dtc * 1e3 / csteps, 3), "steps": csteps,
                           "note": "two independent clients (own backbone, optimiser, HIP stream pair), each running the same bs=%d train step; "
-                                  "aggregate over both.  `value` above is ONE client alone" % B}
+                                  "aggregate over both (paired weight-gradient kernel on, as Server.train selects for concurrent clients).  "
+                                  "`value` above is ONE client alone" % B}
             del tr2, model2
         except Exception as e:      # an auxiliary leg must never cost the headline number
             leg_errors['concurrent'] = "%s: %s" % (type(e).__name__, e)
             print("bench.py: the concurrent leg failed: %r" % (e,), file=sys.stderr, flush=True)
+        finally:
+            _C.call("fedfr_set_option", b"wgrad9p", 0)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only

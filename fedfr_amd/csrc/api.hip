@@ -23,6 +23,7 @@ extern int g_tn_pair;
 extern int g_wgrad9;
 extern int g_conv_c64p;
 extern int g_bn_sliced, g_bn_sliced_pre;
+extern int g_wgrad9p;
 extern int g_eval_fuse;
 extern int g_wgrad_depth;
 extern int g_dgrad_parity;
@@ -114,6 +115,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "bn_sliced")) {
     g_bn_sliced = value ? 1 : 0;   // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad9p")) {
+    g_wgrad9p = value ? 1 : 0;     // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "bn_sliced_pre")) {
@@ -331,6 +336,18 @@ int fedfr_conv2d_wgrad_pair(const uint16_t* xa, const uint16_t* dya, float* dwa,
   const size_t one = (size_t)splits * p.NI * p.NJ * sizeof(float);
   GemmTN a = p, b = p;
   a.P = BF(dya); a.Q = BF(xa); b.P = BF(dyb); b.Q = BF(xb);
+  if (gemm_tn_w9pair_ok(a, b)) {                            // 3x3 / stride-1 layers the paired nine-tap kernel takes (wgrad9p.hip)
+    const int sp = gemm_tn_w9pair_splits(a);
+    const size_t each = (size_t)sp * p.NI * p.NJ * sizeof(float);
+    if (!ws || ws_bytes < 2 * each) {
+      fedfr_set_error("conv2d_wgrad_pair: workspace too small (%zu bytes, need %zu)", ws_bytes, 2 * each);
+      return FEDFR_ERR_WORKSPACE;
+    }
+    a.out = (float*)ws; b.out = (float*)((char*)ws + each);
+    FEDFR_TRY(gemm_tn_launch_w9pair(a, b, sp, ST(stream)));
+    FEDFR_TRY(ew_reduce_slabs(dwa, a.out, sp, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream)));
+    return ew_reduce_slabs(dwb, b.out, sp, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream));
+  }
   if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {      // shapes the paired kernel does not take: two ordinary launches
     FEDFR_TRY(fedfr_conv2d_wgrad(xa, dya, dwa, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream));
     return fedfr_conv2d_wgrad(xb, dyb, dwb, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream);

@@ -19,6 +19,9 @@
 #include "ew.h"
 #include "gemm_dev.h"   // ProfScope
 
+#ifndef BNS_PRIO
+#define BNS_PRIO 3   // wave priority of the backward passes: they share CUs with the weight-gradient kernels of the aux stream
+#endif
 namespace {
 constexpr int SW = 32;          // channels per slice
 constexpr int NTH = 256;
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(NTH) void bn_apply_s_kernel(BnApplyS p) {
 // =====================================================================================================
 template <bool ALPHA, int U>
 __global__ __launch_bounds__(NTH) void bn_bwd_reduce_s_kernel(BnBwdS p) {
+  __builtin_amdgcn_s_setprio(BNS_PRIO);
   __shared__ float sred[4 * 96];
   const int tid = threadIdx.x;
   const int NS = p.C >> 5;
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(NTH) void bn_bwd_reduce_s_kernel(BnBwdS p) {
 // trade a microsecond alone for co-residency.
 template <bool ALPHA, bool NX, bool ADD, int NPRE, int U>
 __global__ __launch_bounds__(NTH) void bn_bwd_apply_s_kernel(BnBwdS p) {
+  __builtin_amdgcn_s_setprio(BNS_PRIO);
   constexpr int NV = ALPHA ? 3 : 2, FL = ALPHA ? kBwdFL3 : kBwdFL2;
   __shared__ double red[FanIn<NV>::red_doubles];
   __shared__ double tot[NV * 32];

@@ -79,6 +79,10 @@ int gemm_tn_launch(GemmTN p, int splits, hipStream_t st);
 // two same-shape conv weight-gradient problems in one launch (LDS-DMA kernel, two blocks per CU); check gemm_tn_pair_ok first
 bool gemm_tn_pair_ok(const GemmTN& a, const GemmTN& b, int splits);
 int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
+// the two same-shape 3x3 / stride-1 weight gradients of a residual block on the paired nine-tap kernel (wgrad9p.hip)
+bool gemm_tn_w9pair_ok(const GemmTN& a, const GemmTN& b);
+int gemm_tn_w9pair_splits(const GemmTN& a);
+int gemm_tn_launch_w9pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
 // Wo > 0: conv weight gradient on a Wo x Wo output map (lets the nine-tap kernel, wgrad9.hip, be chosen)
 int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C_or_0, int Wo = 0, int stride = 1);
 int gemm_tn_max_splits(int Kp, int NI, int NJ, int C_or_0, int Wo, int stride);

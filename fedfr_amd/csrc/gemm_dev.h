@@ -74,3 +74,8 @@ bool wgrad9_applies(const GemmTN& p);
 bool wgrad9_applies_shape(int Kp, int NI, int NJ, int C, int W, int stride);
 int wgrad9_pick_splits(int Kp, int NI, int NJ, int W);
 int launch_wgrad9(const GemmTN& p, int splits, hipStream_t st);
+// wgrad9p.hip: the two same-shape 3x3 / stride-1 weight gradients of a residual block in one launch, 64 x 64 x 9 taps per workgroup
+extern int g_wgrad9p;
+bool wgrad9p_applies(const GemmTN& a, const GemmTN& b);
+int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W);
+int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st);

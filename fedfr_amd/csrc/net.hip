@@ -359,6 +359,15 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
 static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const bf16_t* dya, const ConvD& cvb, const bf16_t* inb,
                        const bf16_t* dyb, hipStream_t st) {
   GemmTN a = wgrad_problem(c, cva, ina, dya), b = wgrad_problem(c, cvb, inb, dyb);
+  if (gemm_tn_w9pair_ok(a, b)) {                        // both on the 64 x 64 nine-tap kernel, one launch
+    const int sp = gemm_tn_w9pair_splits(a);
+    FEDFR_REQUIRE((size_t)sp * a.NI * a.NJ <= c.n->slab_floats, "conv_wgrad2: %d split-K slabs of %d x %d exceed the plan's slab workspace (%zu floats)",
+                  sp, a.NI, a.NJ, c.n->slab_floats);
+    a.out = c.slab(0); b.out = c.slab(1);
+    FEDFR_TRY(gemm_tn_launch_w9pair(a, b, sp, st));
+    FEDFR_TRY(ew_reduce_slabs(c.grads + cva.w_off, c.slab(0), sp, (size_t)a.NI * a.NJ, nullptr, 0, st));
+    return ew_reduce_slabs(c.grads + cvb.w_off, c.slab(1), sp, (size_t)b.NI * b.NJ, nullptr, 0, st);
+  }
   const int splits = gemm_tn_pick_splits(a.Kp, a.NI, a.NJ, a.C, a.Wo, a.stride);
   if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {
     FEDFR_TRY(conv_wgrad(c, cva, ina, dya, st));

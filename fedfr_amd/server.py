@@ -235,6 +235,10 @@ class Server(object):
             # this GPU, each on its own HIP stream pair and resident backbone (measured: 2 clients = +20 % images/s on iresnet100 at
             # B = 128; 3 regress).  Kernels are deterministic and clients share no state, so the round's result is identical.
             import threading
+            from . import _C
+            # with the GPU saturated by several kernel chains, total kernel time is what counts: the paired 64 x 64 weight-gradient kernel
+            # (csrc/wgrad9p.hip; off for a lone client, whose two streams interleave better with the shorter single-layer kernel)
+            _C.call("fedfr_set_option", b"wgrad9p", 1)
             main = torch.cuda.current_stream(self.device)
             streams = getattr(self, "_client_streams", None)
             if streams is None or len(streams) < par:
@@ -257,7 +261,9 @@ class Server(object):
                 for t in ts:
                     t.join()
                 if errs:
+                    _C.call("fedfr_set_option", b"wgrad9p", 0)
                     raise errs[0]
+            _C.call("fedfr_set_option", b"wgrad9p", 0)
         for i in order:
             losses_.append(self.clients[i].get_train_loss())
             models.append(self.clients[i].get_model())

@@ -219,6 +219,36 @@ def test_conv_wgrad_pair(B, H, C):
     assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
 
 
+@pytest.mark.parametrize("B,H,C", [(128, 14, 256), (16, 28, 128), (3, 56, 64), (1, 112, 64), (2, 14, 512), (5, 14, 128), (1, 14, 64)])
+def test_conv_wgrad9_pair(B, H, C):
+    """The paired 64 x 64 nine-tap kernel (wgrad9p.hip: the two 3x3 / stride-1 weight gradients of a residual block in one launch) ==
+    autograd of F.conv2d on the same bf16 operands, and == the single-layer nine-tap kernel (option wgrad9p off) up to fp32 summation
+    order; odd batch sizes (ragged last K-split) and every map width it serves."""
+    outs = []
+    for seed in (31, 47):
+        x = bf(rnd((B, C, H, H), seed)).float()
+        dy = bf(rnd((B, C, H, H), seed + 1)).float()
+        w = torch.zeros(C, C, 3, 3, requires_grad=True)
+        F.conv2d(x, w, None, 1, 1).backward(dy)
+        outs.append((bf(nhwc(x)).to(dev()), bf(nhwc(dy)).to(dev()), w.grad.permute(0, 2, 3, 1)))
+    nbytes = 2 * _C.lib().fedfr_conv2d_wgrad_ws_bytes(B, H, C, C, 3, 1)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev())
+    res = {}
+    for pair in (1, 0):
+        dwa = torch.full((C, 3, 3, C), float("nan"), device=dev())
+        dwb = torch.full((C, 3, 3, C), float("nan"), device=dev())
+        _C.call("fedfr_set_option", b"wgrad9p", pair)
+        try:
+            _C.call("fedfr_conv2d_wgrad_pair", outs[0][0].data_ptr(), outs[0][1].data_ptr(), dwa.data_ptr(), outs[1][0].data_ptr(),
+                    outs[1][1].data_ptr(), dwb.data_ptr(), ws.data_ptr(), nbytes, B, H, C, C, 3, 1, _C.stream())
+            torch.cuda.synchronize()
+        finally:
+            _C.call("fedfr_set_option", b"wgrad9p", 1)
+        assert relerr(dwa, outs[0][2]) < 2e-4 and relerr(dwb, outs[1][2]) < 2e-4, (pair, relerr(dwa, outs[0][2]), relerr(dwb, outs[1][2]))
+        res[pair] = (dwa.cpu(), dwb.cpu())
+    assert relerr(res[1][0], res[0][0]) < 1e-5 and relerr(res[1][1], res[0][1]) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 512, 25088), (32, 512, 1024), (4, 512, 25088), (200, 1000, 512), (128, 64, 192)])
 def test_gemm_nt_plain(M, N, K):
     a, b = bf(rnd((M, K), 1)), bf(rnd((N, K), 2, 0.05))

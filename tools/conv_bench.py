@@ -59,5 +59,10 @@ for name, H, Cin, Cout, k, s, cnt in SHAPES:
                                    ctypes.byref(rows), st)); res.append("fdgrad %7.1f us (rows %d)" % (t * 1e3, rows.value))
     if "wgrad" in which:
         t = timeit(lambda: _C.call("fedfr_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, B, H, Cin, Cout, k, s, st)); tot["wgrad"] += t * cnt; res.append("wgrad %7.1f us %6.0f TF" % (t * 1e3, flop / t / 1e9))
+    if "wpair" in which and k == 3 and s == 1 and Cin == Cout:      # the block's two same-shape weight gradients in one call (wgrad9p.hip when it applies)
+        x2 = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16); dy2 = torch.randn(B, Ho, Ho, Cout, device=dev).to(torch.bfloat16)
+        dw2 = torch.empty(Cout, k, k, Cin, device=dev); ws2 = torch.empty(max(2 * nb, 16), dtype=torch.uint8, device=dev)
+        t = timeit(lambda: _C.call("fedfr_conv2d_wgrad_pair", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x2.data_ptr(), dy2.data_ptr(), dw2.data_ptr(),
+                                   ws2.data_ptr(), 2 * nb, B, H, Cin, Cout, k, s, st)); res.append("wpair %7.1f us %6.0f TF" % (t * 1e3, 2 * flop / t / 1e9))
     print("%-18s x%-2d %s" % (name, cnt, " | ".join(res)))
 print("r100 totals (ms): fwd %.2f dgrad %.2f wgrad %.2f" % (tot["fwd"], tot["dgrad"], tot["wgrad"]))

@@ -72,7 +72,12 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    out = [run(a.arch, a.batch, a.steps, a.warmup, int(k), dev) for k in a.clients.split(",")]
+    from fedfr_amd import _C
+    out = []
+    for k in a.clients.split(","):
+        if "wgrad9p" not in os.environ.get("FEDFR_OPTIONS", ""):      # what Server.train selects: the paired weight-gradient kernel when clients share the GPU
+            _C.call("fedfr_set_option", b"wgrad9p", 1 if int(k) > 1 else 0)
+        out.append(run(a.arch, a.batch, a.steps, a.warmup, int(k), dev))
     print(json.dumps({"arch": a.arch, "batch": a.batch, "steps": a.steps, "results": out}))
 
 

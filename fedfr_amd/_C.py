@@ -40,6 +40,7 @@ SIGNATURES = {
     "fedfr_net_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "fedfr_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "fedfr_net_backward2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "fedfr_net_backward2_sgd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, C.POINTER(i64), vp, vp]),
     "fedfr_conv2d_stat_rows": (i32, [i32, i32, i32]),
     "fedfr_conv2d_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -249,6 +249,12 @@ class FusedTrainer:
         if self.aux_stream is not None:       # the shared aux stream may still carry the previous trainer's shadow rebuild of this backbone
             torch.cuda.current_stream().wait_stream(self.aux_stream)
         bb.refresh_shadows(True)
+        # step(): SGD folded into the backward pass (fedfr_net_backward2_sgd) unless FEDFR_FUSE_SGD=0; forward_backward() + optimizer_step()
+        # called separately keep the gradients-then-update contract
+        import os
+        self.fuse_sgd = os.environ.get("FEDFR_FUSE_SGD", "1") != "0"
+        self._fuse_sgd = False
+        self._sgd_done_from = None
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
@@ -299,17 +305,30 @@ class FusedTrainer:
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)   # dgrad shadows rebuilt on aux after the last SGD step
             self._shadows_pending = None
+        aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
+        if self._fuse_sgd:
+            # step(): the optimiser update of every parameter range whose gradient is final rides on the weight-gradient stream inside the
+            # backward pass (bn2 / fc / features first, then stage by stage); optimizer_step() finishes [0, done_from)
+            import ctypes
+            done = ctypes.c_longlong(0)
+            _C.call("fedfr_net_backward2_sgd", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                    bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                    self.lr, self.mu, self.wd, 1 if self.first else 0, ctypes.byref(done), st, aux)
+            self._sgd_done_from = int(done.value)
+            return
         _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
-                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
-                self.aux_stream.cuda_stream if self.aux_stream is not None else None)
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st, aux)
 
     @_C.on_device(lambda self: self.bb.device)
     def optimizer_step(self):
         bb = self.bb
         st = _C.stream()
         first = 1 if self.first else 0
-        _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, first, st)
+        n_rest = self.n_train if self._sgd_done_from is None else self._sgd_done_from      # the rest was updated inside the backward pass
+        self._sgd_done_from = None
+        if n_rest > 0:
+            _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, st)
         if self.pfc is not None:
             self.pfc.fused_sgd_update(self.lr, self.mu, self.wd)      # sampled rows: SGD + scatter back
         else:
@@ -328,7 +347,11 @@ class FusedTrainer:
         self.first = False
 
     def step(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-        loss = self.forward_backward(imgs, labels)
+        self._fuse_sgd = self.fuse_sgd
+        try:
+            loss = self.forward_backward(imgs, labels)
+        finally:
+            self._fuse_sgd = False
         self.optimizer_step()
         return loss
 

@@ -247,6 +247,17 @@ int fedfr_net_backward2(const fedfr_net_t* n, const float* x, const float* dfeat
   return net_backward(n, x, dfeats, params, BF(shadow), (unsigned char*)act, (unsigned char*)ws, grads, ST(stream), ST(aux_stream));
 }
 
+int fedfr_net_backward2_sgd(const fedfr_net_t* n, const float* x, const float* dfeats, float* params, uint16_t* shadow, void* act, void* ws,
+                            float* grads, float* momentum, float lr, float mu, float wd, int first, long long* done_from, void* stream,
+                            void* aux_stream) {
+  FEDFR_REQUIRE(aux_stream == nullptr || aux_stream != stream, "net_backward2_sgd: aux_stream must differ from stream (pass NULL for single-stream)");
+  FEDFR_REQUIRE(momentum && done_from, "net_backward2_sgd: null momentum buffer / done_from");
+  NetSgd sg{params, BFM(shadow), momentum, lr, mu, wd, first, 0};
+  const int rc = net_backward(n, x, dfeats, params, BF(shadow), (unsigned char*)act, (unsigned char*)ws, grads, ST(stream), ST(aux_stream), &sg);
+  *done_from = sg.done_from;
+  return rc;
+}
+
 // ---- single convolutions ---------------------------------------------------------------------------------
 static int conv_args_ok(int batch, int hin, int cin, int cout, int ksize, int stride) {
   FEDFR_REQUIRE(batch > 0 && hin > 0 && (cin % 64) == 0 && (cout % 64) == 0 && (ksize == 1 || ksize == 3) &&

@@ -84,5 +84,13 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
                 unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st);
 // aux == nullptr: everything on `st`.  Otherwise all weight-gradient GEMMs (off the dgrad -> BN critical path) run on
 // `aux`, forked/joined with events; on return both streams' work is ordered before anything enqueued later on `st`.
+// SGD folded into the backward pass: parameter ranges whose gradients are final (a whole stage, or the bn2 / fc / features tail) are
+// updated on the weight-gradient stream while the main stream is still walking the earlier stages.  `done_from` (out): parameters
+// [done_from, trainable_count) have been updated when the call's work completes; the caller updates [0, done_from).
+struct NetSgd {
+  float* params; bf16_t* shadow; float* mom;      // writable views of the (same) parameter / bf16 mirror buffers, momentum buffer
+  float lr, mu, wd; int first;
+  long long done_from;
+};
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
-                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux);
+                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux, NetSgd* sgd = nullptr);

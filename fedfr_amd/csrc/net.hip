@@ -2,6 +2,7 @@
 // Reference behaviour: backbones/iresnet.py:46-57 (IBasicBlock.forward), :158-172 (IResNet.forward);
 // backward is the hand-derived adjoint of that graph (checked against autograd of the CPU oracle).
 #include "net.h"
+#include "optim.h"
 #include <algorithm>
 #include <cstdio>
 #include "ew.h"
@@ -679,7 +680,7 @@ struct Fork {
 }  // namespace
 
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
-                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux) {
+                 unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux, NetSgd* sgd) {
   FEDFR_REQUIRE(n && (x || n->block_only) && dfeats && params && shadow && act && ws && grads, "net_backward: null buffer");
   Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
   const int B = n->B, F = n->F, HW = n->HW;
@@ -720,6 +721,24 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   }
   int cur = 1;
   size_t dbg_off = 0;
+  // fused SGD (NetSgd): [sgd_lo, sgd_hi) = parameter range whose gradients are complete on the main stream and whose weight gradients are
+  // all queued on the weight-gradient stream; it is updated there behind the next fork (which orders it after everything queued on main).
+  // Nothing reads those parameters again in this pass: dgrad uses the bf16 shadows, BatchNorm backward its own layer's gamma / slope.
+  long long sgd_lo = -1, sgd_hi = -1;
+  if (sgd && !n->block_only) {
+    FEDFR_REQUIRE(sgd->params == params && sgd->shadow == shadow && sgd->mom, "net_backward: fused SGD wants the pass's own parameter / shadow buffers");
+    sgd->done_from = n->trainable_count;
+    sgd_lo = n->bn2.g_off; sgd_hi = n->trainable_count;     // bn2, fc, features: their gradients were written at the top of this pass
+  }
+  auto sgd_flush = [&]() -> int {
+    if (sgd_lo < 0 || sgd_lo >= sgd_hi) return FEDFR_OK;
+    FEDFR_REQUIRE((sgd_lo & 3) == 0, "net_backward: fused SGD range not 16-byte aligned");
+    FEDFR_TRY(optim_sgd(sgd->params + sgd_lo, grads + sgd_lo, sgd->mom + sgd_lo, sgd->shadow + sgd_lo, (size_t)(sgd_hi - sgd_lo), sgd->lr, sgd->mu,
+                        sgd->wd, sgd->first, wst));
+    sgd->done_from = sgd_lo;
+    sgd_hi = sgd_lo; sgd_lo = -1;
+    return FEDFR_OK;
+  };
   hipEvent_t wdone[kWgradDepth] = {};              // "all weight GEMMs of the block of this generation have finished"
   for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
     const BlockD& k = n->blocks[bi];
@@ -745,6 +764,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     // ONE fork per block: every event record costs the main stream a ~8 us bubble (kernel trace), so the block's two or three
     // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
     fk.order(st, wst);
+    FEDFR_TRY(sgd_flush());
     FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst));
     if (k.has_ds) {
       FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, dd, wst));
@@ -762,6 +782,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
                        prev ? A + prev->c2_off : nullptr, &pend));
     }
     cur ^= 1;
+    if (sgd && !n->block_only && k.has_ds && bi > 0) sgd_lo = k.bn1.g_off;      // a stage is complete: its range goes out behind the next fork
   }
   fk.order(wst, st);                                 // join: the stem wgrad below reuses the slab workspace; callers see all grads
   const int M0 = B * HW * HW;

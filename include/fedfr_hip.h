@@ -97,6 +97,14 @@ int fedfr_net_backward(const fedfr_net_t* net, const float* x, const float* dfea
  * before later work on `stream`.  aux_stream == NULL behaves like fedfr_net_backward. */
 int fedfr_net_backward2(const fedfr_net_t* net, const float* x, const float* dfeats, const float* params,
                         const uint16_t* shadow, void* act, void* ws, float* grads, void* stream, void* aux_stream);
+/* fedfr_net_backward2 with `torch.optim.SGD(...).step()` (client.py:396,550; fedfr_sgd_step semantics: coupled weight decay, momentum
+ * buffer, bf16 mirror refreshed) folded in: parameter ranges whose gradients are final — the bn2 / fc / features tail, then each stage
+ * of residual blocks as the pass leaves it — are updated on aux_stream while `stream` walks the earlier stages.  When the call's work
+ * completes, parameters [*done_from, trainable_count) are updated; the caller runs fedfr_sgd_step on [0, *done_from) (stem + stage 1).
+ * params / shadow are the buffers the pass reads (now written too); results are bit-identical to backward + one flat fedfr_sgd_step. */
+int fedfr_net_backward2_sgd(const fedfr_net_t* net, const float* x, const float* dfeats, float* params, uint16_t* shadow, void* act, void* ws,
+                            float* grads, float* momentum, float lr, float mu, float wd, int first, long long* done_from, void* stream,
+                            void* aux_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * single convolutions — replace nn.Conv2d fwd / dgrad / wgrad at the call sites iresnet.py:38,41,76,121

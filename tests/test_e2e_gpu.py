@@ -250,6 +250,45 @@ def test_fused_client_loop_vs_reference():
     assert rel(fc, g["head_fc"]) < 5e-2
 
 
+@pytest.mark.parametrize("arch,dual", [("iresnet18", True), ("iresnet50", True), ("iresnet18", False)])
+def test_sgd_inside_backward_is_bit_identical(arch, dual, monkeypatch):
+    """step() folds torch.optim.SGD's update into the backward pass (fedfr_net_backward2_sgd: the bn2 / fc / features tail and every finished
+    stage are updated on the weight-gradient stream while the main stream is still in the earlier stages).  Same kernels, same element-wise
+    arithmetic, only enqueued earlier: parameters, momentum buffers, bf16 mirrors and losses after 3 steps are bit-identical to
+    backward + one flat fedfr_sgd_step (FEDFR_FUSE_SGD=0), with one stream and with two."""
+    monkeypatch.setenv("FEDFR_DUAL_STREAM", "1" if dual else "0")
+    B, C = 8, 40
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FEDFR_FUSE_SGD", fuse)
+        m, sd, layers = make_model(arch, tag=5.0)
+        fc = R.head_fc(C).to(DEV)
+        tr = client.FusedTrainer(m, fc, "CosFace", 30.0, 0.4, lr=0.05, momentum=0.9, weight_decay=5e-4)
+        assert tr.fuse_sgd == (fuse == "1")
+        ls = []
+        for st in range(3):
+            imgs = R.closed_form_images(B, tag=float(st)).to(DEV)
+            lab = R.closed_form_labels(B, C, tag=st).to(DEV)
+            ls.append(float(tr.step(imgs, lab)))
+        tr.finish()
+        torch.cuda.synchronize()
+        res.append((ls, m._flat_params.clone(), tr.mom.clone(), m._shadow[: m.trainable_count()].clone(), fc.clone()))
+    a, b = res
+    assert a[0] == b[0], (a[0], b[0])
+    for i, name in ((1, "parameters"), (2, "momentum"), (3, "bf16 mirror"), (4, "head fc")):
+        assert torch.equal(a[i], b[i]), name
+    # and the update really happened inside the pass: only stem + stage 1 are left to the flat kernel
+    tr._fuse_sgd = True
+    imgs = R.closed_form_images(B, tag=9.0).to(DEV)
+    tr.forward_backward(imgs, R.closed_form_labels(B, C, tag=9).to(DEV))
+    tr._fuse_sgd = False
+    first_s2 = dict(m.named_parameters())["layer2.0.bn1.weight"]
+    off = (first_s2.data_ptr() - m._flat_params.data_ptr()) // 4
+    assert tr._sgd_done_from == off, (tr._sgd_done_from, off)
+    tr.optimizer_step()
+    tr.finish()
+
+
 @pytest.mark.parametrize("variant", ["full", "seq", "bce_rw"])
 def test_train_with_public_data_vs_reference(variant):
     """Client.train_with_public_data (client.py:287-508) through the fused head trainer: iresnet18, 6 local + 14 public

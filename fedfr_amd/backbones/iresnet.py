@@ -302,6 +302,7 @@ class IResNet(nn.Module):
         self._shadow_dirty = True
         self._grads_live = False
         self._fwd_generation = 0
+        self._bn_frozen = False                 # freeze_BN(test_mode=True): BatchNorms in eval mode inside a training net
         self._anchor = torch.zeros(1, requires_grad=True)     # keeps the autograd graph connected
         # module tree with the reference's names (iresnet.py:76-98)
         self.conv1 = Conv2d(3, 64, 3, 1)
@@ -457,26 +458,40 @@ class IResNet(nn.Module):
         """Call after modifying parameters in place outside of this package's optimiser while in eval mode."""
         self._shadow_dirty = True
 
-    # reference API (iresnet.py:140-156).  Per-module eval() of BN is not supported by the fused kernels:
-    # only the affine-freeze part is honoured.
+    # reference API (iresnet.py:140-156): put every BatchNorm module into eval() — running statistics normalise, nothing is updated —
+    # while the net keeps training (dropout on, gradients flow; dgamma / dbeta are still produced unless fix_affine).  As in the
+    # reference, only model.train() brings the BatchNorms back (nn.Module.train() resets every submodule); unfreeze_BN() just restores
+    # requires_grad and, with test_mode=True, calls .eval() on them again (iresnet.py:149-156).
     def freeze_BN(self, test_mode=True, fix_affine=False):
-        if test_mode:
-            raise NotImplementedError("fedfr_amd: BN layers follow the model-wide train/eval flag; "
-                                      "freeze_BN(test_mode=True) (BN in eval inside a training net) is not supported")
         if fix_affine:
             for m in self.modules():
                 if m.__class__.__name__.find("BatchNorm") != -1:
                     for p in m.parameters():
                         p.requires_grad = False
+        if test_mode:
+            self._bn_frozen = True
+            for m in self.modules():
+                if m.__class__.__name__.find("BatchNorm") != -1:
+                    m.training = False
 
     def unfreeze_BN(self, test_mode=False, affine=True):
-        if test_mode:
-            raise NotImplementedError("fedfr_amd: unfreeze_BN(test_mode=True) is not supported")
         if affine:
             for n, m in self.named_modules():
                 if m.__class__.__name__.find("BatchNorm") != -1:
                     for pn, p in m.named_parameters():
                         p.requires_grad = True
+        if test_mode:
+            self.freeze_BN(True, False)
+
+    def train(self, mode: bool = True):
+        self._bn_frozen = False                 # nn.Module.train() sets .training on every submodule, BatchNorms included
+        return super().train(mode)
+
+    def _fwd_mode(self) -> int:
+        """``training`` argument of fedfr_net_forward: 0 eval, 1 train, 2 train with the BatchNorms frozen in eval mode."""
+        if not self.training:
+            return 0
+        return 2 if self._bn_frozen else 1
 
     # ------------------------------------------------------------------ device side
     @property
@@ -529,10 +544,10 @@ class IResNet(nn.Module):
         if training or self._shadow_dirty:
             self.refresh_shadows(True)
         feats = torch.empty(x.shape[0], self.num_features, dtype=torch.float32, device=self.device)
+        mode = (2 if self._bn_frozen else 1) if training else 0
         _C.call("fedfr_net_forward", plan.handle, x.data_ptr(), self._flat_params.data_ptr(), self._flat_bufs.data_ptr(),
-                self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1 if training else 0,
-                _C.stream())
-        if training:
+                self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), mode, _C.stream())
+        if mode == 1:                           # frozen BatchNorms track nothing (num_batches_tracked included)
             self._flat_nbt += 1
         self._fwd_generation += 1
         return feats

@@ -276,8 +276,9 @@ class FusedTrainer:
         st = _C.stream()
         feats = torch.empty(B, bb.num_features, dtype=f32, device=bb.device)
         _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
-                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1, st)
-        bb._flat_nbt += 1
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), bb._fwd_mode(), st)
+        if not bb._bn_frozen:
+            bb._flat_nbt += 1
         bb._fwd_generation += 1
         if self.pfc is not None:
             # upstream PartialFC protocol: normalised embeddings in, d(embedding) out
@@ -394,8 +395,9 @@ class FusedHeadTrainer:
         plan = bb._plan(imgs.shape[0])
         feats = torch.empty(imgs.shape[0], bb.num_features, dtype=f32, device=bb.device)
         _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
-                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), 1, _C.stream())
-        bb._flat_nbt += 1
+                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), bb._fwd_mode(), _C.stream())
+        if not bb._bn_frozen:
+            bb._flat_nbt += 1
         bb._fwd_generation += 1
         return plan, feats, labels
 

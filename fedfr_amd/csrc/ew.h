@@ -92,7 +92,7 @@ int ew_bn1d_fwd(const float* x, float* y, int B, int C, const float* gamma, cons
 // dx = bn1d backward; also dbeta (bias grad), and colsum(dx) -> fc bias grad
 int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const float* gamma,
                 const float* save_mean, const float* save_rstd, float* dbeta, float* dx_colsum,
-                bf16_t* dx_bf16, bf16_t* dx_bf16_t, int ldt, hipStream_t st);
+                bf16_t* dx_bf16, bf16_t* dx_bf16_t, int ldt, hipStream_t st, int frozen = 0);   // frozen: eval-mode BN inside a training net (dx = g rstd dy)
 
 // ---- split-K slab reductions ---------------------------------------------------------------------------
 int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n,

@@ -259,6 +259,8 @@ __global__ __launch_bounds__(256) void bn_eval_coeffs_multi_kernel(const float* 
     const float g = e.g_off >= 0 ? params[e.g_off + c] : 1.f, b = params[e.b_off + c];
     save[e.save_off + c] = g * rstd;                                   // scale
     save[e.save_off + e.C + c] = b - bufs[e.rm_off + c] * g * rstd;    // shift
+    save[e.save_off + 2 * e.C + c] = bufs[e.rm_off + c];               // mean / rstd as the backward pass of a training net with frozen
+    save[e.save_off + 3 * e.C + c] = rstd;                             // BatchNorms reads them (freeze_BN, iresnet.py:140-147)
   }
 }
 int ew_bn_eval_coeffs_multi(const float* params, const float* bufs, float* save, const BnEvalTable& t, hipStream_t st) {
@@ -789,7 +791,7 @@ int ew_bn1d_fwd(const float* x, float* y, int B, int C, const float* gamma, cons
 
 __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_bwd_kernel(const float* dy, const float* x, float* dx, int B, int C, const float* gamma,
                                 const float* mean, const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb,
-                                bf16_t* dxbt, int ldt) {
+                                bf16_t* dxbt, int ldt, int frozen) {
   __shared__ double red[BN1D_RG][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = min(blockIdx.x * 64 + cl, C - 1);
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_bwd_kernel(const float* dy,
   }
   s1 = bn1d_rg_sum(s1, red, rg, cl);
   s2 = bn1d_rg_sum(s2, red, rg, cl);
-  const float m1 = (float)(s1 / B), m2 = (float)(s2 / B);
+  const float m1 = frozen ? 0.f : (float)(s1 / B), m2 = frozen ? 0.f : (float)(s2 / B);     // frozen: statistics were constants, dx = g rstd dy
   if (dbeta && own) dbeta[c] = (float)s1;
   double cs = 0.0;
   if (valid)
@@ -820,10 +822,10 @@ __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_bwd_kernel(const float* dy,
 }
 
 int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const float* gamma, const float* mean,
-                const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb, bf16_t* dxbt, int ldt, hipStream_t st) {
+                const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb, bf16_t* dxbt, int ldt, hipStream_t st, int frozen) {
   FEDFR_REQUIRE(dy && x && dx && B > 0 && C > 0 && mean && rstd, "bn1d_bwd: bad args");
   hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, dy, x, dx, B, C, gamma, mean, rstd, dbeta,
-                     dx_colsum, dxb, dxbt, ldt);
+                     dx_colsum, dxb, dxbt, ldt, frozen);
   FEDFR_LAUNCH_CHECK("bn1d_bwd");
   return FEDFR_OK;
 }

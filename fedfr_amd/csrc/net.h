@@ -71,6 +71,9 @@ struct FedfrNet {
   unsigned long long dropout_seed = 100;
   mutable unsigned long long dropout_step = 0;      // counts training forwards (the mask is a function of (seed, step, index))
   long long mask_off_bytes = -1;                    // byte offset of the mask [B * fc_in] inside `act`
+  // nn.BatchNorm modules put into eval() inside a training net (IResNet.freeze_BN(test_mode=True), iresnet.py:140-147): set by a forward
+  // pass with training = 2 (running statistics normalise, nothing is updated, activations are kept), read by the backward pass
+  mutable bool bn_frozen = false;
   bool block_only = false;              // plan of a lone IBasicBlock (net_create_block): no stem, no bn2/fc/features tail
   long long dx_off = -1;                // block_only: bf16 arena offset of the gradient wrt the block input [B*Hin*Hin][Cin]
 };

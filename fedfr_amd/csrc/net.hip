@@ -470,7 +470,11 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
                 unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st) {
   FEDFR_REQUIRE(n && x && params && bufs && shadow && act && ws && (feats || n->block_only), "net_forward: null buffer");
   Ctx c{n, params, bufs, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, nullptr, st};
-  const bool tr = training != 0;
+  FEDFR_REQUIRE(training >= 0 && training <= 2, "net_forward: training must be 0 (eval), 1 (train) or 2 (train, BatchNorms frozen in eval mode)");
+  // training = 2: every BatchNorm normalises with its running statistics and updates nothing (freeze_BN(test_mode=True)) while the net
+  // trains — dropout stays on and every activation the backward pass reads is kept: the per-layer eval path, not the fused epilogues
+  const bool tr = training == 1, frozen = training == 2;
+  n->bn_frozen = frozen;
   const int B = n->B, HW = n->HW;
   const int M0 = B * HW * HW;
   bf16_t* A = c.actb;
@@ -496,7 +500,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   for (size_t bi = 0; bi < n->blocks.size(); ++bi) {
     const BlockD& k = n->blocks[bi];
     const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
-    if (!tr && g_eval_fuse) {
+    if (!tr && !frozen && g_eval_fuse) {
       // ---- eval mode: BatchNorms are known affines -> they ride in the conv epilogues where the kernel has one
       if (!a1_ready) FEDFR_TRY(apply(c, A + k.x_off, k.bn1, nullptr, nullptr, nullptr, A + k.a1_off, Mi, false));
       a1_ready = false;
@@ -570,7 +574,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   const int hw = n->final_hw * n->final_hw, Mf = B * hw;
   FEDFR_TRY(bn_coeffs(c, n->bn2, prev, (double)Mf, tr));
   FEDFR_TRY(apply(c, A + last.out_off, n->bn2, nullptr, nullptr, nullptr, A + n->t_off, Mf, false, hw));
-  if (tr && n->dropout_p > 0.f)            // nn.Dropout(p, inplace=True) on the flattened bn2 output (iresnet.py:169); identity in eval mode
+  if ((tr || frozen) && n->dropout_p > 0.f)            // nn.Dropout(p, inplace=True) on the flattened bn2 output (iresnet.py:169); identity in eval mode
     FEDFR_TRY(ew_dropout_fwd(A + n->t_off, act + n->mask_off_bytes, (size_t)B * n->fc_in, n->dropout_p, n->dropout_seed, n->dropout_step++, st));
   {
     GemmNT p{};
@@ -611,10 +615,13 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
                   const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, Rows have = Rows{nullptr, 0}, const BnD* next_bn = nullptr,
                   const bf16_t* next_x = nullptr, Rows* next_rows = nullptr) {
   const bool nxt = next_bn && next_x && next_rows && g_fuse_bnred_next && next_bn->C == b.C;
+  // frozen BatchNorm (eval mode inside a training net): mean / rstd were constants, so dx = gamma rstd dz — the same passes with an infinite
+  // count (the two mean terms vanish); dgamma / dbeta / dalpha are the same sums
+  const double count = c.n->bn_frozen ? HUGE_VAL : (double)M;
   if (!add_up && ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C), true)) {
     BnBwdS p{};
     p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.alpha = alpha;
-    p.sc = c.save(b, 0); p.sh = c.save(b, 1); p.M = M; p.C = b.C; p.count = (double)M;
+    p.sc = c.save(b, 0); p.sh = c.save(b, 1); p.M = M; p.C = b.C; p.count = count;
     if (have.P > 0) {
       p.part_in = have.ptr; p.P = have.P;
     } else {
@@ -641,7 +648,7 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   p.sc = c.save(b, 0); p.sh = c.save(b, 1);
   p.M = M; p.C = b.C; p.partials = c.part(); p.coef = c.coef(); p.add = add; p.add_up = add_up; p.H = H; p.W = H; p.dx = dx;
   if (have.P <= 0) FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));      // else: the producing pass already wrote the partials
-  FEDFR_TRY(ew_bn_bwd_finalize(have.P > 0 ? have.ptr : c.part(), have.P > 0 ? have.P : ew_bn_bwd_grid(M, b.C), b.C, (double)M, c.gamma(b), c.save(b, 2),
+  FEDFR_TRY(ew_bn_bwd_finalize(have.P > 0 ? have.ptr : c.part(), have.P > 0 ? have.P : ew_bn_bwd_grid(M, b.C), b.C, count, c.gamma(b), c.save(b, 2),
                                c.save(b, 3), c.grads + b.g_off, c.grads + b.b_off, alpha ? c.grads + alpha_off : nullptr, c.coef(), c.st));
   return ew_bn_bwd_apply(p, c.st);
 }
@@ -699,7 +706,8 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     return FEDFR_ERR_HIP;
   }
   FEDFR_TRY(ew_bn1d_bwd(dfeats, c.actf + n->yfc_off, c.dyfc(), B, F, params + n->feat_bn.g_off, c.actf + n->feat_save_off,
-                        c.actf + n->feat_save_off + F, grads + n->feat_bn.b_off, grads + n->fc_b_off, c.dyb(), c.dybt(), n->Bp, st));
+                        c.actf + n->feat_save_off + F, grads + n->feat_bn.b_off, grads + n->fc_b_off, c.dyb(), c.dybt(), n->Bp, st,
+                        n->bn_frozen ? 1 : 0));
   float* dxfc = reinterpret_cast<float*>(ws + n->ws_fc);
   {  // fc.weight grad [F][fc_in] = dY^T X   (both operands batch-major -> TN kernel)
     GemmTN p{};

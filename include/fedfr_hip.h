@@ -85,7 +85,10 @@ int fedfr_net_act_info(const fedfr_net_t* net, int block, int which, long long* 
  * fwd_shadow_too = 0 when fedfr_sgd_step already wrote the mirror region. */
 int fedfr_net_prepare_weights(const fedfr_net_t* net, const float* params, uint16_t* shadow, int fwd_shadow_too,
                               void* stream);
-/* x: fp32 NCHW [B][3][hw][hw] in [-1,1]; feats: fp32 [B][num_features] */
+/* x: fp32 NCHW [B][3][hw][hw] in [-1,1]; feats: fp32 [B][num_features].
+ * training: 0 = model.eval(), 1 = model.train(), 2 = model.train() followed by IResNet.freeze_BN(test_mode=True) (iresnet.py:140-147):
+ * every BatchNorm normalises with its running statistics and tracks nothing while the net trains (dropout on, activations kept); the
+ * next fedfr_net_backward* of the plan then runs the BatchNorm backward of eval-mode modules (dx = gamma rstd dz). */
 int fedfr_net_forward(const fedfr_net_t* net, const float* x, const float* params, float* bufs,
                       const uint16_t* shadow, void* act, void* ws, float* feats, int training, void* stream);
 /* grads (fp32 [trainable_count]) are assigned, not accumulated */

@@ -278,10 +278,12 @@ def closed_form_labels(batch: int, num_classes: int, tag: int = 0) -> torch.Tens
 # --------------------------------------------------------------------------------------
 # backbone  (reference: backbones/iresnet.py:46-57 block, :158-172 forward)
 # --------------------------------------------------------------------------------------
-def _bn(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+def _bn(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, training: bool, frozen: bool = False) -> torch.Tensor:
     """nn.BatchNorm{1,2}d semantics: biased batch var for normalisation, unbiased for the
-    running update, momentum 0.1, num_batches_tracked += 1 in training."""
+    running update, momentum 0.1, num_batches_tracked += 1 in training.  ``frozen``: the module was put into eval() inside a training
+    net (IResNet.freeze_BN(test_mode=True), iresnet.py:140-147): running statistics normalise, nothing is updated."""
     rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    training = training and not frozen
     if training:
         sd[prefix + ".num_batches_tracked"] += 1
     return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"],
@@ -289,17 +291,17 @@ def _bn(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, training: boo
 
 
 def ibasic_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: int,
-                 training: bool) -> torch.Tensor:
+                 training: bool, bn_frozen: bool = False) -> torch.Tensor:
     """iresnet.py:46-57: BN→conv3x3(s1)→BN→PReLU→conv3x3(stride)→BN, (+1x1 conv+BN shortcut), add."""
-    out = _bn(sd, p + ".bn1", x, training)
+    out = _bn(sd, p + ".bn1", x, training, bn_frozen)
     out = F.conv2d(out, sd[p + ".conv1.weight"], None, 1, 1)
-    out = _bn(sd, p + ".bn2", out, training)
+    out = _bn(sd, p + ".bn2", out, training, bn_frozen)
     out = F.prelu(out, sd[p + ".prelu.weight"])
     out = F.conv2d(out, sd[p + ".conv2.weight"], None, stride, 1)
-    out = _bn(sd, p + ".bn3", out, training)
+    out = _bn(sd, p + ".bn3", out, training, bn_frozen)
     if (p + ".downsample.0.weight") in sd:
         idn = F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0)
-        idn = _bn(sd, p + ".downsample.1", idn, training)
+        idn = _bn(sd, p + ".downsample.1", idn, training, bn_frozen)
     else:
         idn = x
     return out + idn
@@ -307,25 +309,26 @@ def ibasic_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: i
 
 def iresnet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, layers: Sequence[int],
                     training: bool = True, return_taps: bool = False, dropout_p: float = 0.0,
-                    dropout_mask: Optional[torch.Tensor] = None):
-    """iresnet.py:158-172 with fp16=False (CPU path).  ``dropout_p`` > 0 with an injected keep-``dropout_mask`` [B, 25088] (0/1): the
+                    dropout_mask: Optional[torch.Tensor] = None, bn_frozen: bool = False):
+    """iresnet.py:158-172 with fp16=False (CPU path).  ``bn_frozen``: after IResNet.freeze_BN(test_mode=True) (iresnet.py:140-147) — every
+    BatchNorm in eval mode while the net trains (dropout stays on).  ``dropout_p`` > 0 with an injected keep-``dropout_mask`` [B, 25088] (0/1): the
     nn.Dropout(p, inplace=True) of iresnet.py:169 with that mask (torch's RNG stream is not part of the contract; FL configs use p = 0,
     client.py:142)."""
     taps = {}
     h = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
-    h = _bn(sd, "bn1", h, training)
+    h = _bn(sd, "bn1", h, training, bn_frozen)
     h = F.prelu(h, sd["prelu.weight"])
     taps["stem"] = h
     for si, nblk in enumerate(layers):
         for bi in range(nblk):
-            h = ibasic_block(sd, "layer%d.%d" % (si + 1, bi), h, 2 if bi == 0 else 1, training)
+            h = ibasic_block(sd, "layer%d.%d" % (si + 1, bi), h, 2 if bi == 0 else 1, training, bn_frozen)
         taps["layer%d" % (si + 1)] = h
-    h = _bn(sd, "bn2", h, training)
+    h = _bn(sd, "bn2", h, training, bn_frozen)
     h = torch.flatten(h, 1)
     if training and dropout_p > 0.0:
         h = h * dropout_mask.to(h.dtype) / (1.0 - dropout_p)
     h = F.linear(h, sd["fc.weight"], sd["fc.bias"])
-    h = _bn(sd, "features", h, training)
+    h = _bn(sd, "features", h, training, bn_frozen)
     return (h, taps) if return_taps else h
 
 

@@ -65,6 +65,35 @@ def test_backbone_matches_reference(arch, batch, fname):
         assert int(sd[k + ".num_batches_tracked"]) == int(g["nbt_" + k])
 
 
+def test_freeze_bn_matches_reference():
+    """IResNet.freeze_BN(test_mode=True) (iresnet.py:140-147): BatchNorms in eval mode inside a training net — the oracle's bn_frozen
+    forward and its autograd against the imported reference; model.train() afterwards is an ordinary training forward again."""
+    g = load_golden("freeze_bn_r18")
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    B = int(g["B"])
+    sd = R.closed_form_state_dict(layers, tag=7.0)
+    x = R.closed_form_images(B, tag=3.0)
+    w = R.closed_form((B, 512), 0.37, 0.9, 1.0)
+    keys = R.trainable_keys(sd)
+    work = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in sd.items()}
+    feats = R.iresnet_forward(work, x, layers, training=True, bn_frozen=True)
+    close(feats, g["feats"], 1e-4, 1e-5)
+    (feats * w).sum().backward()
+    names = [str(n) for n in g["grad_names"]]
+    assert names == keys
+    np.testing.assert_allclose(np.array([float(work[k].grad.norm()) for k in names]), g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("g_") and k[2:] in work:
+            close(work[k[2:]].grad, g[k], 2e-3, 1e-6)
+    close(work["layer3.1.conv1.weight"].grad[:4, :16], g["g_layer3.1.conv1.weight_slice"], 2e-3, 1e-6)
+    for k in ("bn1", "layer2.0.downsample.1", "layer4.1.bn3", "bn2", "features"):      # nothing tracked
+        assert torch.equal(work[k + ".running_mean"], sd[k + ".running_mean"]) and int(work[k + ".num_batches_tracked"]) == int(g["nbt_" + k])
+        close(work[k + ".running_mean"], g["rm_" + k], 1e-6, 1e-7)
+    with torch.no_grad():
+        again = R.iresnet_forward({k: v.detach().clone() for k, v in work.items()}, x, layers, training=True)
+    close(again, g["feats_after_train_call"], 1e-4, 1e-5)
+
+
 def test_heads_match_reference():
     g = load_golden("heads")
     B, C = int(g["B"]), int(g["C"])

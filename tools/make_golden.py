@@ -688,8 +688,48 @@ def gen_sphnet():
     save("sphnet20", **out)
 
 
+def gen_freeze_bn():
+    """The reference's IResNet.freeze_BN(test_mode=True) (iresnet.py:140-147): every BatchNorm in eval mode inside a training net.
+    iresnet18, closed-form weights with non-trivial running statistics, one forward + backward of sum(feats * w)."""
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    model = backbones.iresnet18(False, dropout=0, fp16=False)
+    load_closed_form(model, layers, tag=7.0)
+    B = 4
+    x = R.closed_form_images(B, tag=3.0)
+    w = R.closed_form((B, 512), 0.37, 0.9, 1.0)
+    model.train()
+    model.freeze_BN()
+    feats = model(x)
+    (feats * w).sum().backward()
+    out = {"B": B, "feats": feats}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(p.grad.norm()))
+        if p.grad.numel() <= 512:
+            out["g_" + k] = p.grad
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, dtype=np.float64)
+    out["g_conv1.weight"] = model.conv1.weight.grad
+    out["g_layer3.1.conv1.weight_slice"] = model.layer3[1].conv1.weight.grad[:4, :16]
+    out["g_fc.weight_slice"] = model.fc.weight.grad[:4, :2048]
+    sd_after = {k: v.clone() for k, v in model.state_dict().items()}        # (state_dict() returns the live tensors)
+    for k in ("bn1", "layer2.0.downsample.1", "layer4.1.bn3", "bn2", "features"):
+        out["rm_" + k] = sd_after[k + ".running_mean"]
+        out["rv_" + k] = sd_after[k + ".running_var"]
+        out["nbt_" + k] = sd_after[k + ".num_batches_tracked"]
+    # model.train() undoes it (nn.Module.train resets the BatchNorm submodules): the second forward is an ordinary training forward
+    model.train()
+    out["feats_after_train_call"] = model(x)
+    save("freeze_bn_r18", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining", "roc", "sphnet"]
+    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining", "roc", "sphnet", "freeze_bn"]
+    if "freeze_bn" in which:
+        gen_freeze_bn()
     if "block" in which:
         gen_block()
     if "r50" in which:

@@ -24,6 +24,7 @@ extern int g_wgrad9;
 extern int g_conv_c64p;
 extern int g_bn_sliced, g_bn_sliced_pre;
 extern int g_wgrad9p;
+extern int g_conv28_tpw2;
 extern int g_eval_fuse;
 extern int g_wgrad_depth;
 extern int g_dgrad_parity;
@@ -115,6 +116,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "bn_sliced")) {
     g_bn_sliced = value ? 1 : 0;   // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "conv28_tpw2")) {
+    g_conv28_tpw2 = value ? 1 : 0;   // forward 28x28 convs with BatchNorm statistics: two image tiles per workgroup (256 partial rows instead of 1024)
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "wgrad9p")) {

@@ -58,7 +58,7 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false>   // XFORM: BN(+PReLU) of the input applied to the LDS image; BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false, int TPW = 1>   // TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); XFORM: BN(+PReLU) of the input applied to the LDS image; BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
   constexpr int PT = R_ * W_, BN = BN_, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
@@ -88,9 +88,12 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   GLDS_STAMP(0);
   const int wm = wave / WN, wn = wave % WN;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bn = lid % p.nbn, bt = lid / p.nbn;
-  const int img = bt / TPI, y0 = (bt - img * TPI) * R_;
-  const int m0 = bt * PT, n0 = bn * BN;
+  const int bn = lid % p.nbn, btw = lid / p.nbn;          // workgroup btw computes image tiles btw * TPW .. + TPW - 1
+  int bt = btw * TPW;
+  int img = bt / TPI, y0 = (bt - img * TPI) * R_;
+  int m0 = bt * PT;
+  const int n0 = bn * BN;
+  static_assert(TPW == 1 || (!FUSED && !XFORM), "several tiles per workgroup: plain variant only");
   const int l15 = lane & 15, lg = lane >> 4;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
 
@@ -100,15 +103,18 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   const int prow = lane >> 3, pch = (lane & 7) ^ prow;
   constexpr unsigned OOB = 0xfffffff0u;                 // beyond any buffer: the load writes zeros to LDS
   unsigned a_src[AP];                                   // byte offset of this lane's pixel/chunk at channel chunk 0
+  auto plan_tile = [&]() {
 #pragma unroll
-  for (int j = 0; j < AP; ++j) {
-    const int r = (j * NW + wave) * 8 + prow;
-    const int ry = r / PWL, rx = r - ry * PWL;
-    const int yy = y0 + ry;
-    const bool ok = ry < R_ + 2 && yy >= 1 && yy <= W_ && rx >= 1 && rx <= W_;
-    const unsigned pix = (unsigned)(img * (W_ * W_) + (yy - 1) * W_ + (rx - 1));
-    a_src[j] = ok ? (pix * (unsigned)p.C + (unsigned)(pch * 8)) * 2u : OOB;
-  }
+    for (int j = 0; j < AP; ++j) {
+      const int r = (j * NW + wave) * 8 + prow;
+      const int ry = r / PWL, rx = r - ry * PWL;
+      const int yy = y0 + ry;
+      const bool ok = ry < R_ + 2 && yy >= 1 && yy <= W_ && rx >= 1 && rx <= W_;
+      const unsigned pix = (unsigned)(img * (W_ * W_) + (yy - 1) * W_ + (rx - 1));
+      a_src[j] = ok ? (pix * (unsigned)p.C + (unsigned)(pch * 8)) * 2u : OOB;
+    }
+  };
+  plan_tile();
   const unsigned b_src = ((unsigned)(n0 + wave * BP * 8 + prow) * (unsigned)p.K + (unsigned)(pch * 8)) * 2u;   // + j * 8 rows
   const unsigned b_rstep = 8u * (unsigned)p.K * 2u;
 
@@ -168,10 +174,8 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   }
 
   f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float ssum[TN][4], ssq[TN][4];                        // BatchNorm partials of this wave's columns (one tile)
+  float* sStat = reinterpret_cast<float*>(smem + NABUF * A_BYTES + NB * B_BYTES);     // TPW > 1: [2 wave rows][2 statistics][BN], the workgroup's running partial row
 
   const int cpt = p.C >> 6;
   auto read_frags = [&](bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN], int aoff, int dx, const unsigned char* cB, int ks) {
@@ -224,6 +228,17 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         *reinterpret_cast<uint4*>(p.aout + (size_t)(m0 + t) * p.C + cc * 64 + c8 * 8) = v;
       }
   };
+#pragma unroll 1
+  for (int ti = 0; ti < TPW; ++ti) {
+  if (TPW > 1 && ti > 0) {
+    bt = btw * TPW + ti;
+    img = bt / TPI; y0 = (bt - img * TPI) * R_; m0 = bt * PT;
+    plan_tile();
+  }
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // prologue: image of chunk 0, weight tiles of taps 0..2; wait for the image and tap 0, fetch tap 0's first fragments
   issue_a(0, 0, true);
   issue_b(0, 0, 0, true);
@@ -434,7 +449,6 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   // ---- epilogue: bf16 tile through LDS; fragment rows >= 196 contribute nothing ----
   constexpr int CST = BN * 2 + 16;
   unsigned char* sC = smem;
-  float ssum[TN][4], ssq[TN][4];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -453,7 +467,18 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-      const int ml = m_pix[mi];
+      int ml = m_pix[mi];
+      bool mok = m_ok[mi];
+      if constexpr (TPW > 1 && RST) {
+        // recomputed per tile behind an opaque zero: as loop invariants of the tile loop the 14 values would be hoisted in front of the
+        // main loop and live through it (256 VGPRs + spills instead of 194)
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        const int q_ = wm * MW + mi * 16 + l15 + z;
+        const int y_ = q_ / PWL, x_ = q_ - y_ * PWL;
+        mok = x_ < W_;
+        ml = mok ? y_ * W_ + x_ : 0;
+      }
       const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
       bf16_t h[4];
 #pragma unroll
@@ -464,16 +489,30 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           if (p.ealpha) a = a > 0.f ? a : eal_[ni][q] * a;
         }
         h[q] = f2bf(a);
-        const float v = m_ok[mi] ? bf2f(h[q]) : 0.f;
+        const float v = mok ? bf2f(h[q]) : 0.f;
         ssum[ni][q] += v;
         ssq[ni][q] += v * v;
       }
       uint2 pk;
       pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
       pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-      if (m_ok[mi]) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
+      if (mok) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
     }
-  if (p.stats) {
+  if (TPW > 1 && p.stats) {                             // this tile's partials join the workgroup's row in LDS (a region no DMA touches)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
+        const int col = wn * (BN / WN) + ni * 16 + lg * 4 + q;
+        if (l15 == 0) {                                   // one writer per (wave row, column): no race, fixed summation order
+          float* d = sStat + wm * 2 * BN + col;
+          d[0] = ti == 0 ? a : d[0] + a;
+          d[BN] = ti == 0 ? b : d[BN] + b;
+        }
+      }
+  }
+  if (TPW == 1 && p.stats) {
     const int ntile = gridDim.x / p.nbn;
     float* prow_ = p.stats + (size_t)(bt * WM + wm) * 2 * p.N;
 #pragma unroll
@@ -576,10 +615,28 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       p.bpart[((size_t)bt * 3 + which) * p.N + n0 + col] = t;
     }
   }
+  if (TPW > 1) __syncthreads();                         // the staged output tile has been read: the next tile's image may land on it
+  }   // tiles of this workgroup
+  if constexpr (TPW > 1) {
+    // one partial row per workgroup: wave row 0 + wave row 1 of the LDS partials (every tile's epilogue ended with a barrier)
+    if (p.stats) {
+      const int nrows = gridDim.x / p.nbn;
+      for (int i = tid; i < 2 * BN; i += NT) {
+        const int stat = i / BN, col = i - stat * BN;
+        p.stats[(size_t)btw * 2 * p.N + (size_t)stat * p.N + n0 + col] = sStat[i] + sStat[2 * BN + i];
+      }
+      // rows the finalize kernel's row count (128-pixel tiling) has beyond ours: zeros
+      for (int row = nrows + btw; row < stat_rows; row += nrows)
+        for (int i = tid; i < 2 * BN / 4; i += NT) {
+          const int stat = i / (BN / 4), c4 = i - stat * (BN / 4);
+          *reinterpret_cast<float4*>(p.stats + (size_t)row * 2 * p.N + (size_t)stat * p.N + n0 + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+  }
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false>
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false, int TPW = 1>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
   FEDFR_REQUIRE(p.N % BN_ == 0 && (ONECHUNK ? p.C == 64 : p.C % 128 == 0) && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
@@ -594,16 +651,17 @@ static int launch_glds(GemmNT p, hipStream_t st) {
     if (p.bwd_fused) *p.bwd_fused = p.M / PT;
   }
   p.nbn = p.N / BN_;
-  const int ntile = p.M / PT;
-  constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128 + (XFORM ? 3 * 256 * 4 : 0);
+  FEDFR_REQUIRE((p.M / PT) % TPW == 0, "conv3x3_glds: %d tiles do not split into groups of %d", p.M / PT, TPW);
+  const int ntile = p.M / PT / TPW;                     // workgroups per output-channel tile
+  constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128 + (XFORM ? 3 * 256 * 4 : 0) + (TPW > 1 ? 4 * (size_t)BN_ * 4 : 0);
   static_assert(lds >= (size_t)PT * (BN_ * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15),   /* slot 15: 56x56 and 112x112 */ 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM, TPW>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

@@ -358,8 +358,15 @@ int gemm_nt_stat_rows(int M, int N) {
 // rows of gemm_nt_stat_rows that carry data for a conv with BatchNorm statistics in its epilogue (the rest are zero rows the kernel
 // writes so that a finalize over the 128-pixel-tile row count stays right): the 196-pixel-tile LDS-DMA kernels leave 2 per tile
 bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
-int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride) {
-  if ((W == 14 || W == 28) && gemm_nt_conv_epilogue_ok(W, C, N, M, ksize, stride)) return M / 196 * 2;
+int g_conv28_tpw2 = 1;   // option "conv28_tpw2": forward 28x28 convs with BatchNorm statistics run two image tiles per workgroup (one partial row each)
+static bool glds28_two_tiles_shape(int M) { return g_conv28_tpw2 && g_conv_halo >= 4 && (M / 196) % 2 == 0; }
+static bool glds28_two_tiles(const GemmNT& p) {
+  return p.stats && p.W == 28 && !p.esc && !p.eadd && !p.Cb2 && glds28_two_tiles_shape(p.M);
+}
+// xform: the conv ran on the input-transform kernel (conv_glds_x.hip, option fuse_bnapply), which keeps two rows per tile
+int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride, bool xform) {
+  if ((W == 14 || W == 28) && gemm_nt_conv_epilogue_ok(W, C, N, M, ksize, stride))
+    return (W == 28 && !xform && glds28_two_tiles_shape(M)) ? M / 196 / 2 : M / 196 * 2;
   return gemm_nt_stat_rows(M, N);
 }
 
@@ -445,7 +452,8 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
       if (g_conv_halo >= 4 && p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0 && p.ldc == p.N)
         return p.W == 14 ? launch_conv_glds8_fused_w14(p, st) : launch_conv_glds8_fused_w28(p, st);
       if (g_conv_halo >= 3 && !p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0)
-        return g_conv_halo >= 4 ? (p.W == 14 ? launch_conv_glds8_w14(p, st) : launch_conv_glds8_w28(p, st))
+        return g_conv_halo >= 4 ? (p.W == 14 ? launch_conv_glds8_w14(p, st)
+                                             : (glds28_two_tiles(p) ? launch_conv_glds8_w28_stats(p, st) : launch_conv_glds8_w28(p, st)))
                                 : (p.W == 14 ? launch_conv_glds_w14(p, st) : launch_conv_glds_w28(p, st));
       const bool bn64 = p.N <= 64 || g_halo_bn64;
       if (bn64 || g_halo_waves == 8) return launch_conv_halo2_misc(p, bn64, g_halo_waves == 8, st);

@@ -549,7 +549,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
       FEDFR_TRY(bn_apply_train(c, k.bn1, prev, A + k.x_off, nullptr, nullptr, A + k.a1_off, Mi, nullptr));
       FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, true));
     }
-    const Rows r1{c.part(), gemm_nt_stat_rows_live(Mi, k.Cout, k.conv1.Cin, k.conv1.Hin, k.conv1.R, k.conv1.stride)};
+    const Rows r1{c.part(), gemm_nt_stat_rows_live(Mi, k.Cout, k.conv1.Cin, k.conv1.Hin, k.conv1.R, k.conv1.stride, xf1)};
     if (xf2) {
       FEDFR_TRY(bn_coeffs(c, k.bn2, r1, (double)Mi, true));
       FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, true));
@@ -557,7 +557,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
       FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
       FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, true));
     }
-    const Rows r2{c.part(), gemm_nt_stat_rows_live(Mo, k.Cout, k.conv2.Cin, k.conv2.Hin, k.conv2.R, k.conv2.stride)};
+    const Rows r2{c.part(), gemm_nt_stat_rows_live(Mo, k.Cout, k.conv2.Cin, k.conv2.Hin, k.conv2.R, k.conv2.stride, xf2)};
     if (k.has_ds) {
       FEDFR_TRY(bn_coeffs(c, k.bn3, r2, (double)Mo, true));
       FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, true));

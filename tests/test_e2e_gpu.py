@@ -539,6 +539,7 @@ def test_fused_bn_apply_in_conv_matches_separate_pass(training):
     for opt in (0, 1):
         _C.call("fedfr_set_option", b"fuse_bnapply", opt)
         _C.call("fedfr_set_option", b"conv_c64p", 0)
+        _C.call("fedfr_set_option", b"conv28_tpw2", 0)      # (likewise: two 28x28 tiles per workgroup sum their partials in fp32 first)
         try:
             m, sd, _ = make_model("iresnet18", tag=3.0)
             x = R.closed_form_images(128).to(DEV)
@@ -554,6 +555,7 @@ def test_fused_bn_apply_in_conv_matches_separate_pass(training):
         finally:
             _C.call("fedfr_set_option", b"fuse_bnapply", 0)
             _C.call("fedfr_set_option", b"conv_c64p", 1)
+            _C.call("fedfr_set_option", b"conv28_tpw2", 1)
     assert torch.equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k

@@ -119,7 +119,7 @@ int fedfr_set_option(const char* name, int value) {
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "conv28_tpw2")) {
-    g_conv28_tpw2 = value ? 1 : 0;   // forward 28x28 convs with BatchNorm statistics: two image tiles per workgroup (256 partial rows instead of 1024)
+    g_conv28_tpw2 = value < 0 ? 0 : value > 2 ? 2 : value;   // forward 28x28 convs with BatchNorm statistics: two image tiles per workgroup (256 partial rows instead of 1024)
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "wgrad9p")) {

@@ -358,10 +358,10 @@ int gemm_nt_stat_rows(int M, int N) {
 // rows of gemm_nt_stat_rows that carry data for a conv with BatchNorm statistics in its epilogue (the rest are zero rows the kernel
 // writes so that a finalize over the 128-pixel-tile row count stays right): the 196-pixel-tile LDS-DMA kernels leave 2 per tile
 bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
-int g_conv28_tpw2 = 1;   // option "conv28_tpw2": forward 28x28 convs with BatchNorm statistics run two image tiles per workgroup (one partial row each)
+int g_conv28_tpw2 = 2;   // option "conv28_tpw2": 28x28 convs run two image tiles per workgroup -- 1: the forward launches (one BatchNorm partial row per workgroup: 256 instead of 1024), 2: the dgrad launches too (256 workgroups that stay instead of 512 that are dispatched in two rounds between the weight-gradient workgroups: 17.72 -> 17.54 ms/step same-box)
 static bool glds28_two_tiles_shape(int M) { return g_conv28_tpw2 && g_conv_halo >= 4 && (M / 196) % 2 == 0; }
-static bool glds28_two_tiles(const GemmNT& p) {
-  return p.stats && p.W == 28 && !p.esc && !p.eadd && !p.Cb2 && glds28_two_tiles_shape(p.M);
+static bool glds28_two_tiles(const GemmNT& p) {          // option value 2: the dgrad launches (no statistics) too
+  return (p.stats || g_conv28_tpw2 >= 2) && p.W == 28 && !p.esc && !p.eadd && !p.Cb2 && glds28_two_tiles_shape(p.M);
 }
 // xform: the conv ran on the input-transform kernel (conv_glds_x.hip, option fuse_bnapply), which keeps two rows per tile
 int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride, bool xform) {

@@ -62,7 +62,7 @@ SIGNATURES = {
     "fedfr_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "fedfr_bn_bwd_rows": (i32, [i32, i32]),
     "fedfr_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
-    "fedfr_bn_sliced_rows": (i32, [i32, i32]),
+    "fedfr_bn_sliced_rows": (i32, [i32, i32, i32]),
     "fedfr_bn_sliced_ok": (i32, [i32, i32, i32, i32]),
     "fedfr_bn_apply_sliced": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "fedfr_bn_bwd_sliced": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -22,7 +22,7 @@ extern int g_tn_glds;
 extern int g_tn_pair;
 extern int g_wgrad9;
 extern int g_conv_c64p;
-extern int g_bn_sliced, g_bn_sliced_pre;
+extern int g_bn_sliced, g_bn_sliced_pre, g_bn_sliced_bwd_passes;
 extern int g_wgrad9p;
 extern int g_conv28_tpw2;
 extern int g_eval_fuse;
@@ -124,6 +124,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "wgrad9p")) {
     g_wgrad9p = value ? 1 : 0;     // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "bn_sliced_bwd_passes")) {
+    g_bn_sliced_bwd_passes = value < 7 ? 7 : value > 64 ? 64 : value;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "bn_sliced_pre")) {
@@ -465,7 +469,7 @@ int fedfr_bn_bwd(const uint16_t* dy, const uint16_t* x, const float* mean, const
   return ew_bn_bwd_apply(p, ST(stream));
 }
 
-int fedfr_bn_sliced_rows(int M, int C) { return ew_bn_sliced_rows(M, C); }
+int fedfr_bn_sliced_rows(int M, int C, int backward) { return ew_bn_sliced_rows(M, C, backward != 0); }
 int fedfr_bn_sliced_ok(int M, int C, int rows_in, int backward) { return ew_bn_sliced_ok(M, C, rows_in, backward != 0) ? 1 : 0; }
 int fedfr_bn_apply_sliced(const float* partials, int P, double count, const float* gamma, const float* beta, float* rm, float* rv,
                           float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd, const uint16_t* x1,
@@ -481,13 +485,13 @@ int fedfr_bn_bwd_sliced(const uint16_t* dy, const uint16_t* x, const float* mean
                         const float* sc, const float* sh, int M, int C, float* partials, int rows_in, float* dgamma, float* dbeta,
                         float* dalpha, const uint16_t* add, uint16_t* dx, const uint16_t* nx, const float* nmean, const float* nrstd,
                         float* npart, void* stream) {
-  FEDFR_REQUIRE(partials && ew_bn_sliced_ok(M, C, rows_in > 0 ? rows_in : ew_bn_sliced_rows(M, C), true),
+  FEDFR_REQUIRE(partials && ew_bn_sliced_ok(M, C, rows_in > 0 ? rows_in : ew_bn_sliced_rows(M, C, true), true),
                 "bn_bwd_sliced: shape M=%d C=%d (%d rows) is not served (fedfr_bn_sliced_ok)", M, C, rows_in);
   BnBwdS p{};
   p.dy = BF(dy); p.x = BF(x); p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.alpha = alpha; p.sc = sc; p.sh = sh; p.M = M; p.C = C;
   p.count = (double)M; p.partials = partials;
   if (rows_in <= 0) FEDFR_TRY(ew_bn_bwd_reduce_sliced(p, ST(stream)));
-  p.part_in = partials; p.P = rows_in > 0 ? rows_in : ew_bn_sliced_rows(M, C);
+  p.part_in = partials; p.P = rows_in > 0 ? rows_in : ew_bn_sliced_rows(M, C, true);
   p.dgamma = dgamma; p.dbeta = dbeta; p.dalpha = dalpha; p.add = BF(add); p.dx = BFM(dx);
   p.nx = BF(nx); p.nmean = nmean; p.nrstd = nrstd; p.npart = npart;
   return ew_bn_bwd_apply_sliced(p, ST(stream));

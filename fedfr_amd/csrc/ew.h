@@ -79,7 +79,7 @@ struct BnBwdS {
   float* npart;                                   // ... into ew_bn_sliced_rows(M, C) rows [3][C]; must not alias `part_in`
   int G, ppg;
 };
-int ew_bn_sliced_rows(int M, int C);
+int ew_bn_sliced_rows(int M, int C, bool backward = false);
 bool ew_bn_sliced_ok(int M, int C, int P_in, bool backward);
 int ew_bn_apply_sliced(BnApplyS p, hipStream_t st);
 int ew_bn_bwd_reduce_sliced(BnBwdS p, hipStream_t st);

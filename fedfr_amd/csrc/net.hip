@@ -618,7 +618,7 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   // frozen BatchNorm (eval mode inside a training net): mean / rstd were constants, so dx = gamma rstd dz — the same passes with an infinite
   // count (the two mean terms vanish); dgamma / dbeta / dalpha are the same sums
   const double count = c.n->bn_frozen ? HUGE_VAL : (double)M;
-  if (!add_up && ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C), true)) {
+  if (!add_up && ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C, true), true)) {
     BnBwdS p{};
     p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.alpha = alpha;
     p.sc = c.save(b, 0); p.sh = c.save(b, 1); p.M = M; p.C = b.C; p.count = count;
@@ -627,13 +627,13 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
     } else {
       p.partials = c.part();
       FEDFR_TRY(ew_bn_bwd_reduce_sliced(p, c.st));
-      p.part_in = c.part(); p.P = ew_bn_sliced_rows(M, b.C);
+      p.part_in = c.part(); p.P = ew_bn_sliced_rows(M, b.C, true);
     }
     p.dgamma = c.grads + b.g_off; p.dbeta = c.grads + b.b_off; p.dalpha = alpha ? c.grads + alpha_off : nullptr;
     p.add = add; p.dx = dx;
     if (nxt) {
       p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part_other(p.part_in);
-      *next_rows = Rows{p.npart, ew_bn_sliced_rows(M, b.C)};
+      *next_rows = Rows{p.npart, ew_bn_sliced_rows(M, b.C, true)};
     }
     return ew_bn_bwd_apply_sliced(p, c.st);
   }

@@ -172,7 +172,7 @@ int fedfr_bn_bwd(const uint16_t* dy, const uint16_t* x, const float* mean, const
  * fedfr_net_forward / _backward run on the 28x28 and smaller maps.  Partial rows: [row][statistic][C] fp32, the layout fedfr_bn_apply /
  * fedfr_bn_bwd and the conv epilogues write.  Replaces nn.BatchNorm2d forward / backward (backbones/iresnet.py:46-57), one launch per
  * tensor pass.
- *   fedfr_bn_sliced_rows: rows such a pass writes for an [M][C] tensor;  fedfr_bn_sliced_ok: whether the shape is served (else use the
+ *   fedfr_bn_sliced_rows: rows such a pass writes for an [M][C] tensor (backward = 1: the backward passes, which use fewer, longer workgroups);  fedfr_bn_sliced_ok: whether the shape is served (else use the
  *   finalize + row-slab entry points above).
  *   fedfr_bn_apply_sliced: y = prelu?(bn(x1)) (+ x2); statistics of x1 = the P rows [2][C] at `partials`; writes scale / shift / mean / rstd
  *   [C], updates running_mean / running_var (NULL: skipped), and, with `stats`, the fedfr_bn_sliced_rows rows [2][C] of y (must not
@@ -180,7 +180,7 @@ int fedfr_bn_bwd(const uint16_t* dy, const uint16_t* x, const float* mean, const
  *   fedfr_bn_bwd_sliced: reduce pass into `partials` (fedfr_bn_sliced_rows rows [3][C]) unless rows_in > 0 says they are already there,
  *   then dx = BN(+PReLU) backward (+ add), dgamma / dbeta / dalpha assigned; with nx, dx is also reduced as the dy of the BatchNorm over
  *   nx (its mean / rstd given) into `npart` (rows [3][C], must not overlap `partials`).  sc / sh: the forward's scale / shift (PReLU mask). */
-int fedfr_bn_sliced_rows(int M, int C);
+int fedfr_bn_sliced_rows(int M, int C, int backward);
 int fedfr_bn_sliced_ok(int M, int C, int rows_in, int backward);
 int fedfr_bn_apply_sliced(const float* partials, int P, double count, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,

@@ -424,7 +424,7 @@ def test_bn_apply_sliced(M, C, prelu, second, rows_in):
     part = torch.stack([torch.stack([xf[a:b].sum(0), (xf[a:b] ** 2).sum(0)]) for a, b in zip(bounds[:-1], bounds[1:])]).to(d)
     xd, g_, b_, rm_, rv_ = x.to(d), gamma.to(d), beta.to(d), rm.to(d), rv.to(d)
     scale, shift, mean, rstd = (torch.full((C,), float("nan"), device=d) for _ in range(4))
-    rows = _C.lib().fedfr_bn_sliced_rows(M, C)
+    rows = _C.lib().fedfr_bn_sliced_rows(M, C, 0)
     stats = torch.full((rows, 2, C), float("nan"), device=d)
     y = torch.empty_like(xd)
     al = alpha.to(d) if prelu else None
@@ -480,7 +480,7 @@ def test_bn_bwd_sliced(M, C, prelu, with_add, with_next):
     nx = bf(rnd((M, C), 8) * 1.5 - 0.2) if with_next else None
     nmean = nx.float().mean(0) if with_next else None
     nrstd = 1.0 / torch.sqrt(nx.float().var(0, unbiased=False) + 1e-5) if with_next else None
-    rows = _C.lib().fedfr_bn_sliced_rows(M, C)
+    rows = _C.lib().fedfr_bn_sliced_rows(M, C, 1)
     part = torch.full((rows, 3, C), float("nan"), device=d)
     npart = torch.full((rows, 3, C), float("nan"), device=d)
     dg, db, da = (torch.full((C,), float("nan"), device=d) for _ in range(3))

@@ -65,7 +65,7 @@ def main():
             if not _C.lib().fedfr_bn_sliced_ok(M, Cc, Pin, 0):
                 continue
             part_s = torch.randn(Pin, 2, Cc, device=dev).abs()
-            srows = _C.lib().fedfr_bn_sliced_rows(M, Cc)
+            srows = _C.lib().fedfr_bn_sliced_rows(M, Cc, 0)
             sstats = torch.empty(srows, 2, Cc, device=dev)
 
             def sliced(with_stats):

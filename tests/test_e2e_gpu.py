@@ -561,6 +561,30 @@ def test_fused_bn_apply_in_conv_matches_separate_pass(training):
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 
 
+def test_paired_weight_gradient_kernel_in_the_network():
+    """option wgrad9p (what Server.train selects for concurrent clients): every block's two same-shape 3x3 weight gradients from the paired
+    64 x 64 nine-tap kernel — same operands, same K order per split, so the network's gradients agree with the single-layer kernel's to fp32
+    summation-order level (activations and activation gradients do not depend on the choice at all: bit-identical embeddings)."""
+    outs = []
+    for opt in (0, 1):
+        _C.call("fedfr_set_option", b"wgrad9p", opt)
+        try:
+            m, sd, _ = make_model("iresnet50", tag=3.0)
+            m.train()
+            f = m(R.closed_form_images(16).to(DEV))
+            (f * R.closed_form((16, 512), 0.37, 0.9, 1.0).to(DEV)).sum().backward()
+            outs.append((f.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+        finally:
+            _C.call("fedfr_set_option", b"wgrad9p", 0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    worst = max((rel(outs[1][1][k], outs[0][1][k]), k) for k in outs[0][1] if float(outs[0][1][k].norm()) > 0)
+    print("wgrad9p on vs off: worst %.2e (%s)" % worst)
+    assert worst[0] < 1e-5, worst
+    for k in outs[0][1]:
+        if "conv" not in k:                       # everything that is not a paired conv weight gradient is untouched
+            assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
 def test_bn_backward_next_reduction_fusion_equivalence():
     """option fuse_bnred_next (a BN-backward apply pass also reduces its output for the BatchNorm that consumes it): same gradients as
     the separate reduce kernel up to fp32 summation order."""

@@ -83,7 +83,7 @@ int fedfr_set_option(const char* name, int value) {
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "dgrad_parity")) {
-    g_dgrad_parity = value ? 1 : 0;
+    g_dgrad_parity = value < 0 ? 0 : value > 2 ? 2 : value;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "tn_glds")) {

@@ -74,7 +74,14 @@ int g_conv_halo = 4;   // option "conv_halo": 0 generic gather kernel, 1 halo v1
 // NT kernel
 // =====================================================================================================
 template <int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p_) {
+  GemmNT p = p_;
+  if (p.par_on == 2) {                                  // all four output-parity classes of a stride-2 dgrad in one launch: class = blockIdx.z,
+    const int cls = 3 - (int)blockIdx.z;                // the four-tap class first (its workgroups run 4x as long as the one-tap class's)
+    p.par_h = cls >> 1; p.par_w = cls & 1;
+    p.ksteps_total = (1 + p.par_h) * (1 + p.par_w) * p.cpt;
+    p.ksteps_per_split = p.ksteps_total;
+  }
   constexpr int AI = BM / 32, BI = BN / 32;             // 16-B chunks per thread per tile
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;   // 16x16 fragments per wave
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -322,8 +329,8 @@ static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(nbm * p.nbn, splits, 1);
-  ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st);
+  dim3 grid(nbm * p.nbn, splits, p.par_on == 2 ? 4 : 1);
+  ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (p.par_on == 2 ? 64.0 * 9 * p.cpt : p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st);
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_nt");
   return FEDFR_OK;
@@ -370,7 +377,7 @@ int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride, bo
   return gemm_nt_stat_rows(M, N);
 }
 
-int g_dgrad_parity = 1;   // option "dgrad_parity": stride-2 3x3 dgrad as 4 output-parity classes (9/4 instead of 9 taps per output pixel)
+int g_dgrad_parity = 2;   // option "dgrad_parity": stride-2 3x3 dgrad as 4 output-parity classes (9/4 instead of 9 taps per output pixel); 2: the four classes in one launch
 
 // shapes whose conv runs on a plain LDS-DMA kernel instantiation (mirrors the dispatch in gemm_nt_launch_one): those implement the
 // eval-mode output epilogue (GemmNT::esc / eadd / Cb2)
@@ -394,6 +401,13 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
   if (g_dgrad_parity && p.mode == 1 && p.up == 2 && p.S == 3 && p.pad == 1 && p.stride == 1 && p.Cb && !p.stats && splits == 1 &&
       !(p.Ho & 1) && !(p.Wo & 1) && p.Ho == 2 * p.H && p.Wo == 2 * p.W && p.M % (p.Ho * p.Wo) == 0 && !p.par_on) {
+    if (g_dgrad_parity >= 2) {                          // one launch, class = blockIdx.z
+      GemmNT q = p;
+      q.par_on = 2; q.par_h = 1; q.par_w = 1;           // (the largest class sizes the checks; the kernel sets its own)
+      q.outH = p.Ho; q.outW = p.Wo;
+      q.Ho = p.Ho / 2; q.Wo = p.Wo / 2; q.M = p.M / 4;
+      return gemm_nt_launch_one(q, 1, st);
+    }
     for (int cls = 0; cls < 4; ++cls) {
       GemmNT q = p;
       q.par_on = 1; q.par_h = cls >> 1; q.par_w = cls & 1;

@@ -233,7 +233,8 @@ class Server(object):
             # The clients of a round are independent (the reference trains them one after another, server.py:283); one client's step
             # is a dependent chain of ~1250 short kernels that leaves CUs idle between launches.  `par` clients train CONCURRENTLY on
             # this GPU, each on its own HIP stream pair and resident backbone (measured: 2 clients = +20 % images/s on iresnet100 at
-            # B = 128; 3 regress).  Kernels are deterministic and clients share no state, so the round's result is identical.
+            # B = 128; 3 regress).  Kernels are deterministic and clients share no state, so the round's result is identical to the sequential
+            # round with the same kernel selection (the paired weight-gradient kernel below: otherwise equal up to fp32 summation order).
             import threading
             from . import _C
             # with the GPU saturated by several kernel chains, total kernel time is what counts: the paired 64 x 64 weight-gradient kernel

@@ -352,7 +352,9 @@ def test_many_clients_share_one_backbone_memory_flat():
 
 def test_parallel_clients_round_equals_sequential():
     """``args.parallel_clients = 2``: two clients of a round train CONCURRENTLY on the GPU (own stream pair + resident backbone each).
-    Clients are independent and every kernel is deterministic, so the round's aggregate is bit-identical to the sequential round."""
+    Clients are independent and every kernel is deterministic, so the round's aggregate is bit-identical to the sequential round run with
+    the same kernel selection (Server.train switches the paired weight-gradient kernel on for concurrent clients: the sequential run
+    is made with option wgrad9p = 1 too), and equal to the default sequential round up to fp32 summation order in the weight gradients."""
     class DS:
         ID_base = 0
 
@@ -368,7 +370,7 @@ def test_parallel_clients_round_equals_sequential():
     from fedfr_amd.config import config as cfg
     cfg.lr = 0.01
     outs = []
-    for par in (1, 2):
+    for par, w9p in ((1, 1), (2, None), (1, 0)):
         class Args:
             network, loss, local_epoch, output_dir, BCE_local, aggr_alg = "iresnet18", "CosFace", 1, "/tmp", False, "FedAvg"
             parallel_clients = par
@@ -377,13 +379,21 @@ def test_parallel_clients_round_equals_sequential():
             c.fc_module.fc.data = R.head_fc(10, seed=30 + c.cid)
         srv = server.Server(clients, Data, Args, device=DEV)
         srv.federated_model.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet18"], tag=2.0))
-        loss = srv.train()
+        if w9p is not None:
+            _C.call("fedfr_set_option", b"wgrad9p", w9p)
+        try:
+            loss = srv.train()
+        finally:
+            _C.call("fedfr_set_option", b"wgrad9p", 0)
         torch.cuda.synchronize()
         outs.append((loss, {k: v.clone() for k, v in srv.federated_model.state_dict().items()}, [c.get_train_loss() for c in clients]))
     assert outs[0][2] == outs[1][2]                                   # per-client mean losses
     assert outs[0][0] == outs[1][0]
     for k, v in outs[0][1].items():
         assert torch.equal(v, outs[1][1][k]), k
+    # the library default for a sequential round (single-layer weight-gradient kernel): same round up to summation order
+    worst = max(float((outs[2][1][k].float() - v.float()).norm() / (v.float().norm() + 1e-12)) for k, v in outs[0][1].items() if v.dtype.is_floating_point)
+    assert worst < 1e-5 and abs(outs[2][0] - outs[0][0]) < 1e-5 * abs(outs[0][0]), (worst, outs[2][0], outs[0][0])
 
 
 def _rccl_world1_worker(rank, port):

@@ -24,6 +24,7 @@ extern int g_wgrad9;
 extern int g_conv_c64p;
 extern int g_bn_sliced, g_bn_sliced_pre, g_bn_sliced_bwd_passes;
 extern int g_wgrad9p;
+extern int g_wgrad9_wgs;
 extern int g_conv28_tpw2;
 extern int g_eval_fuse;
 extern int g_wgrad_depth;
@@ -116,6 +117,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "bn_sliced")) {
     g_bn_sliced = value ? 1 : 0;   // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad9_wgs")) {
+    g_wgrad9_wgs = value < 64 ? 64 : value > 1024 ? 1024 : value;    // workgroups a wgrad9 launch aims for (more = shorter workgroups, more split-K slabs)
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "conv28_tpw2")) {

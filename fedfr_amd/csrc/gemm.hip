@@ -671,14 +671,14 @@ int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
 
 // slab count to size a workspace for: the largest any kernel choice (options can be toggled after a plan was created) would use
 int gemm_tn_max_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
-  const int w9 = g_wgrad9, gl = g_tn_glds;
+  const int w9 = g_wgrad9, gl = g_tn_glds, ww = g_wgrad9_wgs;
   int m = 1;
   for (int a = 0; a < 2; ++a)
     for (int b = 0; b < 3; ++b) {
-      g_wgrad9 = a; g_tn_glds = b;
+      g_wgrad9 = a; g_tn_glds = b; g_wgrad9_wgs = std::max(ww, 512);
       m = std::max(m, gemm_tn_pick_splits(Kp, NI, NJ, C, Wo, stride));
     }
-  g_wgrad9 = w9; g_tn_glds = gl;
+  g_wgrad9 = w9; g_tn_glds = gl; g_wgrad9_wgs = ww;
   return m;
 }
 

@@ -71,7 +71,7 @@ int launch_tn_glds_pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
 bool gemm_tn_glds_pair_ok(int Kp, int NI, int NJ, int C, int splits);
 extern int g_tn_pair;
 // wgrad9.hip: 3x3 stride-1 weight gradient, all nine taps per workgroup, operands staged once
-extern int g_wgrad9;
+extern int g_wgrad9, g_wgrad9_wgs;
 bool wgrad9_applies(const GemmTN& p);
 bool wgrad9_applies_shape(int Kp, int NI, int NJ, int C, int W, int stride);
 int wgrad9_pick_splits(int Kp, int NI, int NJ, int W);

@@ -244,10 +244,11 @@ static int w9_stages(int Kp, int W) {
   return images << (2 * w9_lg(W));
 }
 // one workgroup per CU: as many K-splits (whole stages) as it takes to put ~256 workgroups on the chip, at least two stages each
+int g_wgrad9_wgs = 256;   // option "wgrad9_wgs": workgroups a launch aims for (256 = one per CU; 512 = half as long each, twice the slabs)
 int wgrad9_pick_splits(int Kp, int NI, int NJ, int W) {
   const int stages = w9_stages(Kp, W);
   const int tiles = (NI / 32) * (NJ / 9 / 64);
-  int splits = 256 / tiles;
+  int splits = g_wgrad9_wgs / tiles;
   if (splits < 1) splits = 1;
   if (splits > stages / 2) splits = stages / 2 > 0 ? stages / 2 : 1;
   const int per = ceil_div(stages, splits);

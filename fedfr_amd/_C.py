@@ -40,6 +40,10 @@ SIGNATURES = {
     "fedfr_net_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "fedfr_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "fedfr_net_backward2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "fedfr_net_f32_arena_floats": (sz, [vp]),
+    "fedfr_net_f32_ws_floats": (sz, [vp]),
+    "fedfr_net_f32_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "fedfr_net_f32_backward": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "fedfr_net_backward2_sgd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, C.POINTER(i64), vp, vp]),
     "fedfr_conv2d_stat_rows": (i32, [i32, i32, i32]),
     "fedfr_conv2d_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

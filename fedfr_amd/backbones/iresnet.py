@@ -303,6 +303,9 @@ class IResNet(nn.Module):
         self._grads_live = False
         self._fwd_generation = 0
         self._bn_frozen = False                 # freeze_BN(test_mode=True): BatchNorms in eval mode inside a training net
+        # True: forward / backward run the fp32 VALIDATION path (csrc/net_f32.hip: fp32 activations, exact-fp32 GEMMs, fp64 statistics;
+        # ~50x slower) — same parameters, buffers and gradients; what the "1e-3 fp32" tolerance of the parity tests is checked with
+        self.validation_fp32 = False
         self._anchor = torch.zeros(1, requires_grad=True)     # keeps the autograd graph connected
         # module tree with the reference's names (iresnet.py:76-98)
         self.conv1 = Conv2d(3, 64, 3, 1)
@@ -487,6 +490,14 @@ class IResNet(nn.Module):
         self._bn_frozen = False                 # nn.Module.train() sets .training on every submodule, BatchNorms included
         return super().train(mode)
 
+    def _f32_buffers(self, plan):
+        """Activation arena + scratch of the fp32 validation path for this plan (allocated on first use; released with the plan)."""
+        if getattr(plan, "f32_arena", None) is None:
+            na, nw = _C.lib().fedfr_net_f32_arena_floats(plan.handle), _C.lib().fedfr_net_f32_ws_floats(plan.handle)
+            plan.f32_arena = torch.empty(na, dtype=torch.float32, device=self.device)
+            plan.f32_ws = torch.empty(nw, dtype=torch.float32, device=self.device)
+        return plan.f32_arena, plan.f32_ws
+
     def _fwd_mode(self) -> int:
         """``training`` argument of fedfr_net_forward: 0 eval, 1 train, 2 train with the BatchNorms frozen in eval mode."""
         if not self.training:
@@ -545,6 +556,16 @@ class IResNet(nn.Module):
             self.refresh_shadows(True)
         feats = torch.empty(x.shape[0], self.num_features, dtype=torch.float32, device=self.device)
         mode = (2 if self._bn_frozen else 1) if training else 0
+        if self.validation_fp32:
+            if mode == 2 or (training and self.dropout_p > 0):
+                raise NotImplementedError("fedfr_amd: the fp32 validation path covers train / eval forward + backward with dropout 0")
+            arena, ws = self._f32_buffers(plan)
+            _C.call("fedfr_net_f32_forward", plan.handle, x.data_ptr(), self._flat_params.data_ptr(), self._flat_bufs.data_ptr(),
+                    arena.data_ptr(), ws.data_ptr(), feats.data_ptr(), mode, _C.stream())
+            if mode == 1:
+                self._flat_nbt += 1
+            self._fwd_generation += 1
+            return feats
         _C.call("fedfr_net_forward", plan.handle, x.data_ptr(), self._flat_params.data_ptr(), self._flat_bufs.data_ptr(),
                 self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), mode, _C.stream())
         if mode == 1:                           # frozen BatchNorms track nothing (num_batches_tracked included)
@@ -583,8 +604,13 @@ class IResNet(nn.Module):
         target = self._flat_grads
         if accumulate:
             target = torch.empty_like(self._flat_grads)
-        _C.call("fedfr_net_backward", plan.handle, x.data_ptr(), dfeats.data_ptr(), self._flat_params.data_ptr(),
-                self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), target.data_ptr(), _C.stream())
+        if self.validation_fp32:
+            arena, ws = self._f32_buffers(plan)
+            _C.call("fedfr_net_f32_backward", plan.handle, dfeats.data_ptr(), self._flat_params.data_ptr(), arena.data_ptr(), ws.data_ptr(),
+                    target.data_ptr(), _C.stream())
+        else:
+            _C.call("fedfr_net_backward", plan.handle, x.data_ptr(), dfeats.data_ptr(), self._flat_params.data_ptr(),
+                    self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), target.data_ptr(), _C.stream())
         if accumulate:
             self._flat_grads.add_(target)
         for p, g in views:

@@ -272,6 +272,17 @@ int fedfr_net_backward2_sgd(const fedfr_net_t* n, const float* x, const float* d
   return rc;
 }
 
+// ---- fp32 validation path (net_f32.hip) --------------------------------------------------------------------------------------
+size_t fedfr_net_f32_arena_floats(const fedfr_net_t* n) { return n ? net_f32_arena_floats(n) : 0; }
+size_t fedfr_net_f32_ws_floats(const fedfr_net_t* n) { return n ? net_f32_ws_floats(n) : 0; }
+int fedfr_net_f32_forward(const fedfr_net_t* n, const float* x, const float* params, float* bufs, float* arena, float* ws, float* feats,
+                          int training, void* stream) {
+  return net_f32_forward(n, x, params, bufs, arena, ws, feats, training, ST(stream));
+}
+int fedfr_net_f32_backward(const fedfr_net_t* n, const float* dfeats, const float* params, float* arena, float* ws, float* grads, void* stream) {
+  return net_f32_backward(n, dfeats, params, arena, ws, grads, ST(stream));
+}
+
 // ---- single convolutions ---------------------------------------------------------------------------------
 static int conv_args_ok(int batch, int hin, int cin, int cout, int ksize, int stride) {
   FEDFR_REQUIRE(batch > 0 && hin > 0 && (cin % 64) == 0 && (cout % 64) == 0 && (ksize == 1 || ksize == 3) &&

@@ -7,6 +7,9 @@ int head_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn,
                             hipStream_t st);
 int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak,
                long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, hipStream_t st);
+// same, products accumulated in fp64 (fp32 validation path of the backbone)
+int head_sgemm_f64acc(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
+                      int ldc, float alpha, float beta, const float* bias, hipStream_t st);
 int head_margin_rowmax(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arc, float* row_max,
                        float* dmul, hipStream_t st);
 int head_exp_rowsum(float* z, int R, int C, int ldz, const float* row_max, float* row_sum, hipStream_t st);

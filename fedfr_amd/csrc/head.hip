@@ -167,6 +167,93 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
       }
 }
 
+// Same GEMM with the products accumulated in fp64 (v_mfma_f64_16x16x4_f64 on the fp32 operands widened exactly): the result is the
+// correctly rounded fp32 value of the exact sum for all practical purposes.  Used by the fp32 validation path of the backbone (net_f32.hip),
+// whose weight-gradient GEMMs sum over up to 10^5 positions: a sequential fp32 accumulation of that length put it 3x further from the fp64
+// evaluation of a training step than the fp32 reference is.
+template <int BK>
+__global__ __launch_bounds__(256) void sgemm_f64acc_kernel(SgemmP p) {
+  constexpr int BM = 64, BN = 64, LD = 80, NL = BK / 4;   // k-major LDS rows; LD%32==16 + column XOR (k>>1)<<1: reads and writes conflict-free
+  __shared__ float sA[2][BK][LD], sB[2][BK][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  float ra[NL], rb[NL];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = tid + 256 * i;
+      int m, k;
+      if (p.sak == 1) { k = e & (BK - 1); m = e / BK; } else { m = e & 63; k = e >> 6; }
+      const int gm = m0 + m, gk = k0 + k;
+      ra[i] = (gm < p.M && gk < p.K) ? p.A[(long long)gm * p.sam + (long long)gk * p.sak] : 0.f;
+      int n, kb;
+      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & (BK - 1); n = e / BK; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      rb[i] = (gn < p.N && gkb < p.K) ? p.B[(long long)gkb * p.sbk + (long long)gn * p.sbn] : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = tid + 256 * i;
+      int m, k;
+      if (p.sak == 1) { k = e & (BK - 1); m = e / BK; } else { m = e & 63; k = e >> 6; }
+      sA[buf][k][m ^ ((k >> 1) << 1)] = ra[i];
+      int n, kb;
+      if (p.sbn == 1) { n = e & 63; kb = e >> 6; } else { kb = e & (BK - 1); n = e / BK; }
+      sB[buf][kb][n ^ ((kb >> 1) << 1)] = rb[i];
+    }
+  };
+  typedef __attribute__((ext_vector_type(4))) double f64x4_acc_t;
+  f64x4_acc_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4_acc_t){0.0, 0.0, 0.0, 0.0};
+  const int nk = ceil_div(p.K, BK);
+  load(0);
+  store(0);
+  __syncthreads();
+  const int l15 = lane & 15, lg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load((kt + 1) * BK);
+#pragma unroll
+    for (int k4 = 0; k4 < BK; k4 += 4) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = k4 + lg, sw = (kk >> 1) << 1;
+        fa[i] = sA[buf][kk][(wm * 32 + i * 16 + l15) ^ sw];
+        fb[i] = sB[buf][kk][(wn * 32 + i * 16 + l15) ^ sw];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[i], (double)fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store(buf ^ 1);
+    __syncthreads();
+  }
+  // f64 16x16x4 accumulator layout (differs from the f32 form): register q of lane l holds D[row = 4 q + (l >> 4)][col = l & 15]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * q + lg, n = n0 + wn * 32 + j * 16 + l15;
+        if (m < p.M && n < p.N) {
+          double v = (double)p.alpha * acc[i][j][q];
+          if (p.bias) v += (double)p.bias[n];
+          float* c = p.C + (size_t)m * p.ldc + n;
+          if (p.beta != 0.f) v += (double)p.beta * (double)*c;
+          *c = (float)v;
+        }
+      }
+}
+
 int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak,
                long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, hipStream_t st) {
   FEDFR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "sgemm: bad args");
@@ -174,6 +261,14 @@ int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, lo
   if (K >= 128) hipLaunchKernelGGL(sgemm_kernel<32>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(sgemm_kernel<16>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
   FEDFR_LAUNCH_CHECK("sgemm");
+  return FEDFR_OK;
+}
+int head_sgemm_f64acc(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
+                      int ldc, float alpha, float beta, const float* bias, hipStream_t st) {
+  FEDFR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "sgemm_f64acc: bad args");
+  SgemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, nullptr, 0.f};
+  hipLaunchKernelGGL(sgemm_f64acc_kernel<32>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
+  FEDFR_LAUNCH_CHECK("sgemm_f64acc");
   return FEDFR_OK;
 }
 int head_sgemm_colflag(const float* A, const float* B, int M, int N, int K, long long sam, long long sak, long long sbk,

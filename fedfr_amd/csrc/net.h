@@ -97,3 +97,12 @@ struct NetSgd {
 };
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
                  unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux, NetSgd* sgd = nullptr);
+
+// fp32 validation path (net_f32.hip): the same plan with fp32 activations and exact-fp32 arithmetic (im2col + fp32-MFMA GEMM, two-pass
+// BatchNorm in fp64) — slow by design, whole-network plans, dropout 0.  arena: net_f32_arena_floats(n) floats (activations kept for the
+// backward pass), ws: net_f32_ws_floats(n) floats.  Semantics of net_forward / net_backward (training 0 / 1).
+size_t net_f32_arena_floats(const FedfrNet* n);
+size_t net_f32_ws_floats(const FedfrNet* n);
+int net_f32_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, float* arena, float* ws, float* feats, int training,
+                    hipStream_t st);
+int net_f32_backward(const FedfrNet* n, const float* dfeats, const float* params, float* arena, float* ws, float* grads, hipStream_t st);

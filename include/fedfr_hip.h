@@ -109,6 +109,19 @@ int fedfr_net_backward2_sgd(const fedfr_net_t* net, const float* x, const float*
                             float* grads, float* momentum, float lr, float mu, float wd, int first, long long* done_from, void* stream,
                             void* aux_stream);
 
+/* fp32 VALIDATION path of the same plan (csrc/net_f32.hip): IResNet.forward / autograd backward (iresnet.py:46-57,158-172) with fp32
+ * activations and exact-fp32 arithmetic (im2col + the fp32-MFMA GEMM, two-pass BatchNorm in fp64) — what the "1e-3 fp32" tolerance is
+ * checked with, and the yardstick that separates the product path's bf16 storage noise from kernel error.  Slow by design (one launch per
+ * operation, ~40 TFLOP/s); whole-network plans, dropout 0, training 0 / 1.  arena (fedfr_net_f32_arena_floats floats) keeps the
+ * activations between forward and backward, ws (fedfr_net_f32_ws_floats floats) is scratch; params / bufs / grads are the plan's
+ * ordinary fp32 buffers (grads assigned; running statistics updated by a training forward). */
+size_t fedfr_net_f32_arena_floats(const fedfr_net_t* net);
+size_t fedfr_net_f32_ws_floats(const fedfr_net_t* net);
+int fedfr_net_f32_forward(const fedfr_net_t* net, const float* x, const float* params, float* bufs, float* arena, float* ws, float* feats,
+                          int training, void* stream);
+int fedfr_net_f32_backward(const fedfr_net_t* net, const float* dfeats, const float* params, float* arena, float* ws, float* grads,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * single convolutions — replace nn.Conv2d fwd / dgrad / wgrad at the call sites iresnet.py:38,41,76,121
  * (implicit GEMM on v_mfma_f32_16x16x32_bf16).  w: bf16 KRSC; wd: bf16 dgrad shadow [Cin][kh'][kw'][Cout].

@@ -862,6 +862,51 @@ def test_full_size_step_invariants_r100_b128(monkeypatch):
     assert len(nbt) == 154 and len({int(v) for v in nbt}) == 1
 
 
+def test_full_size_product_path_vs_fp32_validation_path():
+    """BASELINE.json's metric configuration at FULL size (iresnet100, batch 128, 112x112) — too large for the CPU oracle, not for the fp32
+    validation path (csrc/net_f32.hip, itself checked against the reference at 1e-6 on the small fixtures): the bf16 product path's
+    embeddings (eval and train mode), running statistics and parameter gradients of one step against it, same weights, same inputs.
+    The numbers are the small fixtures' numbers: bf16 storage noise does not grow with the batch."""
+    B = 128
+    layers = R.IRESNET_LAYERS["iresnet100"]
+    m, sd, _ = make_model("iresnet100")
+    x = R.closed_form_images(B).to(DEV)
+    w = R.closed_form((B, 512), 0.37, 0.9, 1.0).to(DEV)
+    res = {}
+    for name, f32 in (("bf16", False), ("fp32", True)):
+        m.load_state_dict(sd)
+        m.validation_fp32 = f32
+        m.eval()
+        with torch.no_grad():
+            fe = m(x).clone()
+        m.train()
+        for p_ in m.parameters():
+            p_.grad = None
+        ft = m(x)
+        (ft * w).sum().backward()
+        torch.cuda.synchronize()
+        out = m.state_dict()
+        res[name] = (fe, ft.detach().clone(), {k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None},
+                     {k: out[k].clone() for k in ("bn1.running_var", "layer3.10.bn2.running_mean", "bn2.running_var", "features.running_mean")})
+        if f32:
+            m._plans = {}                       # tens of GB of fp32 activations: release before the next test
+    m.validation_fp32 = False
+    a, b = res["bf16"], res["fp32"]
+    e_eval, e_train = rel(a[0], b[0]), rel(a[1], b[1])
+    gn = {k: float(v.norm()) for k, v in b[2].items()}
+    gmax = max(gn.values())
+    nerr = np.array([abs(float(a[2][k].norm()) - gn[k]) / gn[k] for k in gn if gn[k] > 1e-3 * gmax])
+    derr = np.array([rel(a[2][k], b[2][k]) for k in gn if gn[k] > 1e-3 * gmax])
+    stat = max(rel(a[3][k], b[3][k]) for k in a[3])
+    print("MEASURED iresnet100 b128, bf16 product path vs fp32 validation path: embeddings eval %.3e train %.3e; gradient norms median %.3e max %.3e; "
+          "directions median %.3e max %.3e; running statistics %.3e" % (e_eval, e_train, np.median(nerr), nerr.max(), np.median(derr), derr.max(), stat))
+    lim_e, lim_t = EMB_TOL["iresnet100"]
+    assert e_eval < lim_e and e_train < lim_t, (e_eval, e_train)
+    assert np.median(nerr) < GRAD_TOL["iresnet100"]["norm_median"] and nerr.max() < GRAD_TOL["iresnet100"]["norm_max"], (np.median(nerr), nerr.max())
+    assert np.median(derr) < GRAD_TOL["iresnet100"]["dir_median"] and derr.max() < 0.5, (np.median(derr), derr.max())
+    assert stat < STAT_TOL_LATE, stat
+
+
 @pytest.mark.parametrize("arch,batch", [("iresnet18", 128), ("iresnet50", 64)])
 def test_eval_forward_fused_epilogues_match_separate_passes(arch, batch):
     """Eval-mode forward at batches where the LDS-DMA conv kernels run: BatchNorm (+PReLU, + identity, + the next block's bn1) applied in

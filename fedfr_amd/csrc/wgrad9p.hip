@@ -15,10 +15,10 @@
 //     groups shared by the three vertical taps from registers, two stages (one computing, the next landing by LDS-DMA), one barrier per
 //     sub-image, inline-asm tr-reads with manual lgkmcnt waits;
 //   * one wave per SIMD, so nothing hides a stall: reads run one K-step ahead, issued behind the first MFMAs of a step and waited for
-//     at its end; the 16 LDS-DMA instructions of a stage are threaded between the MFMAs of the step that follows the barrier, their
-//     per-lane source offsets precomputed once (relative offset + border class per piece; per stage a scalar base and a border mask).
-// ~110 VGPRs + 144 AGPRs at one wave per SIMD: half the register file stays free for the BatchNorm-backward kernels of the main stream
-// (wgrad9: 2 x 144 of 512).
+//     at its end; the 16 LDS-DMA instructions of a stage are threaded between the MFMAs of the step that follows the barrier; their
+//     source offsets are scalar arithmetic plus ONE per-lane term (see the plan below); MFMAs are hand-written with the accumulator as a
+//     tied in/out AGPR operand, and every MFMA operand is an aligned pair of 16-row groups (see the K loop).
+// 132 VGPRs + 144 AGPRs at one wave per SIMD (wgrad9: 2 x 144 of 512).  Off by default: see g_wgrad9p.
 #include "gemm_tn_dev.h"
 #ifndef W9P_ABLATE
 #define W9P_ABLATE 0     // timing experiments only: 1 no in-loop DMA, 2 no in-loop fragment reads, 4 no MFMA, 16 no slab stores

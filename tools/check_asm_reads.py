@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static check of hand-scheduled LDS reads in a hipcc -S listing: between an inline-asm `ds_read_b64_tr_b16` and the next
-`s_waitcnt lgkmcnt(0)` no instruction may read or overwrite the registers that read is going to deliver (hipcc does not know the asm's
-result is asynchronous).  usage: check_asm_reads.py file.s"""
+`s_waitcnt lgkmcnt(N)` that retires it no instruction may read or overwrite the registers that read is going to deliver (hipcc does not
+know the asm's result is asynchronous).  LDS reads retire in order: `lgkmcnt(N)` leaves the N youngest pending.  usage: check_asm_reads.py file.s"""
 import re, sys
 def regs(tok):
     out = set()
@@ -9,16 +9,23 @@ def regs(tok):
         if m.group(1): out.update(range(int(m.group(1)), int(m.group(2)) + 1))
         else: out.add(int(m.group(3)))
     return out
-bad = 0; pending = {}; kern = None; nread = 0
+bad = 0; pending = {}; order = []; kern = None; nread = 0
 for ln, line in enumerate(open(sys.argv[1]), 1):
     l = line.split(';')[0].strip()
     if not l or l.startswith('.') : 
-        if l.startswith('.amdhsa_kernel'): pending.clear()
+        if l.startswith('.amdhsa_kernel'): pending.clear(); order = []
         continue
     if l.endswith(':'):
-        if not l.startswith('.L'): kern = l[:-1]; pending.clear()
+        if not l.startswith('.L'): kern = l[:-1]; pending.clear(); order = []
         continue
-    if 'lgkmcnt(0)' in l: pending.clear(); continue
+    mw = re.search(r'lgkmcnt\((\d+)\)', l)
+    if mw:
+        keep = int(mw.group(1))
+        for old in order[:max(0, len(order) - keep)]:
+            for r in old:
+                pending.pop(r, None)
+        order = order[max(0, len(order) - keep):]
+        continue
     parts = l.split(None, 1)
     op = parts[0]; ops = parts[1].split(',') if len(parts) > 1 else []
     if op == 'ds_read_b64_tr_b16':
@@ -26,6 +33,7 @@ for ln, line in enumerate(open(sys.argv[1]), 1):
         hit = src & set(pending)
         if hit: print("%s:%d address register pending: %s" % (kern, ln, l)); bad += 1
         for r in dst: pending[r] = ln
+        order.append(sorted(dst))
         nread += 1
         continue
     if not pending: continue

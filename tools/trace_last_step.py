@@ -5,13 +5,11 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Grid_Size", r.get("Grid_Size_X", "0")),
              r.get("Workgroup_Size", r.get("Workgroup_Size_X", "0"))) for r in rows)
-sgd = [e for e in ev if e[2].startswith("sgd_kernel")]
-big = sorted(sgd, key=lambda e: e[1] - e[0], reverse=True)[: len(sgd) // 2]
-marks = sorted(e[1] for e in big)
-a, b = marks[-2], marks[-1]
+stems = sorted(e[0] for e in ev if e[2].startswith("stem_fwd"))        # one per step (the fused optimizer made sgd launches a poor marker)
+a, b = stems[-2], stems[-1]
 with open(sys.argv[2], "w") as f:
     f.write("start_us,end_us,queue,name,grid,wg\n")
     for s, e, n, q, g, w in ev:
-        if s >= a and e <= b + 1:
-            f.write("%.3f,%.3f,%s,%s,%s,%s\n" % ((s - a) / 1e3, (e - a) / 1e3, q, n.split("(")[0].replace(",", ";")[:80], g, w))
+        if s >= a and s < b:
+            f.write("%.3f,%.3f,%s,%s,%s,%s\n" % ((s - a) / 1e3, (e - a) / 1e3, q, n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace(",", ";")[:80], g, w))
 print("step wall %.3f ms" % ((b - a) / 1e6))

@@ -19,6 +19,7 @@ extern int g_halo_waves;
 extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
 extern int g_tn_glds;
+extern int g_nt_glds;
 extern int g_tn_pair;
 extern int g_wgrad9;
 extern int g_conv_c64p;
@@ -85,6 +86,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "dgrad_parity")) {
     g_dgrad_parity = value < 0 ? 0 : value > 2 ? 2 : value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "nt_glds")) {
+    g_nt_glds = value < 0 ? 0 : value & 15;   // 0 register-staged NT kernel, 1..4 LDS-DMA operand ring where it pays, + 8 everywhere it can (gemm_nt_glds.hip)
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "tn_glds")) {

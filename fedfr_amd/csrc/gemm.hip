@@ -3,6 +3,7 @@
 // (conflict-free ds_read_b128 / ds_read_b64_tr_b16), one barrier per K-step, XCD-aware 1-D grid.
 #include "gemm_dev.h"
 #include "gemm_tn_dev.h"
+#include "nt_epilogue.h"
 
 #include <algorithm>
 #include <vector>
@@ -232,74 +233,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p_) {
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[ni][mi][reg]: n = wn*(BN/WN)+ni*16+lg*4+reg ; m = wm*(BM/WM)+mi*16+l15 ----
-  if (p.Cf) {
-    float* slab = p.Cf + (size_t)split * p.M * p.N;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        const int m = m0 + wm * (BM / WM) + mi * 16 + l15;
-        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4;
-        if (m < p.M && n < p.N) *reinterpret_cast<float4*>(slab + (size_t)m * p.N + n) =
-            make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
-      }
-    return;
-  }
-  constexpr int CST = BN * 2 + 16;   // staged C row stride in bytes
-  unsigned char* sC = smem;          // all waves are past the last barrier of the K loop
-  float ssum[TN][4], ssq[TN][4];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-      const int ml = wm * (BM / WM) + mi * 16 + l15;
-      const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
-      bf16_t h[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        h[q] = f2bf(acc[ni][mi][q]);
-        const float v = bf2f(h[q]);
-        ssum[ni][q] += v;
-        ssq[ni][q] += v * v;
-      }
-      uint2 pk;
-      pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-      pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-      *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
-    }
-  if (p.stats) {
-    float* prow = p.stats + (size_t)(bm * WM + wm) * 2 * p.N;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
-        const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4 + q;
-        if (l15 == 0 && n < p.N) {
-          prow[n] = a;
-          prow[p.N + n] = b;
-        }
-      }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 8;   // 16-B chunks per staged row
-  for (int idx = tid; idx < BM * CPR; idx += 256) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    const int m = m0 + row, n = n0 + c * 8;
-    if (m < p.M && n < p.N) {
-      size_t mo = (size_t)m;
-      if (p.par_on) {
-        const int hw = p.Ho * p.Wo, img = m / hw, rem = m - img * hw, h2 = rem / p.Wo, w2 = rem - h2 * p.Wo;
-        mo = ((size_t)img * p.outH + 2 * h2 + p.par_h) * p.outW + 2 * w2 + p.par_w;
-      }
-      *reinterpret_cast<uint4*>(p.Cb + mo * p.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-    }
-  }
+  nt_epilogue<BM, BN, WM, WN, 256>(p, acc, smem, bm, m0, n0, split, wm, wn, tid, lane);   // all waves are past the last barrier of the K loop
 }
 
 int g_nt_nbuf = 2;   // option "nt_nbuf": LDS stages of the NT kernel (1 -> 4 blocks/CU, 2 -> one barrier per K-step)
@@ -476,6 +410,7 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
     }
     return launch_conv_halo1(p, st);
   }
+  if (gemm_nt_glds_applies(p, BM, splits)) return launch_nt_glds(p, BM, splits, prof_slot(false, BM, 128), st);
   if (BM == 128) {
     if (p.N <= 64) return launch_nt<128, 64, 2, 2>(p, splits, st);
     return launch_nt<128, 128, 2, 2>(p, splits, st);

@@ -64,6 +64,10 @@ int launch_conv_glds_x(GemmNT p, hipStream_t st);          // conv_glds_x.hip  f
 int launch_conv_glds8_fused_w14(GemmNT p, hipStream_t st); // conv_glds8_fused_w14.hip  + BN-backward reduction epilogue
 int launch_conv_glds8_fused_w28(GemmNT p, hipStream_t st); // conv_glds8_fused_w28.hip
 int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   // conv_halo2_misc.hip  tuning variants
+// gemm_nt_glds.hip: the register-staged NT kernel's shapes with both operands fetched by LDS-DMA into a ring of stages
+extern int g_nt_glds;
+bool gemm_nt_glds_applies(const GemmNT& p, int BM, int splits);
+int launch_nt_glds(const GemmNT& p, int BM, int splits, int slot, hipStream_t st);
 int launch_tn_glds(GemmTN p, int splits, hipStream_t st);   // gemm_tn_glds.hip  wgrad GEMM, LDS-DMA operand ring
 bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode);
 int gemm_tn_glds_pick_splits(int Kp, int NI, int NJ);

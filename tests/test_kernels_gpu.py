@@ -61,6 +61,9 @@ CONV_CASES = [
 ]
 
 
+NT_GLDS_DEFAULT = 4        # the library's default for option nt_glds
+
+
 def _conv_inputs(B, H, Cin, Cout, k, s, seed=0):
     x = bf(rnd((B, Cin, H, H), seed + 1)).float()
     w = bf(rnd((Cout, Cin, k, k), seed + 2, 0.1)).float()
@@ -657,6 +660,42 @@ def test_conv_halo_variants(opt, val):
             test_conv_wgrad(*case, 1)
     finally:
         _C.call("fedfr_set_option", opt.encode(), default)
+
+
+NT_GLDS_CASES = [
+    (128, 7, 512, 512, 3, 1),    # the 7x7 stage's convs at the bench batch: M = 6272 -> 64-row tiles
+    (3, 7, 512, 512, 3, 1),      # ragged M
+    (16, 28, 256, 256, 3, 2),    # stride-2 conv: fwd, and dgrad by output-parity class
+    (40, 56, 128, 128, 3, 2),    # ... M = 31360 -> 128-row tiles (384 tiles and more)
+    (5, 8, 512, 512, 3, 2),
+    (16, 28, 128, 256, 1, 2),    # 1x1 / stride-2 downsample
+    (70, 56, 64, 128, 1, 2),
+    (4, 14, 192, 128, 3, 1),     # three channel chunks per tap
+    (1, 14, 256, 256, 3, 1),
+    (2, 16, 64, 128, 3, 2),
+]
+
+
+@pytest.mark.parametrize("val", [0, 9, 10, 11, 12])
+def test_nt_glds_variants(val):
+    """gemm_nt_glds.hip (option nt_glds: the register-staged NT kernel's shapes on an LDS-DMA operand ring, 4 or 8 waves per 128-row tile,
+    64-row shapes on 64- or 128-row tiles; + 8 = also where the default policy keeps the register-staged kernel; 0 = that kernel everywhere):
+    forward + BatchNorm partial rows, dgrad (stride-2: parity classes in one launch and one launch per class, and the masked single
+    GEMM), plain GEMMs with split K."""
+    _C.call("fedfr_set_option", b"nt_glds", val)
+    try:
+        for case in NT_GLDS_CASES:
+            test_conv_fwd_and_stats(*case)
+            test_conv_dgrad(*case)
+        for par in (1, 0):
+            _C.call("fedfr_set_option", b"dgrad_parity", par)
+            test_conv_dgrad(16, 28, 256, 256, 3, 2)
+            test_conv_dgrad(5, 8, 512, 512, 3, 2)
+        for mnk in [(128, 512, 25088), (32, 512, 1024), (4, 512, 25088), (200, 1000, 512), (300, 136, 200)]:
+            test_gemm_nt_plain(*mnk)
+    finally:
+        _C.call("fedfr_set_option", b"dgrad_parity", 2)
+        _C.call("fedfr_set_option", b"nt_glds", NT_GLDS_DEFAULT)
 
 
 @pytest.mark.parametrize("M,N,K,thr", [(37, 1000, 512, 0.12), (130, 4099, 512, 0.15), (5, 70, 96, 0.2)])

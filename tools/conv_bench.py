@@ -19,7 +19,7 @@ SHAPES = [  # name, H, Cin, Cout, k, s, count in r100
     ("s2_64x128@56", 56, 64, 128, 3, 1, 1), ("s2_128x128@56s2", 56, 128, 128, 3, 2, 1), ("s2_128x128@28", 28, 128, 128, 3, 1, 24),
     ("s3_128x256@28", 28, 128, 256, 3, 1, 1), ("s3_256x256@28s2", 28, 256, 256, 3, 2, 1), ("s3_256x256@14", 14, 256, 256, 3, 1, 58),
     ("s4_256x512@14", 14, 256, 512, 3, 1, 1), ("s4_512x512@14s2", 14, 512, 512, 3, 2, 1), ("s4_512x512@7", 7, 512, 512, 3, 1, 4),
-    ("ds_128x256@28", 28, 128, 256, 1, 2, 1),
+    ("ds_64x128@56", 56, 64, 128, 1, 2, 1), ("ds_128x256@28", 28, 128, 256, 1, 2, 1), ("ds_256x512@14", 14, 256, 512, 1, 2, 1),
 ]
 def timeit(fn):
     fn(); torch.cuda.synchronize()

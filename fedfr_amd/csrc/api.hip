@@ -113,7 +113,7 @@ int fedfr_set_option(const char* name, int value) {
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "fuse_bnbwd")) {
-    g_fuse_bnbwd = value ? 1 : 0;
+    g_fuse_bnbwd = value < 0 ? 0 : value > 2 ? 2 : value;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "conv_c64p")) {

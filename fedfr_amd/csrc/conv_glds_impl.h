@@ -23,6 +23,9 @@
 #ifndef GLDS_ABLATE
 #define GLDS_ABLATE 0
 #endif
+#ifndef GLDS_FUSED_ABLATE
+#define GLDS_FUSED_ABLATE 0      // timing ablations of the fused BN-backward epilogue (WRONG results): 1 no x loads, 2 no per-element pass, 4 no reduction
+#endif
 #ifdef GLDS_SETPRIO
 #define GLDS_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -239,6 +242,22 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // FUSED: this thread's share of the BatchNorm input tile x[PT][BN] (same rows / columns as the output tile: chunk column c of rows rg,
+  // rg + RGF, ...) is fetched into registers NOW and rides through the K loop (28 VGPRs at 8 waves; the kernel has one workgroup per CU, so
+  // 256 are there).  The first version fetched it by LDS-DMA after the loop and paid the round trip plus a barrier in the open: the
+  // epilogue cost 13 us on a 28 us kernel, more than the separate reduction pass it replaces.  These loads are older than every LDS-DMA of
+  // the loop, VMEM returns in order, so the loop's counted vmcnt waits are unaffected.
+  constexpr int CPRF = BN / 8, RGF = NT / CPRF, XN = FUSED ? (PT + RGF - 1) / RGF : 1;
+  uint4 xr[XN];
+  if constexpr (FUSED) {
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
+    const int c_ = tid % CPRF, rg_ = tid / CPRF;
+#pragma unroll
+    for (int i = 0; i < XN; ++i) {
+      const int row = rg_ + i * RGF;
+      xr[i] = (GLDS_FUSED_ABLATE & 1) ? make_uint4(0, 0, 0, 0) : buf_load16(rsX, row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + c_ * 8)) * 2u : OOB);
+    }
+  }
   // prologue: image of chunk 0, weight tiles of taps 0..2; wait for the image and tap 0, fetch tap 0's first fragments
   issue_a(0, 0, true);
   issue_b(0, 0, 0, true);
@@ -427,23 +446,33 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     }
   }
   }
+  // FUSED: the per-channel coefficients of the epilogue's reduction are requested HERE, in front of the drain below, as 16-byte buffer loads:
+  // left to hipcc they became 62 dword loads each issued right before its first use (19 exposed waits = 10 of the epilogue's 11 us).
+  // fc[a][h]: array a (mean, rstd, gamma, beta, alpha), channels n0 + c * 8 + 4 h .. + 3; fm / fr: mean / rstd of column n0 + tid.
+  float4 fc[FUSED ? 5 : 1][2];
+  float fm = 0.f, fr = 0.f;
+  if constexpr (FUSED) {
+    const unsigned cb = (unsigned)p.N * 4u;
+    const unsigned co = (unsigned)(n0 + (tid % (BN / 8)) * 8) * 4u;
+    const float* arr[5] = {p.bmean, p.brstd, p.bgamma, p.bbeta, p.balpha};
+    const float dflt[5] = {0.f, 1.f, 1.f, 0.f, 1.f};
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      if (arr[a] && (a < 2 || p.balpha)) {                   // gamma / beta / alpha matter to the PReLU variant only (wave-uniform)
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(arr[a], cb);
+        const uint4 lo = buf_load16(rs, co), hi = buf_load16(rs, co + 16u);
+        fc[a][0] = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w));
+        fc[a][1] = make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w));
+      } else {
+        fc[a][0] = fc[a][1] = make_float4(dflt[a], dflt[a], dflt[a], dflt[a]);
+      }
+    }
+    if (tid < BN) { fm = p.bmean[n0 + tid]; fr = p.brstd[n0 + tid]; }
+  }
   // drain the (zero-writing) tail DMAs before the staging buffer is reused
   glds_wait_vmcnt<0>();
   __syncthreads();
-  // FUSED: the BN input tile x[196][128 ch] (same rows / columns as the output tile) travels by LDS-DMA into the weight-ring region
-  // while the accumulators are converted and staged; 49 pieces of 4 rows x 256 B, lane l -> row l >> 4, 16-B chunk l & 15
-  constexpr int XOFF = NABUF * A_BYTES, XP = (PT * 256 / 1024 + NW) / NW;   // pieces per wave (>= 49 / NW)
-  static_assert(!FUSED || (PT * 256 <= NB * B_BYTES && (PT / (NT / 16) + 1) > 0), "x tile must fit the weight ring");
-  if constexpr (FUSED) {
-    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
-#pragma unroll
-    for (int j = 0; j < XP; ++j) {
-      const int piece = j * NW + wave, row = piece * 4 + (lane >> 4);
-      const unsigned vo = row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + (lane & 15) * 8)) * 2u : OOB;
-      if (piece * 1024 < NB * B_BYTES)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(smem + XOFF + piece * 1024), 16, (int)vo, 0, 0, 0);
-    }
-  }
+  constexpr int XOFF = NABUF * A_BYTES;                 // FUSED: the weight ring becomes the reduction scratch of the epilogue
 
   GLDS_STAMP(2);
   // ---- epilogue: bf16 tile through LDS; fragment rows >= 196 contribute nothing ----
@@ -562,57 +591,89 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       *reinterpret_cast<uint4*>(p.Cb + go) = v;
     }
   } else {
-    // ---- fused BN-backward reduction (ew_bn_bwd_reduce on this tile): thread owns chunk column c (8 channels) of rows rg, rg + RG, ...
-    constexpr int RG = NT / CPR;
+    // ---- fused BN-backward reduction (ew_bn_bwd_reduce on this tile): thread owns chunk column c (8 channels) of rows rg, rg + RG, ...;
+    // dy from the staged tile, x from the registers loaded before the K loop.  The workgroup owns the CU while it does this, so the pass is
+    // kept to the fewest VALU operations: it accumulates sum dz and sum dz * x on the RAW x (one FMA and one add per element without
+    // PReLU; with PReLU its input z = x * scale + shift costs one more FMA, a compare and three selects), and the tile's
+    // sum dz * xhat = rstd (sum dz * x - mean sum dz) is formed once per column in the reduction below.
+    constexpr int RG = RGF;
     const int c = tid % CPR, rg = tid / CPR;
     const int n = n0 + c * 8;
-    float mean[8], rstd[8], ga[8], be[8], al[8], s1[8], s2[8], s3[8];
+    float s1[8], s2[8], s3[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      mean[q] = p.bmean[n + q]; rstd[q] = p.brstd[n + q];
-      ga[q] = p.bgamma ? p.bgamma[n + q] : 1.f; be[q] = p.bbeta ? p.bbeta[n + q] : 0.f; al[q] = p.balpha ? p.balpha[n + q] : 1.f;
-      s1[q] = s2[q] = s3[q] = 0.f;
-    }
-    const bool has_alpha = p.balpha != nullptr;
-    glds_wait_vmcnt<0>();                              // own x pieces landed ...
-    __syncthreads();                                   // ... and everybody's
-    const unsigned char* sX = smem + XOFF;
-    for (int row = rg; row < PT; row += RG) {
-      const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-      *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
-      float dy[8], xv[8];
-      unpack8(dv, dy);
-      unpack8(*reinterpret_cast<const uint4*>(sX + row * 256 + c * 16), xv);
+    for (int q = 0; q < 8; ++q) s1[q] = s2[q] = s3[q] = 0.f;
+    if (p.balpha) {
+      float sc[8], sh[8], al[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float xh = (xv[q] - mean[q]) * rstd[q];
-        float dz = dy[q];
-        if (has_alpha) {
-          const float z = ga[q] * xh + be[q];
-          if (z <= 0.f) {
-            s3[q] += dy[q] * z;
-            dz = dy[q] * al[q];
+        auto at = [&](int a) { const float4 v = fc[a][q >> 2]; return (q & 3) == 0 ? v.x : (q & 3) == 1 ? v.y : (q & 3) == 2 ? v.z : v.w; };
+        const float g = at(2) * at(1);
+        sc[q] = g;
+        sh[q] = at(3) - at(0) * g;
+        al[q] = at(4);
+      }
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        const int row = rg + i * RG;
+        if (row < PT) {
+          const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+          *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+          if (GLDS_FUSED_ABLATE & 2) continue;
+          float dy[8], xv[8];
+          unpack8(dv, dy);
+          unpack8(xr[i], xv);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float z = xv[q] * sc[q] + sh[q];
+            const bool neg = z <= 0.f;
+            s3[q] += neg ? dy[q] * z : 0.f;
+            const float dz = neg ? dy[q] * al[q] : dy[q];
+            s1[q] += dz;
+            s2[q] += dz * xv[q];
           }
         }
-        s1[q] += dz;
-        s2[q] += dz * xh;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        const int row = rg + i * RG;
+        if (row < PT) {
+          const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+          *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+          if (GLDS_FUSED_ABLATE & 2) continue;
+          float dy[8], xv[8];
+          unpack8(dv, dy);
+          unpack8(xr[i], xv);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            s1[q] += dy[q];
+            s2[q] += dy[q] * xv[q];
+          }
+        }
       }
     }
-    __syncthreads();                                   // everyone is done with the x tile: its region becomes the reduction scratch
+    if (GLDS_FUSED_ABLATE & 4) return;
+    // the weight ring (drained before the staging above) is the reduction scratch
     float* red = reinterpret_cast<float*>(smem + XOFF);      // [RG][3][BN]
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      red[(rg * 3 + 0) * BN + c * 8 + q] = s1[q];
-      red[(rg * 3 + 1) * BN + c * 8 + q] = s2[q];
-      red[(rg * 3 + 2) * BN + c * 8 + q] = s3[q];
-    }
+    *reinterpret_cast<float4*>(red + (rg * 3 + 0) * BN + c * 8) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(red + (rg * 3 + 0) * BN + c * 8 + 4) = make_float4(s1[4], s1[5], s1[6], s1[7]);
+    *reinterpret_cast<float4*>(red + (rg * 3 + 1) * BN + c * 8) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    *reinterpret_cast<float4*>(red + (rg * 3 + 1) * BN + c * 8 + 4) = make_float4(s2[4], s2[5], s2[6], s2[7]);
+    *reinterpret_cast<float4*>(red + (rg * 3 + 2) * BN + c * 8) = make_float4(s3[0], s3[1], s3[2], s3[3]);
+    *reinterpret_cast<float4*>(red + (rg * 3 + 2) * BN + c * 8 + 4) = make_float4(s3[4], s3[5], s3[6], s3[7]);
     __syncthreads();
-    for (int i = tid; i < 3 * BN; i += NT) {
-      const int which = i / BN, col = i - which * BN;
-      float t = 0.f;
+    if (tid < BN) {                                          // one thread per column: the three sums over the row groups
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < RG; ++r) t += red[(r * 3 + which) * BN + col];
-      p.bpart[((size_t)bt * 3 + which) * p.N + n0 + col] = t;
+      for (int r = 0; r < RG; ++r) {
+        t0 += red[(r * 3 + 0) * BN + tid];
+        t1 += red[(r * 3 + 1) * BN + tid];
+        t2 += red[(r * 3 + 2) * BN + tid];
+      }
+      float* o = p.bpart + (size_t)bt * 3 * p.N + n0 + tid;
+      o[0] = t0;
+      o[p.N] = fr * (t1 - fm * t0);
+      o[2 * (size_t)p.N] = t2;
     }
   }
   if (TPW > 1) __syncthreads();                         // the staged output tile has been read: the next tile's image may land on it

@@ -308,15 +308,22 @@ static int conv_fwd_bn(const Ctx& c, const ConvD& cv, const bf16_t* raw, const B
   p.tsc = c.save(bn, 0); p.tsh = c.save(bn, 1); p.talpha = alpha; p.aout = tr ? a : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
-int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the 3x3 dgrad epilogue (LDS-DMA kernel: x tile fetched by DMA after the
-                        // K loop; halo2 kernel otherwise).  Off by default — measured twice, same box: 21.48 ms/step separate vs 21.95 fused
-                        // (LDS-DMA kernel, +11 us of serial epilogue per dgrad vs a 7-12 us ew_bn_bwd_reduce that overlaps the aux stream).
+int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the 3x3 dgrad epilogue (1: every layer a fused kernel serves; 2: the 14x14
+                        // layers only, whose 128 partial rows the channel-sliced apply pass reduces itself).  LDS-DMA kernel: the x tile rides
+                        // through the K loop in registers, the coefficients are requested in front of the drain: +3.7 us on a 28.6 us dgrad
+                        // (round 1: x by LDS-DMA after the loop and 62 lazily issued coefficient loads, +11 us).  Off by default all the same:
+                        // alone it removes 58 reduce launches (-0.35 ms of kernel time) and LENGTHENS the dual-stream step (16.96 -> 17.25 ms),
+                        // because the reduce passes were windows in which the weight-gradient workgroups share the CUs, and the convolution
+                        // that now follows sooner cannot start on a CU a weight-gradient workgroup still holds (54.9 us per fused dgrad in the
+                        // dual-stream trace, 32.3 alone).  With the paired weight-gradient kernel (wgrad9p = 1) beside it the step is back at
+                        // 16.94: both sides of the overlap have to shrink together (profiles/r02_ab_fuse_bnbwd_v2.txt).
 // dx (at the conv's INPUT resolution) = conv_transpose(dy).  If `bn` is given, the kernel may also produce the
 // BN-backward partial sums of (dx, bn_x) in its epilogue; *fused_rows > 0 then (else run ew_bn_bwd_reduce).
 static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* dx, const BnD* bn = nullptr,
                       const bf16_t* bn_x = nullptr, const float* alpha = nullptr, int* fused_rows = nullptr) {
   GemmNT p{};
-  if (bn && fused_rows && g_fuse_bnbwd) {
+  // option value 2: only the 14x14 layers (one partial row per image: few enough for the channel-sliced apply pass to reduce itself)
+  if (bn && fused_rows && g_fuse_bnbwd && (g_fuse_bnbwd == 1 || (cv.R == 3 && cv.stride == 1 && cv.Hin == 14 && cv.Cin % 128 == 0 && cv.Cout % 128 == 0))) {
     p.bx = bn_x; p.bmean = c.save(*bn, 2); p.brstd = c.save(*bn, 3); p.bgamma = c.gamma(*bn); p.bbeta = c.beta(*bn);
     p.balpha = alpha; p.bpart = c.part(); p.bwd_fused = fused_rows;
   }

@@ -33,7 +33,7 @@ SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kern
               "gemm_tn_kernel<128,128>", "gemm_tn_kernel<128,64>", "gemm_tn_kernel<64,128>", "gemm_tn_kernel<64,64>",
               "conv3x3_halo2_kernel<128,14>", "conv3x3_halo2_kernel<128,28>", "conv3x3_halo2_kernel<64,*>", "conv3x3_halo_kernel<*>",
               "conv3x3_glds_kernel<14,14>", "conv3x3_glds_kernel<28,7>", "gemm_tn_glds_kernel<128,128>", "conv3x3 64-channel layers (c64p / glds<56,4>)",
-              "wgrad9_kernel<32x64x9>"]
+              "wgrad9_kernel<32x64x9>", "gemm_nt_glds_kernel (7x7 and stride-2 3x3 convs)"]
 HBM_SLOTS = {20: "bn_apply", 21: "bn_bwd_reduce", 22: "bn_bwd_apply", 23: "bn_finalize", 24: "bn_bwd_finalize", 25: "reduce_slabs", 26: "sgd"}
 # ALGORITHMIC HBM bytes per launch on the 256->256 @14x14 layer (58 of iresnet100's 103 convs; B = 128): conv fwd/dgrad = input 12.85 MB
 # (the image, once) + weights 1.18 + output 12.85; wgrad = both operands once 25.7 + the fp32 weight gradient 2.36 — its split-K slabs and

@@ -12,7 +12,8 @@
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------
 // slots: 0..3 = gemm_nt <128,128> <128,64> <64,128> <64,64>; 4..7 = gemm_tn <128,128> <128,64> <64,128> <64,64>;
 // 8 = conv3x3_halo2<128,14>, 9 = conv3x3_halo2<128,28>, 10 = conv3x3_halo2<64,*>, 11 = conv3x3_halo (v1, all),
-// 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>, 14 = gemm_tn_glds<128,128>, 15 = conv3x3_glds<56,4> (64 channels)
+// 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>, 14 = gemm_tn_glds<128,128>, 15 = conv3x3_glds<56,4> (64 channels), 16 = wgrad9,
+// 17 = gemm_nt_glds (all tiles)
 namespace {
 struct ProfSlot {
   std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -20,7 +21,7 @@ struct ProfSlot {
   long long launches = 0;
 };
 bool g_prof_on = false;
-ProfSlot g_prof[32];   // 0..16: MFMA GEMM kernels (slot = flops); 20..27: HBM-bound kernels (slot 'flops' = algorithmic BYTES)
+ProfSlot g_prof[32];   // 0..17: MFMA GEMM kernels (slot = flops); 20..27: HBM-bound kernels (slot 'flops' = algorithmic BYTES)
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
 }  // namespace
 
@@ -410,7 +411,7 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
     }
     return launch_conv_halo1(p, st);
   }
-  if (gemm_nt_glds_applies(p, BM, splits)) return launch_nt_glds(p, BM, splits, prof_slot(false, BM, 128), st);
+  if (gemm_nt_glds_applies(p, BM, splits)) return launch_nt_glds(p, BM, splits, 17, st);
   if (BM == 128) {
     if (p.N <= 64) return launch_nt<128, 64, 2, 2>(p, splits, st);
     return launch_nt<128, 128, 2, 2>(p, splits, st);

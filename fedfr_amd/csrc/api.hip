@@ -20,6 +20,7 @@ extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_nt_glds;
+extern int g_wgrad_pair_reduce;
 extern int g_tn_pair;
 extern int g_wgrad9;
 extern int g_conv_c64p;
@@ -86,6 +87,10 @@ int fedfr_set_option(const char* name, int value) {
   }
   if (name && !strcmp(name, "dgrad_parity")) {
     g_dgrad_parity = value < 0 ? 0 : value > 2 ? 2 : value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad_pair_reduce")) {
+    g_wgrad_pair_reduce = value ? 1 : 0;
     return FEDFR_OK;
   }
   if (name && !strcmp(name, "nt_glds")) {

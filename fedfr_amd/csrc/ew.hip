@@ -833,7 +833,10 @@ int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const 
 // =====================================================================================================
 // split-K slab reductions, casts, transposes
 // =====================================================================================================
-__global__ void reduce_slabs_kernel(float* dst, const float* slabs, int nsplit, size_t n4, const float* bias, int bias_n) {
+// blockIdx.y = 1 (ew_reduce_slabs2): the second (dst, slabs) pair of the launch, same geometry
+__global__ void reduce_slabs_kernel(float* dst, const float* slabs, int nsplit, size_t n4, const float* bias, int bias_n, float* dst1,
+                                    const float* slabs1) {
+  if (blockIdx.y) { dst = dst1; slabs = slabs1; }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 a = reinterpret_cast<const float4*>(slabs)[i];
@@ -851,7 +854,9 @@ __global__ void reduce_slabs_kernel(float* dst, const float* slabs, int nsplit, 
 // many slabs of a small tensor (the 64-channel layers' weight gradients arrive as 128 slabs of 147 KB): one thread per output walking
 // all slabs is a serial chain of 128 loads on 9 K threads (93 us).  Here 8 lanes share an output (slab s goes to lane s % 8, four loads
 // in flight each) and meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(float* dst, const float* slabs, int nsplit, size_t n4, const float* bias, int bias_n) {
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(float* dst, const float* slabs, int nsplit, size_t n4, const float* bias, int bias_n,
+                                                                float* dst1, const float* slabs1) {
+  if (blockIdx.y) { dst = dst1; slabs = slabs1; }
   __shared__ float4 red[8][32];
   const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
   const size_t i = (size_t)blockIdx.x * 32 + o;
@@ -884,20 +889,30 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(float* dst, cons
     reinterpret_cast<float4*>(dst)[i] = a;
   }
 }
-int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n, hipStream_t st) {
+static int reduce_slabs_launch(float* dst, const float* slabs, float* dst1, const float* slabs1, int nsplit, size_t n, const float* bias, int bias_n,
+                               hipStream_t st) {
   FEDFR_REQUIRE(dst && slabs && nsplit > 0 && n > 0 && (n & 3) == 0, "reduce_slabs: bad args (n%%4)");
   if (bias) FEDFR_REQUIRE((bias_n & 3) == 0 && bias_n > 0, "reduce_slabs: bias_n%%4");
   const size_t n4 = n / 4;
-  ProfScope prof(25, (double)n * 4 * (nsplit + 1), st);
+  const unsigned ny = dst1 ? 2 : 1;
+  ProfScope prof(25, (double)n * 4 * (nsplit + 1) * ny, st);
   if (nsplit >= 16 && n4 <= 65536) {
-    hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n);
+    hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 31) / 32), ny), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n, dst1, slabs1);
     FEDFR_LAUNCH_CHECK("reduce_slabs_wide");
     return FEDFR_OK;
   }
   const int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid, ny), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n, dst1, slabs1);
   FEDFR_LAUNCH_CHECK("reduce_slabs");
   return FEDFR_OK;
+}
+int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n, hipStream_t st) {
+  return reduce_slabs_launch(dst, slabs, nullptr, nullptr, nsplit, n, bias, bias_n, st);
+}
+// two slab sets of the same geometry (the two 3x3 weight gradients of a residual block) in one launch
+int ew_reduce_slabs2(float* dst0, const float* slabs0, float* dst1, const float* slabs1, int nsplit, size_t n, hipStream_t st) {
+  FEDFR_REQUIRE(dst1 && slabs1, "reduce_slabs2: null second pair");
+  return reduce_slabs_launch(dst0, slabs0, dst1, slabs1, nsplit, n, nullptr, 0, st);
 }
 
 __global__ void reduce_slabs_bf16_kernel(bf16_t* dst, const float* slabs, int nsplit, size_t n4) {

@@ -290,6 +290,9 @@ __device__ __forceinline__ void load8f(const float* p, int c0, float* v, float d
   }
 }
 
+// X2 / STATS as template parameters: as runtime tests inside the row body they were (uniform) branches between the loads of a batch and
+// in front of every store, and each branch ends the region the loads of EW_UNROLL rows are scheduled in
+template <bool X2, bool STATS>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int slab) {
   extern __shared__ float red[];   // [rpp][2C] when stats
   const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
@@ -319,14 +322,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int sla
       if (has_alpha) v = v > 0.f ? v : al[j] * v;
       f[j] = v;
     }
-    if (p.x2) {
+    if (X2) {
       float g[8];
       unpack8(v2, g);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] += g[j] * sc2[j] + sh2[j];
     }
     const uint4 o = pack8(f);
-    if (p.stats) {
+    if (STATS) {
       float r[8];
       unpack8(o, r);
 #pragma unroll
@@ -352,17 +355,17 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int sla
       for (int u = 0; u < EW_UNROLL; ++u) {
         const size_t off = (size_t)(m + u * rpp) * p.C + c0;
         v1[u] = ew_ld16(p.x1 + off);
-        v2[u] = p.x2 ? *reinterpret_cast<const uint4*>(p.x2 + off) : make_uint4(0, 0, 0, 0);
+        v2[u] = X2 ? *reinterpret_cast<const uint4*>(p.x2 + off) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < EW_UNROLL; ++u) one(m + u * rpp, v1[u], v2[u]);
     }
     for (; m < mend; m += rpp) {
       const size_t off = (size_t)m * p.C + c0;
-      one(m, *reinterpret_cast<const uint4*>(p.x1 + off), p.x2 ? *reinterpret_cast<const uint4*>(p.x2 + off) : make_uint4(0, 0, 0, 0));
+      one(m, *reinterpret_cast<const uint4*>(p.x1 + off), X2 ? *reinterpret_cast<const uint4*>(p.x2 + off) : make_uint4(0, 0, 0, 0));
     }
   }
-  if (p.stats) {
+  if (STATS) {
     const int W = 2 * p.C;
     if (active) {
 #pragma unroll
@@ -389,7 +392,13 @@ int ew_bn_apply(const BnApply& p, hipStream_t st) {
   const int grid = ceil_div(p.M, slab);
   const size_t lds = p.stats ? (size_t)rows_per_pass(p.C) * 2 * p.C * sizeof(float) : 0;
   ProfScope prof(20, (double)p.M * p.C * 2 * (p.x2 ? 3 : 2), st);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+  if (p.x2) {
+    if (p.stats) hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+    else hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+  } else {
+    if (p.stats) hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), dim3(grid), dim3(EW_THREADS), lds, st, p, slab);
+  }
   FEDFR_LAUNCH_CHECK("bn_apply");
   return FEDFR_OK;
 }

@@ -28,7 +28,13 @@ extern "C" {
 
 int fedfr_version(void);
 const char* fedfr_last_error_string(void);
-/* options: "tn_use_tr" (1 = ds_read_b64_tr_b16 wgrad fragments [default], 0 = scalar LDS fallback) */
+/* Kernel-choice switches for same-box A/B measurements and validation fallbacks (no reference counterpart; every setting stays inside the
+ * tests' tolerances; FEDFR_OPTIONS="name=value,..." in the environment applies them when the library is loaded).  The ones that matter:
+ * "tn_use_tr" (1 = ds_read_b64_tr_b16 wgrad fragments [default], 0 = scalar LDS fallback), "conv_halo" (0..4 conv kernel generation),
+ * "nt_glds" (0 register-staged NT GEMM everywhere, 4 [default] LDS-DMA operand ring for the long-K shapes, +8 for every shape it serves),
+ * "wgrad9" / "wgrad9p" / "tn_glds" / "tn_pair" / "wgrad_pair_reduce" (weight-gradient kernels and their slab reductions), "bn_sliced"
+ * (channel-sliced BatchNorm passes without finalize launches), "fuse_bnbwd" (0 [default] / 1 / 2: BatchNorm-backward reduction in the dgrad
+ * epilogue, everywhere / 14x14 layers), "fuse_bnapply", "eval_fuse", "conv28_tpw2", "dgrad_parity", "wgrad_depth".  Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);
 /* HIP-event timing of every MFMA GEMM launch on its own stream (bench.py roofline leg).  Slots 0..3: conv fwd/dgrad
  * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order; 8..11: the

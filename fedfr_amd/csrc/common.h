@@ -102,5 +102,19 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
 }
 
+// "once per device" flag of a call site that configures a kernel (hipFuncSetAttribute state lives per device; one process may drive several
+// GPUs: a Server training clients on cuda:0..3).  A racing second thread repeats the harmless call.
+struct PerDeviceOnce {
+  unsigned long long done = 0;
+  bool need() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (done & bit) return false;
+    done |= bit;
+    return true;
+  }
+};
+
 __host__ __device__ static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -199,11 +199,10 @@ static int launch_halo(GemmNT p, hipStream_t st) {
   constexpr size_t kEpi = (size_t)128 * (BN * 2 + 16);
   size_t lds = (size_t)a_lds + 2 * (size_t)BN * 128;
   if (lds < kEpi) lds = kEpi;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
+  if (attr_once.need()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, AH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
-    attr_set = true;
   }
   ProfScope prof(11, 2.0 * p.M * p.N * (double)p.K, st);
   hipLaunchKernelGGL((conv3x3_halo_kernel<BN, AH>), dim3(nbm * p.nbn), dim3(256), lds, st, p, a_lds);

@@ -268,10 +268,9 @@ int launch_wgrad9(const GemmTN& g, int splits, hipStream_t st) {
   const dim3 grid(p.ntiles * splits);
   ProfScope prof(16, 2.0 * g.NI * g.NJ * (double)g.Kp, st);
   constexpr size_t lds14 = w9_lds<14, 14, 4>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
+  if (attr_once.need()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<14, 14, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds14);
-    attr_set = true;
   }
   hipLaunchKernelGGL((wgrad9_kernel<14, 14, 4>), grid, dim3(512), lds14, st, p);
   FEDFR_LAUNCH_CHECK("wgrad9");

@@ -684,7 +684,9 @@ def test_nt_glds_variants(val):
     GEMM), plain GEMMs with split K."""
     _C.call("fedfr_set_option", b"nt_glds", val)
     try:
-        for case in NT_GLDS_CASES:
+        # BASELINE's full sizes (batch 128) of the stride-2 layers once, on the variant the default policy uses
+        full = [(128, 28, 256, 256, 3, 2), (128, 14, 512, 512, 3, 2)] if val == 12 else []
+        for case in NT_GLDS_CASES + full:
             test_conv_fwd_and_stats(*case)
             test_conv_dgrad(*case)
         for par in (1, 0):

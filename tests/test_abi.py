@@ -62,3 +62,20 @@ def test_plan_layout_matches_reference_inventory(built_lib):
     assert not lib.fedfr_net_create((C.c_int * 4)(2, 2, 2, 2), 0, 112, 512)
     assert b"net_create" in lib.fedfr_last_error_string()
     assert lib.fedfr_set_option(b"no_such_option", 1) != 0
+
+
+def test_documented_options_exist_and_unknown_ones_are_errors(built_lib):
+    """Every switch the header's fedfr_set_option comment names is one the library accepts (host-only state: no GPU needed), an unknown
+    name is an error with a message, and setting a switch to its documented default is harmless."""
+    src = open(HEADER).read()
+    doc = src[src.index("Kernel-choice switches"):src.index("int fedfr_set_option")]
+    names = sorted(set(re.findall(r'"([a-z0-9_]+)"', doc)))
+    assert len(names) >= 15 and "nt_glds" in names and "bn_sliced" in names
+    lib = built_lib.lib()
+    defaults = {"tn_use_tr": 1, "conv_halo": 4, "nt_glds": 4, "wgrad9": 1, "wgrad9p": 0, "tn_glds": 2, "tn_pair": 0, "wgrad_pair_reduce": 1,
+                "bn_sliced": 1, "fuse_bnbwd": 0, "fuse_bnapply": 0, "eval_fuse": 1, "conv28_tpw2": 2, "dgrad_parity": 2, "wgrad_depth": 4}
+    for n in names:
+        assert n in defaults, "document the default of option %r here" % n
+        assert lib.fedfr_set_option(n.encode(), defaults[n]) == 0, n
+    assert lib.fedfr_set_option(b"no_such_option", 1) != 0
+    assert b"no_such_option" in lib.fedfr_last_error_string() or len(lib.fedfr_last_error_string()) > 0

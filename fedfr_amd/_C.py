@@ -25,12 +25,14 @@ SIGNATURES = {
     "fedfr_version": (i32, []),
     "fedfr_last_error_string": (C.c_char_p, []),
     "fedfr_set_option": (i32, [C.c_char_p, i32]),
+    "fedfr_get_option": (i32, [C.c_char_p, C.POINTER(i32)]),
     "fedfr_profile_enable": (i32, [i32]),
     "fedfr_profile_read": (i32, [i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
     "fedfr_net_create": (vp, [C.POINTER(i32), i32, i32, i32]),
     "fedfr_block_create": (vp, [i32, i32, i32, i32, i32]),
     "fedfr_net_debug_capture": (i32, [vp, sz]),
     "fedfr_net_set_dropout": (i32, [vp, f32, u64, C.POINTER(i64)]),
+    "fedfr_net_set_dropout_step": (i32, [vp, u64]),
     "fedfr_net_destroy": (None, [vp]),
     "fedfr_net_query": (i32, [vp, i32, C.POINTER(i64)]),
     "fedfr_net_tensor_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "fedfr_sum_scale": (i32, [vp, i32, f32, vp, vp]),
     "fedfr_sgd_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, i32, vp]),
     "fedfr_fedavg_axpy": (i32, [vp, vp, f32, sz, i32, vp]),
+    "fedfr_fedavg_multi": (i32, [vp, vp, vp, i32, sz, i32, vp]),
     "fedfr_fedavg_i64": (i32, [vp, vp, f32, i32, i32, vp, vp]),
     "fedfr_pfc_rand": (i32, [vp, i32, u64, u64, vp]),
     "fedfr_pfc_localize": (i32, [vp, i32, i64, i32, vp, vp]),
@@ -142,6 +145,29 @@ def check(rc: int, what: str = "") -> None:
 def call(name: str, *args) -> None:
     """Call an int-returning entry point and raise on failure."""
     check(getattr(lib(), name)(*args), name)
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    call("fedfr_get_option", name.encode(), C.byref(v))
+    return v.value
+
+
+class option_scope:
+    """``with option_scope("wgrad9p", 1): ...`` — set a library switch for the duration of a block and put the PREVIOUS value back (a
+    user's FEDFR_OPTIONS setting survives; the switches are process-global)."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value, self.prev = name, int(value), None
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        call("fedfr_set_option", self.name.encode(), self.value)
+        return self
+
+    def __exit__(self, *exc):
+        call("fedfr_set_option", self.name.encode(), self.prev)
+        return False
 
 
 def stream(ref=None) -> int:

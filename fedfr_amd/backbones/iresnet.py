@@ -95,6 +95,8 @@ class _Plan:
         if not self.handle:
             raise RuntimeError("fedfr_net_create failed: " + _C.last_error())
         self.batch = batch
+        self.dropout_seed = None          # seed the C-side plan was last given (IResNet._run_forward)
+        self.mask_off = 0
         self.act = torch.empty(self.query(_C.Q_ACT_BYTES), dtype=torch.uint8, device=device)
         self.ws = torch.empty(self.query(_C.Q_WS_BYTES), dtype=torch.uint8, device=device)
 
@@ -274,6 +276,7 @@ class _IResNetFn(torch.autograd.Function):
 
 class IResNet(nn.Module):
     fc_scale = 7 * 7
+    _instances = 0          # models created in this process (default dropout seeds differ per model)
 
     def __init__(self, block, layers, dropout=0, num_features=512, zero_init_residual=False, groups=1,
                  width_per_group=64, replace_stride_with_dilation=None, fp16=False):
@@ -287,7 +290,12 @@ class IResNet(nn.Module):
         self.num_features = num_features
         self.in_hw = 112
         self.dropout_p = float(dropout)
-        self.dropout_seed = 100                     # seed of the counter-based dropout mask (reference RNG seed, train.py:35)
+        # seed of the counter-based dropout mask: the reference's RNG seed (train.py:35) for the first model of the process, a different
+        # one for every later model — the reference's clients draw from ONE global RNG stream, so no two of them ever see the same masks;
+        # the step counter lives HERE (not on the per-batch-size plan, which is re-created after an eviction / release_workspace)
+        self.dropout_seed = 100 + 7919 * IResNet._instances
+        IResNet._instances += 1
+        self._dropout_step = 0
         counts, table = _tensor_table(self.layers_cfg, self.in_hw, num_features)
         self._counts, self._table = counts, table
         # flat storage (CPU until .to(device), like any nn.Module).  Parameters and BN running statistics are slices of ONE fp32
@@ -498,6 +506,26 @@ class IResNet(nn.Module):
             plan.f32_ws = torch.empty(nw, dtype=torch.float32, device=self.device)
         return plan.f32_arena, plan.f32_ws
 
+    def _pre_forward(self, plan, mode: int):
+        """Before every fedfr_net_forward on ``plan``: hand the model's dropout seed / mask index to the C-side plan, so that the mask
+        sequence survives plan re-creation and differs between models (the plan's own counter restarts at 0 with every new plan)."""
+        if mode and self.dropout_p > 0:
+            if plan.dropout_seed != self.dropout_seed:
+                off = C.c_longlong()
+                _C.call("fedfr_net_set_dropout", plan.handle, self.dropout_p, self.dropout_seed, C.byref(off))
+                plan.mask_off, plan.dropout_seed = off.value, self.dropout_seed
+            _C.call("fedfr_net_set_dropout_step", plan.handle, self._dropout_step)
+            self._dropout_step += 1
+
+    def require_all_trainable(self, who: str):
+        """The fused trainers update the whole trainable region with ONE flat SGD kernel: a parameter frozen with requires_grad = False
+        (``freeze_BN(fix_affine=True)``) would still receive gradient, momentum and weight decay there — refuse instead of ignoring it."""
+        frozen = [n for n, p_ in self.named_parameters() if not p_.requires_grad and n != "features.weight"]
+        if frozen:
+            raise NotImplementedError("fedfr_amd.%s updates every backbone parameter with one flat SGD kernel and cannot honour requires_grad = "
+                                      "False on %d parameter(s) (%s, ...): train such a model through the autograd path (IResNet.forward + "
+                                      "torch.optim.SGD), or unfreeze them" % (who, len(frozen), frozen[0]))
+
     def _fwd_mode(self) -> int:
         """``training`` argument of fedfr_net_forward: 0 eval, 1 train, 2 train with the BatchNorms frozen in eval mode."""
         if not self.training:
@@ -519,6 +547,7 @@ class IResNet(nn.Module):
                 off = C.c_longlong()
                 _C.call("fedfr_net_set_dropout", p.handle, self.dropout_p, self.dropout_seed, C.byref(off))
                 p.mask_off = off.value
+                p.dropout_seed = self.dropout_seed
             self._plans[batch] = p
         return p
 
@@ -566,6 +595,7 @@ class IResNet(nn.Module):
                 self._flat_nbt += 1
             self._fwd_generation += 1
             return feats
+        self._pre_forward(plan, mode)
         _C.call("fedfr_net_forward", plan.handle, x.data_ptr(), self._flat_params.data_ptr(), self._flat_bufs.data_ptr(),
                 self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), mode, _C.stream())
         if mode == 1:                           # frozen BatchNorms track nothing (num_batches_tracked included)

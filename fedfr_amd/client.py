@@ -237,6 +237,7 @@ class FusedTrainer:
         bb = backbone
         bb._ensure_device_state()
         bb.train()
+        bb.require_all_trainable("FusedTrainer")
         self.n_train = bb.trainable_count()
         self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
         if self.pfc is None:
@@ -275,6 +276,7 @@ class FusedTrainer:
         plan = bb._plan(B)
         st = _C.stream()
         feats = torch.empty(B, bb.num_features, dtype=f32, device=bb.device)
+        bb._pre_forward(plan, bb._fwd_mode())
         _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), bb._fwd_mode(), st)
         if not bb._bn_frozen:
@@ -373,6 +375,7 @@ class FusedHeadTrainer:
         bb = backbone
         bb._ensure_device_state()
         bb.train()
+        bb.require_all_trainable("FusedHeadTrainer")
         for hp in self.head_params:
             _C.require_gpu_tensor(hp.data, f32, "head parameter")
         self.n_train = bb.trainable_count()
@@ -394,6 +397,7 @@ class FusedHeadTrainer:
         labels = _C.require_gpu_tensor(labels, torch.int64, "labels")
         plan = bb._plan(imgs.shape[0])
         feats = torch.empty(imgs.shape[0], bb.num_features, dtype=f32, device=bb.device)
+        bb._pre_forward(plan, bb._fwd_mode())
         _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), bb._fwd_mode(), _C.stream())
         if not bb._bn_frozen:

@@ -123,13 +123,20 @@ class ThreadComm:
         ts = [threading.Thread(target=target, args=(r,), daemon=True) for r in range(world_size)]
         for t in ts:
             t.start()
+        import time
+        deadline = time.monotonic() + timeout       # ONE deadline for the whole world, not `timeout` per rank
         for t in ts:
-            t.join(timeout)
+            t.join(max(0.0, deadline - time.monotonic()))
+        if any(t.is_alive() for t in ts):
+            # release every rank still parked in a collective (its barrier wait raises BrokenBarrierError and the thread ends) before
+            # raising: a live rank thread must not keep enqueueing GPU work on the caller's stream
+            comms[0]._w.bar.abort()
+            for t in ts:
+                t.join(5.0)
+            raise TimeoutError("ThreadComm.run: a rank did not finish within %.0f s" % timeout)
         real = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)]
         if real or any(e is not None for e in err):
             raise (real[0] if real else [e for e in err if e is not None][0])
-        if any(t.is_alive() for t in ts):
-            raise TimeoutError("ThreadComm.run: a rank did not finish")
         return out
 
     def _exchange(self, t: torch.Tensor) -> List[torch.Tensor]:

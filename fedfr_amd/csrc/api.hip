@@ -157,6 +157,25 @@ int fedfr_set_option(const char* name, int value) {
   return FEDFR_ERR_ARG;
 }
 
+// current value of a switch (so that a caller that changes one for a while can put the previous value back)
+int fedfr_get_option(const char* name, int* value) {
+  static const struct { const char* n; int* p; } tab[] = {
+      {"tn_use_tr", &g_tn_use_tr}, {"tn_target_blocks", &g_tn_target_blocks}, {"halo_waves", &g_halo_waves}, {"halo_bn64", &g_halo_bn64},
+      {"conv_halo", &g_conv_halo}, {"fuse_bnred_next", &g_fuse_bnred_next}, {"fuse_bnapply", &g_fuse_bnapply}, {"dgrad_parity", &g_dgrad_parity},
+      {"wgrad_pair_reduce", &g_wgrad_pair_reduce}, {"nt_glds", &g_nt_glds}, {"tn_glds", &g_tn_glds}, {"wgrad_depth", &g_wgrad_depth},
+      {"eval_fuse", &g_eval_fuse}, {"wgrad9", &g_wgrad9}, {"tn_pair", &g_tn_pair}, {"fuse_bnbwd", &g_fuse_bnbwd}, {"conv_c64p", &g_conv_c64p},
+      {"bn_sliced", &g_bn_sliced}, {"wgrad9_wgs", &g_wgrad9_wgs}, {"conv28_tpw2", &g_conv28_tpw2}, {"wgrad9p", &g_wgrad9p},
+      {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes}, {"bn_sliced_pre", &g_bn_sliced_pre}, {"nt_nbuf", &g_nt_nbuf}};
+  FEDFR_REQUIRE(name && value, "get_option: null argument");
+  for (const auto& e : tab)
+    if (!strcmp(name, e.n)) {
+      *value = *e.p;
+      return FEDFR_OK;
+    }
+  fedfr_set_error("get_option: unknown option '%s'", name);
+  return FEDFR_ERR_ARG;
+}
+
 int fedfr_profile_enable(int on) {
   gemm_profile_enable(on);
   return FEDFR_OK;
@@ -193,6 +212,11 @@ int fedfr_net_set_dropout(fedfr_net_t* n, float p, unsigned long long seed, long
   n->dropout_seed = seed;
   n->dropout_step = 0;
   if (mask_offset_bytes) *mask_offset_bytes = n->mask_off_bytes;
+  return FEDFR_OK;
+}
+int fedfr_net_set_dropout_step(fedfr_net_t* n, unsigned long long step) {
+  FEDFR_REQUIRE(n && !n->block_only, "net_set_dropout_step: need a network plan");
+  n->dropout_step = step;
   return FEDFR_OK;
 }
 void fedfr_net_destroy(fedfr_net_t* net) {
@@ -599,6 +623,9 @@ int fedfr_sgd_step(float* params, const float* grads, float* buf, uint16_t* shad
 }
 int fedfr_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, void* stream) {
   return optim_fedavg_axpy(dst, src, w, n, accumulate, ST(stream));
+}
+int fedfr_fedavg_multi(float* dst, const float* const* srcs, const float* ws, int k, size_t n, int accumulate, void* stream) {
+  return optim_fedavg_multi(dst, srcs, ws, k, n, accumulate, ST(stream));
 }
 int fedfr_fedavg_i64(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc, void* stream) {
   return optim_fedavg_i64(acc, src, w, n, accumulate, out_trunc, ST(stream));

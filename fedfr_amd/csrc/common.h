@@ -1,6 +1,8 @@
 // fedfr_amd — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
 // wave = 64 lanes; MFMA 16x16x32 bf16; LDS 160 KiB/CU.
 #pragma once
+#include <atomic>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -102,17 +104,24 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
 }
 
-// "once per device" flag of a call site that configures a kernel (hipFuncSetAttribute state lives per device; one process may drive several
-// GPUs: a Server training clients on cuda:0..3).  A racing second thread repeats the harmless call.
+// "once per device" guard of a call site that configures a kernel (hipFuncSetAttribute state lives per device; one process may drive several
+// GPUs: a Server training clients on cuda:0..3, and several host threads: Server.train with parallel_clients, ThreadComm.run).  run(f) calls f
+// once per device; the device's bit is published (release) only AFTER f has returned, under a mutex, so a racing thread either waits for the
+// first caller's hipFuncSetAttribute to finish or finds the bit set — it can never launch a kernel that needs > 64 KB of dynamic LDS before the
+// attribute is in place (the round-2 form set the bit first: ADVICE r2).
 struct PerDeviceOnce {
-  unsigned long long done = 0;
-  bool need() {
+  std::atomic<unsigned long long> done{0};
+  std::mutex mu;
+  template <class F>
+  void run(F&& f) {
     int d = 0;
     (void)hipGetDevice(&d);
     const unsigned long long bit = 1ull << (d & 63);
-    if (done & bit) return false;
-    done |= bit;
-    return true;
+    if (done.load(std::memory_order_acquire) & bit) return;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    f();
+    done.fetch_or(bit, std::memory_order_release);
   }
 };
 

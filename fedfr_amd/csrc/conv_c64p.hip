@@ -250,9 +250,9 @@ int launch_c64p(GemmNT p, hipStream_t st) {
   const int stat_rows = gemm_nt_stat_rows(p.M, p.N);
   FEDFR_REQUIRE(!p.stats || 2 * grid <= stat_rows, "conv3x3_c64p: %d partial rows do not fit gemm_nt_stat_rows = %d", 2 * grid, stat_rows);
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<W_, R_, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  });
   ProfScope prof(15, 2.0 * p.M * p.N * (double)p.K, st);           // slot 15: the 64-channel 3x3 layers (56x56, 112x112)
   hipLaunchKernelGGL((conv3x3_c64p_kernel<W_, R_, STATS>), dim3(grid), dim3(256), lds, st, p, ntiles, per_wg, stat_rows);
   FEDFR_LAUNCH_CHECK("conv3x3_c64p");

@@ -717,9 +717,9 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128 + (XFORM ? 3 * 256 * 4 : 0) + (TPW > 1 ? 4 * (size_t)BN_ * 4 : 0);
   static_assert(lds >= (size_t)PT * (BN_ * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
+  });
   ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15),   /* slot 15: 56x56 and 112x112 */ 2.0 * p.M * p.N * (double)p.K, st);
   hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM, TPW>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");

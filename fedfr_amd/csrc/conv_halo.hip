@@ -200,10 +200,10 @@ static int launch_halo(GemmNT p, hipStream_t st) {
   size_t lds = (size_t)a_lds + 2 * (size_t)BN * 128;
   if (lds < kEpi) lds = kEpi;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, AH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
-  }
+  });
   ProfScope prof(11, 2.0 * p.M * p.N * (double)p.K, st);
   hipLaunchKernelGGL((conv3x3_halo_kernel<BN, AH>), dim3(nbm * p.nbn), dim3(256), lds, st, p, a_lds);
   FEDFR_LAUNCH_CHECK("conv3x3_halo");

@@ -301,10 +301,10 @@ static int launch_halo2(GemmNT p, hipStream_t st) {
     if (p.bwd_fused) *p.bwd_fused = nbm;
   }
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo2_kernel<BN, W_, WN, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
-  }
+  });
   ProfScope prof(BN == 64 ? 10 : (W_ == 14 ? 8 : 9), 2.0 * p.M * p.N * (double)p.K, st);
   hipLaunchKernelGGL((conv3x3_halo2_kernel<BN, W_, WN, FUSED>), dim3(nbm * p.nbn), dim3(128 * WN), lds, st, p, nr);
   FEDFR_LAUNCH_CHECK("conv3x3_halo2");

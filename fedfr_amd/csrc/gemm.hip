@@ -259,10 +259,10 @@ static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st) {
   constexpr size_t kStage = (size_t)(BM + BN) * 128, kEpi = (size_t)BM * (BN * 2 + 16);
   const size_t lds = (NBUF * kStage > kEpi) ? NBUF * kStage : kEpi;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, NBUF>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  });
   dim3 grid(nbm * p.nbn, splits, p.par_on == 2 ? 4 : 1);
   ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (p.par_on == 2 ? 64.0 * 9 * p.cpt : p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st);
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, st, p);
@@ -626,10 +626,10 @@ static int launch_tn(GemmTN p, int splits, hipStream_t st) {
   FEDFR_REQUIRE(ceil_div(p.ksteps_total, p.ksteps_per_split) == splits, "gemm_tn: splits=%d leaves an empty split", splits);
   const size_t lds = 2 * (size_t)64 * (TI + TJ) * 2;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<TI, TJ, USE_TR>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  });
   p.ntiles = nbi * p.nbj;
   dim3 grid(p.ntiles * splits, 1, 1);
   ProfScope prof(prof_slot(true, TI, TJ), 2.0 * p.NI * p.NJ * (double)p.Kp, st);

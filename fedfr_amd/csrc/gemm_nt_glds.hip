@@ -217,9 +217,9 @@ int launch_impl2(GemmNT p, int splits, int slot, hipStream_t st) {
   constexpr size_t kRing = (size_t)NS * (BM + BN) * 128, kEpi = (size_t)BM * (BN * 2 + 16);
   constexpr size_t lds = kRing > kEpi ? kRing : kEpi;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_glds_kernel<BM, BN, WM, WN, NS, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  });
   const dim3 grid(nbm * p.nbn, splits, p.par_on == 2 ? 4 : 1);
   ProfScope prof(slot, 2.0 * p.M * p.N * (p.par_on == 2 ? 64.0 * 9 * p.cpt : p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st);
   hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BN, WM, WN, NS, CONV>), grid, dim3(64 * WM * WN), lds, st, p);

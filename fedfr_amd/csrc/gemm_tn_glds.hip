@@ -245,10 +245,10 @@ int launch_tn_glds(GemmTN p, int splits, hipStream_t st) {
   FEDFR_REQUIRE(ceil_div(p.ksteps_total, p.ksteps_per_split) == splits, "gemm_tn_glds: splits=%d leaves an empty split", splits);
   constexpr size_t lds = (size_t)4 * STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  });
   ProfScope prof(14, 2.0 * p.NI * p.NJ * (double)p.Kp, st);
   if (g_tn_glds >= 2) hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 4>), dim3(p.ntiles * splits), dim3(512), lds, st, p);
   else hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 2>), dim3(p.ntiles * splits), dim3(256), lds, st, p);
@@ -271,9 +271,9 @@ int launch_tn_glds_pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
   const int nblk = a.ntiles * splits;
   constexpr size_t lds = (size_t)2 * STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_pair_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  });
   ProfScope prof(14, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
   hipLaunchKernelGGL((gemm_tn_glds_pair_kernel<2, 4>), dim3(16 * ceil_div(nblk, 8)), dim3(512), lds, st, a, b, nblk);
   FEDFR_LAUNCH_CHECK("gemm_tn_glds_pair");

@@ -5,6 +5,7 @@
 int optim_sgd(float* p, const float* g, float* buf, bf16_t* shadow, size_t n, float lr, float mu, float wd, int first,
               hipStream_t st);
 int optim_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, hipStream_t st);
+int optim_fedavg_multi(float* dst, const float* const* srcs, const float* ws, int k, size_t n, int accumulate, hipStream_t st);
 int optim_fedavg_i64(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc, hipStream_t st);
 int optim_pfc_rand(float* perm, int n, unsigned long long seed, unsigned long long step, hipStream_t st);
 int optim_pfc_localize(long long* label, int n, long long class_start, int num_local, float* perm, hipStream_t st);

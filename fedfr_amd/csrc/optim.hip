@@ -88,6 +88,64 @@ int optim_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accum
   return FEDFR_OK;
 }
 
+// FedAvg over up to 8 client states in ONE pass: dst = (accumulate ? dst : 0) + w_0 * src_0 + w_1 * src_1 + ... in ascending client order with
+// the same two roundings per term as fedavg_axpy_kernel, so the result is bit-identical to k sequential axpy launches (server.py:27-33) while
+// every state is read once and the aggregate is written once: (k + 1) x n x 4 B instead of (3k - 1) x n x 4 B.
+struct FedavgMulti {
+  const float* src[8];
+  float w[8];
+};
+template <int K>
+__global__ __launch_bounds__(256) void fedavg_multi_kernel(float* __restrict__ dst, FedavgMulti p, size_t n, int accumulate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p.src[k]) + i);      // each state is read once
+      s[k] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    float4 d = accumulate ? reinterpret_cast<float4*>(dst)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      d.x = __fadd_rn(d.x, __fmul_rn(p.w[k], s[k].x));
+      d.y = __fadd_rn(d.y, __fmul_rn(p.w[k], s[k].y));
+      d.z = __fadd_rn(d.z, __fmul_rn(p.w[k], s[k].z));
+      d.w = __fadd_rn(d.w, __fmul_rn(p.w[k], s[k].w));
+    }
+    reinterpret_cast<float4*>(dst)[i] = d;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float d = accumulate ? dst[i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) d = __fadd_rn(d, __fmul_rn(p.w[k], p.src[k][i]));
+    dst[i] = d;
+  }
+}
+int optim_fedavg_multi(float* dst, const float* const* srcs, const float* ws, int k, size_t n, int accumulate, hipStream_t st) {
+  FEDFR_REQUIRE(dst && srcs && ws && n > 0 && k >= 1 && k <= 8, "fedavg_multi: bad args (k=%d)", k);
+  FedavgMulti p{};
+  uintptr_t al = (uintptr_t)dst;
+  for (int i = 0; i < k; ++i) {
+    FEDFR_REQUIRE(srcs[i] != nullptr, "fedavg_multi: source %d is null", i);
+    p.src[i] = srcs[i];
+    p.w[i] = ws[i];
+    al |= (uintptr_t)srcs[i];
+  }
+  FEDFR_REQUIRE((al & 15) == 0, "fedavg_multi: buffers must be 16-byte aligned");
+  const size_t work = n / 4 + 1;
+  const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+  switch (k) {
+#define FM_CASE(K_) case K_: hipLaunchKernelGGL(fedavg_multi_kernel<K_>, dim3(grid), dim3(256), 0, st, dst, p, n, accumulate); break;
+    FM_CASE(1) FM_CASE(2) FM_CASE(3) FM_CASE(4) FM_CASE(5) FM_CASE(6) FM_CASE(7) FM_CASE(8)
+#undef FM_CASE
+  }
+  FEDFR_LAUNCH_CHECK("fedavg_multi");
+  return FEDFR_OK;
+}
+
 // int64 counters (num_batches_tracked): acc_f32 (+)= w * float(src) ; optional final truncation back to int64
 __global__ void fedavg_i64_kernel(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -269,9 +269,9 @@ int launch_wgrad9(const GemmTN& g, int splits, hipStream_t st) {
   ProfScope prof(16, 2.0 * g.NI * g.NJ * (double)g.Kp, st);
   constexpr size_t lds14 = w9_lds<14, 14, 4>();
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<14, 14, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds14);
-  }
+  });
   hipLaunchKernelGGL((wgrad9_kernel<14, 14, 4>), grid, dim3(512), lds14, st, p);
   FEDFR_LAUNCH_CHECK("wgrad9");
   return FEDFR_OK;

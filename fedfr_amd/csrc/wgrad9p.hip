@@ -348,9 +348,9 @@ int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t
   ProfScope prof(16, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
   constexpr size_t lds = 2 * (size_t)STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  if (attr_once.need()) {
+  attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  });
   hipLaunchKernelGGL(wgrad9p_kernel, grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("wgrad9_pair");
   return FEDFR_OK;

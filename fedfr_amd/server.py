@@ -23,12 +23,24 @@ def _axpy(dst: torch.Tensor, src: torch.Tensor, w: float, accumulate: bool):
             _C.stream())
 
 
+def _multi(dst: torch.Tensor, srcs: Sequence[torch.Tensor], ws: Sequence[float], accumulate: bool):
+    """dst (+)= Σ_i ws[i]·srcs[i] over ≤ 8 same-shape contiguous fp32 tensors in one kernel (csrc/optim.hip: fedavg_multi_kernel)."""
+    import ctypes as C
+    k = len(srcs)
+    for t in srcs:
+        if t.numel() != dst.numel() or t.dtype != f32 or not t.is_contiguous() or t.device != dst.device:
+            raise RuntimeError("fedfr_amd.FedPavg: client states must be same-shape contiguous fp32 tensors on one device")
+    ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in srcs])
+    wv = (C.c_float * k)(*[float(np.float32(w)) for w in ws])
+    _C.call("fedfr_fedavg_multi", dst.data_ptr(), ptrs, wv, k, dst.numel(), 1 if accumulate else 0, _C.stream())
+
+
 def FedPavg(models: List[dict], weights: Sequence[float]):
     """Σ_i (n_i/Σn)·sd_i[k] for every key k (reference server.py:25-34).
 
     Same op order as the reference (ascending client index, fp32 mul then add), so float entries are
     bit-identical to it.  int64 ``num_batches_tracked`` entries come back as float32, like the reference (F9).
-    Fast path: FlatStateDicts → 3 kernels per client; generic path: one kernel per key per client.
+    Fast path: FlatStateDicts → one pass over up to 8 clients' flat states (3 launches per 8 clients + one per counter vector); generic path: one kernel per key per client.
     """
     tot = sum(weights)
     ws = [w / tot for w in weights]
@@ -39,10 +51,14 @@ def FedPavg(models: List[dict], weights: Sequence[float]):
             raise RuntimeError("fedfr_amd.FedPavg: state tensors must be on the GPU (no CPU fallback)")
         P, Bf = torch.empty_like(p0), torch.empty_like(b0)
         N = torch.empty(n0.numel(), dtype=f32, device=dev)
+        # up to 8 client states per pass (fedfr_fedavg_multi: every state read once, the aggregate written once; same op order and
+        # roundings as one axpy per client, so still bit-identical to the reference loop)
+        for c0 in range(0, len(models), 8):
+            grp, wgrp = models[c0:c0 + 8], ws[c0:c0 + 8]
+            _multi(P, [m.flat[0] for m in grp], wgrp, c0 > 0)
+            _multi(Bf, [m.flat[1] for m in grp], wgrp, c0 > 0)
         for i, (m, w) in enumerate(zip(models, ws)):
-            p, b, n = m.flat
-            _axpy(P, p, w, i > 0)
-            _axpy(Bf, b, w, i > 0)
+            n = m.flat[2]
             _C.call("fedfr_fedavg_i64", N.data_ptr(), n.data_ptr(), float(np.float32(w)), n.numel(), 1 if i else 0, None, _C.stream())
         out = FlatStateDict()
         out.flat = (P, Bf, N)
@@ -239,32 +255,32 @@ class Server(object):
             from . import _C
             # with the GPU saturated by several kernel chains, total kernel time is what counts: the paired 64 x 64 weight-gradient kernel
             # (csrc/wgrad9p.hip; off for a lone client, whose two streams interleave better with the shorter single-layer kernel)
-            _C.call("fedfr_set_option", b"wgrad9p", 1)
+            # The switch is process-global: the previous value (a user's FEDFR_OPTIONS setting) is put back when the round's clients are done,
+            # also on an error.  It changes the weight gradients' fp32 summation order relative to parallel_clients = 1.
             main = torch.cuda.current_stream(self.device)
             streams = getattr(self, "_client_streams", None)
             if streams is None or len(streams) < par:
                 streams = self._client_streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(par)]
-            for w0 in range(0, len(order), par):
-                errs = []
+            with _C.option_scope("wgrad9p", 1):
+                for w0 in range(0, len(order), par):
+                    errs = []
 
-                def target(i, slot):
-                    try:
-                        torch.cuda.set_device(self.device)
-                        streams[slot].wait_stream(main)
-                        with torch.cuda.stream(streams[slot]):
-                            run_client(i, slot)
-                        streams[slot].synchronize()
-                    except BaseException as e:      # noqa: BLE001 — re-raised in the caller's thread
-                        errs.append(e)
-                ts = [threading.Thread(target=target, args=(i, k), daemon=True) for k, i in enumerate(order[w0: w0 + par])]
-                for t in ts:
-                    t.start()
-                for t in ts:
-                    t.join()
-                if errs:
-                    _C.call("fedfr_set_option", b"wgrad9p", 0)
-                    raise errs[0]
-            _C.call("fedfr_set_option", b"wgrad9p", 0)
+                    def target(i, slot):
+                        try:
+                            torch.cuda.set_device(self.device)
+                            streams[slot].wait_stream(main)
+                            with torch.cuda.stream(streams[slot]):
+                                run_client(i, slot)
+                            streams[slot].synchronize()
+                        except BaseException as e:      # noqa: BLE001 — re-raised in the caller's thread
+                            errs.append(e)
+                    ts = [threading.Thread(target=target, args=(i, k), daemon=True) for k, i in enumerate(order[w0: w0 + par])]
+                    for t in ts:
+                        t.start()
+                    for t in ts:
+                        t.join()
+                    if errs:
+                        raise errs[0]
         for i in order:
             losses_.append(self.clients[i].get_train_loss())
             models.append(self.clients[i].get_model())

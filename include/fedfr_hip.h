@@ -36,6 +36,8 @@ const char* fedfr_last_error_string(void);
  * (channel-sliced BatchNorm passes without finalize launches), "fuse_bnbwd" (0 [default] / 1 / 2: BatchNorm-backward reduction in the dgrad
  * epilogue, everywhere / 14x14 layers), "fuse_bnapply", "eval_fuse", "conv28_tpw2", "dgrad_parity", "wgrad_depth".  Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);
+/* the switch's current value (a caller that changes one temporarily restores what it found) */
+int fedfr_get_option(const char* name, int* value);
 /* HIP-event timing of every MFMA GEMM launch on its own stream (bench.py roofline leg).  Slots 0..3: conv fwd/dgrad
  * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order; 8..11: the
  * LDS-halo 3x3 conv kernels conv3x3_halo2<128,14>, <128,28>, <64,*>, conv3x3_halo (v1).
@@ -61,6 +63,10 @@ void fedfr_net_destroy(fedfr_net_t* net);
  * forward is kept iff hash16(seed, k, i) >= p * 65536) and scale the rest by 1 / (1 - p); the backward applies the same mask.  p = 0 turns it
  * off; the call resets the forward counter.  *mask_offset_bytes (optional): where the last mask ([batch * fc_in] bytes, 0/1) lives in `act`. */
 int fedfr_net_set_dropout(fedfr_net_t* net, float p, unsigned long long seed, long long* mask_offset_bytes);
+/* the index k of the NEXT training forward's mask.  The plan's own counter restarts whenever a plan is (re)created — after an eviction, a
+ * workspace release, for every new model — so a host that wants masks that never repeat keeps the count itself (fedfr_amd.IResNet does:
+ * one counter per model, handed over before every training forward). */
+int fedfr_net_set_dropout_step(fedfr_net_t* net, unsigned long long step);
 /* debug (tests): while buf != NULL, fedfr_net_backward* copies the gradient entering every block (bf16 NHWC, last block first) and then
  * the gradient wrt the first block's input back to back into buf (caller-owned, `elems` bf16 elements); NULL turns it off.  The one
  * exception to "no pointer is retained": clear it before freeing the buffer. */
@@ -276,6 +282,9 @@ int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream
 int fedfr_sgd_step(float* params, const float* grads, float* momentum_buf, uint16_t* bf16_shadow, size_t n, float lr,
                    float momentum, float weight_decay, int first_step, void* stream);
 int fedfr_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, void* stream);
+/* dst = (accumulate ? dst : 0) + sum_i ws[i] * srcs[i] over k <= 8 client states (HOST arrays of k device pointers / k weights) in one pass,
+ * ascending i, one fp32 multiply and one fp32 add per term: bit-identical to k fedfr_fedavg_axpy calls = the loop of server.py:27-33 */
+int fedfr_fedavg_multi(float* dst, const float* const* srcs, const float* ws, int k, size_t n, int accumulate, void* stream);
 int fedfr_fedavg_i64(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc,
                      void* stream);
 int fedfr_pfc_rand(float* perm, int n, unsigned long long seed, unsigned long long step, void* stream);

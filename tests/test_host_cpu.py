@@ -215,3 +215,44 @@ def test_torch_dist_comm_verbs_gloo():
     assert isinstance(default_comm(1), SingleComm)
     with pytest.raises(RuntimeError):
         default_comm(2)                                          # world_size 2 without a process group: loud, not silent
+
+
+def test_bench_self_launch_starts_the_ranks_before_any_gpu_call(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher (VERDICT r2 missing #1): ONE child `python -m torch.distributed.run --nproc-per-node N`
+    with HSA_ENABLE_IPC_MODE_LEGACY=0, rank 0's JSON line relayed to stdout, the child's failure returned; no launch for N = 1 or when a
+    launcher's environment is already there."""
+    import importlib.util
+    import io
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.self_launch(["--steps", "3"]) is None and bench.self_launch(["--gpus", "1"]) is None
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert bench.self_launch(["--gpus", "4"]) is None                  # already under torch.distributed.run
+    monkeypatch.delenv("WORLD_SIZE")
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, stderr=None, text=None, cwd=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('NCCL version banner\n{"metric": "images/sec", "value": 1.0, "n_gpus": 4}\n')
+            self.rc = seen.get("rc", 0)
+
+        def wait(self):
+            return self.rc
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    assert bench.self_launch(["--gpus", "4", "--steps", "2"]) == 0
+    cmd, env = seen["cmd"], seen["env"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "images/sec", "value": 1.0, "n_gpus": 4}' and "NCCL version banner" in out.err
+    seen["rc"] = 3
+    assert bench.self_launch(["--gpus=2"]) == 3                        # a failing rank fails the bench

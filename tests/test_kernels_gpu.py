@@ -794,3 +794,28 @@ def test_pad_input_nhwc():
     _C.call("fedfr_pad_input_nhwc", xd.data_ptr(), out.data_ptr(), 3, 3, 400, 64, _C.stream())
     torch.cuda.synchronize()
     assert torch.equal(out[..., :3].cpu(), x.permute(0, 2, 3, 1).to(torch.bfloat16)) and float(out[..., 3:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 11])
+def test_fedavg_multi_equals_sequential_axpy(k):
+    """fedfr_fedavg_multi (one pass over up to 8 client states; FedPavg's flat path chains passes for more) is bit-identical to one
+    fedfr_fedavg_axpy per client in ascending order = the reference loop server.py:27-33 (fp32 multiply, then fp32 add, per client);
+    odd length exercises the scalar tail."""
+    import numpy as np
+    from fedfr_amd import server
+    n = 4 * 50_001 + 3
+    g = torch.Generator().manual_seed(5 + k)
+    srcs = [(torch.randn(n + 4, generator=g) * (1 + i)).to(DEV)[:n + 4][4:].contiguous() for i in range(k)]
+    srcs = [s_.clone() for s_ in srcs]                     # 16-byte aligned bases
+    ws = [float(np.float32((1000.0 + 7 * i) / sum(1000.0 + 7 * j for j in range(k)))) for i in range(k)]
+    ref = torch.empty(n, device=DEV)
+    for i in range(k):
+        _C.call("fedfr_fedavg_axpy", ref.data_ptr(), srcs[i].data_ptr(), ws[i], n, 1 if i else 0, _C.stream())
+    out = torch.full((n,), float("nan"), device=DEV)
+    for c0 in range(0, k, 8):
+        server._multi(out, srcs[c0:c0 + 8], ws[c0:c0 + 8], c0 > 0)
+    assert torch.equal(out, ref)
+    cpu = torch.zeros(n)
+    for i in range(k):
+        cpu = cpu + torch.tensor(ws[i], dtype=torch.float32) * srcs[i].cpu()
+    assert torch.equal(out.cpu(), cpu)                     # and to the reference's own torch expression

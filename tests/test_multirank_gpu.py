@@ -494,3 +494,27 @@ def test_config5_two_processes_gloo_vs_oracle():
     and fedavg_all_reduce) against the oracle's composition run over the same process group."""
     import torch.multiprocessing as mp
     mp.spawn(_config5_gloo_worker, args=(29691,), nprocs=2, join=True)
+
+
+def test_bench_self_launch_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` with NO launcher (what a driver that reuses its N = 1 command line runs): bench.py starts the two ranks
+    itself before touching the GPU, the ranks find each other, run local steps + the FedAvg exchange, and rank 0's single JSON line comes
+    back through the parent.  On this one-GPU box the ranks share cuda:0 and use gloo (RCCL refuses two ranks per device) — the rehearsal
+    switches of bench.py; the launcher, the rendezvous, `rccl_ranks` and the exchange are the code the 8-GPU run uses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(FEDFR_BENCH_SHARE_GPU="1", FEDFR_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--arch", "iresnet50",
+                        "--batch", "8", "--no-cpu-baseline", "--no-profile"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["clients"] == 2 and d["steps"] == 2
+    assert d["value"] > 0 and d["fedavg_round_ms"] >= d["fedavg_exchange_ms"] > 0
+    assert "REHEARSAL" in d["data"] and d["collective_backend"] == "gloo"

@@ -449,6 +449,19 @@ class IResNet(nn.Module):
         self._bind(create=False)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
+        # a FlatStateDict nobody has looked into (views never built, so no entry can have been replaced) of the same architecture: three
+        # flat copies instead of 925 (FedAvg's hand-back, server.py:330-335; int64 counters take the float average truncated, F9)
+        flat = getattr(state_dict, "flat", None)
+        if (flat is not None and getattr(state_dict, "_built", True) is False and list(getattr(state_dict, "layers", ())) == list(self.layers_cfg)
+                and flat[0].numel() == self._flat_params.numel() and flat[1].numel() == self._flat_bufs.numel()
+                and flat[2].numel() == self._flat_nbt.numel() and flat[0].dtype == torch.float32):
+            with torch.no_grad():
+                self._flat_params.copy_(flat[0])
+                self._flat_bufs.copy_(flat[1])
+                self._flat_nbt.copy_(flat[2])
+            self._shadow_dirty = True
+            from torch.nn.modules.module import _IncompatibleKeys
+            return _IncompatibleKeys([], [])
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._shadow_dirty = True
         return out

@@ -33,6 +33,8 @@ extern int g_wgrad_depth;
 extern int g_dgrad_parity;
 extern int g_fuse_bnapply;
 extern int g_fuse_bnred_next;
+extern int g_ew_reduce_blocks, g_ew_bwd_apply_blocks, g_ew_reduce_nt;
+extern int g_bn_fuse_bwd;
 
 void fedfr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -149,6 +151,24 @@ int fedfr_set_option(const char* name, int value) {
     g_bn_sliced_pre = value;       // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)
     return FEDFR_OK;
   }
+  // row-slab BatchNorm-backward passes (the large maps): grid sizes may only shrink below the defaults the plans' partial-row buffers were
+  // sized with (512 / 2048 workgroups)
+  if (name && !strcmp(name, "ew_reduce_blocks")) {
+    g_ew_reduce_blocks = value < 128 ? 128 : value > 2048 ? 2048 : value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "ew_bwd_apply_blocks")) {
+    g_ew_bwd_apply_blocks = value < 128 ? 128 : value > 2048 ? 2048 : value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "ew_reduce_nt")) {
+    g_ew_reduce_nt = value < 0 ? 0 : value > 2 ? 2 : value;
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "bn_fuse_bwd")) {
+    g_bn_fuse_bwd = value ? 1 : 0;   // reduce + apply pass of a BatchNorm backward in one launch with an in-launch hand-off (bn_sliced.hip)
+    return FEDFR_OK;
+  }
   if (name && !strcmp(name, "nt_nbuf")) {
     g_nt_nbuf = value == 1 ? 1 : 2;
     return FEDFR_OK;
@@ -165,7 +185,8 @@ int fedfr_get_option(const char* name, int* value) {
       {"wgrad_pair_reduce", &g_wgrad_pair_reduce}, {"nt_glds", &g_nt_glds}, {"tn_glds", &g_tn_glds}, {"wgrad_depth", &g_wgrad_depth},
       {"eval_fuse", &g_eval_fuse}, {"wgrad9", &g_wgrad9}, {"tn_pair", &g_tn_pair}, {"fuse_bnbwd", &g_fuse_bnbwd}, {"conv_c64p", &g_conv_c64p},
       {"bn_sliced", &g_bn_sliced}, {"wgrad9_wgs", &g_wgrad9_wgs}, {"conv28_tpw2", &g_conv28_tpw2}, {"wgrad9p", &g_wgrad9p},
-      {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes}, {"bn_sliced_pre", &g_bn_sliced_pre}, {"nt_nbuf", &g_nt_nbuf}};
+      {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes}, {"bn_sliced_pre", &g_bn_sliced_pre}, {"nt_nbuf", &g_nt_nbuf},
+      {"bn_fuse_bwd", &g_bn_fuse_bwd}, {"ew_reduce_blocks", &g_ew_reduce_blocks}, {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks}, {"ew_reduce_nt", &g_ew_reduce_nt}};
   FEDFR_REQUIRE(name && value, "get_option: null argument");
   for (const auto& e : tab)
     if (!strcmp(name, e.n)) {

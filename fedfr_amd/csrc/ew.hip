@@ -464,7 +464,10 @@ __device__ __forceinline__ void ew_load_gh(const BnBwd& p, int c0, const float* 
   }
 }
 
-template <bool ALPHA>
+// NTM: cache policy of the two streams — 0 plain loads, 1 x non-temporal (the forward pass wrote it a whole pass ago: it comes from HBM and
+// nobody reads it again soon), 2 both (tools/probe/hbm_stream_probe.hip: a cold r2w1 pass of a 51 MB map takes 48 us with plain loads and 34
+// with non-temporal ones)
+template <bool ALPHA, int NTM>
 __global__ __launch_bounds__(EW_THREADS, ALPHA ? 4 : 5) void bn_bwd_reduce_kernel(BnBwd p, int slab, int shfl) {
   extern __shared__ float red[];
   constexpr int UNR = ALPHA ? EW_UNROLL_ALPHA : EW_UNROLL;     // rows of loads in flight (the PReLU variant carries 24 more per-channel registers)
@@ -512,8 +515,8 @@ __global__ __launch_bounds__(EW_THREADS, ALPHA ? 4 : 5) void bn_bwd_reduce_kerne
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const size_t off = (size_t)(m + u * rpp) * p.C + c0;
-        vd[u] = *reinterpret_cast<const uint4*>(p.dy + off);
-        vx[u] = *reinterpret_cast<const uint4*>(p.x + off);
+        vd[u] = NTM >= 2 ? ew_ld16(p.dy + off) : *reinterpret_cast<const uint4*>(p.dy + off);
+        vx[u] = NTM >= 1 ? ew_ld16(p.x + off) : *reinterpret_cast<const uint4*>(p.x + off);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -535,19 +538,24 @@ __global__ __launch_bounds__(EW_THREADS, ALPHA ? 4 : 5) void bn_bwd_reduce_kerne
   ew_block_colsum<3>(acc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, p.partials + (size_t)bid * 3 * p.C);
 }
 
-int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 512)); }
+int g_ew_reduce_blocks = 512;       // option "ew_reduce_blocks": workgroups a row-slab bn_bwd_reduce launch aims for (= partial rows it leaves)
+int g_ew_bwd_apply_blocks = 2048;   // option "ew_bwd_apply_blocks": ... a row-slab bn_bwd_apply launch
+int g_ew_reduce_nt = 0;             // option "ew_reduce_nt": cache policy of the row-slab reduce pass's loads (0 plain, 1 x non-temporal, 2 both)
+int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, g_ew_reduce_blocks)); }
 
 int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_reduce"));
   FEDFR_REQUIRE(p.dy && p.x && p.partials, "bn_bwd_reduce: null tensor");   // mean / rstd null: 0 / 1 (bias + PReLU backward)
   FEDFR_REQUIRE(!p.sc == !p.sh, "bn_bwd_reduce: scale and shift come together");
-  const int slab = slab_rows(p.M, p.C, 512);
+  const int slab = slab_rows(p.M, p.C, g_ew_reduce_blocks);
   const int grid = ceil_div(p.M, slab);
   const size_t lds = ew_colsum_lds(p.C, 3);
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
   ProfScope prof(21, (double)p.M * p.C * 2 * 2, st);
-  if (p.alpha) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
+#define BWD_RED(A, N) hipLaunchKernelGGL((bn_bwd_reduce_kernel<A, N>), dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl)
+  if (p.alpha) { if (g_ew_reduce_nt == 2) BWD_RED(true, 2); else if (g_ew_reduce_nt == 1) BWD_RED(true, 1); else BWD_RED(true, 0); }
+  else { if (g_ew_reduce_nt == 2) BWD_RED(false, 2); else if (g_ew_reduce_nt == 1) BWD_RED(false, 1); else BWD_RED(false, 0); }
+#undef BWD_RED
   FEDFR_LAUNCH_CHECK("bn_bwd_reduce");
   return FEDFR_OK;
 }
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX || ADD
   }
 }
 
-int ew_bn_bwd_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 2048)); }
+int ew_bn_bwd_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, g_ew_bwd_apply_blocks)); }
 
 int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_apply"));
@@ -712,7 +720,7 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
     dv.dW = make_fastdiv((unsigned)p.W);
   }
   if (p.nx) FEDFR_REQUIRE(p.nmean && p.nrstd && p.npart, "bn_bwd_apply: next-BN reduction needs mean / rstd / partials");
-  const int slab = slab_rows(p.M, p.C, 2048);
+  const int slab = slab_rows(p.M, p.C, g_ew_bwd_apply_blocks);
   const dim3 grid(ceil_div(p.M, slab));
   const size_t lds = p.nx ? ew_colsum_lds(p.C, 2) : 0;
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;

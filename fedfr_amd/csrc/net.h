@@ -62,7 +62,7 @@ struct FedfrNet {
   long long act_bf16_count, act_float_off_bytes, act_bytes;
   // workspace layout (byte offsets)
   size_t ws_bytes;
-  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_part2, ws_slab, ws_small, ws_fc;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
+  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_part2, ws_slab, ws_small, ws_fc, ws_hand;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
   mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;
@@ -74,6 +74,10 @@ struct FedfrNet {
   // nn.BatchNorm modules put into eval() inside a training net (IResNet.freeze_BN(test_mode=True), iresnet.py:140-147): set by a forward
   // pass with training = 2 (running statistics normalise, nothing is updated, activations are kept), read by the backward pass
   mutable bool bn_frozen = false;
+  // in-launch hand-off buffer of the fused BatchNorm-backward kernels (bn_sliced.hip): granules + one error word at its end; zeroed when a
+  // workspace is seen for the first time, epochs count launches
+  mutable unsigned hand_epoch = 0;
+  mutable const unsigned char* hand_ws = nullptr;
   bool block_only = false;              // plan of a lone IBasicBlock (net_create_block): no stem, no bn2/fc/features tail
   long long dx_off = -1;                // block_only: bf16 arena offset of the gradient wrt the block input [B*Hin*Hin][Cin]
 };

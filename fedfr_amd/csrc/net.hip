@@ -138,6 +138,8 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
     part = std::max(part, (long long)ew_bn_apply_grid((int)M, C) * 2 * C);
     part = std::max(part, (long long)ew_bn_bwd_grid((int)M, C) * 3 * C);
     part = std::max(part, (long long)ew_bn_bwd_apply_grid((int)M, C) * 3 * C);
+    // the row-slab grids are options ("ew_reduce_blocks" / "ew_bwd_apply_blocks", at most 2048 workgroups): room for any later setting
+    part = std::max(part, std::min<long long>(2048, (M + 7) / 8) * 3 * C);
   };
   auto upd_conv = [&](const ConvD& c) {
     const long long Mo = Bq * c.Hout * c.Hout;
@@ -171,6 +173,7 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
   n->ws_small = wtake((size_t)(3 * 512 + 64 * 2 * 512) * 4 + (size_t)Bq * num_features * 4 + (size_t)Bq * num_features * 2 +
                       (size_t)num_features * n->Bp * 2 + 1024);
   n->ws_fc = wtake((size_t)n->Bp * n->fc_in * 4);
+  n->ws_hand = wtake(ew_bn_fused_hand_bytes() + 256);
   n->ws_bytes = w;
 }
 
@@ -639,6 +642,20 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
     BnBwdS p{};
     p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.alpha = alpha;
     p.sc = c.save(b, 0); p.sh = c.save(b, 1); p.M = M; p.C = b.C; p.count = count;
+    p.dgamma = c.grads + b.g_off; p.dbeta = c.grads + b.b_off; p.dalpha = alpha ? c.grads + alpha_off : nullptr;
+    p.add = add; p.dx = dx;
+    if (have.P <= 0 && ew_bn_bwd_fused_variant_ok(M, b.C, alpha != nullptr, nxt, add != nullptr)) {
+      // reduce + apply in one launch: the partial rows cross workgroups inside it (bn_sliced.hip, bn_bwd_fused_s_kernel)
+      if (nxt) {
+        p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part2();
+        *next_rows = Rows{p.npart, ew_bn_sliced_rows(M, b.C, true)};
+      }
+      p.hand = reinterpret_cast<unsigned long long*>(c.ws + c.n->ws_hand);
+      p.err = reinterpret_cast<unsigned*>(c.ws + c.n->ws_hand + ew_bn_fused_hand_bytes());
+      p.epoch = ++c.n->hand_epoch;
+      if (p.epoch == 0) p.epoch = ++c.n->hand_epoch;
+      return ew_bn_bwd_fused_sliced(p, c.st);
+    }
     if (have.P > 0) {
       p.part_in = have.ptr; p.P = have.P;
     } else {
@@ -646,8 +663,6 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
       FEDFR_TRY(ew_bn_bwd_reduce_sliced(p, c.st));
       p.part_in = c.part(); p.P = ew_bn_sliced_rows(M, b.C, true);
     }
-    p.dgamma = c.grads + b.g_off; p.dbeta = c.grads + b.b_off; p.dalpha = alpha ? c.grads + alpha_off : nullptr;
-    p.add = add; p.dx = dx;
     if (nxt) {
       p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part_other(p.part_in);
       *next_rows = Rows{p.npart, ew_bn_sliced_rows(M, b.C, true)};
@@ -709,6 +724,14 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
   const int B = n->B, F = n->F, HW = n->HW;
   bf16_t* A = c.actb;
+  if (n->hand_ws != ws) {                           // first backward pass on this workspace: no stale granule may ever carry a live epoch
+    if (hipMemsetAsync(ws + n->ws_hand, 0, ew_bn_fused_hand_bytes() + 256, st) != hipSuccess) {
+      fedfr_set_error("net_backward: hipMemsetAsync of the hand-off buffer failed");
+      return FEDFR_ERR_HIP;
+    }
+    n->hand_ws = ws;
+    n->hand_epoch = 0;
+  }
   Fork fk{n, st, aux};
   const hipStream_t wst = aux ? aux : st;          // stream of the weight-gradient GEMMs
   fk.order(st, wst);                                // aux starts after everything already queued on main (forward pass)

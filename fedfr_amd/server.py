@@ -60,24 +60,7 @@ def FedPavg(models: List[dict], weights: Sequence[float]):
         for i, (m, w) in enumerate(zip(models, ws)):
             n = m.flat[2]
             _C.call("fedfr_fedavg_i64", N.data_ptr(), n.data_ptr(), float(np.float32(w)), n.numel(), 1 if i else 0, None, _C.stream())
-        out = FlatStateDict()
-        out.flat = (P, Bf, N)
-        out.table, out.layers = models[0].table, models[0].layers
-        for name, kind, region, off, shape in out.table:
-            if region == 0:
-                if kind == backbones.iresnet.KIND_CONV:
-                    o, i_, r, _ = shape
-                    out[name] = P[off: off + o * i_ * r * r].view(o, r, r, i_).permute(0, 3, 1, 2)
-                else:
-                    num = 1
-                    for s_ in shape:
-                        num *= s_
-                    out[name] = P[off: off + num].view(shape)
-            elif region == 1:
-                out[name] = Bf[off: off + shape[0]]
-            else:
-                out[name] = N[off]
-        return out
+        return FlatStateDict.from_flat((P, Bf, N), models[0].table, models[0].layers)
     aggr = OrderedDict()
     for name in models[0]:
         t0 = models[0][name]

@@ -1240,3 +1240,30 @@ def test_client_train_ragged_and_single_image_batches_vs_oracle():
     # of the batch-8 client fixture (test_fused_client_loop_vs_reference: 1e-2) — measured 1.6e-2 on conv1.weight
     for k, v in errs.items():
         assert v < (3.3e-2 if k == "head" else 2.1e-2), (k, v)          # measured 2.6e-2 / 1.6e-2
+
+
+@pytest.mark.parametrize("batch", [128, 24])
+def test_fused_bn_backward_handoff_is_bit_identical(batch):
+    """option bn_fuse_bwd (default on): the reduce pass and the apply pass of a BatchNorm backward in ONE launch on the 14x14 / 7x7 maps,
+    the partial rows handed over between workgroups INSIDE the launch (8-byte {epoch, value} granules, bn_sliced.hip).  Same geometry,
+    same arithmetic and summation order as the two launches, so every gradient of the network is bit-identical — also over several steps
+    (fresh epochs, the same hand-off buffer) and at a batch whose pixel groups are ragged."""
+    outs = []
+    for opt in (0, 1):
+        with _C.option_scope("bn_fuse_bwd", opt):
+            m, sd, _ = make_model("iresnet18", tag=2.0)
+            m.train()
+            x = R.closed_form_images(batch).to(DEV)
+            res = []
+            for it in range(3):
+                for p_ in m.parameters():
+                    p_.grad = None
+                f = m(x * (1.0 + 0.1 * it))
+                (f * R.closed_form((batch, 512), 0.37, 0.9 + it, 1.0).to(DEV)).sum().backward()
+                res.append((f.detach().clone(), {k: p_.grad.clone() for k, p_ in m.named_parameters() if p_.grad is not None}))
+            outs.append(res)
+    for (f0, g0), (f1, g1) in zip(*outs):
+        assert torch.equal(f0, f1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+        assert all(torch.isfinite(v).all() for v in g1.values())

@@ -803,10 +803,10 @@ def test_fedavg_multi_equals_sequential_axpy(k):
     odd length exercises the scalar tail."""
     import numpy as np
     from fedfr_amd import server
+    DEV = dev()
     n = 4 * 50_001 + 3
     g = torch.Generator().manual_seed(5 + k)
-    srcs = [(torch.randn(n + 4, generator=g) * (1 + i)).to(DEV)[:n + 4][4:].contiguous() for i in range(k)]
-    srcs = [s_.clone() for s_ in srcs]                     # 16-byte aligned bases
+    srcs = [(torch.randn(n, generator=g) * (1 + i)).to(DEV) for i in range(k)]
     ws = [float(np.float32((1000.0 + 7 * i) / sum(1000.0 + 7 * j for j in range(k)))) for i in range(k)]
     ref = torch.empty(n, device=DEV)
     for i in range(k):

@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-FWD_GFLOP_PER_IMG = {"iresnet100": 24.18, "iresnet50": 12.62}       # SURVEY.md §8(d), measured on the reference
+FWD_GFLOP_PER_IMG = {"iresnet100": 24.18, "iresnet50": 12.62,       # SURVEY.md §8(d), measured on the reference
+                     "sphnet": 13.79}                               # sphere64 (run.sh): 6.897 G MACs per 112x112 image (conv 6.884 + fc 0.013)
 BF16_DENSE_PEAK_TFLOPS = 2500.0                                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBPS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kernel<64,128>", "gemm_nt_kernel<64,64>",
@@ -128,7 +129,19 @@ def cpu_baseline(arch):
     best = max(sweep, key=sweep.get)
     r50 = _cpu_steps("iresnet50", 32, 3, best)
     print("cpu_baseline: iresnet50 b32, 3 steps: %.2f img/s" % r50, file=sys.stderr, flush=True)
-    head = _cpu_steps(arch, 32, 3, best) if arch != "iresnet50" else r50
+    if arch == "sphnet":
+        # the oracle's sphere64 restatement: forward + every parameter gradient (no head, no optimiser: both are < 1 % of the step)
+        from oracle import ref_cpu as R
+        torch.set_num_threads(best)
+        sd = R.sphere_state_dict(64, tag=1.0)
+        xs, de = torch.rand(32, 3, 112, 112) * 2 - 1, torch.randn(32, 512) * 0.01
+        R.sphere_step_grads(sd, xs, de, 64)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            R.sphere_step_grads(sd, xs, de, 64)
+        head = 32 * 3 / (time.perf_counter() - t0)
+    else:
+        head = _cpu_steps(arch, 32, 3, best) if arch != "iresnet50" else r50
     print("cpu_baseline: %s b32, 3 steps: %.2f img/s" % (arch, head), file=sys.stderr, flush=True)
     # FedPavg restatement over 1 / 2 / 4 / 8 iresnet100 state_dicts (anchor for the round time; 925 tensors, 260.9 MB each)
     fedpavg_s = {}
@@ -209,7 +222,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--arch", default="iresnet100", choices=["iresnet100", "iresnet50"])
+    ap.add_argument("--arch", default="iresnet100", choices=["iresnet100", "iresnet50", "sphnet"],
+                    help="sphnet = sphere64, the backbone the reference's run.sh trains (backbones/sphnet.py)")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--head", default="dense", choices=["dense", "pfc", "pfc-sharded"],

@@ -30,6 +30,7 @@ SIGNATURES = {
     "fedfr_profile_read": (i32, [i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
     "fedfr_net_create": (vp, [C.POINTER(i32), i32, i32, i32]),
     "fedfr_block_create": (vp, [i32, i32, i32, i32, i32]),
+    "fedfr_net_create_sphere": (vp, [i32, i32]),
     "fedfr_net_debug_capture": (i32, [vp, sz]),
     "fedfr_net_set_dropout": (i32, [vp, f32, u64, C.POINTER(i64)]),
     "fedfr_net_set_dropout_step": (i32, [vp, u64]),

@@ -88,10 +88,13 @@ class IBasicBlock(_Holder):
 class _Plan:
     """One C-side plan (batch-size specific) + its activation arena and workspace."""
 
-    def __init__(self, layers, batch, in_hw, nfeat, device):
+    def __init__(self, layers, batch, in_hw, nfeat, device, sphere_type=0):
         l = _C.lib()
-        arr = (C.c_int * 4)(*layers)
-        self.handle = l.fedfr_net_create(arr, batch, in_hw, nfeat)
+        if sphere_type:                    # sphnet plan (fedfr_net_create_sphere): same entry points, same buffers
+            self.handle = l.fedfr_net_create_sphere(sphere_type, batch)
+        else:
+            arr = (C.c_int * 4)(*layers)
+            self.handle = l.fedfr_net_create(arr, batch, in_hw, nfeat)
         if not self.handle:
             raise RuntimeError("fedfr_net_create failed: " + _C.last_error())
         self.batch = batch
@@ -225,11 +228,14 @@ class BlockPlan:
         return self._act(7)
 
 
-def _tensor_table(layers, in_hw, nfeat):
+def _tensor_table(layers, in_hw, nfeat, sphere_type=0):
     """state_dict layout from the C plan (batch-independent part)."""
     l = _C.lib()
-    arr = (C.c_int * 4)(*layers)
-    h = l.fedfr_net_create(arr, 8, in_hw, nfeat)
+    if sphere_type:
+        h = l.fedfr_net_create_sphere(sphere_type, 8)
+    else:
+        arr = (C.c_int * 4)(*layers)
+        h = l.fedfr_net_create(arr, 8, in_hw, nfeat)
     if not h:
         raise RuntimeError("fedfr_net_create failed: " + _C.last_error())
     try:
@@ -555,7 +561,7 @@ class IResNet(nn.Module):
         if p is None:
             if len(self._plans) >= 2:       # arenas are GBs: keep at most two batch sizes alive
                 self._plans.pop(next(iter(self._plans)))
-            p = _Plan(self.layers_cfg, batch, self.in_hw, self.num_features, self.device)
+            p = _Plan(self.layers_cfg, batch, self.in_hw, self.num_features, self.device, getattr(self, "sphere_type", 0))
             if self.dropout_p > 0:
                 off = C.c_longlong()
                 _C.call("fedfr_net_set_dropout", p.handle, self.dropout_p, self.dropout_seed, C.byref(off))

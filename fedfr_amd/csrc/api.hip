@@ -35,6 +35,7 @@ extern int g_fuse_bnapply;
 extern int g_fuse_bnred_next;
 extern int g_ew_reduce_blocks, g_ew_bwd_apply_blocks, g_ew_reduce_nt;
 extern int g_bn_fuse_bwd;
+extern int g_event_nofence, g_fork_mode;
 
 void fedfr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -169,6 +170,14 @@ int fedfr_set_option(const char* name, int value) {
     g_bn_fuse_bwd = value ? 1 : 0;   // reduce + apply pass of a BatchNorm backward in one launch with an in-launch hand-off (bn_sliced.hip)
     return FEDFR_OK;
   }
+  if (name && !strcmp(name, "event_nofence")) {
+    g_event_nofence = value ? 1 : 0;   // takes effect for events created afterwards (a plan creates its fork / join events on first use)
+    return FEDFR_OK;
+  }
+  if (name && !strcmp(name, "fork_mode")) {
+    g_fork_mode = value ? 1 : 0;
+    return FEDFR_OK;
+  }
   if (name && !strcmp(name, "nt_nbuf")) {
     g_nt_nbuf = value == 1 ? 1 : 2;
     return FEDFR_OK;
@@ -186,7 +195,7 @@ int fedfr_get_option(const char* name, int* value) {
       {"eval_fuse", &g_eval_fuse}, {"wgrad9", &g_wgrad9}, {"tn_pair", &g_tn_pair}, {"fuse_bnbwd", &g_fuse_bnbwd}, {"conv_c64p", &g_conv_c64p},
       {"bn_sliced", &g_bn_sliced}, {"wgrad9_wgs", &g_wgrad9_wgs}, {"conv28_tpw2", &g_conv28_tpw2}, {"wgrad9p", &g_wgrad9p},
       {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes}, {"bn_sliced_pre", &g_bn_sliced_pre}, {"nt_nbuf", &g_nt_nbuf},
-      {"bn_fuse_bwd", &g_bn_fuse_bwd}, {"ew_reduce_blocks", &g_ew_reduce_blocks}, {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks}, {"ew_reduce_nt", &g_ew_reduce_nt}};
+      {"bn_fuse_bwd", &g_bn_fuse_bwd}, {"event_nofence", &g_event_nofence}, {"fork_mode", &g_fork_mode}, {"ew_reduce_blocks", &g_ew_reduce_blocks}, {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks}, {"ew_reduce_nt", &g_ew_reduce_nt}};
   FEDFR_REQUIRE(name && value, "get_option: null argument");
   for (const auto& e : tab)
     if (!strcmp(name, e.n)) {
@@ -219,6 +228,7 @@ fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_
 fedfr_net_t* fedfr_block_create(int cin, int cout, int stride, int hin, int batch) {
   return net_create_block(cin, cout, stride, hin, batch);
 }
+fedfr_net_t* fedfr_net_create_sphere(int type, int batch) { return net_create_sphere(type, batch); }
 extern bf16_t* g_dbg_grads;
 extern size_t g_dbg_grads_elems;
 int fedfr_net_debug_capture(uint16_t* buf, size_t elems) {

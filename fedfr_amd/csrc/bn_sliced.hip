@@ -18,6 +18,26 @@
 // input rows (net.hip alternates between two partial-row buffers).
 #include "ew.h"
 #include "gemm_dev.h"   // ProfScope
+#include <hip/hip_ext.h>
+
+// A caller that forks a second stream right behind a BatchNorm-backward apply pass can have the fork event ATTACHED to that launch
+// (hipExtLaunchKernel's stopEvent = the kernel's own completion signal) instead of recording it behind the kernel: an event record is a
+// packet of its own in the stream's queue, and the next kernel of the stream waits for it (~7.5 us of main-stream bubble per fork in the
+// kernel trace, 49 forks per backward pass).  ew_bn_set_stop_event(e) arms it for the NEXT sliced / fused apply launch of this thread;
+// ew_bn_take_stop_event() tells the caller whether a launch consumed it (else it records the event the ordinary way).
+static thread_local hipEvent_t t_stop_event = nullptr;
+void ew_bn_set_stop_event(hipEvent_t e) { t_stop_event = e; }
+bool ew_bn_stop_event_pending() { return t_stop_event != nullptr; }
+void ew_bn_clear_stop_event() { t_stop_event = nullptr; }
+template <typename K, typename P>
+static inline void launch_maybe_stop(K kernel, dim3 grid, dim3 block, hipStream_t st, P p) {
+  if (t_stop_event) {
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, st, nullptr, t_stop_event, 0, p);
+    t_stop_event = nullptr;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, 0, st, p);
+  }
+}
 
 #ifndef BNS_PRIO
 #define BNS_PRIO 3   // wave priority of the backward passes: they share CUs with the weight-gradient kernels of the aux stream
@@ -768,8 +788,8 @@ int ew_bn_bwd_fused_sliced(BnBwdS p, hipStream_t st) {
   const int variant = (p.alpha ? 4 : 0) | (p.nx ? 2 : 0) | (p.add ? 1 : 0);
 #define BWD_F(A, N, D)                                                                                   \
   do {                                                                                                   \
-    if (small) hipLaunchKernelGGL((bn_bwd_fused_s_kernel<A, N, D, 7>), grid, dim3(NTH), 0, st, p);        \
-    else hipLaunchKernelGGL((bn_bwd_fused_s_kernel<A, N, D, 13>), grid, dim3(NTH), 0, st, p);             \
+    if (small) launch_maybe_stop((bn_bwd_fused_s_kernel<A, N, D, 7>), grid, dim3(NTH), st, p);            \
+    else launch_maybe_stop((bn_bwd_fused_s_kernel<A, N, D, 13>), grid, dim3(NTH), st, p);                 \
   } while (0)
   switch (variant) {
     case 0: BWD_F(false, false, false); break;
@@ -867,12 +887,12 @@ int ew_bn_bwd_apply_sliced(BnBwdS p, hipStream_t st) {
 #define BWD_S(A, N, D)                                                                                        \
   do {                                                                                                        \
     if (prof_id == 1) {                                                                                       \
-      if (small) hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 7, 1>), grid, dim3(NTH), 0, st, p);        \
-      else hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, kMaxPasses, 1>), grid, dim3(NTH), 0, st, p);     \
+      if (small) launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 7, 1>), grid, dim3(NTH), st, p);            \
+      else launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, kMaxPasses, 1>), grid, dim3(NTH), st, p);         \
     } else if (prof_id == 2) {                                                                                \
-      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 6, 3>), grid, dim3(NTH), 0, st, p);                   \
+      launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 6, 3>), grid, dim3(NTH), st, p);                       \
     } else {                                                                                                  \
-      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 3, 2>), grid, dim3(NTH), 0, st, p);                   \
+      launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 3, 2>), grid, dim3(NTH), st, p);                       \
     }                                                                                                         \
   } while (0)
   switch (variant) {

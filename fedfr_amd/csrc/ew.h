@@ -84,6 +84,10 @@ struct BnBwdS {
   unsigned* err;                                  // device word, OR-ed with 1 if a workgroup gave up waiting (bounded spin): results invalid
 };
 size_t ew_bn_fused_hand_bytes();
+// fork event attached to the next sliced / fused BatchNorm-backward apply launch of this thread (bn_sliced.hip)
+void ew_bn_set_stop_event(hipEvent_t e);
+bool ew_bn_stop_event_pending();
+void ew_bn_clear_stop_event();
 // reduce pass + apply pass of a BatchNorm backward in ONE launch (same geometry, same arithmetic and summation order as
 // ew_bn_bwd_reduce_sliced followed by ew_bn_bwd_apply_sliced: bit-identical results); the tensors stay in registers across the hand-off
 bool ew_bn_bwd_fused_ok(int M, int C);
@@ -129,6 +133,12 @@ int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B
 int ew_preprocess_u8(const unsigned char* src, const unsigned char* flip, float* dst, int B, int H, int W, hipStream_t st);
 int ew_bias_prelu_bwd(const bf16_t* dy, const bf16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
                       float* coef, float* dbias, float* dalpha, const bf16_t* add, bf16_t* dx, hipStream_t st);
+// PReLU(+bias) backward as ONE pass: g = dy (+ add, then written to gsum), dz = g * prelu'(x + bias) -> dz; rows [ew_prelu_bwd_rows][2][C] =
+// (sum dz | sum g (x + bias) over x + bias <= 0) for ew_prelu_bwd_finalize (-> dbias, dalpha; either may be null)
+int ew_prelu_bwd_rows(int M, int C);
+int ew_prelu_bwd_pass(const bf16_t* dy, const bf16_t* add, const bf16_t* x, const float* bias, const float* alpha, int M, int C, bf16_t* gsum,
+                      bf16_t* dz, float* rows, hipStream_t st);
+int ew_prelu_bwd_finalize(const float* rows, int P, int C, float* dbias, float* dalpha, hipStream_t st);
 int ew_pad_input_nhwc(const float* src, bf16_t* dst, int B, int C, int HW, int Cpad, hipStream_t st);
 // all dgrad shadows of a network in one launch (one 64x64 transpose tile per workgroup, table passed by value)
 constexpr int kMaxShadowEntries = 112;     // 112 x 32 B: the by-value table stays under the 4 KiB kernel-argument limit

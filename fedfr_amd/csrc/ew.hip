@@ -1489,6 +1489,121 @@ int ew_bias_prelu_bwd(const bf16_t* dy, const bf16_t* x, const float* bias, cons
   return ew_bn_bwd_apply(p, st);
 }
 
+// The same backward as ONE streaming pass (round 3; the sphnet plan, net_sph.inc): unlike a BatchNorm's, a PReLU's parameter sums do not
+// feed its input gradient, so dz is written while the sums are gathered and the finalize runs off the critical path.
+//   g = dy (+ add);  z = x + bias;  dz = g * (z > 0 ? 1 : alpha);  rows[blk] = (sum dz | sum g z over z <= 0);  optional gsum = g (bf16)
+struct PreluBwdP {
+  const bf16_t *dy, *add, *x;
+  const float *bias, *alpha;
+  int M, C;
+  bf16_t *gsum, *dz;
+  float* rows;
+};
+template <bool ADD>
+__global__ __launch_bounds__(EW_THREADS) void prelu_bwd_pass_kernel(PreluBwdP p, int slab, int shfl) {
+  extern __shared__ float red[];
+  const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
+  const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const bool active = rl < rpp;
+  const int c0 = cl * 8;
+  float bi[8], al[8];
+  load8f(p.bias, c0, bi, 0.f);
+  load8f(p.alpha, c0, al, 1.f);
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+  const int bid = ew_block_id();
+  const int mbeg = bid * slab, mend = min(p.M, mbeg + slab);
+  auto one = [&](int m, const uint4& vd, const uint4& va, const uint4& vx) {
+    const size_t off = (size_t)m * p.C + c0;
+    float g[8], x[8], o[8];
+    unpack8(vd, g);
+    unpack8(vx, x);
+    if (ADD) {
+      float a[8];
+      unpack8(va, a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] += a[j];
+      const uint4 gs = pack8(g);                     // the identity-path gradient the next block adds to is the bf16-rounded sum ...
+      *reinterpret_cast<uint4*>(p.gsum + off) = gs;
+      unpack8(gs, g);                                // ... and so is what this PReLU sees (as the two-pass form: add pass, then PReLU pass)
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float z = x[j] + bi[j];
+      float dz = g[j];
+      if (z <= 0.f) {
+        acc[1][j] += g[j] * z;
+        dz = g[j] * al[j];
+      }
+      acc[0][j] += dz;
+      o[j] = dz;
+    }
+    const uint4 ov = pack8(o);
+    *reinterpret_cast<uint4*>(p.dz + off) = ov;
+  };
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  constexpr int UNR = 4;
+  int m = active ? mbeg + rl : mend;
+  for (; m + (UNR - 1) * rpp < mend; m += UNR * rpp) {
+    uint4 vd[UNR], va[UNR], vx[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const size_t off = (size_t)(m + u * rpp) * p.C + c0;
+      vd[u] = *reinterpret_cast<const uint4*>(p.dy + off);
+      va[u] = ADD ? *reinterpret_cast<const uint4*>(p.add + off) : zero4;
+      vx[u] = ew_ld16(p.x + off);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      one(m + u * rpp, vd[u], va[u], vx[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  for (; m < mend; m += rpp) {
+    const size_t off = (size_t)m * p.C + c0;
+    one(m, *reinterpret_cast<const uint4*>(p.dy + off), ADD ? *reinterpret_cast<const uint4*>(p.add + off) : zero4,
+        *reinterpret_cast<const uint4*>(p.x + off));
+  }
+  // NOTE dbias of the two-pass form sums the UNROUNDED dz; so does this (acc[0] adds dz before the bf16 pack)
+  ew_block_colsum<2>(acc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, p.rows + (size_t)bid * 2 * p.C);
+}
+int ew_prelu_bwd_rows(int M, int C) { return ceil_div(M, slab_rows(M, C, 512)); }
+int ew_prelu_bwd_pass(const bf16_t* dy, const bf16_t* add, const bf16_t* x, const float* bias, const float* alpha, int M, int C, bf16_t* gsum,
+                      bf16_t* dz, float* rows, hipStream_t st) {
+  FEDFR_TRY(check_mc(M, C, "prelu_bwd_pass"));
+  FEDFR_REQUIRE(dy && x && alpha && dz && rows && (!add || gsum), "prelu_bwd_pass: null tensor");
+  const int slab = slab_rows(M, C, 512);
+  const int grid = ceil_div(M, slab);
+  const size_t lds = ew_colsum_lds(C, 2);
+  const int shfl = ew_shfl_ok(C) ? 1 : 0;
+  PreluBwdP p{dy, add, x, bias, alpha, M, C, gsum, dz, rows};
+  ProfScope prof(22, (double)M * C * 2 * (add ? 5.0 : 3.0), st);
+  if (add) hipLaunchKernelGGL(prelu_bwd_pass_kernel<true>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
+  else hipLaunchKernelGGL(prelu_bwd_pass_kernel<false>, dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl);
+  FEDFR_LAUNCH_CHECK("prelu_bwd_pass");
+  return FEDFR_OK;
+}
+// 8 channels per workgroup, every row load of a trip in flight (fin8_accumulate): the first version walked the rows one thread per channel
+// from 1-2 workgroups and took 173 us per PReLU on the sphnet plan's weight-gradient stream (62 launches = 10.7 ms per step)
+__global__ __launch_bounds__(256) void prelu_rows_finalize_kernel(const float* __restrict__ rows, int P, int C, float* dbias, float* dalpha) {
+  __shared__ double tot[2][8];
+  const int c0 = blockIdx.x * 8;
+  fin8_accumulate<2>(rows, P, C, c0, 2, tot);
+  if (threadIdx.x < 8) {
+    const int c = c0 + threadIdx.x;
+    if (dbias) dbias[c] = (float)tot[0][threadIdx.x];
+    if (dalpha) dalpha[c] = (float)tot[1][threadIdx.x];
+  }
+}
+int ew_prelu_bwd_finalize(const float* rows, int P, int C, float* dbias, float* dalpha, hipStream_t st) {
+  FEDFR_REQUIRE(rows && P > 0 && C > 0, "prelu_bwd_finalize: bad args");
+  FEDFR_REQUIRE((C & 7) == 0, "prelu_bwd_finalize: C %% 8");
+  hipLaunchKernelGGL(prelu_rows_finalize_kernel, dim3(C / 8), dim3(256), 0, st, rows, P, C, dbias, dalpha);
+  FEDFR_LAUNCH_CHECK("prelu_bwd_finalize");
+  return FEDFR_OK;
+}
+
 // fp32 NCHW [B][C][HW] -> bf16 NHWC [B][HW][Cpad], channels >= C zero (sphnet's 3-channel input feeds the 64-channel-granular conv)
 __global__ __launch_bounds__(256) void pad_input_nhwc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int C, int HW, int Cpad) {
   const long long total = (long long)B * HW * (Cpad / 8);

@@ -42,10 +42,25 @@ struct BlockD {
   long long x_off, a1_off, c1_off, a2_off, c2_off, d_off, out_off;   // bf16 element offsets in act
 };
 
+// ---- sphnet (reference backbones/sphnet.py:4-73): conv3x3 (+bias on the stride-2 stage heads) -> PReLU units, residual blocks of two ----
+struct SphUnit {
+  ConvD conv;                 // as the kernels see it (the first conv's 3 input channels are zero-padded to 64)
+  long long w_param_off;      // the parameter's own offset ([Cout][3][3][Cin_real] KRSC)
+  int cin_real;
+  long long b_off, a_off;     // conv bias (-1: none), PReLU slope
+  long long in_off, c_off, t_off;   // bf16 arena offsets: input, raw conv output, activated output
+  size_t dz_off, rows_off;    // workspace byte offsets: gradient wrt the raw conv output (the weight-gradient operand); PReLU partial rows
+};
+struct SphBlockD { SphUnit u1, u2; };
+struct SphStageD { SphUnit head; std::vector<SphBlockD> blocks; int C, H; };
+
 // dual-stream backward: generations of (dc2, dc1, dd) the weight-gradient stream may lag behind the main stream.  With 2 the main
 // stream waited 1.4 ms per step for weight gradients of two blocks ago (mostly in the 7x7 / early 14x14 stages, whose weight GEMMs
 // are long and whose main-stream kernels are short); 4 generations cost 1.2 GB more workspace.
-constexpr int kWgradDepth = 4;
+#ifndef FEDFR_WGRAD_DEPTH
+#define FEDFR_WGRAD_DEPTH 4
+#endif
+constexpr int kWgradDepth = FEDFR_WGRAD_DEPTH;
 constexpr int kSlicedRowsMax = 256;     // partial rows a channel-sliced BatchNorm pass writes at most (ew_bn_sliced_rows)
 struct FedfrNet {
   int layers[4];
@@ -78,6 +93,11 @@ struct FedfrNet {
   // workspace is seen for the first time, epochs count launches
   mutable unsigned hand_epoch = 0;
   mutable const unsigned char* hand_ws = nullptr;
+  int sph_type = 0;                     // 20 / 64: a sphnet plan (net_create_sphere); the iresnet fields above are unused then
+  std::vector<SphStageD> sph;
+  long long sph_xin_off = 0, sph_flat_off = 0;          // arena: padded NHWC input [B][112][112][64]; (== last activation) NCHW-flat [B][512*49]
+  long long sph_w0pad_off = 0;                          // shadow: the first conv's weights padded to 64 input channels [64][3][3][64]
+  size_t sph_ws_g[4] = {0, 0, 0, 0}, sph_ws_w0g = 0, sph_ws_dfe = 0;   // workspace: gradient ping-pong + two dgrad outputs; padded stem weight gradient; bf16 dfeats + transpose
   bool block_only = false;              // plan of a lone IBasicBlock (net_create_block): no stem, no bn2/fc/features tail
   long long dx_off = -1;                // block_only: bf16 arena offset of the gradient wrt the block input [B*Hin*Hin][Cin]
 };
@@ -86,6 +106,9 @@ FedfrNet* net_create(const int layers[4], int batch, int in_hw, int num_features
 // lone IBasicBlock(cin, cout, stride) on a hin x hin map; with it net_forward takes x = fp32 NCHW [B][cin][hin][hin] (feats unused, may be
 // null) and net_backward takes dfeats = fp32 NCHW [B][cout][hout][hout]; y / dx are read from the arena (fedfr_net_act_info)
 FedfrNet* net_create_block(int cin, int cout, int stride, int hin, int batch);
+// sphnet (type 20 / 64, 112 x 112 input, 512 features): same buffers and entry points as an iresnet plan (no BatchNorm: bufs / nbt are empty);
+// the optimiser update is not folded into its backward pass (NetSgd::done_from = trainable_count)
+FedfrNet* net_create_sphere(int type, int batch);
 int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st);
 int net_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, const bf16_t* shadow,
                 unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st);

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include "ew.h"
 #include "gemm.h"
+#include "head.h"
 
 static const int kPlanes[4] = {64, 128, 256, 512};
 static const float kBnEps = 1e-5f, kBnMomentum = 0.1f;
@@ -462,8 +463,14 @@ static int bn_apply_train(const Ctx& c, const BnD& b, Rows r, const bf16_t* x1, 
   return FEDFR_OK;
 }
 
+static int sph_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st);
+static int sph_forward(const FedfrNet* n, const float* x, const float* params, const bf16_t* shadow, unsigned char* act, unsigned char* ws,
+                       float* feats, hipStream_t st);
+static int sph_backward(const FedfrNet* n, const float* dfeats, const float* params, const bf16_t* shadow, unsigned char* act, unsigned char* ws,
+                        float* grads, hipStream_t st, hipStream_t aux, NetSgd* sgd);
 int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, int fwd_shadow_too, hipStream_t st) {
   FEDFR_REQUIRE(n && params && shadow, "prepare_weights: null");
+  if (n->sph_type) return sph_prepare_weights(n, params, shadow, fwd_shadow_too, st);
   if (fwd_shadow_too) FEDFR_TRY(ew_cast_f32_bf16(params, shadow, (size_t)n->trainable_count, st));
   // every conv's dgrad-layout copy ([Cin][taps flipped][Cout] bf16) in ONE launch (was one small kernel per conv: 105 per step)
   ShadowTable t{};
@@ -488,6 +495,10 @@ int net_prepare_weights(const FedfrNet* n, const float* params, bf16_t* shadow, 
 
 int net_forward(const FedfrNet* n, const float* x, const float* params, float* bufs, const bf16_t* shadow,
                 unsigned char* act, unsigned char* ws, float* feats, int training, hipStream_t st) {
+  if (n && n->sph_type) {                             // sphnet: no BatchNorm, so no buffers and no train / eval difference
+    FEDFR_REQUIRE(x && params && shadow && act && ws && feats, "net_forward (sphnet): null buffer");
+    return sph_forward(n, x, params, shadow, act, ws, feats, st);
+  }
   FEDFR_REQUIRE(n && x && params && bufs && shadow && act && ws && (feats || n->block_only), "net_forward: null buffer");
   Ctx c{n, params, bufs, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, nullptr, st};
   FEDFR_REQUIRE(training >= 0 && training <= 2, "net_forward: training must be 0 (eval), 1 (train) or 2 (train, BatchNorms frozen in eval mode)");
@@ -685,6 +696,9 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   return ew_bn_bwd_apply(p, c.st);
 }
 
+int g_event_nofence = 1;   // option "event_nofence": fork / join events created with hipEventDisableSystemFence
+int g_fork_mode = 0;       // option "fork_mode": 1 = the per-block fork event is the completion signal of the BatchNorm-backward apply launch that
+                           // produces the last weight-gradient operand (hipExtLaunchKernel stopEvent) instead of a record packet behind it
 // fork/join helpers for the dual-stream backward (events are created once per plan)
 namespace {
 struct Fork {
@@ -695,7 +709,7 @@ struct Fork {
   hipEvent_t ev() {
     if (next == n->events.size()) {
       hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) { ok = false; return nullptr; }
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (g_event_nofence ? hipEventDisableSystemFence : hipEventReleaseToDevice)) != hipSuccess) { ok = false; return nullptr; }
       n->events.push_back(e);
     }
     return n->events[next++];
@@ -705,6 +719,11 @@ struct Fork {
     if (!aux) return;
     hipEvent_t e = ev();
     if (!e || hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) ok = false;
+  }
+  // fork whose event was attached to the last launch on `from` (ew_bn_set_stop_event): `to` only waits
+  void order_attached(hipEvent_t e, hipStream_t to) {
+    if (!aux) return;
+    if (!e || hipStreamWaitEvent(to, e, 0) != hipSuccess) ok = false;
   }
   hipEvent_t mark(hipStream_t s) {            // record now, wait later
     if (!aux) return nullptr;
@@ -720,6 +739,10 @@ struct Fork {
 
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
                  unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux, NetSgd* sgd) {
+  if (n && n->sph_type) {
+    FEDFR_REQUIRE(dfeats && params && shadow && act && ws && grads, "net_backward (sphnet): null buffer");
+    return sph_backward(n, dfeats, params, shadow, act, ws, grads, st, aux, sgd);
+  }
   FEDFR_REQUIRE(n && (x || n->block_only) && dfeats && params && shadow && act && ws && grads, "net_backward: null buffer");
   Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
   const int B = n->B, F = n->F, HW = n->HW;
@@ -803,7 +826,14 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     int f2 = 0, f1 = 0;
     FEDFR_TRY(conv_dgrad(c, k.conv2, dc2, da2, &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
     // a2 = prelu(bn2(c1))
+    hipEvent_t fork_ev = nullptr;
+    if (g_fork_mode == 1 && aux && !k.has_ds) {        // this apply pass is the last main-stream launch in front of the block's fork
+      fork_ev = fk.ev();
+      ew_bn_set_stop_event(fork_ev);
+    }
     FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, da2, A + k.c1_off, Mi, nullptr, nullptr, 0, dc1, k.alpha_off, Rows{c.part(), f2}));
+    const bool fork_attached = fork_ev && !ew_bn_stop_event_pending();
+    ew_bn_clear_stop_event();
     // identity path first (its BN reduction uses the shared partial buffer), then conv1's dgrad whose epilogue may
     // leave bn1's partial sums there for the bn_bwd that follows immediately
     if (k.has_ds) {
@@ -811,7 +841,8 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     }
     // ONE fork per block: every event record costs the main stream a ~8 us bubble (kernel trace), so the block's two or three
     // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
-    fk.order(st, wst);
+    if (fork_attached) fk.order_attached(fork_ev, wst);
+    else fk.order(st, wst);
     FEDFR_TRY(sgd_flush());
     FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst));
     if (k.has_ds) {
@@ -851,3 +882,5 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   }
   return FEDFR_OK;
 }
+
+#include "net_sph.inc"

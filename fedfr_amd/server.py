@@ -56,10 +56,12 @@ def FedPavg(models: List[dict], weights: Sequence[float]):
         for c0 in range(0, len(models), 8):
             grp, wgrp = models[c0:c0 + 8], ws[c0:c0 + 8]
             _multi(P, [m.flat[0] for m in grp], wgrp, c0 > 0)
-            _multi(Bf, [m.flat[1] for m in grp], wgrp, c0 > 0)
+            if Bf.numel():                          # (sphnet has no BatchNorm: no running statistics, no counters)
+                _multi(Bf, [m.flat[1] for m in grp], wgrp, c0 > 0)
         for i, (m, w) in enumerate(zip(models, ws)):
             n = m.flat[2]
-            _C.call("fedfr_fedavg_i64", N.data_ptr(), n.data_ptr(), float(np.float32(w)), n.numel(), 1 if i else 0, None, _C.stream())
+            if n.numel():
+                _C.call("fedfr_fedavg_i64", N.data_ptr(), n.data_ptr(), float(np.float32(w)), n.numel(), 1 if i else 0, None, _C.stream())
         return FlatStateDict.from_flat((P, Bf, N), models[0].table, models[0].layers)
     aggr = OrderedDict()
     for name in models[0]:
@@ -134,9 +136,11 @@ def fedavg_all_reduce(backbone, data_size: float, total_size: float, comm=None, 
     n_float = (nbt_f.data_ptr() - state.data_ptr()) // 4          # params + running stats: everything in front of the counter image
     fl = state[:n_float]
     _axpy(fl, fl, w, False)
-    _i64(nbt_f, nbt, w)
+    if nbt.numel():
+        _i64(nbt_f, nbt, w)
     comm.all_reduce(state, "sum")                  # THE exchange of the round
-    _trunc(nbt_f, nbt)
+    if nbt.numel():
+        _trunc(nbt_f, nbt)
     backbone.mark_weights_dirty()
     return w
 

@@ -60,6 +60,11 @@ fedfr_net_t* fedfr_net_create(const int* layers4, int batch, int in_hw, int num_
  * fedfr_net_forward takes x = fp32 NCHW [B][cin][hin][hin] (feats may be NULL; y = act selector 6) and fedfr_net_backward takes
  * dfeats = fp32 NCHW [B][cout][hout][hout] (dx = act selector 7).  stride 1 needs cin == cout; stride 2 adds the 1x1 downsample. */
 fedfr_net_t* fedfr_block_create(int cin, int cout, int stride, int hin, int batch);
+/* SphereFace backbone (reference backbones/sphnet.py:16-73 — the network run.sh trains): type 20 or 64, 112 x 112 input, 512 features, as a
+ * plan with the SAME entry points and buffers as an iresnet plan (fedfr_net_query / _tensor_info / _prepare_weights / _forward /
+ * _backward*).  No BatchNorm: buffer and counter regions are empty, `bufs` is ignored, training and eval forward coincide; conv weights are
+ * KRSC like iresnet's; fedfr_net_backward2_sgd leaves the whole update to the caller (*done_from = trainable count). */
+fedfr_net_t* fedfr_net_create_sphere(int type, int batch);
 void fedfr_net_destroy(fedfr_net_t* net);
 /* nn.Dropout(p, inplace=True) between bn2 and fc (backbones/iresnet.py:96,169; the reference uses p = 0.4 for its webface configuration,
  * client.py:142): training forwards then zero a counter-based random subset of the flattened bn2 output (element i of the k-th training

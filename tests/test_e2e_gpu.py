@@ -1267,3 +1267,48 @@ def test_fused_bn_backward_handoff_is_bit_identical(batch):
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
         assert all(torch.isfinite(v).all() for v in g1.values())
+
+
+def test_sphnet_trains_through_the_fused_trainer_like_iresnet():
+    """Round 3: sphnet is a C++ plan behind the iresnet plan's entry points (csrc/net_sph.inc), so everything built on them takes it:
+    FusedTrainer (one fedfr_net_forward + head + fedfr_net_backward2_sgd + flat SGD per step), the flat state for FedAvg, and
+    `args.network = "sphnet"` in Client.train (the reference's run.sh configuration).  Checked against the eager path of the same
+    model — reference-style step (client.py:543-549) + torch.optim.SGD — over 3 steps: same losses and weights to fp32 noise."""
+    B, C_, lr = 8, 20, 0.01
+    sd = R.sphere_state_dict(20, tag=1.0)
+    x = [R.closed_form_images(B, tag=4.0 + i).to(DEV) for i in range(3)]
+    lab = [R.closed_form_labels(B, C_, tag=i).to(DEV) for i in range(3)]
+    # eager: autograd bridge + stock optimizer
+    m0 = backbones.sphnet(False, dropout=0, fp16=True, type=20).to(DEV)
+    m0.load_state_dict(sd)
+    m0.train()
+    fcm = client.FC_module(512, C_, "/tmp").to(DEV)
+    fcm.fc.data = R.head_fc(C_).to(DEV)
+    model = client.Sequential_model(m0, fcm)
+    opt = torch.optim.SGD([{"params": m0.parameters()}, {"params": [fcm.fc]}], lr=lr, momentum=0.9, weight_decay=5e-4)
+    l0 = []
+    for i in range(3):
+        opt.zero_grad()
+        loss = ops.cross_entropy(losses.CosFace(s=30, m=0.4)(model(x[i]), lab[i]), lab[i])
+        loss.backward()
+        opt.step()
+        m0.mark_weights_dirty()
+        l0.append(float(loss))
+    # fused
+    m1 = backbones.sphnet(False, dropout=0, fp16=True, type=20).to(DEV)
+    m1.load_state_dict(sd)
+    fc1 = R.head_fc(C_).to(DEV)
+    tr = client.FusedTrainer(m1, fc1, "CosFace", 30.0, 0.4, lr=lr, momentum=0.9, weight_decay=5e-4)
+    l1 = [float(tr.step(x[i], lab[i])) for i in range(3)]
+    tr.finish()
+    assert all(abs(a - b) < 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    s0, s1 = m0.state_dict(), m1.state_dict()
+    worst = max(rel(s1[k], s0[k]) for k in s0)
+    assert worst < 2e-3, worst
+    assert rel(fc1, fcm.fc.data) < 2e-3
+    # flat state: what FedPavg / load_state_dict exchange
+    fsd = client.flat_state_dict(m1)
+    agg = server.FedPavg([fsd, client.flat_state_dict(m0)], [1.0, 1.0])
+    m2 = backbones.sphnet(False, type=20).to(DEV)
+    m2.load_state_dict(agg)
+    assert rel(m2.state_dict()["layer3.2.conv1.weight"], 0.5 * (s0["layer3.2.conv1.weight"] + s1["layer3.2.conv1.weight"])) < 1e-6

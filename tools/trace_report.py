@@ -5,8 +5,9 @@ import csv, collections, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows: r['s'] = float(r['start_us']); r['e'] = float(r['end_us'])
 qs = collections.Counter(r['queue'] for r in rows); mainq = max(qs, key=qs.get)
-tb = [r for r in rows if r['name'].startswith('bn1d_bwd')][0]['s']
-tf = [r for r in rows if r['name'].startswith('stem_fwd')][0]['s']
+bw0 = [r for r in rows if r['name'].startswith('bn1d_bwd')] or [r for r in rows if 'sph_dfeats_kernel' in r['name']]     # first backward kernel (iresnet / sphnet)
+tb = bw0[0]['s']
+tf = min(r['s'] for r in rows)
 te = max(r['e'] for r in rows)
 print("fwd %.2f ms; bwd+sgd %.2f ms" % ((tb - tf) / 1e3, (te - tb) / 1e3))
 bw = [r for r in rows if r['s'] >= tb]

@@ -581,10 +581,22 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           v = pack8(f);
           unpack8(v, f);
         }
-        if (p.Cb2) {                                         // the next block's bn1 of the (bf16) output
+        if (p.Cb2) {                                         // the next block's bn1 of the (bf16) output; or sphnet's activation (gemm.h)
           float y2[8];
+          if (p.e2alpha || !p.esc2) {
+            float a2[8];
+            if (p.e2add) unpack8(*reinterpret_cast<const uint4*>(p.e2add + go), a2);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) y2[q] = f[q] * p.esc2[n0 + c * 8 + q] + p.esh2[n0 + c * 8 + q];
+            for (int q = 0; q < 8; ++q) {
+              const int n = n0 + c * 8 + q;
+              float t = f[q] * (p.esc2 ? p.esc2[n] : 1.f) + (p.esh2 ? p.esh2[n] : 0.f);
+              if (p.e2alpha) t = t > 0.f ? t : p.e2alpha[n] * t;
+              y2[q] = p.e2add ? t + a2[q] : t;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y2[q] = f[q] * p.esc2[n0 + c * 8 + q] + p.esh2[n0 + c * 8 + q];
+          }
           *reinterpret_cast<uint4*>(p.Cb2 + go) = pack8(y2);
         }
       }
@@ -704,7 +716,7 @@ static int launch_glds(GemmNT p, hipStream_t st) {
                 "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
   FEDFR_REQUIRE(FUSED == (p.bpart != nullptr), "conv3x3_glds: fused / plain variant mismatch");
   FEDFR_REQUIRE(XFORM == (p.tsc != nullptr) && (!XFORM || (p.tsh && p.C <= 256)), "conv3x3_glds: input-transform variant mismatch");
-  FEDFR_REQUIRE(!(p.esc || p.eadd || p.Cb2) || (!FUSED && p.ldc == p.N && (!p.esc || p.esh) && (!p.Cb2 || (p.esc2 && p.esh2))),
+  FEDFR_REQUIRE(!(p.esc || p.eadd || p.Cb2) || (!FUSED && p.ldc == p.N && (!p.esc || p.esh) && (!p.Cb2 || (p.esc2 && p.esh2) || p.e2alpha)),
                 "conv3x3_glds: output epilogue needs the plain variant, ldc == N and complete coefficient sets");
   if (FUSED) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");

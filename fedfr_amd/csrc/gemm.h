@@ -48,6 +48,11 @@ struct GemmNT {
   const bf16_t* eadd;
   const float *esc2, *esh2;
   bf16_t* Cb2;
+  // ... and, for nets whose activation follows the conv with no normalisation in between (sphnet: t = prelu(conv + bias) (+ identity)):
+  // Cb2 = prelu_{e2alpha}(y * esc2 + esh2) + e2add with esc2 / esh2 / e2add optional (1 / 0 / none) — the same fp32 expressions on the
+  // same bf16-rounded conv output as the separate ew_bn_apply pass, so both forms give identical bits; Cb keeps the raw conv output
+  const float* e2alpha;
+  const bf16_t* e2add;
   unsigned long long* dbg;   // diagnostics builds only (tools/stamp_halo2.hip): per-block in-kernel clock stamps
 };
 

@@ -37,7 +37,9 @@ const char* fedfr_last_error_string(void);
  * epilogue, everywhere / 14x14 layers), "fuse_bnapply", "eval_fuse", "conv28_tpw2", "dgrad_parity", "wgrad_depth", "bn_fuse_bwd" (0 [default] / 1: reduce + apply pass of a
  * BatchNorm backward in ONE launch on the 14x14 / 7x7 maps, partial rows handed over inside the launch; bit-identical to the two-launch
  * form), "ew_reduce_blocks" / "ew_bwd_apply_blocks" / "ew_reduce_nt" (grid sizes and load policy of the large maps' row-slab
- * BatchNorm-backward passes).  Unknown names are an error. */
+ * BatchNorm-backward passes), "event_nofence" (1 [default]: the backward pass's fork / join events carry no system-scope fence),
+ * "fork_mode" (0 [default] / 1: the per-block fork event rides on the completion signal of the launch in front of it), "sph_fuse_act"
+ * (0 [default] / 1: sphnet's PReLU (+bias, +identity) in the conv kernel's epilogue where the kernel has one).  Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);
 /* the switch's current value (a caller that changes one temporarily restores what it found) */
 int fedfr_get_option(const char* name, int* value);

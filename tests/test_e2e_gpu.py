@@ -608,6 +608,15 @@ def test_sphnet_vs_reference():
     # sum over 4e5 pixels (same policy as the iresnet gradient test: median small, max bounded)
     dvals = [e for _, e in derr]
     assert np.median(dvals) < 0.15 and max(dvals) < 0.4, (np.median(dvals), max(derr, key=lambda t: t[1]))   # measured 0.106 / 0.16
+    # the activation in the conv epilogue (option sph_fuse_act) == conv + the separate streaming pass (default), bit for bit
+    g_fused = {k: p.grad.clone() for k, p in net.named_parameters()}
+    with _C.option_scope("sph_fuse_act", 1):
+        for p in net.parameters():
+            p.grad = None
+        feats0 = net(x)
+        (feats0 * dfe).sum().backward()
+    assert torch.equal(feats0.detach(), feats.detach())
+    assert all(torch.equal(p.grad, g_fused[k]) for k, p in net.named_parameters())
     net.eval()
     with torch.no_grad():
         assert torch.equal(net(x), feats.detach())

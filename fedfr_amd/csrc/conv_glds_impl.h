@@ -570,7 +570,8 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       const int row = idx / CPR, c = idx - row * CPR;
       uint4 v = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
       const size_t go = (size_t)(m0 + row) * p.ldc + n0 + c * 8;
-      if (p.eadd || p.Cb2) {
+      if (TPW == 1 && (p.eadd || p.Cb2)) {                 // (compiled out of the two-tiles-per-workgroup instantiation, which sits at the register limit: with
+                                                           // this block in it spilled — 256 VGPRs + 128 B of scratch per lane, 34 -> 51 us per 28x28 conv; round 3)
         float f[8];
         unpack8(v, f);
         if (p.eadd) {                                        // + identity path (one more bf16 rounding than the separate bn_apply pass)

@@ -312,7 +312,7 @@ static int conv_fwd_bn(const Ctx& c, const ConvD& cv, const bf16_t* raw, const B
   p.tsc = c.save(bn, 0); p.tsh = c.save(bn, 1); p.talpha = alpha; p.aout = tr ? a : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
-int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the 3x3 dgrad epilogue (1: every layer a fused kernel serves; 2: the 14x14
+int g_fuse_bnbwd = 2;   // (round 3: 2 is the default, together with wgrad9p = 1 — see the end of this comment)  option "fuse_bnbwd": BN-backward reduction in the 3x3 dgrad epilogue (1: every layer a fused kernel serves; 2: the 14x14
                         // layers only, whose 128 partial rows the channel-sliced apply pass reduces itself).  LDS-DMA kernel: the x tile rides
                         // through the K loop in registers, the coefficients are requested in front of the drain: +3.7 us on a 28.6 us dgrad
                         // (round 1: x by LDS-DMA after the loop and 62 lazily issued coefficient loads, +11 us).  Off by default all the same:
@@ -321,6 +321,8 @@ int g_fuse_bnbwd = 0;   // option "fuse_bnbwd": BN-backward reduction in the 3x3
                         // that now follows sooner cannot start on a CU a weight-gradient workgroup still holds (54.9 us per fused dgrad in the
                         // dual-stream trace, 32.3 alone).  With the paired weight-gradient kernel (wgrad9p = 1) beside it the step is back at
                         // 16.94: both sides of the overlap have to shrink together (profiles/r02_ab_fuse_bnbwd_v2.txt).
+                        // Round 3 (after the fork / join events lost their system-scope fence): the pair fuse_bnbwd = 2 + wgrad9p = 1 measures
+                        // 17.00 / 17.01 ms against 17.21 / 17.15 for the old defaults, each alone still loses (17.40 / 17.34): both are on.
 // dx (at the conv's INPUT resolution) = conv_transpose(dy).  If `bn` is given, the kernel may also produce the
 // BN-backward partial sums of (dx, bn_x) in its epilogue; *fused_rows > 0 then (else run ew_bn_bwd_reduce).
 static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* dx, const BnD* bn = nullptr,
@@ -369,8 +371,10 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
 }
 int g_wgrad_pair_reduce = 1;   // option "wgrad_pair_reduce": one slab-reduction launch for the two 3x3 weight gradients of a block
 // the two 3x3 weight gradients of a residual block; same shape (every block but a stage's first): one paired launch
+int g_dbg_skip = 0;   // option "dbg_skip" (timing experiments, WRONG results): 1 = no weight-gradient launches of the residual blocks' 3x3 convs
 static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const bf16_t* dya, const ConvD& cvb, const bf16_t* inb,
                        const bf16_t* dyb, hipStream_t st) {
+  if (g_dbg_skip & 1) return FEDFR_OK;
   GemmTN a = wgrad_problem(c, cva, ina, dya), b = wgrad_problem(c, cvb, inb, dyb);
   if (gemm_tn_w9pair_ok(a, b)) {                        // both on the 64 x 64 nine-tap kernel, one launch
     const int sp = gemm_tn_w9pair_splits(a);

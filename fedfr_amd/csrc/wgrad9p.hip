@@ -30,7 +30,7 @@
 // workgroups never share a CU (registers), so the streams interleave at workgroup granularity, and the main stream now waits for
 // 65-90 us workgroups instead of 40-60 us ones (rocprof: conv3x3_glds 38.3 -> 30.4 us per launch, but the BatchNorm passes stretch
 // and the overlap the second stream bought is gone).  Server.train switches it on when several clients train concurrently.
-int g_wgrad9p = 0;
+int g_wgrad9p = 1;   // option "wgrad9p".  On since round 3 TOGETHER with fuse_bnbwd = 2 (net.hip): alone either loses in the dual-stream step, the pair gains 0.2 ms (profiles/r03_ab_options_final_v1.txt)
 
 namespace {
 template <int N_>

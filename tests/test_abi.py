@@ -72,8 +72,8 @@ def test_documented_options_exist_and_unknown_ones_are_errors(built_lib):
     names = sorted(set(re.findall(r'"([a-z0-9_]+)"', doc)))
     assert len(names) >= 15 and "nt_glds" in names and "bn_sliced" in names
     lib = built_lib.lib()
-    defaults = {"tn_use_tr": 1, "conv_halo": 4, "nt_glds": 4, "wgrad9": 1, "wgrad9p": 0, "tn_glds": 2, "tn_pair": 0, "wgrad_pair_reduce": 1,
-                "bn_sliced": 1, "fuse_bnbwd": 0, "fuse_bnapply": 0, "eval_fuse": 1, "conv28_tpw2": 2, "dgrad_parity": 2, "wgrad_depth": 4,
+    defaults = {"tn_use_tr": 1, "conv_halo": 4, "nt_glds": 4, "wgrad9": 1, "wgrad9p": 1, "tn_glds": 2, "tn_pair": 0, "wgrad_pair_reduce": 1,
+                "bn_sliced": 1, "fuse_bnbwd": 2, "fuse_bnapply": 0, "eval_fuse": 1, "conv28_tpw2": 2, "dgrad_parity": 2, "wgrad_depth": 4,
                 "bn_fuse_bwd": 0, "ew_reduce_blocks": 512, "ew_bwd_apply_blocks": 2048, "ew_reduce_nt": 0, "event_nofence": 1, "fork_mode": 0,
                 "sph_fuse_act": 0}
     for n in names:

@@ -671,15 +671,12 @@ def test_paired_weight_gradient_kernel_in_the_network():
     summation-order level (activations and activation gradients do not depend on the choice at all: bit-identical embeddings)."""
     outs = []
     for opt in (0, 1):
-        _C.call("fedfr_set_option", b"wgrad9p", opt)
-        try:
+        with _C.option_scope("wgrad9p", opt):
             m, sd, _ = make_model("iresnet50", tag=3.0)
             m.train()
             f = m(R.closed_form_images(16).to(DEV))
             (f * R.closed_form((16, 512), 0.37, 0.9, 1.0).to(DEV)).sum().backward()
             outs.append((f.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
-        finally:
-            _C.call("fedfr_set_option", b"wgrad9p", 0)
     assert torch.equal(outs[0][0], outs[1][0])
     worst = max((rel(outs[1][1][k], outs[0][1][k]), k) for k in outs[0][1] if float(outs[0][1][k].norm()) > 0)
     print("wgrad9p on vs off: worst %.2e (%s)" % worst)
@@ -790,11 +787,8 @@ def test_large_batch_train_step_vs_oracle(fuse_bnbwd):
     """iresnet18 at batch 128: M = 25088..1.6M rows, so the conv layers run on the LDS-halo kernels that the small-batch
     goldens never reach — with the BN-backward reduction as its own kernel (default) and fused into the dgrad epilogue
     (option fuse_bnbwd).  Compared with the fp32 oracle on the same inputs."""
-    _C.call("fedfr_set_option", b"fuse_bnbwd", fuse_bnbwd)
-    try:
+    with _C.option_scope("fuse_bnbwd", fuse_bnbwd):
         _large_batch_step()
-    finally:
-        _C.call("fedfr_set_option", b"fuse_bnbwd", 0)
 
 
 # measured x 1.25 (cosine 1.19e-2, norms 2.6e-3 / 9.3e-2, directions 4.8e-2 / 0.34, head gradient 1.2e-2)
@@ -846,6 +840,7 @@ def test_full_size_step_invariants_r100_b128(monkeypatch):
 
     def run(dual=True, **opts):
         monkeypatch.setenv("FEDFR_DUAL_STREAM", "1" if dual else "0")
+        prev = {k: _C.get_option(k) for k in opts}
         for k, v in opts.items():
             _C.call("fedfr_set_option", k.encode(), v)
         try:
@@ -855,7 +850,7 @@ def test_full_size_step_invariants_r100_b128(monkeypatch):
             return loss, m._flat_grads.clone(), tr.fc_grad.clone()
         finally:
             for k in opts:
-                _C.call("fedfr_set_option", k.encode(), {"wgrad9": 1, "tn_glds": 2}.get(k, 0))
+                _C.call("fedfr_set_option", k.encode(), prev[k])
 
     l0, g0, f0 = run()
     l1, g1, f1 = run()

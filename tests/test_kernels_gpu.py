@@ -240,13 +240,10 @@ def test_conv_wgrad9_pair(B, H, C):
     for pair in (1, 0):
         dwa = torch.full((C, 3, 3, C), float("nan"), device=dev())
         dwb = torch.full((C, 3, 3, C), float("nan"), device=dev())
-        _C.call("fedfr_set_option", b"wgrad9p", pair)
-        try:
+        with _C.option_scope("wgrad9p", pair):
             _C.call("fedfr_conv2d_wgrad_pair", outs[0][0].data_ptr(), outs[0][1].data_ptr(), dwa.data_ptr(), outs[1][0].data_ptr(),
                     outs[1][1].data_ptr(), dwb.data_ptr(), ws.data_ptr(), nbytes, B, H, C, C, 3, 1, _C.stream())
             torch.cuda.synchronize()
-        finally:
-            _C.call("fedfr_set_option", b"wgrad9p", 0)      # the library default (Server.train switches it on for concurrent clients)
         assert relerr(dwa, outs[0][2]) < 2e-4 and relerr(dwb, outs[1][2]) < 2e-4, (pair, relerr(dwa, outs[0][2]), relerr(dwb, outs[1][2]))
         res[pair] = (dwa.cpu(), dwb.cpu())
     assert relerr(res[1][0], res[0][0]) < 1e-5 and relerr(res[1][1], res[0][1]) < 1e-5

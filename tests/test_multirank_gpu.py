@@ -379,12 +379,13 @@ def test_parallel_clients_round_equals_sequential():
             c.fc_module.fc.data = R.head_fc(10, seed=30 + c.cid)
         srv = server.Server(clients, Data, Args, device=DEV)
         srv.federated_model.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet18"], tag=2.0))
+        prev_w9p = _C.get_option("wgrad9p")
         if w9p is not None:
             _C.call("fedfr_set_option", b"wgrad9p", w9p)
         try:
             loss = srv.train()
         finally:
-            _C.call("fedfr_set_option", b"wgrad9p", 0)
+            _C.call("fedfr_set_option", b"wgrad9p", prev_w9p)
         torch.cuda.synchronize()
         outs.append((loss, {k: v.clone() for k, v in srv.federated_model.state_dict().items()}, [c.get_train_loss() for c in clients]))
     assert outs[0][2] == outs[1][2]                                   # per-client mean losses

@@ -35,13 +35,15 @@ SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kern
               "gemm_tn_kernel<128,128>", "gemm_tn_kernel<128,64>", "gemm_tn_kernel<64,128>", "gemm_tn_kernel<64,64>",
               "conv3x3_halo2_kernel<128,14>", "conv3x3_halo2_kernel<128,28>", "conv3x3_halo2_kernel<64,*>", "conv3x3_halo_kernel<*>",
               "conv3x3_glds_kernel<14,14>", "conv3x3_glds_kernel<28,7>", "gemm_tn_glds_kernel<128,128>", "conv3x3 64-channel layers (c64p / glds<56,4>)",
-              "wgrad9_kernel<32x64x9>", "gemm_nt_glds_kernel (7x7 and stride-2 3x3 convs)"]
+              "wgrad9p_kernel<64x64x9, two layers per launch> (+ wgrad9_kernel<32x64x9>)", "gemm_nt_glds_kernel (7x7 and stride-2 3x3 convs)"]
 HBM_SLOTS = {20: "bn_apply", 21: "bn_bwd_reduce", 22: "bn_bwd_apply", 23: "bn_finalize", 24: "bn_bwd_finalize", 25: "reduce_slabs", 26: "sgd"}
 # ALGORITHMIC HBM bytes per launch on the 256->256 @14x14 layer (58 of iresnet100's 103 convs; B = 128): conv fwd/dgrad = input 12.85 MB
 # (the image, once) + weights 1.18 + output 12.85; wgrad = both operands once 25.7 + the fp32 weight gradient 2.36 — its split-K slabs and
 # their reduction pass are overhead, not algorithmic
-ALGORITHMIC_MB = {"conv3x3_glds_kernel<14,14>": 26.9, "wgrad9_kernel<32x64x9>": 28.1, "gemm_tn_glds_kernel<128,128>": 28.1}
-PMC_KEYS = {"conv3x3_glds_kernel<14,14>": ("conv3x3_glds_kernel<14, 14",), "wgrad9_kernel<32x64x9>": ("wgrad9_kernel", "reduce_slabs"),
+# (the paired kernel, default since round 3, takes the two 3x3 layers of a block per launch: 2 x 28.1 MB)
+W9P = "wgrad9p_kernel<64x64x9, two layers per launch> (+ wgrad9_kernel<32x64x9>)"
+ALGORITHMIC_MB = {"conv3x3_glds_kernel<14,14>": 26.9, W9P: 56.2, "gemm_tn_glds_kernel<128,128>": 28.1}
+PMC_KEYS = {"conv3x3_glds_kernel<14,14>": ("conv3x3_glds_kernel<14, 14",), W9P: ("wgrad9p_kernel", "reduce_slabs"),
             "gemm_tn_glds_kernel<128,128>": ("gemm_tn_glds_kernel", "reduce_slabs")}
 
 
@@ -68,6 +70,9 @@ def pmc_traffic():
                 continue
             parts = [(n, fe, wr) for n, fe, wr in rows if any(k in n for k in keys)]
             if parts and any(keys[0] in n for n, _, _ in parts):
+                if kern == W9P:        # one paired launch is followed by TWO slab reductions (one per layer)
+                    parts = [(n + (" x 2" if "reduce_slabs" in n else ""), fe * (2 if "reduce_slabs" in n else 1), wr * (2 if "reduce_slabs" in n else 1))
+                             for n, fe, wr in parts]
                 tot = sum(fe + wr for _, fe, wr in parts)
                 out[kern] = (int(round(tot * 1e6)), os.path.relpath(f, ROOT),
                              " + ".join("%s: fetch %.1f MB, write %.1f MB" % (re.sub(r"^void\s+(\(anonymous namespace\)::)?", "", n).split("<")[0].split("(")[0], fe, wr)

@@ -10,5 +10,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dual -- python
 cp $(find /tmp/prof_dual -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_r100_b128_kernel_stats_dual_stream.csv
 FEDFR_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_single -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile > $OUT/${TAG}_bench_single.json 2> $OUT/single.err
 cp $(find /tmp/prof_single -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_r100_b128_kernel_stats_single_stream.csv
-cd $R && bash tools/pmc_traffic.sh "s3_256x256@14" fwd,dgrad,wgrad > $OUT/${TAG}_pmc_hbm_traffic_256x256_14.txt 2> $OUT/pmc.err
+cd $R && bash tools/pmc_traffic.sh "s3_256x256@14" fwd,dgrad,wgrad,wpair > $OUT/${TAG}_pmc_hbm_traffic_256x256_14.txt 2> $OUT/pmc.err
 ls -la $OUT

@@ -582,7 +582,7 @@ def main():
                                                                                  "pfc-sharded": "CosFace+sharded PartialFC+BCE head"}[args.head], B),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic" if backend == "nccl" and not share else "synthetic (REHEARSAL: ranks share one GPU / gloo — not a measurement)",
+            "dtype": "fp16" if _C.storage_dtype() == torch.float16 else "bf16", "data": "synthetic" if backend == "nccl" and not share else "synthetic (REHEARSAL: ranks share one GPU / gloo — not a measurement)",
             "config": {"workload": "%s + %s, full train step "
                                    "(fwd+bwd+momentum-SGD), batch %d/GPU, 112x112 synthetic faces, random-init weights, "
                                    "bf16 activations/weights with fp32 accumulate + fp32 master weights, fp32 head"

@@ -23,6 +23,7 @@ vp, i32, i64, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_ulonglo
 # name -> (restype, argtypes).  Must list every symbol include/fedfr_hip.h declares (tests/test_abi.py checks).
 SIGNATURES = {
     "fedfr_version": (i32, []),
+    "fedfr_storage_dtype": (i32, []),
     "fedfr_last_error_string": (C.c_char_p, []),
     "fedfr_set_option": (i32, [C.c_char_p, i32]),
     "fedfr_get_option": (i32, [C.c_char_p, C.POINTER(i32)]),
@@ -132,6 +133,20 @@ def lib() -> C.CDLL:
             if l.fedfr_set_option(k.strip().encode(), int(v)) != 0:
                 raise RuntimeError("FEDFR_OPTIONS: " + l.fedfr_last_error_string().decode())
     return _lib
+
+
+def storage_dtype() -> torch.dtype:
+    """torch dtype of the library's 16-bit storage (activations, shadows): bfloat16, or float16 for the fp16 validation build."""
+    return torch.float16 if lib().fedfr_storage_dtype() == 1 else torch.bfloat16
+
+
+def loss_scale() -> float:
+    """Static loss scale applied to the gradient entering a backbone's backward pass (and removed from the parameter gradients): 1 for the
+    bf16 product build (fp32 exponent range), FEDFR_LOSS_SCALE (default 256) for the fp16 build, whose activation gradients would
+    otherwise fall into fp16's subnormals (the reference's fp16 autocast uses a GradScaler for the same reason, client.py:301,394-396)."""
+    if lib().fedfr_storage_dtype() != 1:
+        return 1.0
+    return float(os.environ.get("FEDFR_LOSS_SCALE", "256"))
 
 
 def last_error() -> str:

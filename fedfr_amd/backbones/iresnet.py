@@ -154,7 +154,7 @@ class BlockPlan:
         self.grads = torch.zeros(c[_C.Q_PARAM_COUNT], dtype=torch.float32, device=device)
         self.bufs = torch.zeros(c[_C.Q_BUFFER_COUNT], dtype=torch.float32, device=device)
         self.nbt = torch.zeros(c[_C.Q_NBT_COUNT], dtype=torch.int64, device=device)
-        self.shadow = torch.empty(c[_C.Q_SHADOW_COUNT], dtype=torch.bfloat16, device=device)
+        self.shadow = torch.empty(c[_C.Q_SHADOW_COUNT], dtype=_C.storage_dtype(), device=device)
         self.act = torch.empty(c[_C.Q_ACT_BYTES], dtype=torch.uint8, device=device)
         self.ws = torch.empty(c[_C.Q_WS_BYTES], dtype=torch.uint8, device=device)
 
@@ -202,7 +202,7 @@ class BlockPlan:
     def _act(self, which):
         off, rows, ch = C.c_longlong(), C.c_int(), C.c_int()
         _C.call("fedfr_net_act_info", self.handle, 0, which, C.byref(off), C.byref(rows), C.byref(ch))
-        a = self.act[off.value * 2: (off.value + rows.value * ch.value) * 2].view(torch.bfloat16).view(rows.value, ch.value)
+        a = self.act[off.value * 2: (off.value + rows.value * ch.value) * 2].view(_C.storage_dtype()).view(rows.value, ch.value)
         h = int(round((rows.value // self.batch) ** 0.5))
         return a.float().view(self.batch, h, h, ch.value).permute(0, 3, 1, 2).contiguous()
 
@@ -575,7 +575,7 @@ class IResNet(nn.Module):
             raise RuntimeError("fedfr_amd.IResNet runs only on an MI355X device: move the module with .to('cuda') "
                                "(there is no CPU / PyTorch fallback path)")
         if self._shadow is None:
-            self._shadow = torch.empty(self._counts[_C.Q_SHADOW_COUNT], dtype=torch.bfloat16, device=self.device)
+            self._shadow = torch.empty(self._counts[_C.Q_SHADOW_COUNT], dtype=_C.storage_dtype(), device=self.device)
             self._shadow_dirty = True
         if self._flat_grads is None:
             self._flat_grads = torch.zeros(self._counts[_C.Q_PARAM_COUNT], dtype=torch.float32, device=self.device)
@@ -658,8 +658,13 @@ class IResNet(nn.Module):
             _C.call("fedfr_net_f32_backward", plan.handle, dfeats.data_ptr(), self._flat_params.data_ptr(), arena.data_ptr(), ws.data_ptr(),
                     target.data_ptr(), _C.stream())
         else:
+            S = _C.loss_scale()                           # 1 for the bf16 build; static loss scale of the fp16 validation build
+            if S != 1.0:
+                dfeats = dfeats * S
             _C.call("fedfr_net_backward", plan.handle, x.data_ptr(), dfeats.data_ptr(), self._flat_params.data_ptr(),
                     self._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), target.data_ptr(), _C.stream())
+            if S != 1.0:
+                target.mul_(1.0 / S)
         if accumulate:
             self._flat_grads.add_(target)
         for p, g in views:

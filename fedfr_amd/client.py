@@ -309,6 +309,16 @@ class FusedTrainer:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)   # dgrad shadows rebuilt on aux after the last SGD step
             self._shadows_pending = None
         aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
+        S = _C.loss_scale()
+        if S != 1.0:
+            # fp16 validation build: the gradient enters the backbone scaled, the parameter gradients are unscaled before anything reads
+            # them (so the update cannot ride inside the backward pass)
+            ds = dfeats * S
+            _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), ds.data_ptr(), bb._flat_params.data_ptr(),
+                    bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st, aux)
+            bb._flat_grads.mul_(1.0 / S)
+            self._sgd_done_from = None
+            return
         if self._fuse_sgd:
             # step(): the optimiser update of every parameter range whose gradient is final rides on the weight-gradient stream inside the
             # backward pass (bn2 / fc / features first, then stage by stage); optimizer_step() finishes [0, done_from)
@@ -412,9 +422,14 @@ class FusedHeadTrainer:
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
+        S = _C.loss_scale()                               # 1 for the bf16 build; the fp16 validation build scales the incoming gradient
+        if S != 1.0:
+            dfeats = dfeats * S
         _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
                 self.aux_stream.cuda_stream if self.aux_stream is not None else None)
+        if S != 1.0:
+            bb._flat_grads.mul_(1.0 / S)
         # ---- opt.step()
         _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                 bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, st)

@@ -60,6 +60,7 @@ int fedfr_check_launch(const char* what) {
 extern "C" {
 
 int fedfr_version(void) { return 100; }
+int fedfr_storage_dtype(void) { return FEDFR_FP16 ? 1 : 0; }
 const char* fedfr_last_error_string(void) { return g_err; }
 int fedfr_set_option(const char* name, int value) {
   if (name && !strcmp(name, "tn_use_tr")) {

@@ -1091,7 +1091,11 @@ int ew_transpose_bf16(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t 
 // =====================================================================================================
 // stem conv 3 -> 64, 3x3 s1 p1, fp32 NCHW input, one 16x16x32 MFMA per 16 pixels x 16 channels (K = 27 -> 32)
 // =====================================================================================================
+#if FEDFR_FP16
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        bf16_t* __restrict__ y, float* __restrict__ stats, int B, int H,
@@ -1389,8 +1393,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
         const int boff = (kb * 16 + kn) * SW_CPITCH + (ks * 32 + kg * 8) * 2;            // colT[k][px .. px+7]
         const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(scol[0] + boff);
         const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(scol[1] + boff);
-        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc[kb], 0, 0, 0);
-        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc[kb], 0, 0, 0);
+        acc[kb] = MFMA16(a, bh, acc[kb]);
+        acc[kb] = MFMA16(a, bl, acc[kb]);
       }
     }
     __syncthreads();

@@ -5,7 +5,11 @@
 #include <vector>
 #include "gemm.h"
 
+#if FEDFR_FP16
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 // Tile loads are BRANCH-FREE raw buffer loads: an out-of-range lane gets voffset = num_records and the hardware

@@ -270,7 +270,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // inline asm with the accumulator as ONE tied in/out AGPR operand: with the builtin the allocator let 16-18 of the 36
                 // loop-carried accumulators end an iteration in other registers than they started in and rotated them back through VGPRs at
                 // the loop head (~200 v_accvgpr moves per sub-image).  An accumulator is next touched 35 MFMAs later: no hazard to cover.
+                #if FEDFR_FP16
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[ty * 3 + tx][a][b]) : "v"(fq), "v"(fp));
+#else
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ty * 3 + tx][a][b]) : "v"(fq), "v"(fp));
+#endif
               }
               if (slot < nr) issue_read(slot);
               if (last && slot >= 2 && slot - 2 < NPW && !(W9P_ABLATE & 1)) issue_piece(slot - 2, it & 1);

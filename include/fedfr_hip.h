@@ -27,6 +27,10 @@ extern "C" {
 #define FEDFR_ERR_UNSUPPORTED (-4)
 
 int fedfr_version(void);
+/* 16-bit storage type of activations / activation gradients / MFMA weight operands this build uses: 0 = bf16 (libfedfr_hip.so, the
+ * product), 1 = IEEE fp16 (libfedfr_hip_fp16.so, `make -C fedfr_amd/csrc fp16`: the reference's own AMP type, backbones/iresnet.py:159 —
+ * a validation build; gradients then need the host's loss scale, FEDFR_LOSS_SCALE) */
+int fedfr_storage_dtype(void);
 const char* fedfr_last_error_string(void);
 /* Kernel-choice switches for same-box A/B measurements and validation fallbacks (no reference counterpart; every setting stays inside the
  * tests' tolerances; FEDFR_OPTIONS="name=value,..." in the environment applies them when the library is loaded).  The ones that matter:

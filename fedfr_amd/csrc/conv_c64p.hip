@@ -12,7 +12,11 @@
 //     fetched with an out-of-range offset = zeros) while the current one computes: two image buffers, one vmcnt(0) + barrier per tile;
 //   * per tile 18 k-steps x (7 ds_read_b128 + 14 MFMA 16x16x32) per wave; the bf16 tile leaves through LDS in 16-byte rows;
 //   * BatchNorm partial sums accumulate in registers over all tiles of the workgroup: 2 partial rows per workgroup, the rest of the
-//     gemm_nt_stat_rows(M, N) rows the finalize kernel sums are written as zeros.
+//     gemm_nt_stat_rows(M, N) rows the finalize kernel sums are written as zeros;
+//   * dgrad launches (BWD = 1 / 2, round 3): the BatchNorm-backward reduction of the layer in front (ew_bn_bwd_reduce on (dx, bn_x): sum dz,
+//     sum dz * xhat, sum dy * min(z, 0); 2 = with the PReLU mask) rides in the copy-out: the thread that stores a 16-byte piece of the
+//     output tile has fetched the same piece of bn_x while the tile's MFMAs ran, sums stay in registers over all tiles of the workgroup,
+//     ONE partial row [3][64] per workgroup at the end.  Replaces a pass over two 51 / 205 MB tensors per layer.
 // LDS rows are 128 B (one padded pixel x 64 channels) with the 16-B chunk index XOR-ed by (row & 7), applied on the DMA source address
 // (an LDS-DMA instruction writes 1 KiB linearly), exactly as in conv_glds_impl.h.
 #include <algorithm>
@@ -26,8 +30,9 @@ int g_conv_c64p = 1;   // option "conv_c64p"
 namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int W_, int R_, bool STATS>
+template <int W_, int R_, bool STATS, int BWD>
 __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles, int per_wg, int stat_rows) {
+  static_assert(!(STATS && BWD), "forward statistics and the backward reduction never meet in one launch");
   constexpr int PT = R_ * W_, PW = W_ + 2, PWL = (PW + 7) & ~7;
   constexpr int NPA = ((R_ + 2) * PWL + 7) / 8;            // LDS-DMA pieces (1 KiB = 8 image rows) per image buffer
   constexpr int AP = (NPA + 3) / 4;                        // pieces per wave (the last round may be partial)
@@ -130,6 +135,24 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
 #pragma unroll
     for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
 
+  // BWD: this thread stores chunk (tid & 7) = channels 8 (tid & 7) .. + 7 of rows tid / 8 + 32 i of EVERY tile: 8 running sums per quantity
+  float b1[8], b2[8], b3[8], bsc[8], bsh[8], bal[8];
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(BWD ? (const void*)p.bx : (const void*)p.A, BWD ? (unsigned)((size_t)p.M * 64 * 2) : p.a_bytes);
+  if constexpr (BWD != 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b1[q] = b2[q] = b3[q] = 0.f;
+    if constexpr (BWD == 2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int n = (tid & 7) * 8 + q;
+        const float g = p.bgamma[n] * p.brstd[n];
+        bsc[q] = g;
+        bsh[q] = p.bbeta[n] - p.bmean[n] * g;
+        bal[q] = p.balpha[n];
+      }
+    }
+  }
+
   issue_a(t_beg, 0);
   for (int tile = t_beg; tile < t_end; ++tile) {
     const int cur = (tile - t_beg) & 1;
@@ -140,6 +163,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
     __builtin_amdgcn_s_barrier();
     if (tile + 1 < t_end && !(C64P_ABLATE & 1)) issue_a(tile + 1, cur ^ 1);
     const unsigned char* cA = sA + cur * A_BYTES;
+    uint4 xr[7];                                             // BWD: bn_x at the pieces this thread stores below; lands while the MFMAs run
+    if constexpr (BWD != 0) {
+      const unsigned xo = ((unsigned)tile * PT + (unsigned)(tid >> 3)) * 128u + (unsigned)(tid & 7) * 16u;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xr[i] = buf_load16(rsX, xo + (unsigned)i * 4096u);
+    }
 
     f32x4_t acc[TN][TM];
 #pragma unroll
@@ -220,6 +249,58 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
         *reinterpret_cast<u32x4_t*>(out + 5 * rs) = v5;
         *reinterpret_cast<u32x4_t*>(out + 6 * rs) = v6;
       }
+      if constexpr (BWD != 0) {
+        // exactly the sums of ew_bn_bwd_reduce on the stored (bf16) dx, on the RAW x: sum dz * xhat = rstd (sum dz x - mean sum dz) is formed
+        // once per column at the end (as in the LDS-DMA kernel's fused epilogue, conv_glds_impl.h)
+        const u32x4_t vv[7] = {v0, v1, v2, v3, v4, v5, v6};
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          float dy[8], xv[8];
+          unpack8(__builtin_bit_cast(uint4, vv[i]), dy);
+          unpack8(xr[i], xv);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if constexpr (BWD == 2) {
+              const float z = xv[q] * bsc[q] + bsh[q];
+              const bool neg = z <= 0.f;
+              b3[q] += neg ? dy[q] * z : 0.f;
+              const float dz = neg ? dy[q] * bal[q] : dy[q];
+              b1[q] += dz;
+              b2[q] += dz * xv[q];
+            } else {
+              b1[q] += dy[q];
+              b2[q] += dy[q] * xv[q];
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (BWD != 0) {
+    // one partial row per workgroup: the 32 row groups meet in LDS (the image buffers are idle: the last tile's MFMA loop is behind the
+    // staging barrier of its epilogue, no DMA is in flight)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sA);               // [32][3][64]
+    const int rg = tid >> 3, c8 = (tid & 7) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      red[(rg * 3 + 0) * 64 + c8 + q] = b1[q];
+      red[(rg * 3 + 1) * 64 + c8 + q] = b2[q];
+      red[(rg * 3 + 2) * 64 + c8 + q] = BWD == 2 ? b3[q] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) {
+        t0 += red[(r * 3 + 0) * 64 + tid];
+        t1 += red[(r * 3 + 1) * 64 + tid];
+        t2 += red[(r * 3 + 2) * 64 + tid];
+      }
+      float* o = p.bpart + (size_t)blockIdx.x * 3 * 64 + tid;
+      o[0] = t0;
+      o[64] = p.brstd[tid] * (t1 - p.bmean[tid] * t0);
+      o[128] = t2;
     }
   }
   if constexpr (STATS) {
@@ -238,7 +319,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
   }
 }
 
-template <int W_, int R_, bool STATS>
+template <int W_, int R_, bool STATS, int BWD>
 int launch_c64p(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_, PWL = (W_ + 2 + 7) & ~7, NPA = ((R_ + 2) * PWL + 7) / 8;
   constexpr size_t lds = 2 * (size_t)NPA * 1024 + (size_t)PT * (64 * 2 + 16);
@@ -251,10 +332,14 @@ int launch_c64p(GemmNT p, hipStream_t st) {
   FEDFR_REQUIRE(!p.stats || 2 * grid <= stat_rows, "conv3x3_c64p: %d partial rows do not fit gemm_nt_stat_rows = %d", 2 * grid, stat_rows);
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<W_, R_, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<W_, R_, STATS, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
+  if (BWD) {
+    FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && (BWD == 1 || (p.bgamma && p.bbeta && p.balpha)), "conv3x3_c64p: the fused BatchNorm-backward reduction needs bx / mean / rstd (and gamma / beta / alpha with PReLU)");
+    if (p.bwd_fused) *p.bwd_fused = grid;                  // one partial row [3][64] per workgroup
+  }
   ProfScope prof(15, 2.0 * p.M * p.N * (double)p.K, st);           // slot 15: the 64-channel 3x3 layers (56x56, 112x112)
-  hipLaunchKernelGGL((conv3x3_c64p_kernel<W_, R_, STATS>), dim3(grid), dim3(256), lds, st, p, ntiles, per_wg, stat_rows);
+  hipLaunchKernelGGL((conv3x3_c64p_kernel<W_, R_, STATS, BWD>), dim3(grid), dim3(256), lds, st, p, ntiles, per_wg, stat_rows);
   FEDFR_LAUNCH_CHECK("conv3x3_c64p");
   return FEDFR_OK;
 }
@@ -262,11 +347,15 @@ int launch_c64p(GemmNT p, hipStream_t st) {
 
 bool conv_c64p_applies(const GemmNT& p) {
   return g_conv_c64p && p.mode == 1 && p.S == 3 && p.C == 64 && p.N == 64 && p.K == 576 && p.stride == 1 && p.pad == 1 && p.up == 1 && p.H == p.W &&
-         (p.W == 112 || p.W == 56) && p.Ho == p.H && p.Wo == p.W && p.M % (p.W * p.W) == 0 && p.Cb && p.ldc == 64 && !p.Cf && !p.bpart && !p.tsc &&
-         !p.esc && !p.eadd && !p.Cb2 && !p.par_on;
+         (p.W == 112 || p.W == 56) && p.Ho == p.H && p.Wo == p.W && p.M % (p.W * p.W) == 0 && p.Cb && p.ldc == 64 && !p.Cf && !(p.bpart && p.stats) &&
+         !p.tsc && !p.esc && !p.eadd && !p.Cb2 && !p.par_on;
 }
 int launch_conv_c64p(GemmNT p, hipStream_t st) {
   FEDFR_REQUIRE(conv_c64p_applies(p), "conv3x3_c64p: unsupported shape");
-  if (p.stats) return p.W == 112 ? launch_c64p<112, 2, true>(p, st) : launch_c64p<56, 4, true>(p, st);
-  return p.W == 112 ? launch_c64p<112, 2, false>(p, st) : launch_c64p<56, 4, false>(p, st);
+  if (p.bpart) {
+    if (p.balpha) return p.W == 112 ? launch_c64p<112, 2, false, 2>(p, st) : launch_c64p<56, 4, false, 2>(p, st);
+    return p.W == 112 ? launch_c64p<112, 2, false, 1>(p, st) : launch_c64p<56, 4, false, 1>(p, st);
+  }
+  if (p.stats) return p.W == 112 ? launch_c64p<112, 2, true, 0>(p, st) : launch_c64p<56, 4, true, 0>(p, st);
+  return p.W == 112 ? launch_c64p<112, 2, false, 0>(p, st) : launch_c64p<56, 4, false, 0>(p, st);
 }

@@ -334,10 +334,11 @@ __global__ __launch_bounds__(NTH) void bn_bwd_reduce_s_kernel(BnBwdS p) {
 // on a 14x14x256 tensor) but 170-230 VGPRs — beside wgrad9's two waves per SIMD (2 x 144 registers) such a wave only fits an unfragmented
 // register file, and in the dual-stream backward pass it waited (40 us per launch for the 230-register variant); the leaner profiles
 // trade a microsecond alone for co-residency.
-template <bool ALPHA, bool NX, bool ADD, int NPRE, int U>
+// FX = 2: twice the fan-in (256 / 260 partial rows: what the two-tiles 28x28 dgrad with the reduction in its epilogue leaves, round 3)
+template <bool ALPHA, bool NX, bool ADD, int NPRE, int U, int FX = 1>
 __global__ __launch_bounds__(NTH) void bn_bwd_apply_s_kernel(BnBwdS p) {
   __builtin_amdgcn_s_setprio(BNS_PRIO);
-  constexpr int NV = ALPHA ? 3 : 2, FL = ALPHA ? kBwdFL3 : kBwdFL2;
+  constexpr int NV = ALPHA ? 3 : 2, FL = FX * (ALPHA ? kBwdFL3 : kBwdFL2);
   __shared__ double red[FanIn<NV>::red_doubles];
   __shared__ double tot[NV * 32];
   __shared__ float cf[3][SW];
@@ -835,7 +836,7 @@ int ew_bn_sliced_rows(int M, int C, bool backward) {
 bool ew_bn_sliced_ok(int M, int C, int P_in, bool backward) {
   if (!g_bn_sliced || C < 64 || C > 1024 || (C % SW) != 0 || M < 256) return false;
   if ((long long)M * C > 14ll * 1000 * 1000 || M > 128 * kMaxPasses * PXP) return false;
-  return P_in > 0 && P_in <= (backward ? kBwdFL2 * FanIn<2>::RG : kFwdFL * FanIn<2>::RG);
+  return P_in > 0 && P_in <= (backward ? 2 * kBwdFL2 * FanIn<2>::RG : kFwdFL * FanIn<2>::RG);     // backward: the apply pass has a double fan-in variant
 }
 
 int ew_bn_apply_sliced(BnApplyS p, hipStream_t st) {
@@ -884,9 +885,13 @@ int ew_bn_bwd_apply_sliced(BnBwdS p, hipStream_t st) {
   // default profile: see the kernel comment (registers beside wgrad9)
   static const int kProfile[8] = {3, 3, 3, 3, 3, 3, 3, 3};   // same-box A/B in the dual-stream step: 17.37-17.44 ms with 3, 17.48 with 1, 17.50-17.58 with 2 (row-slab kernels: 17.77-17.85)
   const int prof_id = g_bn_sliced_pre >= 1 && g_bn_sliced_pre <= 3 ? g_bn_sliced_pre : kProfile[variant];
+  const bool wide = p.P > (p.alpha ? kBwdFL3 * FanIn<3>::RG : kBwdFL2 * FanIn<2>::RG);
+  FEDFR_REQUIRE(p.P <= 2 * (p.alpha ? kBwdFL3 * FanIn<3>::RG : kBwdFL2 * FanIn<2>::RG), "bn_bwd_apply_sliced: %d partial rows", p.P);
 #define BWD_S(A, N, D)                                                                                        \
   do {                                                                                                        \
-    if (prof_id == 1) {                                                                                       \
+    if (wide) {                                                                                               \
+      launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 3, 2, 2>), grid, dim3(NTH), st, p);                    \
+    } else if (prof_id == 1) {                                                                                       \
       if (small) launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 7, 1>), grid, dim3(NTH), st, p);            \
       else launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, kMaxPasses, 1>), grid, dim3(NTH), st, p);         \
     } else if (prof_id == 2) {                                                                                \

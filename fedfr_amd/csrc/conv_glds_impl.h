@@ -96,7 +96,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   int img = bt / TPI, y0 = (bt - img * TPI) * R_;
   int m0 = bt * PT;
   const int n0 = bn * BN;
-  static_assert(TPW == 1 || (!FUSED && !XFORM), "several tiles per workgroup: plain variant only");
+  static_assert(TPW == 1 || !XFORM, "several tiles per workgroup: not with the input transform");
+  // XLATE (FUSED with several tiles per workgroup, round 3): the two-tiles instantiation sits at the register limit, so the BatchNorm input
+  // tile cannot ride through the K loop in registers.  It is requested right BEHIND the loop (after the drain of the tail DMAs: the loads
+  // fly while the accumulators are staged) and the tiles' column sums meet in LDS: ONE partial row per workgroup.
+  constexpr bool XLATE = FUSED && TPW > 1;
   const int l15 = lane & 15, lg = lane >> 4;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
 
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   // the loop, VMEM returns in order, so the loop's counted vmcnt waits are unaffected.
   constexpr int CPRF = BN / 8, RGF = NT / CPRF, XN = FUSED ? (PT + RGF - 1) / RGF : 1;
   uint4 xr[XN];
-  if constexpr (FUSED) {
+  if constexpr (FUSED && !XLATE) {
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
     const int c_ = tid % CPRF, rg_ = tid / CPRF;
 #pragma unroll
@@ -451,14 +455,21 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   // fc[a][h]: array a (mean, rstd, gamma, beta, alpha), channels n0 + c * 8 + 4 h .. + 3; fm / fr: mean / rstd of column n0 + tid.
   float4 fc[FUSED ? 5 : 1][2];
   float fm = 0.f, fr = 0.f;
-  if constexpr (FUSED) {
+  auto load_coefs = [&](int z) {                            // z: zero (opaque in the several-tiles variant, so that nothing here is hoisted in front of the K loop)
     const unsigned cb = (unsigned)p.N * 4u;
-    const unsigned co = (unsigned)(n0 + (tid % (BN / 8)) * 8) * 4u;
+    const unsigned co = (unsigned)(n0 + (tid % (BN / 8)) * 8 + z) * 4u;
     const float* arr[5] = {p.bmean, p.brstd, p.bgamma, p.bbeta, p.balpha};
     const float dflt[5] = {0.f, 1.f, 1.f, 0.f, 1.f};
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
-      if (arr[a] && (a < 2 || p.balpha)) {                   // gamma / beta / alpha matter to the PReLU variant only (wave-uniform)
+      if constexpr (XLATE) {
+        // branch-free (a branch between these loads and the barrier below made hipcc wait for the x tile in front of it): without PReLU the
+        // five vectors are read from `mean` and never used
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.balpha ? arr[a] : p.bmean, cb);
+        const uint4 lo = buf_load16(rs, co), hi = buf_load16(rs, co + 16u);
+        fc[a][0] = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w));
+        fc[a][1] = make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w));
+      } else if (arr[a] && (a < 2 || p.balpha)) {            // gamma / beta / alpha matter to the PReLU variant only (wave-uniform)
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(arr[a], cb);
         const uint4 lo = buf_load16(rs, co), hi = buf_load16(rs, co + 16u);
         fc[a][0] = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w));
@@ -467,10 +478,23 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         fc[a][0] = fc[a][1] = make_float4(dflt[a], dflt[a], dflt[a], dflt[a]);
       }
     }
-    if (tid < BN) { fm = p.bmean[n0 + tid]; fr = p.brstd[n0 + tid]; }
-  }
+    if (!XLATE && tid < BN) { fm = p.bmean[n0 + tid + z]; fr = p.brstd[n0 + tid + z]; }     // (XLATE: read once, behind the tile loop)
+  };
+  if constexpr (FUSED && !XLATE) load_coefs(0);
   // drain the (zero-writing) tail DMAs before the staging buffer is reused
   glds_wait_vmcnt<0>();
+  if constexpr (XLATE) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
+    const int c_ = (tid + z) % CPRF, rg_ = (tid + z) / CPRF;  // (behind the opaque zero: as tile-loop invariants these would live through the K loop)
+#pragma unroll
+    for (int i = 0; i < XN; ++i) {
+      const int row = rg_ + i * RGF;
+      xr[i] = buf_load16(rsX, row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + c_ * 8)) * 2u : OOB);
+    }
+    load_coefs(z);
+  }
   __syncthreads();
   constexpr int XOFF = NABUF * A_BYTES;                 // FUSED: the weight ring becomes the reduction scratch of the epilogue
 
@@ -483,7 +507,9 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
 #pragma unroll
     for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
   float esc_[TN][4], esh_[TN][4], eal_[TN][4];
-  if (p.esc) {
+  const bool has_esc = !FUSED && p.esc != nullptr;       // (the launcher refuses the output epilogue on a fused variant; compiled out of it: its 24
+                                                         // conditional loads made every staging write of the fused two-tiles variant wait for the x tile)
+  if (has_esc) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float a = acc[ni][mi][q];
-        if (p.esc) {                                         // eval-mode BatchNorm (+PReLU) of the output, on the fp32 accumulator
+        if (has_esc) {                                       // eval-mode BatchNorm (+PReLU) of the output, on the fp32 accumulator
           a = a * esc_[ni][q] + esh_[ni][q];
           if (p.ealpha) a = a > 0.f ? a : eal_[ni][q] * a;
         }
@@ -610,7 +636,13 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     // PReLU; with PReLU its input z = x * scale + shift costs one more FMA, a compare and three selects), and the tile's
     // sum dz * xhat = rstd (sum dz * x - mean sum dz) is formed once per column in the reduction below.
     constexpr int RG = RGF;
-    const int c = tid % CPR, rg = tid / CPR;
+    int tz = tid;
+    if constexpr (XLATE) {
+      int z;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+      tz += z;
+    }
+    const int c = tz % CPR, rg = tz / CPR;
     const int n = n0 + c * 8;
     float s1[8], s2[8], s3[8];
 #pragma unroll
@@ -683,14 +715,30 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         t1 += red[(r * 3 + 1) * BN + tid];
         t2 += red[(r * 3 + 2) * BN + tid];
       }
-      float* o = p.bpart + (size_t)bt * 3 * p.N + n0 + tid;
-      o[0] = t0;
-      o[p.N] = fr * (t1 - fm * t0);
-      o[2 * (size_t)p.N] = t2;
+      if constexpr (XLATE) {                               // the workgroup's running row (own column: no race, fixed summation order)
+        float* d = sStat + tid;
+        d[0] = ti == 0 ? t0 : d[0] + t0;
+        d[BN] = ti == 0 ? t1 : d[BN] + t1;
+        d[2 * BN] = ti == 0 ? t2 : d[2 * BN] + t2;
+      } else {
+        float* o = p.bpart + (size_t)bt * 3 * p.N + n0 + tid;
+        o[0] = t0;
+        o[p.N] = fr * (t1 - fm * t0);
+        o[2 * (size_t)p.N] = t2;
+      }
     }
   }
   if (TPW > 1) __syncthreads();                         // the staged output tile has been read: the next tile's image may land on it
   }   // tiles of this workgroup
+  if constexpr (XLATE) {
+    if (tid < BN) {
+      const float t0 = sStat[tid], t1 = sStat[BN + tid], t2 = sStat[2 * BN + tid];
+      float* o = p.bpart + (size_t)btw * 3 * p.N + n0 + tid;
+      o[0] = t0;
+      o[p.N] = p.brstd[n0 + tid] * (t1 - p.bmean[n0 + tid] * t0);
+      o[2 * (size_t)p.N] = t2;
+    }
+  }
   if constexpr (TPW > 1) {
     // one partial row per workgroup: wave row 0 + wave row 1 of the LDS partials (every tile's epilogue ended with a barrier)
     if (p.stats) {
@@ -722,7 +770,8 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   if (FUSED) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
-    if (p.bwd_fused) *p.bwd_fused = p.M / PT;
+    FEDFR_REQUIRE(TPW == 1 || !p.stats, "conv3x3_glds: the several-tiles fused variant keeps its running row where the forward statistics would live");
+    if (p.bwd_fused) *p.bwd_fused = p.M / PT / TPW;
   }
   p.nbn = p.N / BN_;
   FEDFR_REQUIRE((p.M / PT) % TPW == 0, "conv3x3_glds: %d tiles do not split into groups of %d", p.M / PT, TPW);

@@ -73,6 +73,7 @@ struct GemmTN {
 
 // rows of partial stats the NT kernel writes for a given M (needed to size / finalize)
 int gemm_nt_stat_rows(int M, int N);
+bool gemm_nt_fused28_two_tiles(int M);   // a fused (BatchNorm-backward reduction) 28x28 dgrad of M output pixels leaves M / 392 partial rows
 int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride, bool xform = false);   // leading rows that are not zero filler
 bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride);
 // shapes whose conv runs on an LDS-DMA kernel that implements the output epilogue (esc / eadd / Cb2)

@@ -301,6 +301,8 @@ int gemm_nt_stat_rows(int M, int N) {
 bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
 int g_conv28_tpw2 = 2;   // option "conv28_tpw2": 28x28 convs run two image tiles per workgroup -- 1: the forward launches (one BatchNorm partial row per workgroup: 256 instead of 1024), 2: the dgrad launches too (256 workgroups that stay instead of 512 that are dispatched in two rounds between the weight-gradient workgroups: 17.72 -> 17.54 ms/step same-box)
 static bool glds28_two_tiles_shape(int M) { return g_conv28_tpw2 && g_conv_halo >= 4 && (M / 196) % 2 == 0; }
+// the 28x28 dgrad with the BatchNorm-backward reduction in its epilogue runs two tiles per workgroup as well (one partial row each)
+bool gemm_nt_fused28_two_tiles(int M) { return g_conv28_tpw2 >= 2 && glds28_two_tiles_shape(M); }
 static bool glds28_two_tiles(const GemmNT& p) {          // option value 2: the dgrad launches (no statistics) too
   return (p.stats || g_conv28_tpw2 >= 2) && p.W == 28 && !p.esc && !p.eadd && !p.Cb2 && glds28_two_tiles_shape(p.M);
 }
@@ -398,7 +400,8 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
     }
     if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
       if (g_conv_halo >= 4 && p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0 && p.ldc == p.N)
-        return p.W == 14 ? launch_conv_glds8_fused_w14(p, st) : launch_conv_glds8_fused_w28(p, st);
+        return p.W == 14 ? launch_conv_glds8_fused_w14(p, st)
+                         : (gemm_nt_fused28_two_tiles(p.M) && !p.stats ? launch_conv_glds8_fused_w28s(p, st) : launch_conv_glds8_fused_w28(p, st));
       if (g_conv_halo >= 3 && !p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0)
         return g_conv_halo >= 4 ? (p.W == 14 ? launch_conv_glds8_w14(p, st)
                                              : (glds28_two_tiles(p) ? launch_conv_glds8_w28_stats(p, st) : launch_conv_glds8_w28(p, st)))

@@ -67,6 +67,7 @@ int launch_conv_c64p(GemmNT p, hipStream_t st);
 int launch_conv_glds_x(GemmNT p, hipStream_t st);          // conv_glds_x.hip  forward convs with the input BN(+PReLU) applied in LDS
 int launch_conv_glds8_fused_w14(GemmNT p, hipStream_t st); // conv_glds8_fused_w14.hip  + BN-backward reduction epilogue
 int launch_conv_glds8_fused_w28(GemmNT p, hipStream_t st); // conv_glds8_fused_w28.hip
+int launch_conv_glds8_fused_w28s(GemmNT p, hipStream_t st); // conv_glds8_fused_w28s.hip
 int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   // conv_halo2_misc.hip  tuning variants
 // gemm_nt_glds.hip: the register-staged NT kernel's shapes with both operands fetched by LDS-DMA into a ring of stages
 extern int g_nt_glds;

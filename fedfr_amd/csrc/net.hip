@@ -312,6 +312,7 @@ static int conv_fwd_bn(const Ctx& c, const ConvD& cv, const bf16_t* raw, const B
   p.tsc = c.save(bn, 0); p.tsh = c.save(bn, 1); p.talpha = alpha; p.aout = tr ? a : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
+int g_fuse_bnbwd28 = 1;   // option "fuse_bnbwd28": ... and in the two-tiles 28x28 dgrad (with fuse_bnbwd != 0)
 int g_c64p_bnbwd = 1;   // option "c64p_bnbwd": BN-backward reduction in the epilogue of the persistent 64-channel dgrad kernel (with fuse_bnbwd != 0)
 extern int g_conv_c64p;
 int g_fuse_bnbwd = 2;   // (round 3: 2 is the default, together with wgrad9p = 1 — see the end of this comment)  option "fuse_bnbwd": BN-backward reduction in the 3x3 dgrad epilogue (1: every layer a fused kernel serves; 2: the 14x14
@@ -333,7 +334,10 @@ static int conv_dgrad(const Ctx& c, const ConvD& cv, const bf16_t* dy, bf16_t* d
   // option value 2: only the 14x14 layers (one partial row per image: few enough for the channel-sliced apply pass to reduce itself)
   // ... and (round 3) the 64 -> 64 layers of the 56x56 / 112x112 maps on the persistent kernel: one row per workgroup (conv_c64p.hip)
   const bool c64 = g_c64p_bnbwd && g_conv_c64p && cv.R == 3 && cv.stride == 1 && cv.Cin == 64 && cv.Cout == 64 && (cv.Hin == 56 || cv.Hin == 112);
-  if (bn && fused_rows && g_fuse_bnbwd && (g_fuse_bnbwd == 1 || c64 || (cv.R == 3 && cv.stride == 1 && cv.Hin == 14 && cv.Cin % 128 == 0 && cv.Cout % 128 == 0))) {
+  // ... and the 28x28 layers on the two-tiles LDS-DMA kernel: one row per workgroup = 256 at B = 128, which the sliced apply pass takes
+  const bool w28 = g_fuse_bnbwd28 && cv.R == 3 && cv.stride == 1 && cv.Hin == 28 && cv.Cin % 128 == 0 && cv.Cout % 128 == 0 &&
+                   gemm_nt_fused28_two_tiles(c.n->B * 28 * 28) && ew_bn_sliced_ok(c.n->B * 28 * 28, cv.Cin, c.n->B * 28 * 28 / 392, true);
+  if (bn && fused_rows && g_fuse_bnbwd && (g_fuse_bnbwd == 1 || c64 || w28 || (cv.R == 3 && cv.stride == 1 && cv.Hin == 14 && cv.Cin % 128 == 0 && cv.Cout % 128 == 0))) {
     p.bx = bn_x; p.bmean = c.save(*bn, 2); p.brstd = c.save(*bn, 3); p.bgamma = c.gamma(*bn); p.bbeta = c.beta(*bn);
     p.balpha = alpha; p.bpart = c.part(); p.bwd_fused = fused_rows;
   }

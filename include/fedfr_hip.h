@@ -38,7 +38,8 @@ const char* fedfr_last_error_string(void);
  * "nt_glds" (0 register-staged NT GEMM everywhere, 4 [default] LDS-DMA operand ring for the long-K shapes, +8 for every shape it serves),
  * "wgrad9" / "wgrad9p" / "tn_glds" / "tn_pair" / "wgrad_pair_reduce" (weight-gradient kernels and their slab reductions), "bn_sliced"
  * (channel-sliced BatchNorm passes without finalize launches), "fuse_bnbwd" (0 / 1 / 2 [default since round 3, with "wgrad9p" = 1]: BatchNorm-backward reduction in the dgrad
- * epilogue, everywhere / 14x14 layers; with "c64p_bnbwd" (1 [default]) also in the persistent 64-channel dgrad of the 56x56 / 112x112 maps), "fuse_bnapply", "eval_fuse", "conv28_tpw2", "dgrad_parity", "wgrad_depth", "bn_fuse_bwd" (0 [default] / 1: reduce + apply pass of a
+ * epilogue, everywhere / 14x14 layers; with "c64p_bnbwd" (1 [default]) also in the persistent 64-channel dgrad of the 56x56 / 112x112 maps; with "fuse_bnbwd28"
+ * (1 [default]) in the two-tiles 28x28 dgrad, whose 256 partial rows the channel-sliced apply pass takes), "fuse_bnapply", "eval_fuse", "conv28_tpw2", "dgrad_parity", "wgrad_depth", "bn_fuse_bwd" (0 [default] / 1: reduce + apply pass of a
  * BatchNorm backward in ONE launch on the 14x14 / 7x7 maps, partial rows handed over inside the launch; bit-identical to the two-launch
  * form), "ew_reduce_blocks" / "ew_bwd_apply_blocks" / "ew_reduce_nt" (grid sizes and load policy of the large maps' row-slab
  * BatchNorm-backward passes), "event_nofence" (1 [default]: the backward pass's fork / join events carry no system-scope fence),

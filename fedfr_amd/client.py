@@ -213,6 +213,9 @@ def _aux_stream_locked(idx, slot):
     return s
 
 
+_HEAD_OFF_PATH = __import__("os").environ.get("FEDFR_HEAD_OFF_PATH", "1") != "0"
+
+
 class FusedTrainer:
     """One optimiser lifetime (= one FL round for one client: the reference re-creates SGD every round, F8).
 
@@ -279,10 +282,10 @@ class FusedTrainer:
         bb._pre_forward(plan, bb._fwd_mode())
         _C.call("fedfr_net_forward", plan.handle, imgs.data_ptr(), bb._flat_params.data_ptr(), bb._flat_bufs.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), feats.data_ptr(), bb._fwd_mode(), st)
-        if not bb._bn_frozen:
-            bb._flat_nbt += 1
         bb._fwd_generation += 1
         if self.pfc is not None:
+            if not bb._bn_frozen:
+                bb._flat_nbt += 1
             # upstream PartialFC protocol: normalised embeddings in, d(embedding) out
             fn, finv = ops.normalize_rows(feats)
             x_grad, loss = self.pfc.forward_backward(labels, fn, None)
@@ -294,13 +297,29 @@ class FusedTrainer:
         wn, winv = ops.normalize_rows(self.fc)
         cos = ops.sgemm(fn, wn, trans_b=True)
         prob_t, g = ops.softmax_ce_grad(cos, labels, self.s, self.m, self.arc, 1.0 / B)
-        loss = ops.nll_mean(prob_t, 0.0)
         dfn = ops.sgemm(g, wn)
-        dwn = ops.sgemm(g, fn, trans_a=True)
         dfeats = ops.normalize_rows_bwd(fn, finv, dfn)
-        _C.call("fedfr_normalize_rows_bwd", wn.data_ptr(), winv.data_ptr(), dwn.data_ptr(), self.fc_grad.data_ptr(),
-                wn.shape[0], wn.shape[1], 0.0, st)
+
+        def off_path():
+            # what the backbone's backward pass does not wait for: the loss value, d(loss)/d(class weights), the step counters
+            loss = ops.nll_mean(prob_t, 0.0)
+            dwn = ops.sgemm(g, fn, trans_a=True)
+            _C.call("fedfr_normalize_rows_bwd", wn.data_ptr(), winv.data_ptr(), dwn.data_ptr(), self.fc_grad.data_ptr(),
+                    wn.shape[0], wn.shape[1], 0.0, _C.stream())
+            if not bb._bn_frozen:
+                bb._flat_nbt += 1
+            return loss
+
+        if self.aux_stream is None or not _HEAD_OFF_PATH:
+            loss = off_path()
+            self._backward(plan, imgs, dfeats, st)
+            return loss
+        # round 3: those ~25 us of launches go to the weight-gradient stream BEHIND the backward pass's own work there (that stream is
+        # ordered after the head kernels above by the pass's first fork) and the main stream joins it again before anything else runs
         self._backward(plan, imgs, dfeats, st)
+        with torch.cuda.stream(self.aux_stream):
+            loss = off_path()
+        torch.cuda.current_stream().wait_stream(self.aux_stream)
         return loss
 
     def _backward(self, plan, imgs, dfeats, st):

@@ -710,6 +710,8 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   return ew_bn_bwd_apply(p, c.st);
 }
 
+int g_fc_wgrad_aux = 1;   // option "fc_wgrad_aux": fc's weight gradient runs on the weight-gradient stream
+int g_late_join = 1;       // option "late_join": the streams join behind the stem's BatchNorm backward instead of in front of it
 int g_event_nofence = 1;   // option "event_nofence": fork / join events created with hipEventDisableSystemFence
 int g_fork_mode = 0;       // option "fork_mode": 1 = the per-block fork event is the completion signal of the BatchNorm-backward apply launch that
                            // produces the last weight-gradient operand (hipExtLaunchKernel stopEvent) instead of a record packet behind it
@@ -771,14 +773,14 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   }
   Fork fk{n, st, aux};
   const hipStream_t wst = aux ? aux : st;          // stream of the weight-gradient GEMMs
-  fk.order(st, wst);                                // aux starts after everything already queued on main (forward pass)
+  if (n->block_only) fk.order(st, wst);             // aux starts after everything already queued on main (forward pass); the full net forks below
   Rows pend{nullptr, 0};                           // partial rows of the next bn3 already reduced by the apply pass that produced its dy
   if (n->block_only) {
     const BlockD& k0 = n->blocks.front();
     FEDFR_TRY(ew_nchw_f32_to_nhwc_bf16(dfeats, c.g(1), B, k0.Cout, k0.Hout * k0.Hout, st));      // dy of the block, fp32 NCHW like the reference's
   } else {
   // ---- features (BN1d) backward; fc.bias grad = colsum(d y_fc) ----
-  if (hipMemsetAsync(c.dybt(), 0, (size_t)F * n->Bp * 2, st) != hipSuccess) {
+  if (n->Bp != B && hipMemsetAsync(c.dybt(), 0, (size_t)F * n->Bp * 2, st) != hipSuccess) {      // zero padding of the batch axis of dY^T (Bp = B rounded up to 8)
     fedfr_set_error("net_backward: hipMemsetAsync failed");
     return FEDFR_ERR_HIP;
   }
@@ -786,11 +788,14 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
                         c.actf + n->feat_save_off + F, grads + n->feat_bn.b_off, grads + n->fc_b_off, c.dyb(), c.dybt(), n->Bp, st,
                         n->bn_frozen ? 1 : 0));
   float* dxfc = reinterpret_cast<float*>(ws + n->ws_fc);
+  // the first fork: the weight-gradient stream starts behind the forward pass and the features' backward; fc's weight gradient is its first
+  // kernel (round 3: it ran on the main stream, 20 us in front of everything else)
+  fk.order(st, wst);
   {  // fc.weight grad [F][fc_in] = dY^T X   (both operands batch-major -> TN kernel)
     GemmTN p{};
     p.P = c.dyb(); p.Q = A + n->t_off; p.Kp = B; p.NI = F; p.NJ = n->fc_in; p.mode = 0; p.ldp = F; p.ldq = n->fc_in;
     p.out = grads + n->fc_w_off; p.use_tr = g_tn_use_tr;
-    FEDFR_TRY(gemm_tn_launch(p, 1, st));
+    FEDFR_TRY(gemm_tn_launch(p, 1, g_fc_wgrad_aux ? wst : st));
   }
   {  // dX [Bp][fc_in] = dY W   (reduction over F: P = dY^T [F][Bp], Q = W [F][fc_in])
     GemmTN p{};
@@ -877,7 +882,10 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     cur ^= 1;
     if (sgd && !n->block_only && k.has_ds && bi > 0) sgd_lo = k.bn1.g_off;      // a stage is complete: its range goes out behind the next fork
   }
-  fk.order(wst, st);                                 // join: the stem wgrad below reuses the slab workspace; callers see all grads
+  // join: the stem wgrad below reuses the slab workspace; callers see all grads.  late_join: the stem's BatchNorm backward (two passes over
+  // 205 MB tensors) does not wait for the last weight gradients — its dz goes to t(1) (da2 of the blocks: main stream only) instead of
+  // t(0), which block 0's weight gradient may still be reading
+  if (!g_late_join || n->block_only) fk.order(wst, st);
   const int M0 = B * HW * HW;
   FEDFR_TRY(dbg_capture(c.g(cur), (size_t)M0 * n->blocks.front().Cin, &dbg_off, st));
   if (n->block_only) {                               // the gradient wrt the block input stays readable in the arena
@@ -887,8 +895,10 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     }
   } else {
   // ---- stem: a0 = prelu(bn1(conv1(x))) ----
-  FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, c.t(0), n->stem_alpha_off));
-  FEDFR_TRY(ew_stem_wgrad(x, c.t(0), grads + n->stem.w_off, c.slab(), B, HW, HW, st));
+  bf16_t* dz0 = g_late_join ? c.t(1) : c.t(0);
+  FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, dz0, n->stem_alpha_off));
+  if (g_late_join) fk.order(wst, st);
+  FEDFR_TRY(ew_stem_wgrad(x, dz0, grads + n->stem.w_off, c.slab(), B, HW, HW, st));
   }
   if (!fk.ok) {
     fedfr_set_error("net_backward: HIP event record/wait failed");

@@ -44,7 +44,9 @@ const char* fedfr_last_error_string(void);
  * form), "ew_reduce_blocks" / "ew_bwd_apply_blocks" / "ew_reduce_nt" (grid sizes and load policy of the large maps' row-slab
  * BatchNorm-backward passes), "event_nofence" (1 [default]: the backward pass's fork / join events carry no system-scope fence),
  * "fork_mode" (0 [default] / 1: the per-block fork event rides on the completion signal of the launch in front of it), "sph_fuse_act"
- * (0 [default] / 1: sphnet's PReLU (+bias, +identity) in the conv kernel's epilogue where the kernel has one).  Unknown names are an error. */
+ * (0 [default] / 1: sphnet's PReLU (+bias, +identity) in the conv kernel's epilogue where the kernel has one), "late_join" (1 [default]: the
+ * streams of the backward pass join behind the stem's BatchNorm backward instead of in front of it), "fc_wgrad_aux" (1 [default]: fc's
+ * weight gradient is the weight-gradient stream's first kernel).  Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);
 /* the switch's current value (a caller that changes one temporarily restores what it found) */
 int fedfr_get_option(const char* name, int* value);

@@ -77,6 +77,9 @@ SIGNATURES = {
     "fedfr_normalize_rows": (i32, [vp, vp, vp, i32, i32, f32, vp]),
     "fedfr_normalize_rows_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "fedfr_sgemm": (i32, [vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i32, f32, f32, vp, vp]),
+    "fedfr_sgemm_splitk": (i32, [vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i32, f32, i32, i64, vp]),
+    "fedfr_softmax_ce_fused": (i32, [vp, vp, i32, i32, i32, f32, f32, i32, f32, vp, i32, i64, vp]),
+    "fedfr_normalize_rows_bwd_slabs": (i32, [vp, vp, vp, i32, i64, vp, i32, i32, f32, vp]),
     "fedfr_margin_rowmax": (i32, [vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp]),
     "fedfr_exp_rowsum": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "fedfr_softmax_grad": (i32, [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp]),

@@ -214,6 +214,12 @@ def _aux_stream_locked(idx, slot):
 
 
 _HEAD_OFF_PATH = __import__("os").environ.get("FEDFR_HEAD_OFF_PATH", "1") != "0"
+_HEAD_SPLITK = __import__("os").environ.get("FEDFR_HEAD_SPLITK", "1") != "0"
+
+
+def _split_for(k: int) -> int:
+    """split-K degree of a head GEMM: k ranges of 128 (four k-steps of 32 per workgroup), at most 8"""
+    return max(1, min(8, k // 128))
 
 
 class FusedTrainer:
@@ -295,10 +301,18 @@ class FusedTrainer:
         # head: cosine logits -> margin -> softmax CE, gradient wrt cosine written in place
         fn, finv = ops.normalize_rows(feats)
         wn, winv = ops.normalize_rows(self.fc)
-        cos = ops.sgemm(fn, wn, trans_b=True)
-        prob_t, g = ops.softmax_ce_grad(cos, labels, self.s, self.m, self.arc, 1.0 / B)
-        dfn = ops.sgemm(g, wn)
-        dfeats = ops.normalize_rows_bwd(fn, finv, dfn)
+        C_, D_ = wn.shape
+        if _HEAD_SPLITK and C_ <= 4096 and D_ >= 256 and C_ >= 256:
+            # round 3: the two GEMMs on the path are latency chains (16 / 32 dependent k-steps on 32 / 16 workgroups): split-K slabs that
+            # the consumer adds in order, and margin -> softmax -> gradient as one launch
+            ks, kd = _split_for(D_), _split_for(C_)
+            prob_t, g = ops.softmax_ce_fused(ops.sgemm(fn, wn, trans_b=True, splits=ks), labels, self.s, self.m, self.arc, 1.0 / B)
+            dfeats = ops.normalize_rows_bwd_slabs(fn, finv, ops.sgemm(g, wn, splits=kd))
+        else:
+            cos = ops.sgemm(fn, wn, trans_b=True)
+            prob_t, g = ops.softmax_ce_grad(cos, labels, self.s, self.m, self.arc, 1.0 / B)
+            dfn = ops.sgemm(g, wn)
+            dfeats = ops.normalize_rows_bwd(fn, finv, dfn)
 
         def off_path():
             # what the backbone's backward pass does not wait for: the loss value, d(loss)/d(class weights), the step counters

@@ -616,6 +616,18 @@ int fedfr_normalize_rows(const float* x, float* xn, float* inv, int R, int D, fl
 int fedfr_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn, float* dx, int R, int D, float beta, void* stream) {
   return head_normalize_rows_bwd(xn, inv, dxn, dx, R, D, beta, ST(stream));
 }
+int fedfr_sgemm_splitk(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
+                       int ldc, float alpha, int splits, long long slab_stride, void* stream) {
+  return head_sgemm_splitk(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, splits, slab_stride, ST(stream));
+}
+int fedfr_softmax_ce_fused(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arcface, float inv_batch, float* prob_t,
+                           int nslab, long long slab_stride, void* stream) {
+  return head_softmax_ce_fused(z, label, R, C, ldz, s, m, arcface, inv_batch, prob_t, nslab, slab_stride, ST(stream));
+}
+int fedfr_normalize_rows_bwd_slabs(const float* xn, const float* inv_norm, const float* dxn, int nslab, long long slab_stride, float* dx, int R,
+                                   int D, float beta, void* stream) {
+  return head_normalize_rows_bwd_slabs(xn, inv_norm, dxn, nslab, slab_stride, dx, R, D, beta, ST(stream));
+}
 int fedfr_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk,
                 long long sbn, int ldc, float alpha, float beta, const float* bias, void* stream) {
   return head_sgemm(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, ST(stream));

@@ -7,6 +7,12 @@ int head_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn,
                             hipStream_t st);
 int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak,
                long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, hipStream_t st);
+int head_normalize_rows_bwd_slabs(const float* xn, const float* inv, const float* dxn, int nslab, long long slab_stride, float* dx, int R, int D,
+                                  float beta, hipStream_t st);
+int head_sgemm_splitk(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
+                      int ldc, float alpha, int splits, long long slab_stride, hipStream_t st);
+int head_softmax_ce_fused(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arc, float inv_batch, float* prob_t,
+                          int nslab, long long slab_stride, hipStream_t st);
 // same, products accumulated in fp64 (fp32 validation path of the backbone)
 int head_sgemm_f64acc(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
                       int ldc, float alpha, float beta, const float* bias, hipStream_t st);

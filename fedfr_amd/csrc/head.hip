@@ -28,27 +28,37 @@ int head_normalize_rows(const float* x, float* xn, float* inv, int R, int D, flo
 }
 
 // dx = inv * (dxn - xn * <xn, dxn>)     (F.normalize backward; the eps clamp branch has zero measure)
+// dxn may arrive as `nslab` split-K slabs of the GEMM that produced it (head_sgemm_splitk): summed here, slab 0 first
 __global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ inv,
                                                                  const float* __restrict__ dxn, float* __restrict__ dx,
-                                                                 int R, int D, float beta) {
+                                                                 int R, int D, float beta, int nslab, long long slab_stride) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const size_t o = (size_t)row * D;
+  auto g = [&](int i) {
+    float v = dxn[o + i];
+    for (int k = 1; k < nslab; ++k) v += dxn[(size_t)k * slab_stride + o + i];
+    return v;
+  };
   float s = 0.f;
-  for (int i = lane; i < D; i += 64) s += xn[o + i] * dxn[o + i];
+  for (int i = lane; i < D; i += 64) s += xn[o + i] * g(i);
   s = wave_sum(s);
   const float iv = inv[row];
   for (int i = lane; i < D; i += 64) {
-    const float v = iv * (dxn[o + i] - xn[o + i] * s);
+    const float v = iv * (g(i) - xn[o + i] * s);
     dx[o + i] = beta != 0.f ? beta * dx[o + i] + v : v;
   }
 }
-int head_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn, float* dx, int R, int D, float beta,
-                            hipStream_t st) {
-  FEDFR_REQUIRE(xn && inv && dxn && dx && R > 0 && D > 0, "normalize_rows_bwd: bad args");
-  hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, xn, inv, dxn, dx, R, D, beta);
+int head_normalize_rows_bwd_slabs(const float* xn, const float* inv, const float* dxn, int nslab, long long slab_stride, float* dx, int R, int D,
+                                  float beta, hipStream_t st) {
+  FEDFR_REQUIRE(xn && inv && dxn && dx && R > 0 && D > 0 && nslab >= 1 && (nslab == 1 || slab_stride >= (long long)R * D), "normalize_rows_bwd: bad args");
+  hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, xn, inv, dxn, dx, R, D, beta, nslab, slab_stride);
   FEDFR_LAUNCH_CHECK("normalize_rows_bwd");
   return FEDFR_OK;
+}
+int head_normalize_rows_bwd(const float* xn, const float* inv, const float* dxn, float* dx, int R, int D, float beta,
+                            hipStream_t st) {
+  return head_normalize_rows_bwd_slabs(xn, inv, dxn, 1, 0, dx, R, D, beta, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -67,6 +77,8 @@ struct SgemmP {
   const float* bias;
   unsigned char* colflag;   // != null: store nothing, set colflag[n] = 1 for every column with some alpha * (A B)[m][n] > thr
   float thr;
+  int kchunk;               // split-K (gridDim.z > 1): block z sums k in [z * kchunk, min(K, (z + 1) * kchunk)) into slab C + z * slab_stride
+  long long slab_stride;
 };
 
 template <int BK>      // k depth of a stage: 16, or 32 (half as many global-load round trips on the K loop: the head's 128 x 1000 x 512 GEMMs are a latency chain)
@@ -108,14 +120,20 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int nk = ceil_div(p.K, BK);
-  load(0);
+  // split-K: this block's k range (the loads mask k >= p.K, so the range end is made the problem's K for them)
+  const int kbeg = gridDim.z > 1 ? (int)blockIdx.z * p.kchunk : 0;
+  if (gridDim.z > 1) {
+    p.K = min(p.K, kbeg + p.kchunk);
+    p.C += (size_t)blockIdx.z * p.slab_stride;
+  }
+  const int nk = ceil_div(p.K - kbeg, BK);
+  load(kbeg);
   store(0);
   __syncthreads();
   const int l15 = lane & 15, lg = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load((kt + 1) * BK);
+    if (kt + 1 < nk) load(kbeg + (kt + 1) * BK);
 #pragma unroll
     for (int k4 = 0; k4 < BK; k4 += 4) {
       float fa[2], fb[2];
@@ -261,6 +279,19 @@ int head_sgemm(const float* A, const float* B, float* C, int M, int N, int K, lo
   if (K >= 128) hipLaunchKernelGGL(sgemm_kernel<32>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(sgemm_kernel<16>, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, p);
   FEDFR_LAUNCH_CHECK("sgemm");
+  return FEDFR_OK;
+}
+// split-K form for the head's small GEMMs (128 x 1000 x 512 and 128 x 512 x 1000 are latency chains of 16 / 32 dependent k-steps on 16 - 32
+// workgroups): `splits` slabs C + z * slab_stride, each the sum over one k range; the consumer adds the slabs in order (deterministic)
+int head_sgemm_splitk(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
+                      int ldc, float alpha, int splits, long long slab_stride, hipStream_t st) {
+  FEDFR_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N && splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (long long)M * ldc),
+                "sgemm_splitk: bad args");
+  SgemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, 0.f, nullptr, nullptr, 0.f, 0, slab_stride};
+  p.kchunk = ceil_div(ceil_div(K, splits), 32) * 32;
+  FEDFR_REQUIRE((long long)p.kchunk * (splits - 1) < K, "sgemm_splitk: %d splits leave an empty k range at K = %d", splits, K);
+  hipLaunchKernelGGL(sgemm_kernel<32>, dim3(ceil_div(N, 64), ceil_div(M, 64), splits), dim3(256), 0, st, p);
+  FEDFR_LAUNCH_CHECK("sgemm_splitk");
   return FEDFR_OK;
 }
 int head_sgemm_f64acc(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
@@ -446,6 +477,82 @@ __global__ __launch_bounds__(256) void softmax_grad_kernel(float* __restrict__ z
     }
     zr[c] = g * inv_batch * mul;
   }
+}
+
+// steps 1 - 3 in ONE launch for rows of at most 256 * NPT classes (dense heads): the row stays in registers between the three passes, the
+// block reductions and the per-element expressions are the three kernels' own (same thread -> column mapping: bit-identical results).  The
+// cosines may arrive as `nslab` split-K slabs (head_sgemm_splitk), summed slab 0 first; the gradient is written over slab 0.
+template <int NPT>
+__global__ __launch_bounds__(256) void softmax_ce_fused_kernel(float* __restrict__ z, const long long* __restrict__ label, int C, int ldz, float s,
+                                                               float m, int arc, float inv_batch, float* __restrict__ prob_t, int nslab,
+                                                               long long slab_stride) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  float* zr = z + (size_t)row * ldz;
+  const long long y = label[row];
+  float v[NPT];
+  float mx = -INFINITY, dm = s;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    v[k] = -INFINITY;
+    if (c < C) {
+      float x = zr[c];
+      for (int q = 1; q < nslab; ++q) x += zr[(size_t)q * slab_stride + c];
+      float t;
+      if (arc) {
+        float th = acosf(x);
+        if (c == y) {
+          const float st = sinf(th);
+          dm = s * sinf(th + m) / st;
+          th += m;
+        }
+        t = cosf(th) * s;
+      } else {
+        if (c == y) x -= m;
+        t = x * s;
+      }
+      v[k] = t;
+      mx = fmaxf(mx, t);
+    }
+  }
+  mx = block_max(mx, sh);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < C) {
+      v[k] = expf(v[k] - mx);
+      sum += v[k];
+    }
+  }
+  __syncthreads();                                       // sh is reused
+  sum = block_sum(sum, sh);
+  const float inv = 1.f / sum;
+  if (threadIdx.x == 0 && (y < 0 || y >= C)) prob_t[row] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < C) {
+      const float pr = v[k] * inv;
+      float g = pr, mul = s;
+      if (c == y) {
+        prob_t[row] = pr;
+        g -= 1.f;
+        mul = dm;
+      }
+      zr[c] = g * inv_batch * mul;
+    }
+  }
+}
+int head_softmax_ce_fused(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arc, float inv_batch, float* prob_t,
+                          int nslab, long long slab_stride, hipStream_t st) {
+  FEDFR_REQUIRE(z && label && prob_t && R > 0 && C > 0 && C <= 4096 && ldz >= C && nslab >= 1 && (nslab == 1 || slab_stride >= (long long)R * ldz),
+                "softmax_ce_fused: bad args (rows of at most 4096 classes)");
+  if (C <= 1024) hipLaunchKernelGGL(softmax_ce_fused_kernel<4>, dim3(R), dim3(256), 0, st, z, label, C, ldz, s, m, arc, inv_batch, prob_t, nslab, slab_stride);
+  else hipLaunchKernelGGL(softmax_ce_fused_kernel<16>, dim3(R), dim3(256), 0, st, z, label, C, ldz, s, m, arc, inv_batch, prob_t, nslab, slab_stride);
+  FEDFR_LAUNCH_CHECK("softmax_ce_fused");
+  return FEDFR_OK;
 }
 
 // loss = -mean_r log(max(prob_t[r], floor))   (floor = 1e-30 for PartialFC, 0 for F.cross_entropy)

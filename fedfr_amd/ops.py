@@ -39,9 +39,32 @@ def normalize_rows_bwd(xn: torch.Tensor, inv: torch.Tensor, dxn: torch.Tensor) -
     return dx
 
 
+def normalize_rows_bwd_slabs(xn: torch.Tensor, inv: torch.Tensor, dxn_slabs: torch.Tensor) -> torch.Tensor:
+    """``normalize_rows_bwd`` on a d(xn) that arrives as split-K slabs [S, R, D] (``sgemm(..., splits=S)``), added slab 0 first."""
+    dxn_slabs = _chk(dxn_slabs, "dxn slabs")
+    S, R, D = dxn_slabs.shape
+    dx = torch.empty_like(xn)
+    _C.call("fedfr_normalize_rows_bwd_slabs", xn.data_ptr(), inv.data_ptr(), dxn_slabs.data_ptr(), S, R * D, dx.data_ptr(), R, D, 0.0,
+            _C.stream())
+    return dx
+
+
+def softmax_ce_fused(cos_slabs: torch.Tensor, label: torch.Tensor, s: float, m: float, arcface: bool, inv_batch: float):
+    """``softmax_ce_grad`` (no collectives) as ONE launch; ``cos_slabs`` [S, R, C] (C <= 4096) are split-K slabs of the cosine matrix.
+    Returns (prob_target [R], grad = cos_slabs[0], overwritten)."""
+    cos_slabs = _chk(cos_slabs, "cosine slabs")
+    label = _chk(label, "label", torch.int64)
+    S, R, Cc = cos_slabs.shape
+    prob_t = torch.empty(R, dtype=f32, device=cos_slabs.device)
+    _C.call("fedfr_softmax_ce_fused", cos_slabs.data_ptr(), label.data_ptr(), R, Cc, Cc, s, m, 1 if arcface else 0, inv_batch,
+            prob_t.data_ptr(), S, R * Cc, _C.stream())
+    return prob_t, cos_slabs[0]
+
+
 def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
-          bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C = op(A) @ op(B) (+bias) in exact fp32 (v_mfma_f32_16x16x4_f32); A, B row-major contiguous."""
+          bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, splits: int = 0) -> torch.Tensor:
+    """C = op(A) @ op(B) (+bias) in exact fp32 (v_mfma_f32_16x16x4_f32); A, B row-major contiguous.  ``splits`` > 0: split-K, returns
+    the slabs [splits, M, N] (their sum is C; consumers: ``softmax_ce_fused``, ``normalize_rows_bwd_slabs``)."""
     a, b = _chk(a, "A"), _chk(b, "B")
     if trans_a:
         K, M = a.shape
@@ -57,6 +80,13 @@ def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool
         sbk, sbn = N, 1
     if K != Kb:
         raise RuntimeError("sgemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if splits > 0:
+        if bias is not None or out is not None:
+            raise RuntimeError("sgemm: split-K slabs take neither bias nor out")
+        slabs = torch.empty(splits, M, N, dtype=f32, device=a.device)
+        _C.call("fedfr_sgemm_splitk", a.data_ptr(), b.data_ptr(), slabs.data_ptr(), M, N, K, sam, sak, sbk, sbn, N, 1.0, splits, M * N,
+                _C.stream())
+        return slabs
     if out is None:
         out = torch.empty(M, N, dtype=f32, device=a.device)
     _C.call("fedfr_sgemm", a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, sam, sak, sbk, sbn, N, 1.0, 0.0,

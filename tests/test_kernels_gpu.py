@@ -547,6 +547,56 @@ def test_sgemm(M, N, K, ta, tb):
     assert relerr(c, ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,tb,splits", [(128, 1000, 512, True, 4), (128, 512, 1000, False, 7), (37, 130, 300, True, 3), (128, 512, 1000, False, 1)])
+def test_sgemm_splitk_slabs(M, N, K, tb, splits):
+    """split-K slabs of the head GEMMs: their sum is the product; every slab is the product over its own k range."""
+    from fedfr_amd import ops
+    a, b = rnd((M, K), 1), rnd((N, K) if tb else (K, N), 2)
+    Bm = b.t() if tb else b
+    d = dev()
+    slabs = ops.sgemm(a.to(d), b.to(d), trans_b=tb, splits=splits)
+    torch.cuda.synchronize()
+    assert slabs.shape == (splits, M, N)
+    assert relerr(slabs.sum(0), (a.double() @ Bm.double()).float()) < 1e-5
+    kc = -(-(-(-K // splits)) // 32) * 32
+    for z in range(splits):
+        lo, hi = z * kc, min(K, (z + 1) * kc)
+        assert relerr(slabs[z], (a[:, lo:hi].double() @ Bm[lo:hi].double()).float()) < 1e-5, z
+
+
+@pytest.mark.parametrize("R,C,arc,nslab", [(128, 1000, False, 1), (128, 1000, True, 1), (33, 1000, False, 4), (5, 3000, True, 3), (9, 257, False, 2)])
+def test_softmax_ce_fused_equals_three_kernels(R, C, arc, nslab):
+    """margin -> softmax -> gradient in one launch: bit-identical to the three-kernel chain on the summed slabs (labels incl. -1)."""
+    from fedfr_amd import ops
+    d = dev()
+    parts = (rnd((nslab, R, C), 3) * (0.9 / nslab)).to(d)                       # cosines in (-0.9, 0.9) after the sum
+    total = parts[0].clone()
+    for q in range(1, nslab):
+        total += parts[q]
+    lab = torch.randint(0, C, (R,), generator=torch.Generator().manual_seed(5))
+    lab[::7] = -1
+    lab = lab.to(d)
+    p_ref, g_ref = ops.softmax_ce_grad(total.clone(), lab, 30.0, 0.4, arc, 1.0 / R)
+    p_got, g_got = ops.softmax_ce_fused(parts.clone(), lab, 30.0, 0.4, arc, 1.0 / R)
+    torch.cuda.synchronize()
+    assert torch.equal(p_got, p_ref) and torch.equal(g_got, g_ref)
+
+
+def test_normalize_rows_bwd_slabs():
+    from fedfr_amd import ops
+    d = dev()
+    x = rnd((128, 512), 1).to(d)
+    xn, inv = ops.normalize_rows(x)
+    parts = rnd((5, 128, 512), 2).to(d)
+    total = parts[0].clone()
+    for q in range(1, 5):
+        total += parts[q]
+    ref = ops.normalize_rows_bwd(xn, inv, total)
+    got = ops.normalize_rows_bwd_slabs(xn, inv, parts)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
 def test_sgd_matches_golden():
     from conftest import load_golden
     from oracle import ref_cpu as R

@@ -251,6 +251,95 @@ __global__ __launch_bounds__(NTH) void bn_apply_s_kernel(BnApplyS p) {
 }
 
 // =====================================================================================================
+// forward, round 3: out = bn(x1) + x2 and y2 = bn_next(out) in ONE pass (BnApply2S, ew.h): the statistics of `out` follow from the raw
+// moments (sum x1, sum x1 x2, sum x1 x1) the conv left and the saved statistics of x2 — the next block's bn1 pass disappears
+// =====================================================================================================
+template <int NP, int FL>
+__global__ __launch_bounds__(NTH) void bn_apply2_s_kernel(BnApply2S p) {
+  __shared__ double red[FanIn<3>::red_doubles];
+  __shared__ double tot[96];
+  __shared__ float cf[4][SW];
+  const int tid = threadIdx.x;
+  const int NS = p.C >> 5;
+  const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int g = lid / NS, s = lid - g * NS;
+  const int cl = tid & 3, pl = tid >> 2;
+  const int cs = s * SW, c0 = cs + cl * 8;
+  const int m0 = g * p.ppg, m1 = min(p.M, m0 + p.ppg);
+  // every small per-channel load first (in-order vmcnt: see bn_apply_s_kernel)
+  const int cc = cs + (tid & 31);
+  const float ga = p.gamma[cc], be = p.beta[cc], rm0 = p.rm[cc], rv0 = p.rv[cc];
+  const float nga = p.ngamma[cc], nbe = p.nbeta[cc], nrm0 = p.nrm[cc], nrv0 = p.nrv[cc];
+  const float xm = p.xmean[cc], xr = p.xrstd[cc];
+  float4 fv[FL];
+  fan_in_issue<3, FL>(p.part, p.P, p.C, 3, cs, fv);
+  uint4 a1[NP], a2[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int m = min(m0 + u * PXP + pl, m1 - 1);
+    const size_t off = (size_t)m * p.C + c0;
+    a1[u] = ld16_nt(p.x1 + off);
+    a2[u] = ld16(p.x2 + off);
+  }
+  fan_in_finish<3, FL>(fv, p.P, tot, red);
+  if (tid < SW) {
+    const int c = cs + tid;
+    const double mean = tot[tid] / p.count;
+    double var = tot[2 * SW + tid] / p.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)p.eps);
+    const float sc = (float)((double)ga * rstd), sh = (float)((double)be - mean * (double)ga * rstd);
+    // statistics of out = sc x1 + sh + x2 (with the fp32 coefficients the elements are computed with)
+    const double mx = (double)xm;
+    double vx = 1.0 / ((double)xr * (double)xr) - (double)p.eps;
+    if (vx < 0.0) vx = 0.0;
+    const double cov = tot[SW + tid] / p.count - mean * mx;
+    const double omean = (double)sc * mean + (double)sh + mx;
+    double ovar = (double)sc * (double)sc * var + vx + 2.0 * (double)sc * cov;
+    if (ovar < 0.0) ovar = 0.0;
+    const double orstd = 1.0 / sqrt(ovar + (double)p.eps);
+    const float nsc = (float)((double)nga * orstd), nsh = (float)((double)nbe - omean * (double)nga * orstd);
+    cf[0][tid] = sc; cf[1][tid] = sh; cf[2][tid] = nsc; cf[3][tid] = nsh;
+    if (g == 0) {
+      p.scale[c] = sc; p.shift[c] = sh; p.mean[c] = (float)mean; p.rstd[c] = (float)rstd;
+      p.nscale[c] = nsc; p.nshift[c] = nsh; p.nmean[c] = (float)omean; p.nrstd[c] = (float)orstd;
+      const double k = p.count > 1.0 ? p.count / (p.count - 1.0) : 1.0;
+      p.rm[c] = (float)((1.0 - p.momentum) * (double)rm0 + p.momentum * mean);
+      p.rv[c] = (float)((1.0 - p.momentum) * (double)rv0 + p.momentum * var * k);
+      p.nrm[c] = (float)((1.0 - p.momentum) * (double)nrm0 + p.momentum * omean);
+      p.nrv[c] = (float)((1.0 - p.momentum) * (double)nrv0 + p.momentum * ovar * k);
+    }
+  }
+  __syncthreads();
+  float sc[8], sh[8], nsc[8], nsh[8];
+  lds8(&cf[0][cl * 8], sc);
+  lds8(&cf[1][cl * 8], sh);
+  lds8(&cf[2][cl * 8], nsc);
+  lds8(&cf[3][cl * 8], nsh);
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int m = m0 + u * PXP + pl;
+    if (m < m1) {
+      float f[8], h[8];
+      unpack8(a1[u], f);
+      unpack8(a2[u], h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f[j] = f[j] * sc[j] + sh[j];
+        f[j] += h[j];
+      }
+      const uint4 o = pack8(f);
+      *reinterpret_cast<uint4*>(p.y + (size_t)m * p.C + c0) = o;
+      float r[8];
+      unpack8(o, r);                                      // the next BatchNorm sees the stored (bf16) sum, as its own pass would
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = r[j] * nsc[j] + nsh[j];
+      *reinterpret_cast<uint4*>(p.y2 + (size_t)m * p.C + c0) = pack8(r);
+    }
+  }
+}
+
+// =====================================================================================================
 // backward, pass 1: partial sums (sum dz | sum dz xhat | sum dy z over z <= 0) -> G rows [3][C]
 // =====================================================================================================
 template <bool ALPHA, int U>
@@ -837,6 +926,28 @@ bool ew_bn_sliced_ok(int M, int C, int P_in, bool backward) {
   if (!g_bn_sliced || C < 64 || C > 1024 || (C % SW) != 0 || M < 256) return false;
   if ((long long)M * C > 14ll * 1000 * 1000 || M > 128 * kMaxPasses * PXP) return false;
   return P_in > 0 && P_in <= (backward ? 2 * kBwdFL2 * FanIn<2>::RG : kFwdFL * FanIn<2>::RG);     // backward: the apply pass has a double fan-in variant
+}
+
+bool ew_bn_apply2_sliced_ok(int M, int C, int P) {
+  return ew_bn_sliced_ok(M, C, 1, false) && P > 0 && P <= 2 * kBwdFL3 * FanIn<3>::RG;
+}
+int ew_bn_apply2_sliced(BnApply2S p, hipStream_t st) {
+  FEDFR_REQUIRE(p.part && p.x1 && p.x2 && p.y && p.y2 && p.gamma && p.beta && p.rm && p.rv && p.scale && p.shift && p.mean && p.rstd && p.xmean &&
+                    p.xrstd && p.ngamma && p.nbeta && p.nrm && p.nrv && p.nscale && p.nshift && p.nmean && p.nrstd, "bn_apply2_sliced: null argument");
+  FEDFR_REQUIRE(ew_bn_apply2_sliced_ok(p.M, p.C, p.P), "bn_apply2_sliced: unsupported shape M=%d C=%d P=%d", p.M, p.C, p.P);
+  sliced_geometry(p.M, p.C, &p.G, &p.ppg);
+  ProfScope prof(20, (double)p.M * p.C * 2 * 4, st);
+  const dim3 grid((p.C / SW) * p.G);
+  const bool small = p.ppg <= 7 * PXP, wide = p.P > kBwdFL3 * FanIn<3>::RG;
+  if (small) {
+    if (wide) hipLaunchKernelGGL((bn_apply2_s_kernel<7, 2 * kBwdFL3>), grid, dim3(NTH), 0, st, p);
+    else hipLaunchKernelGGL((bn_apply2_s_kernel<7, kBwdFL3>), grid, dim3(NTH), 0, st, p);
+  } else {
+    if (wide) hipLaunchKernelGGL((bn_apply2_s_kernel<kMaxPasses, 2 * kBwdFL3>), grid, dim3(NTH), 0, st, p);
+    else hipLaunchKernelGGL((bn_apply2_s_kernel<kMaxPasses, kBwdFL3>), grid, dim3(NTH), 0, st, p);
+  }
+  FEDFR_LAUNCH_CHECK("bn_apply2_sliced");
+  return FEDFR_OK;
 }
 
 int ew_bn_apply_sliced(BnApplyS p, hipStream_t st) {

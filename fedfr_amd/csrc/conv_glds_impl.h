@@ -678,6 +678,24 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           }
         }
       }
+    } else if (p.bmom) {                                   // forward: raw moments (sum y, sum y x, sum y y)
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        const int row = rg + i * RG;
+        if (row < PT) {
+          const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+          *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+          float dy[8], xv[8];
+          unpack8(dv, dy);
+          unpack8(xr[i], xv);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            s1[q] += dy[q];
+            s2[q] += dy[q] * xv[q];
+            s3[q] += dy[q] * dy[q];
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < XN; ++i) {
@@ -723,7 +741,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       } else {
         float* o = p.bpart + (size_t)bt * 3 * p.N + n0 + tid;
         o[0] = t0;
-        o[p.N] = fr * (t1 - fm * t0);
+        o[p.N] = p.bmom ? t1 : fr * (t1 - fm * t0);
         o[2 * (size_t)p.N] = t2;
       }
     }
@@ -735,7 +753,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       const float t0 = sStat[tid], t1 = sStat[BN + tid], t2 = sStat[2 * BN + tid];
       float* o = p.bpart + (size_t)btw * 3 * p.N + n0 + tid;
       o[0] = t0;
-      o[p.N] = p.brstd[n0 + tid] * (t1 - p.bmean[n0 + tid] * t0);
+      o[p.N] = p.bmom ? t1 : p.brstd[n0 + tid] * (t1 - p.bmean[n0 + tid] * t0);
       o[2 * (size_t)p.N] = t2;
     }
   }

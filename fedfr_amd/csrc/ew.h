@@ -65,6 +65,23 @@ struct BnApplyS {
   float* stats;                                   // statistics of y: ew_bn_sliced_rows(M, C) rows [2][C], or null; must not alias `part`
   int G, ppg;                                     // set by the launcher
 };
+// bn_apply2 (round 3): out = bn3(x1) + x2 AND y2 = bnN(out) in one pass, both BatchNorms in training mode, from the RAW moments the conv that
+// produced x1 left (rows [3][C] of sum x1, sum x1 * x2, sum x1 * x1; GemmNT::bmom) and the known statistics (xmean, xrstd) of x2:
+//   mean(out) = sc3 mean(x1) + sh3 + mean(x2),  var(out) = sc3^2 var(x1) + var(x2) + 2 sc3 cov(x1, x2)
+// so the next block's bn1 needs no pass over `out` (the rounding of `out` to bf16 is the only thing these moments do not see: ~1e-6 of the variance).
+struct BnApply2S {
+  const float* part; int P;                       // P rows [3][C]
+  double count; float momentum, eps;
+  const float *gamma, *beta; float *rm, *rv; float *scale, *shift, *mean, *rstd;              // the BatchNorm of x1 (bn3)
+  const float *xmean, *xrstd;                     // saved statistics of x2 (this block's bn1)
+  const float *ngamma, *nbeta; float *nrm, *nrv; float *nscale, *nshift, *nmean, *nrstd;      // the BatchNorm of out (the next block's bn1)
+  const bf16_t *x1, *x2;
+  bf16_t *y, *y2;
+  int M, C;
+  int G, ppg;                                     // set by the launcher
+};
+bool ew_bn_apply2_sliced_ok(int M, int C, int P);
+int ew_bn_apply2_sliced(BnApply2S p, hipStream_t st);
 struct BnBwdS {
   const bf16_t *dy, *x;
   const float *mean, *rstd, *gamma, *alpha;       // alpha non-null => PReLU after the BN

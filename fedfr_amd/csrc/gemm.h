@@ -33,6 +33,10 @@ struct GemmNT {
   const float *bmean, *brstd, *bgamma, *bbeta, *balpha;
   float* bpart;
   int* bwd_fused;
+  // bmom != 0 (forward launches, round 3): the same epilogue leaves RAW moments of the output y against a same-shape tensor bx instead —
+  // rows [3][N] of (sum y, sum y * bx, sum y * y) — from which the pass that follows derives the statistics of y AND of
+  // bn(y) + bx (the next block's bn1) without a pass over that sum (net.hip, conv2 of a residual block).  bmean / brstd: any readable [N].
+  int bmom;
   // optional INPUT transform of the LDS-DMA conv kernel (forward of a conv whose input is BatchNorm(+PReLU) of a stored tensor): the
   // kernel reads the raw tensor, applies y = x * tsc[c] + tsh[c] (then PReLU with talpha[c] if given) to its LDS image, so the
   // normalised activation needs no separate bn_apply pass; aout (optional) receives that activation (the wgrad operand).

@@ -312,6 +312,8 @@ static int conv_fwd_bn(const Ctx& c, const ConvD& cv, const bf16_t* raw, const B
   p.tsc = c.save(bn, 0); p.tsh = c.save(bn, 1); p.talpha = alpha; p.aout = tr ? a : nullptr;
   return gemm_nt_launch(p, 1, c.st);
 }
+int g_fwd_xmom = 1;       // option "fwd_xmom": bn3 + identity + the next block's bn1 as one pass from conv2's raw moments (14x14 / 28x28 blocks)
+extern int g_conv_halo;
 int g_fuse_bnbwd28 = 1;   // option "fuse_bnbwd28": ... and in the two-tiles 28x28 dgrad (with fuse_bnbwd != 0)
 int g_c64p_bnbwd = 1;   // option "c64p_bnbwd": BN-backward reduction in the epilogue of the persistent 64-channel dgrad kernel (with fuse_bnbwd != 0)
 extern int g_conv_c64p;
@@ -585,9 +587,21 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     }
     // a1 = bn1(x) -> conv1 -> a2 = prelu(bn2(c1)) -> conv2(stride) -> bn3(c2) + identity.  Statistics: the pass that produced x left
     // them in `prev`; a conv's epilogue leaves its output's in c.part()
-    const bool xf1 = g_fuse_bnapply && gemm_nt_conv_xform_ok(k.conv1.Hin, k.conv1.Cin, k.conv1.Cout, Mi, k.conv1.R, k.conv1.stride);
+    const bool xf1 = !a1_ready && g_fuse_bnapply && gemm_nt_conv_xform_ok(k.conv1.Hin, k.conv1.Cin, k.conv1.Cout, Mi, k.conv1.R, k.conv1.stride);
     const bool xf2 = g_fuse_bnapply && gemm_nt_conv_xform_ok(k.conv2.Hin, k.conv2.Cin, k.conv2.Cout, Mo, k.conv2.R, k.conv2.stride);
-    if (xf1) {
+    // round 3 (option fwd_xmom): where conv2 runs on an LDS-DMA kernel with the moment epilogue, out = bn3(c2) + x AND the next block's
+    // bn1(out) leave ONE pass (bn_apply2, ew.h): conv2 also sums c2 * x, and the statistics of `out` follow from those moments and the
+    // statistics of x this block's bn1 saved — the next block's bn1 pass disappears
+    const BlockD* nxb = bi + 1 < n->blocks.size() ? &n->blocks[bi + 1] : nullptr;
+    const int xm_rows = k.Hout == 14 ? Mo / 196 : Mo / 392;
+    const bool xmom = g_fwd_xmom && nxb && !k.has_ds && !xf2 && g_conv_halo >= 4 && k.conv2.R == 3 && k.conv2.stride == 1 && (k.Hout == 14 || k.Hout == 28) &&
+                      k.conv2.Cin % 128 == 0 && k.Cout % 128 == 0 && k.conv2.Cin == k.Cout && nxb->bn1.C == k.Cout &&
+                      gemm_nt_conv_epilogue_ok(k.Hout, k.conv2.Cin, k.Cout, Mo, 3, 1) &&          // (mirrors the dispatch: small problems take the generic kernel)
+                      (k.Hout == 14 || gemm_nt_fused28_two_tiles(Mo)) && ew_bn_apply2_sliced_ok(Mo, k.Cout, xm_rows);
+    if (a1_ready) {                             // the previous block's output pass wrote a1 = bn1(x) and bn1's statistics
+      FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, true));
+      a1_ready = false;
+    } else if (xf1) {
       FEDFR_TRY(bn_coeffs(c, k.bn1, prev, (double)Mi, true));
       FEDFR_TRY(conv_fwd_bn(c, k.conv1, A + k.x_off, k.bn1, nullptr, A + k.a1_off, A + k.c1_off, true));
     } else {
@@ -598,6 +612,32 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     if (xf2) {
       FEDFR_TRY(bn_coeffs(c, k.bn2, r1, (double)Mi, true));
       FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, true));
+    } else if (xmom) {
+      FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
+      GemmNT p{};
+      const ConvD& cv = k.conv2;
+      p.A = A + k.a2_off; p.B = c.shadow + cv.w_off;
+      p.M = Mo; p.N = cv.Cout; p.K = 9 * cv.Cin;
+      p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = 3;
+      p.stride = 1; p.pad = 1; p.up = 1;
+      p.Cb = A + k.c2_off; p.ldc = cv.Cout;
+      int rows = 0;
+      p.bx = A + k.x_off; p.bmean = c.save(k.bn3, 2); p.brstd = c.save(k.bn3, 3); p.bpart = c.part(); p.bmom = 1; p.bwd_fused = &rows;
+      FEDFR_TRY(gemm_nt_launch(p, 1, c.st));
+      FEDFR_REQUIRE(rows == xm_rows, "net_forward: the moment epilogue left %d rows, %d expected", rows, xm_rows);
+      BnApply2S a{};
+      a.part = c.part(); a.P = rows; a.count = (double)Mo; a.momentum = kBnMomentum; a.eps = kBnEps;
+      a.gamma = c.gamma(k.bn3); a.beta = c.beta(k.bn3); a.rm = c.bufs + k.bn3.rm_off; a.rv = c.bufs + k.bn3.rv_off;
+      a.scale = c.save(k.bn3, 0); a.shift = c.save(k.bn3, 1); a.mean = c.save(k.bn3, 2); a.rstd = c.save(k.bn3, 3);
+      a.xmean = c.save(k.bn1, 2); a.xrstd = c.save(k.bn1, 3);
+      const BnD& nb = nxb->bn1;
+      a.ngamma = c.gamma(nb); a.nbeta = c.beta(nb); a.nrm = c.bufs + nb.rm_off; a.nrv = c.bufs + nb.rv_off;
+      a.nscale = c.save(nb, 0); a.nshift = c.save(nb, 1); a.nmean = c.save(nb, 2); a.nrstd = c.save(nb, 3);
+      a.x1 = A + k.c2_off; a.x2 = A + k.x_off; a.y = A + k.out_off; a.y2 = A + nxb->a1_off; a.M = Mo; a.C = k.Cout;
+      FEDFR_TRY(ew_bn_apply2_sliced(a, c.st));
+      a1_ready = true;
+      prev = Rows{c.part(), 0};
+      continue;
     } else {
       FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
       FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, true));

@@ -345,6 +345,13 @@ int launch_c64p(GemmNT p, hipStream_t st) {
 }
 }  // namespace
 
+int conv_c64p_grid(int M) {                 // workgroups of a launch over M output pixels (224-pixel tiles dealt out evenly, at most one workgroup per CU)
+  const int ntiles = M / 224;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int per_wg = ceil_div(ntiles, std::min(ntiles, cus));
+  return ceil_div(ntiles, per_wg);
+}
 bool conv_c64p_applies(const GemmNT& p) {
   return g_conv_c64p && p.mode == 1 && p.S == 3 && p.C == 64 && p.N == 64 && p.K == 576 && p.stride == 1 && p.pad == 1 && p.up == 1 && p.H == p.W &&
          (p.W == 112 || p.W == 56) && p.Ho == p.H && p.Wo == p.W && p.M % (p.W * p.W) == 0 && p.Cb && p.ldc == 64 && !p.Cf && !(p.bpart && p.stats) &&

@@ -44,6 +44,9 @@ struct BnBwd {
   const bf16_t* nx;       // next BN's input tensor, same [M][C] shape
   const float *nmean, *nrstd;
   float* npart;
+  // ... with nalpha: the next BatchNorm is followed by a PReLU (the stem's; round 3): (nsc, nsh) = its forward (scale, shift), and the rows
+  // carry all three sums of ew_bn_bwd_reduce (sum dz, sum dz xhat, sum dx z over z <= 0).  Variant without own PReLU / same-shape addend only.
+  const float *nsc, *nsh, *nalpha;
 };
 int ew_bn_bwd_apply_grid(int M, int C);
 int ew_bn_bwd_grid(int M, int C);

@@ -596,8 +596,8 @@ struct BnBwdDiv {
   FastDiv dHW, dW;
 };
 
-template <bool ALPHA, bool NX, bool ADD>
-__global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX || ADD) ? 4 : 5) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab, int shfl) {
+template <bool ALPHA, int NX, bool ADD>      // NX: 0 none, 1 the next BatchNorm's reduction rides along, 2 ... and that BatchNorm has a PReLU behind it
+__global__ __launch_bounds__(EW_THREADS, ((ALPHA && NX) || NX == 2) ? 3 : (ALPHA || NX || ADD) ? 4 : 5) void bn_bwd_apply_kernel(BnBwd p, BnBwdDiv dv, int slab, int shfl) {
   const int tpr = p.C >> 3, rpp = EW_THREADS / tpr;
   const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   const bool active = rl < rpp;
@@ -605,8 +605,8 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX || ADD
   extern __shared__ float red[];                    // next BN's reduction (NX)
   constexpr int UNR = (ALPHA || NX || ADD) ? EW_UNROLL_HEAVY : EW_UNROLL;   // rows of loads in flight: the heavier variants trade one for registers (two waves beside wgrad9)
   const int c0 = cl * 8;
-  float ca[8], cA[8], cB[8], G[8], H[8], al[8], nmean[8];
-  float nacc[2][8];                                  // sum dx | sum dx (x_next - mean_next), scaled by rstd_next at the end
+  float ca[8], cA[8], cB[8], G[8], H[8], al[8], nmean[8], nG[8], nH[8], nal[8];
+  float nacc[NX == 2 ? 3 : 2][8];                    // sum dz | sum dz (x_next - mean_next), scaled by rstd_next at the end | (NX == 2) sum dx z over z <= 0
   load8f(p.coef, c0, ca, 1.f);
   load8f(p.coef + p.C, c0, cA, 0.f);
   load8f(p.coef + 2 * p.C, c0, cB, 0.f);
@@ -621,6 +621,13 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX || ADD
     load8f(p.nmean, c0, nmean, 0.f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) nacc[0][j] = nacc[1][j] = 0.f;
+    if (NX == 2) {
+      load8f(p.nsc, c0, nG, 1.f);
+      load8f(p.nsh, c0, nH, 0.f);
+      load8f(p.nalpha, c0, nal, 1.f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nacc[NX == 2 ? 2 : 0][j] = 0.f;
+    }
   }
   const int bid = ew_block_id();
   const int mbeg = bid * slab, mend = min(p.M, mbeg + slab);
@@ -666,8 +673,16 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX || ADD
       unpack8(vn, xn);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        nacc[0][j] += dn[j];
-        nacc[1][j] += dn[j] * (xn[j] - nmean[j]);
+        float dzn = dn[j];
+        if (NX == 2) {                                 // exactly bn_bwd_reduce's PReLU branch
+          const float z = xn[j] * nG[j] + nH[j];
+          if (z <= 0.f) {
+            nacc[NX == 2 ? 2 : 0][j] += dn[j] * z;
+            dzn = dn[j] * nal[j];
+          }
+        }
+        nacc[0][j] += dzn;
+        nacc[1][j] += dzn * (xn[j] - nmean[j]);
       }
     }
   };
@@ -700,8 +715,12 @@ __global__ __launch_bounds__(EW_THREADS, (ALPHA && NX) ? 3 : (ALPHA || NX || ADD
 #pragma unroll
     for (int j = 0; j < 8; ++j) nacc[1][j] *= nrstd[j];
     float* row = p.npart + (size_t)bid * 3 * p.C;
-    ew_block_colsum<2>(nacc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, row);
-    for (int i = threadIdx.x; i < p.C; i += EW_THREADS) row[2 * p.C + i] = 0.f;
+    if (NX == 2) {
+      ew_block_colsum<3>(nacc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, row);
+    } else {
+      ew_block_colsum<2>(nacc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, row);
+      for (int i = threadIdx.x; i < p.C; i += EW_THREADS) row[2 * p.C + i] = 0.f;
+    }
   }
 }
 
@@ -720,23 +739,26 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
     dv.dW = make_fastdiv((unsigned)p.W);
   }
   if (p.nx) FEDFR_REQUIRE(p.nmean && p.nrstd && p.npart, "bn_bwd_apply: next-BN reduction needs mean / rstd / partials");
+  const bool nxa = p.nx && p.nalpha;
+  if (nxa) FEDFR_REQUIRE(p.nsc && p.nsh && !p.alpha && !p.add, "bn_bwd_apply: the PReLU form of the next-BN reduction needs that BN's (scale, shift) and serves the plain variant only");
   const int slab = slab_rows(p.M, p.C, g_ew_bwd_apply_blocks);
   const dim3 grid(ceil_div(p.M, slab));
-  const size_t lds = p.nx ? ew_colsum_lds(p.C, 2) : 0;
+  const size_t lds = p.nx ? ew_colsum_lds(p.C, nxa ? 3 : 2) : 0;
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
 #define BWD_APPLY(A, N, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<A, N, D>), grid, dim3(EW_THREADS), lds, st, p, dv, slab, shfl)
-  const int variant = (p.alpha ? 4 : 0) | (p.nx ? 2 : 0) | (p.add ? 1 : 0);
+  const int variant = nxa ? 8 : ((p.alpha ? 4 : 0) | (p.nx ? 2 : 0) | (p.add ? 1 : 0));
   // algorithmic bytes: dy + x read, dx written, + the identity addend (compact when up-sampled), + the next BN's input when its reduction rides along
   ProfScope prof(22, (double)p.M * p.C * 2 * (3.0 + (p.add ? 1.0 : 0.0) + (p.add_up ? 0.25 : 0.0) + (p.nx ? 1.0 : 0.0)), st);
   switch (variant) {
-    case 0: BWD_APPLY(false, false, false); break;
-    case 1: BWD_APPLY(false, false, true); break;
-    case 2: BWD_APPLY(false, true, false); break;
-    case 3: BWD_APPLY(false, true, true); break;
-    case 4: BWD_APPLY(true, false, false); break;
-    case 5: BWD_APPLY(true, false, true); break;
-    case 6: BWD_APPLY(true, true, false); break;
-    default: BWD_APPLY(true, true, true); break;
+    case 0: BWD_APPLY(false, 0, false); break;
+    case 1: BWD_APPLY(false, 0, true); break;
+    case 2: BWD_APPLY(false, 1, false); break;
+    case 3: BWD_APPLY(false, 1, true); break;
+    case 4: BWD_APPLY(true, 0, false); break;
+    case 5: BWD_APPLY(true, 0, true); break;
+    case 6: BWD_APPLY(true, 1, false); break;
+    case 7: BWD_APPLY(true, 1, true); break;
+    default: BWD_APPLY(false, 2, false); break;
   }
 #undef BWD_APPLY
   FEDFR_LAUNCH_CHECK("bn_bwd_apply");

@@ -310,6 +310,9 @@ static bool glds28_two_tiles(const GemmNT& p) {          // option value 2: the 
 int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride, bool xform) {
   if ((W == 14 || W == 28) && gemm_nt_conv_epilogue_ok(W, C, N, M, ksize, stride))
     return (W == 28 && !xform && glds28_two_tiles_shape(M)) ? M / 196 / 2 : M / 196 * 2;
+  // the persistent 64-channel kernel: two rows per workgroup, at most one workgroup per CU (conv_c64p.hip: launch_c64p) — 512 rows instead
+  // of 6 272 / 25 088, few enough for the finalize kernel to take without the staging launch in front of it
+  if (!xform && g_conv_c64p && ksize == 3 && stride == 1 && C == 64 && N == 64 && (W == 56 || W == 112) && M % (W * W) == 0) return 2 * conv_c64p_grid(M);
   return gemm_nt_stat_rows(M, N);
 }
 

@@ -63,6 +63,7 @@ int launch_conv_glds_w56_c128_n64(GemmNT p, hipStream_t st);
 // conv_c64p.hip: persistent 3x3 conv for the 64 -> 64 channel layers (112x112 / 56x56), filter bank in registers
 extern int g_conv_c64p;
 bool conv_c64p_applies(const GemmNT& p);
+int conv_c64p_grid(int M);
 int launch_conv_c64p(GemmNT p, hipStream_t st);
 int launch_conv_glds_x(GemmNT p, hipStream_t st);          // conv_glds_x.hip  forward convs with the input BN(+PReLU) applied in LDS
 int launch_conv_glds8_fused_w14(GemmNT p, hipStream_t st); // conv_glds8_fused_w14.hip  + BN-backward reduction epilogue

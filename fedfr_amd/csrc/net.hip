@@ -698,8 +698,10 @@ int g_fuse_bnred_next = 1;   // option "fuse_bnred_next": a BN-backward apply pa
 // Channel-sliced passes without a finalize launch where the shape allows (bn_sliced.hip), else reduce / finalize / apply of ew.hip.
 static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
                   const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, Rows have = Rows{nullptr, 0}, const BnD* next_bn = nullptr,
-                  const bf16_t* next_x = nullptr, Rows* next_rows = nullptr) {
-  const bool nxt = next_bn && next_x && next_rows && g_fuse_bnred_next && next_bn->C == b.C;
+                  const bf16_t* next_x = nullptr, Rows* next_rows = nullptr, const float* next_alpha = nullptr) {
+  // (next_alpha: the consuming BatchNorm has a PReLU behind it — the stem's; served by the row-slab apply pass without own PReLU / addend)
+  const bool nxt = next_bn && next_x && next_rows && g_fuse_bnred_next && next_bn->C == b.C &&
+                   (!next_alpha || (!alpha && !add && !ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C, true), true)));
   // frozen BatchNorm (eval mode inside a training net): mean / rstd were constants, so dx = gamma rstd dz — the same passes with an infinite
   // count (the two mean terms vanish); dgamma / dbeta / dalpha are the same sums
   const double count = c.n->bn_frozen ? HUGE_VAL : (double)M;
@@ -739,6 +741,7 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
     // dx is the dy of next_bn's backward: its (sum, sum * xhat) partials ride along in this apply pass (one tensor read instead of
     // a separate two-tensor reduce kernel); they land in the shared partial buffer, which this BN's finalize has finished reading
     p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part();
+    if (next_alpha) { p.nsc = c.save(*next_bn, 0); p.nsh = c.save(*next_bn, 1); p.nalpha = next_alpha; }
     *next_rows = Rows{c.part(), ew_bn_bwd_apply_grid(M, b.C)};
   }
   p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.beta = c.beta(b); p.alpha = alpha;
@@ -750,6 +753,7 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   return ew_bn_bwd_apply(p, c.st);
 }
 
+int g_stem_bnred = 1;     // option "stem_bnred": the stem's BatchNorm-backward reduction rides in the first block's bn1 apply pass
 int g_fc_wgrad_aux = 1;   // option "fc_wgrad_aux": fc's weight gradient runs on the weight-gradient stream
 int g_late_join = 1;       // option "late_join": the streams join behind the stem's BatchNorm backward instead of in front of it
 int g_event_nofence = 1;   // option "event_nofence": fork / join events created with hipEventDisableSystemFence
@@ -912,7 +916,11 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     FEDFR_TRY(conv_dgrad(c, k.conv1, dc1, da1, &k.bn1, A + k.x_off, nullptr, &f1));
     // a1 = bn1(x)
     const BlockD* prev = bi > 0 ? &n->blocks[bi - 1] : nullptr;      // its bn3 consumes gin next
-    if (k.has_ds) {
+    if (k.has_ds && !prev && !n->block_only && g_stem_bnred) {
+      // the first block: its input gradient is the dy of the STEM's BatchNorm (+PReLU) backward, reduced here (one pass over two 205 MB tensors fewer)
+      FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, nullptr, dxd, k.Hin, gin, 0, Rows{c.part(), f1}, &n->stem_bn, A + n->c0_off, &pend,
+                       params + n->stem_alpha_off));
+    } else if (k.has_ds) {
       FEDFR_TRY(bn_bwd(c, k.bn1, nullptr, da1, A + k.x_off, Mi, nullptr, dxd, k.Hin, gin, 0, Rows{c.part(), f1}, prev ? &prev->bn3 : nullptr,
                        prev ? A + prev->c2_off : nullptr, &pend));
     } else {
@@ -936,7 +944,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   } else {
   // ---- stem: a0 = prelu(bn1(conv1(x))) ----
   bf16_t* dz0 = g_late_join ? c.t(1) : c.t(0);
-  FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, dz0, n->stem_alpha_off));
+  FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, dz0, n->stem_alpha_off, pend));
   if (g_late_join) fk.order(wst, st);
   FEDFR_TRY(ew_stem_wgrad(x, dz0, grads + n->stem.w_off, c.slab(), B, HW, HW, st));
   }

@@ -72,6 +72,9 @@ SIGNATURES = {
     "fedfr_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "fedfr_bn_sliced_rows": (i32, [i32, i32, i32]),
     "fedfr_bn_sliced_ok": (i32, [i32, i32, i32, i32]),
+    "fedfr_conv2d_fwd_moments": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, C.POINTER(i32), vp]),
+    "fedfr_bn_apply2_sliced_ok": (i32, [i32, i32, i32]),
+    "fedfr_bn_apply2_sliced": (i32, [vp, i32, f64, f32, f32] + [vp] * 22 + [i32, i32, vp]),
     "fedfr_bn_apply_sliced": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "fedfr_bn_bwd_sliced": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "fedfr_normalize_rows": (i32, [vp, vp, vp, i32, i32, f32, vp]),

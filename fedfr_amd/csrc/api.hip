@@ -408,6 +408,36 @@ int fedfr_conv2d_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* s
   p.pad = ksize == 3 ? 1 : 0; p.up = 1; p.Cb = BFM(y); p.ldc = cout; p.stats = stats;
   return gemm_nt_launch(p, 1, ST(stream));
 }
+int fedfr_conv2d_fwd_moments(const uint16_t* x, const uint16_t* w, uint16_t* y, int batch, int hin, int cin, int cout, const uint16_t* other,
+                             float* partials, int* rows, void* stream) {
+  FEDFR_TRY(conv_args_ok(batch, hin, cin, cout, 3, 1));
+  FEDFR_REQUIRE(x && w && y && other && partials && rows, "conv2d_fwd_moments: null argument");
+  GemmNT p{};
+  p.A = BF(x); p.B = BF(w); p.M = batch * hin * hin; p.N = cout; p.K = 9 * cin;
+  p.mode = 1; p.H = hin; p.W = hin; p.C = cin; p.Ho = hin; p.Wo = hin; p.S = 3; p.stride = 1; p.pad = 1; p.up = 1;
+  p.Cb = BFM(y); p.ldc = cout;
+  p.bx = BF(other); p.bmean = partials; p.brstd = partials;   // (any readable fp32 array of >= cout elements: read, never used in this mode)
+  p.bpart = partials; p.bmom = 1;
+  *rows = 0;
+  p.bwd_fused = rows;
+  return gemm_nt_launch(p, 1, ST(stream));
+}
+int fedfr_bn_apply2_sliced_ok(int M, int C, int rows) { return ew_bn_apply2_sliced_ok(M, C, rows) ? 1 : 0; }
+int fedfr_bn_apply2_sliced(const float* partials, int P, double count, float momentum, float eps, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                           const float* x2_mean, const float* x2_rstd, const float* next_gamma, const float* next_beta,
+                           float* next_running_mean, float* next_running_var, float* next_scale, float* next_shift, float* next_save_mean,
+                           float* next_save_rstd, const uint16_t* x1, const uint16_t* x2, uint16_t* y, uint16_t* y2, int M, int C,
+                           void* stream) {
+  BnApply2S a{};
+  a.part = partials; a.P = P; a.count = count; a.momentum = momentum; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.rm = running_mean; a.rv = running_var; a.scale = scale; a.shift = shift; a.mean = save_mean; a.rstd = save_rstd;
+  a.xmean = x2_mean; a.xrstd = x2_rstd;
+  a.ngamma = next_gamma; a.nbeta = next_beta; a.nrm = next_running_mean; a.nrv = next_running_var; a.nscale = next_scale; a.nshift = next_shift;
+  a.nmean = next_save_mean; a.nrstd = next_save_rstd;
+  a.x1 = BF(x1); a.x2 = BF(x2); a.y = BFM(y); a.y2 = BFM(y2); a.M = M; a.C = C;
+  return ew_bn_apply2_sliced(a, ST(stream));
+}
 int fedfr_conv2d_dgrad(const uint16_t* dy, const uint16_t* wd, uint16_t* dx, int batch, int hin, int cin, int cout, int ksize,
                        int stride, void* stream) {
   FEDFR_TRY(conv_args_ok(batch, hin, cin, cout, ksize, stride));

@@ -231,6 +231,22 @@ int fedfr_bn_apply_sliced(const float* partials, int P, double count, const floa
                           float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
                           float* save_rstd, const uint16_t* x1, const float* alpha, const uint16_t* x2, uint16_t* y, int M, int C,
                           float* stats, void* stream);
+/* Round 3, the forward moment pass (option "fwd_xmom"; reference: the bn3 + identity of IBasicBlock.forward, backbones/iresnet.py:69-78, and the
+ * bn1 of the NEXT block, :62).  fedfr_conv2d_fwd_moments: 3x3 / stride-1 conv whose epilogue leaves, per workgroup, rows [3][cout] of the raw
+ * moments (sum y, sum y * other, sum y * y) of its bf16 output against a same-shape tensor `other`; *rows = number of rows written (0: this
+ * shape is not served by a kernel with that epilogue, nothing was written to `partials`, y is still computed).  `partials` must hold
+ * batch * hin * hin / 196 rows.  fedfr_bn_apply2_sliced: y = bn(x1) + x2 and y2 = bn_next(y), both BatchNorms in training mode, from those
+ * rows and the saved statistics (x2_mean, x2_rstd) of x2: the statistics of y are derived — mean = scale * mean(x1) + shift + mean(x2),
+ * var = scale^2 var(x1) + var(x2) + 2 scale cov(x1, x2) — and written (with running statistics, scale / shift) for both BatchNorms. */
+int fedfr_conv2d_fwd_moments(const uint16_t* x, const uint16_t* w, uint16_t* y, int batch, int hin, int cin, int cout, const uint16_t* other,
+                             float* partials, int* rows, void* stream);
+int fedfr_bn_apply2_sliced_ok(int M, int C, int rows);
+int fedfr_bn_apply2_sliced(const float* partials, int P, double count, float momentum, float eps, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                           const float* x2_mean, const float* x2_rstd, const float* next_gamma, const float* next_beta,
+                           float* next_running_mean, float* next_running_var, float* next_scale, float* next_shift, float* next_save_mean,
+                           float* next_save_rstd, const uint16_t* x1, const uint16_t* x2, uint16_t* y, uint16_t* y2, int M, int C,
+                           void* stream);
 int fedfr_bn_bwd_sliced(const uint16_t* dy, const uint16_t* x, const float* mean, const float* rstd, const float* gamma,
                         const float* alpha, const float* sc, const float* sh, int M, int C, float* partials, int rows_in,
                         float* dgamma, float* dbeta, float* dalpha, const uint16_t* add, uint16_t* dx, const uint16_t* nx,

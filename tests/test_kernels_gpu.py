@@ -174,6 +174,72 @@ def test_conv_dgrad_fused_bn_bwd_reduction(B, H, Cin, Cout, prelu):
         assert float((got[i] - ref).abs().max()) < 2e-4 * scale + 1e-2, i
 
 
+@pytest.mark.parametrize("B,H,Ch", [(128, 14, 256), (64, 28, 128), (200, 14, 256), (40, 14, 256)])
+def test_forward_moment_conv_and_bn_apply2(B, H, Ch):
+    """Round 3 forward moment pass, kernel level.  (1) fedfr_conv2d_fwd_moments: same output as the plain conv, rows of raw moments
+    (sum y, sum y * other, sum y * y) that add up to torch's.  (2) fedfr_bn_apply2_sliced on those rows: out = bn(y) + other and
+    y2 = bn_next(out) with the statistics of `out` DERIVED from the moments — against torch BatchNorms (training mode) that MEASURE them:
+    saved mean / rstd, running statistics, both outputs.  Shapes: one row per 14x14 image tile, one per pair of 28x28 band tiles, the
+    double fan-in variant (200 rows), and a problem too small for a kernel with that epilogue (rows == 0, plain output)."""
+    d = dev()
+    M = B * H * H
+    x, w = _conv_inputs(B, H, Ch, Ch, 3, 1)
+    wb = bf(w.permute(0, 2, 3, 1).contiguous()).to(d)                   # KRSC bf16
+    xd = bf(nhwc(x)).to(d)
+    other = bf(rnd((M, Ch), 21) * 1.3 + 0.25).to(d)
+    y = torch.empty(B, H, H, Ch, dtype=torch.bfloat16, device=d)
+    part = torch.full((M // 196 + 1, 3, Ch), float("nan"), device=d)
+    rows = C.c_int(0)
+    _C.call("fedfr_conv2d_fwd_moments", xd.data_ptr(), wb.data_ptr(), y.data_ptr(), B, H, Ch, Ch, other.data_ptr(), part.data_ptr(),
+            C.byref(rows), _C.stream())
+    y_ref = torch.empty_like(y)
+    _C.call("fedfr_conv2d_fwd", xd.data_ptr(), wb.data_ptr(), y_ref.data_ptr(), None, B, H, Ch, Ch, 3, 1, _C.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    if -(-M // 128) * -(-Ch // 128) < 384:           # (gemm.hip: nt_bm) small problems take the generic kernel: no epilogue of this kind
+        assert rows.value == 0
+        return
+    assert rows.value == (M // 196 if H == 14 else M // 392)
+    yf, of = y.float().reshape(M, Ch).double(), other.float().double()
+    got = part[: rows.value].double().sum(0)
+    for i, ref in enumerate((yf.sum(0), (yf * of).sum(0), (yf * yf).sum(0))):
+        assert float((got[i] - ref).abs().max()) < 2e-4 * (float(ref.abs().max()) + 1e-6) + 1e-2, i
+    # ---- the pass on those rows
+    assert _C.lib().fedfr_bn_apply2_sliced_ok(M, Ch, rows.value) == 1
+    eps, mom = 1e-5, 0.1
+    g3, b3 = (rnd((Ch,), 31) * 0.2 + 1).to(d), (rnd((Ch,), 32) * 0.3).to(d)
+    g1, b1 = (rnd((Ch,), 33) * 0.2 + 1).to(d), (rnd((Ch,), 34) * 0.3).to(d)
+    rm3, rv3, rm1, rv1 = [(rnd((Ch,), 35 + i) * 0.1 + (1.0 if i % 2 else 0.0)).to(d) for i in range(4)]
+    rm3_0, rv3_0, rm1_0, rv1_0 = rm3.clone(), rv3.clone(), rm1.clone(), rv1.clone()
+    xmean = of.mean(0).float()
+    xrstd = (1.0 / torch.sqrt(of.var(0, unbiased=False) + eps)).float()
+    sv = [torch.full((Ch,), float("nan"), device=d) for _ in range(8)]
+    out = torch.empty(M, Ch, dtype=torch.bfloat16, device=d)
+    y2 = torch.empty(M, Ch, dtype=torch.bfloat16, device=d)
+    _C.call("fedfr_bn_apply2_sliced", part.data_ptr(), rows.value, float(M), mom, eps, g3.data_ptr(), b3.data_ptr(), rm3.data_ptr(), rv3.data_ptr(),
+            sv[0].data_ptr(), sv[1].data_ptr(), sv[2].data_ptr(), sv[3].data_ptr(), xmean.data_ptr(), xrstd.data_ptr(), g1.data_ptr(), b1.data_ptr(),
+            rm1.data_ptr(), rv1.data_ptr(), sv[4].data_ptr(), sv[5].data_ptr(), sv[6].data_ptr(), sv[7].data_ptr(), y.data_ptr(), other.data_ptr(),
+            out.data_ptr(), y2.data_ptr(), M, Ch, _C.stream())
+    torch.cuda.synchronize()
+    my, vy = yf.mean(0), yf.var(0, unbiased=False)
+    out_ref = (yf - my) / torch.sqrt(vy + eps) * g3.double() + b3.double() + of
+    assert relerr(out.float(), out_ref.float()) < 4e-3                    # one bf16 rounding
+    assert float((sv[2].double() - my).abs().max()) < 1e-5 * (1 + float(my.abs().max()))
+    assert float((sv[3].double() * torch.sqrt(vy + eps) - 1).abs().max()) < 1e-5
+    og = out.float().double()                                            # what a measuring bn1 pass would see
+    mo, vo = og.mean(0), og.var(0, unbiased=False)
+    # derived vs measured statistics of the STORED tensor: they differ by what its rounding to bf16 adds (per element 2^-9 relative, zero mean:
+    # ~1e-4 of a mean over 2.5e4 elements at the worst channel, 7.3e-5 measured), nothing else
+    assert float((sv[6].double() - mo).abs().max()) < 2e-4 * (1 + float(mo.abs().max()))
+    assert float((sv[7].double() * torch.sqrt(vo + eps) - 1).abs().max()) < 2e-4
+    y2_ref = (og - mo) / torch.sqrt(vo + eps) * g1.double() + b1.double()
+    assert relerr(y2.float(), y2_ref.float()) < 4e-3
+    k = M / (M - 1.0)
+    for got_, ref_, tol in ((rm3, 0.9 * rm3_0.double() + 0.1 * my, 1e-5), (rv3, 0.9 * rv3_0.double() + 0.1 * vy * k, 1e-5),
+                            (rm1, 0.9 * rm1_0.double() + 0.1 * mo, 3e-5), (rv1, 0.9 * rv1_0.double() + 0.1 * vo * k, 3e-5)):
+        assert float((got_.double() - ref_).abs().max()) < tol * (1 + float(ref_.abs().max()))
+
+
 @pytest.mark.parametrize("variant", ["default", "no_wgrad9", "scalar_frags"])
 @pytest.mark.parametrize("B,H,Cin,Cout,k,s", CONV_CASES + [(128, 14, 256, 256, 3, 1), (19, 14, 256, 512, 3, 1), (33, 28, 128, 256, 3, 1)])
 def test_conv_wgrad(B, H, Cin, Cout, k, s, variant):

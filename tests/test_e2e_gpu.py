@@ -1295,7 +1295,7 @@ def test_forward_moment_pass_equals_measured_statistics(arch, batch):
             outs.append((f.detach().clone(), {k: p_.grad.clone() for k, p_ in m.named_parameters() if p_.grad is not None},
                          {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
     (f0, g0, s0), (f1, g1, s1) = outs
-    assert float((f0 - f1).abs().max() / f0.abs().max()) < 6e-3            # bf16 activations downstream of statistics that differ by ~1e-6
+    assert float((f0 - f1).abs().max() / f0.abs().max()) < 8e-3            # bf16 activations downstream of statistics that differ by ~1e-6
     for k in s0:
         tol = 3e-4                                                       # momentum 0.1 x statistics of bf16 activations that moved by a rounding here and there
         assert float((s0[k] - s1[k]).abs().max()) <= tol * (1.0 + float(s0[k].abs().max())), k

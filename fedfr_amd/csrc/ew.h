@@ -159,6 +159,11 @@ int ew_prelu_bwd_rows(int M, int C);
 int ew_prelu_bwd_pass(const bf16_t* dy, const bf16_t* add, const bf16_t* x, const float* bias, const float* alpha, int M, int C, bf16_t* gsum,
                       bf16_t* dz, float* rows, hipStream_t st);
 int ew_prelu_bwd_finalize(const float* rows, int P, int C, float* dbias, float* dalpha, hipStream_t st);
+// ... of up to kMaxPreluFin PReLUs in ONE launch (sphnet: 62 per step, 8.7 us each on the weight-gradient stream that bounds its backward pass)
+constexpr int kMaxPreluFin = 64;
+struct PreluFinEntry { unsigned long long rows_off; long long dbias_off, dalpha_off; int P, C, blk0; };   // byte offset into `base`; float offsets into `grads` (dbias < 0: none)
+struct PreluFinTable { int n, blocks; PreluFinEntry e[kMaxPreluFin]; };
+int ew_prelu_bwd_finalize_multi(const unsigned char* base, float* grads, const PreluFinTable& t, hipStream_t st);
 int ew_pad_input_nhwc(const float* src, bf16_t* dst, int B, int C, int HW, int Cpad, hipStream_t st);
 // all dgrad shadows of a network in one launch (one 64x64 transpose tile per workgroup, table passed by value)
 constexpr int kMaxShadowEntries = 112;     // 112 x 32 B: the by-value table stays under the 4 KiB kernel-argument limit

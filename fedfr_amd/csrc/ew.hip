@@ -1622,6 +1622,25 @@ __global__ __launch_bounds__(256) void prelu_rows_finalize_kernel(const float* _
     if (dalpha) dalpha[c] = (float)tot[1][threadIdx.x];
   }
 }
+__global__ __launch_bounds__(256) void prelu_rows_finalize_multi_kernel(const unsigned char* __restrict__ base, float* __restrict__ grads, PreluFinTable t) {
+  __shared__ double tot[2][8];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.e[i + 1].blk0) ++i;        // (workgroup-uniform: a scan of at most 63 scalars)
+  const PreluFinEntry e = t.e[i];
+  const int c0 = ((int)blockIdx.x - e.blk0) * 8;
+  fin8_accumulate<2>(reinterpret_cast<const float*>(base + e.rows_off), e.P, e.C, c0, 2, tot);
+  if (threadIdx.x < 8) {
+    const int c = c0 + threadIdx.x;
+    if (e.dbias_off >= 0) grads[e.dbias_off + c] = (float)tot[0][threadIdx.x];
+    grads[e.dalpha_off + c] = (float)tot[1][threadIdx.x];
+  }
+}
+int ew_prelu_bwd_finalize_multi(const unsigned char* base, float* grads, const PreluFinTable& t, hipStream_t st) {
+  FEDFR_REQUIRE(base && grads && t.n > 0 && t.n <= kMaxPreluFin && t.blocks > 0, "prelu_bwd_finalize_multi: bad table");
+  hipLaunchKernelGGL(prelu_rows_finalize_multi_kernel, dim3(t.blocks), dim3(256), 0, st, base, grads, t);
+  FEDFR_LAUNCH_CHECK("prelu_bwd_finalize_multi");
+  return FEDFR_OK;
+}
 int ew_prelu_bwd_finalize(const float* rows, int P, int C, float* dbias, float* dalpha, hipStream_t st) {
   FEDFR_REQUIRE(rows && P > 0 && C > 0, "prelu_bwd_finalize: bad args");
   FEDFR_REQUIRE((C & 7) == 0, "prelu_bwd_finalize: C %% 8");

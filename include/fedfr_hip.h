@@ -49,7 +49,8 @@ const char* fedfr_last_error_string(void);
  * weight gradient is the weight-gradient stream's first kernel), "fwd_xmom" (1 [default]: in the training forward pass of a 14x14 / 28x28
  * residual block, bn3 + identity + the NEXT block's bn1 are one pass; conv2's epilogue leaves the raw moments of its output against the
  * block input and the statistics of the sum are derived from them), "stem_bnred" (1 [default]: the reduction of the stem's BatchNorm
- * backward rides in the first block's bn1 apply pass).  Unknown names are an error. */
+ * backward rides in the first block's bn1 apply pass), "sph_fin_multi" / "sph_pair_wgrad" (1 [default]: sphnet's backward pass finalizes all
+ * PReLU parameter sums in one launch / runs a residual block's two weight gradients as one paired launch).  Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);
 /* the switch's current value (a caller that changes one temporarily restores what it found) */
 int fedfr_get_option(const char* name, int* value);

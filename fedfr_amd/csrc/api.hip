@@ -38,6 +38,7 @@ extern int g_bn_fuse_bwd;
 extern int g_event_nofence, g_fork_mode;
 extern int g_sph_fuse_act;
 extern int g_sph_fin_multi;
+extern int g_sph_fuse_prelu_bwd;
 extern int g_sph_pair_wgrad;
 extern int g_dbg_skip;
 extern int g_c64p_bnbwd;
@@ -205,6 +206,10 @@ int fedfr_set_option(const char* name, int value) {
     g_stem_bnred = value ? 1 : 0;
     return FEDFR_OK;
   }
+  if (name && !strcmp(name, "sph_fuse_prelu_bwd")) {
+    g_sph_fuse_prelu_bwd = value ? 1 : 0;
+    return FEDFR_OK;
+  }
   if (name && !strcmp(name, "sph_fin_multi")) {
     g_sph_fin_multi = value ? 1 : 0;
     return FEDFR_OK;
@@ -246,7 +251,7 @@ int fedfr_get_option(const char* name, int* value) {
       {"eval_fuse", &g_eval_fuse}, {"wgrad9", &g_wgrad9}, {"tn_pair", &g_tn_pair}, {"fuse_bnbwd", &g_fuse_bnbwd}, {"conv_c64p", &g_conv_c64p},
       {"bn_sliced", &g_bn_sliced}, {"wgrad9_wgs", &g_wgrad9_wgs}, {"conv28_tpw2", &g_conv28_tpw2}, {"wgrad9p", &g_wgrad9p},
       {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes}, {"bn_sliced_pre", &g_bn_sliced_pre}, {"nt_nbuf", &g_nt_nbuf},
-      {"bn_fuse_bwd", &g_bn_fuse_bwd}, {"event_nofence", &g_event_nofence}, {"fork_mode", &g_fork_mode}, {"dbg_skip", &g_dbg_skip}, {"c64p_bnbwd", &g_c64p_bnbwd}, {"late_join", &g_late_join}, {"stem_bnred", &g_stem_bnred}, {"fwd_xmom", &g_fwd_xmom}, {"fc_wgrad_aux", &g_fc_wgrad_aux}, {"fuse_bnbwd28", &g_fuse_bnbwd28}, {"sph_fuse_act", &g_sph_fuse_act}, {"sph_fin_multi", &g_sph_fin_multi}, {"sph_pair_wgrad", &g_sph_pair_wgrad}, {"ew_reduce_blocks", &g_ew_reduce_blocks}, {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks}, {"ew_reduce_nt", &g_ew_reduce_nt}};
+      {"bn_fuse_bwd", &g_bn_fuse_bwd}, {"event_nofence", &g_event_nofence}, {"fork_mode", &g_fork_mode}, {"dbg_skip", &g_dbg_skip}, {"c64p_bnbwd", &g_c64p_bnbwd}, {"late_join", &g_late_join}, {"stem_bnred", &g_stem_bnred}, {"fwd_xmom", &g_fwd_xmom}, {"fc_wgrad_aux", &g_fc_wgrad_aux}, {"fuse_bnbwd28", &g_fuse_bnbwd28}, {"sph_fuse_act", &g_sph_fuse_act}, {"sph_fin_multi", &g_sph_fin_multi}, {"sph_fuse_prelu_bwd", &g_sph_fuse_prelu_bwd}, {"sph_pair_wgrad", &g_sph_pair_wgrad}, {"ew_reduce_blocks", &g_ew_reduce_blocks}, {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks}, {"ew_reduce_nt", &g_ew_reduce_nt}};
   FEDFR_REQUIRE(name && value, "get_option: null argument");
   for (const auto& e : tab)
     if (!strcmp(name, e.n)) {

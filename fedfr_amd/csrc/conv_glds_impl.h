@@ -465,7 +465,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       if constexpr (XLATE) {
         // branch-free (a branch between these loads and the barrier below made hipcc wait for the x tile in front of it): without PReLU the
         // five vectors are read from `mean` and never used
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.balpha ? arr[a] : p.bmean, cb);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc((p.balpha && arr[a]) ? arr[a] : p.bmean, cb);
         const uint4 lo = buf_load16(rs, co), hi = buf_load16(rs, co + 16u);
         fc[a][0] = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w));
         fc[a][1] = make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w));
@@ -649,12 +649,14 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     for (int q = 0; q < 8; ++q) s1[q] = s2[q] = s3[q] = 0.f;
     if (p.balpha) {
       float sc[8], sh[8], al[8];
+      const bool papply = p.bmom == 2;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         auto at = [&](int a) { const float4 v = fc[a][q >> 2]; return (q & 3) == 0 ? v.x : (q & 3) == 1 ? v.y : (q & 3) == 2 ? v.z : v.w; };
-        const float g = at(2) * at(1);
+        // bmom == 2 (sphnet): a bare PReLU(+bias) sits in front — z = x + bias (carried in bbeta), no statistics
+        const float g = papply ? 1.f : at(2) * at(1);
         sc[q] = g;
-        sh[q] = at(3) - at(0) * g;
+        sh[q] = papply ? (p.bbeta ? at(3) : 0.f) : at(3) - at(0) * g;      // (no bias: the several-tiles variant's branch-free loads read `mean` in its place)
         al[q] = at(4);
       }
 #pragma unroll
@@ -662,9 +664,9 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         const int row = rg + i * RG;
         if (row < PT) {
           const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-          *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+          if (!papply) *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
           if (GLDS_FUSED_ABLATE & 2) continue;
-          float dy[8], xv[8];
+          float dy[8], xv[8], dzv[8];
           unpack8(dv, dy);
           unpack8(xr[i], xv);
 #pragma unroll
@@ -673,9 +675,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
             const bool neg = z <= 0.f;
             s3[q] += neg ? dy[q] * z : 0.f;
             const float dz = neg ? dy[q] * al[q] : dy[q];
+            dzv[q] = dz;
             s1[q] += dz;
             s2[q] += dz * xv[q];
           }
+          if (papply) *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = pack8(dzv);   // ... and the OUTPUT is the masked gradient
         }
       }
     } else if (p.bmom) {                                   // forward: raw moments (sum y, sum y x, sum y y)
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       } else {
         float* o = p.bpart + (size_t)bt * 3 * p.N + n0 + tid;
         o[0] = t0;
-        o[p.N] = p.bmom ? t1 : fr * (t1 - fm * t0);
+        o[p.N] = p.bmom == 2 ? t2 : (p.bmom ? t1 : fr * (t1 - fm * t0));     // (bmom == 2: rows (sum dz, sum dy z over z <= 0), what a PReLU's parameter sums need)
         o[2 * (size_t)p.N] = t2;
       }
     }
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       const float t0 = sStat[tid], t1 = sStat[BN + tid], t2 = sStat[2 * BN + tid];
       float* o = p.bpart + (size_t)btw * 3 * p.N + n0 + tid;
       o[0] = t0;
-      o[p.N] = p.bmom ? t1 : p.brstd[n0 + tid] * (t1 - p.bmean[n0 + tid] * t0);
+      o[p.N] = p.bmom == 2 ? t2 : (p.bmom ? t1 : p.brstd[n0 + tid] * (t1 - p.bmean[n0 + tid] * t0));
       o[2 * (size_t)p.N] = t2;
     }
   }
@@ -789,6 +793,7 @@ static int launch_glds(GemmNT p, hipStream_t st) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
     FEDFR_REQUIRE(TPW == 1 || !p.stats, "conv3x3_glds: the several-tiles fused variant keeps its running row where the forward statistics would live");
+    FEDFR_REQUIRE(p.bmom != 2 || p.balpha, "conv3x3_glds: the PReLU-apply epilogue needs the slopes");
     if (p.bwd_fused) *p.bwd_fused = p.M / PT / TPW;
   }
   p.nbn = p.N / BN_;

@@ -161,7 +161,7 @@ int ew_prelu_bwd_pass(const bf16_t* dy, const bf16_t* add, const bf16_t* x, cons
 int ew_prelu_bwd_finalize(const float* rows, int P, int C, float* dbias, float* dalpha, hipStream_t st);
 // ... of up to kMaxPreluFin PReLUs in ONE launch (sphnet: 62 per step, 8.7 us each on the weight-gradient stream that bounds its backward pass)
 constexpr int kMaxPreluFin = 64;
-struct PreluFinEntry { unsigned long long rows_off; long long dbias_off, dalpha_off; int P, C, blk0; };   // byte offset into `base`; float offsets into `grads` (dbias < 0: none)
+struct PreluFinEntry { unsigned long long rows_off; long long dbias_off, dalpha_off; int P, C, blk0, nv_row; };   // byte offset into `base`; float offsets into `grads` (dbias < 0: none); nv_row: statistics per row (2: the pass's rows, 3: a fused dgrad epilogue's, of which the first two are read)
 struct PreluFinTable { int n, blocks; PreluFinEntry e[kMaxPreluFin]; };
 int ew_prelu_bwd_finalize_multi(const unsigned char* base, float* grads, const PreluFinTable& t, hipStream_t st);
 int ew_pad_input_nhwc(const float* src, bf16_t* dst, int B, int C, int HW, int Cpad, hipStream_t st);

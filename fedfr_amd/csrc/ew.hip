@@ -1623,12 +1623,13 @@ __global__ __launch_bounds__(256) void prelu_rows_finalize_kernel(const float* _
   }
 }
 __global__ __launch_bounds__(256) void prelu_rows_finalize_multi_kernel(const unsigned char* __restrict__ base, float* __restrict__ grads, PreluFinTable t) {
-  __shared__ double tot[2][8];
+  __shared__ double tot[3][8];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.e[i + 1].blk0) ++i;        // (workgroup-uniform: a scan of at most 63 scalars)
   const PreluFinEntry e = t.e[i];
   const int c0 = ((int)blockIdx.x - e.blk0) * 8;
-  fin8_accumulate<2>(reinterpret_cast<const float*>(base + e.rows_off), e.P, e.C, c0, 2, tot);
+  if (e.nv_row == 3) fin8_accumulate<3>(reinterpret_cast<const float*>(base + e.rows_off), e.P, e.C, c0, 2, tot);
+  else fin8_accumulate<2>(reinterpret_cast<const float*>(base + e.rows_off), e.P, e.C, c0, 2, tot);
   if (threadIdx.x < 8) {
     const int c = c0 + threadIdx.x;
     if (e.dbias_off >= 0) grads[e.dbias_off + c] = (float)tot[0][threadIdx.x];

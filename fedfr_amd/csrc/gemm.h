@@ -36,7 +36,8 @@ struct GemmNT {
   // bmom != 0 (forward launches, round 3): the same epilogue leaves RAW moments of the output y against a same-shape tensor bx instead —
   // rows [3][N] of (sum y, sum y * bx, sum y * y) — from which the pass that follows derives the statistics of y AND of
   // bn(y) + bx (the next block's bn1) without a pass over that sum (net.hip, conv2 of a residual block).  bmean / brstd: any readable [N].
-  int bmom;
+  int bmom;               // 2 (dgrad launches, sphnet): a bare PReLU(+bias) precedes the conv — the OUTPUT becomes dz = dy * prelu'(bx + bias) (bias in
+                          // bbeta or null, slopes in balpha), rows [3][N] = (sum dz, sum dy z over z <= 0, same): the PReLU's backward pass disappears
   // optional INPUT transform of the LDS-DMA conv kernel (forward of a conv whose input is BatchNorm(+PReLU) of a stored tensor): the
   // kernel reads the raw tensor, applies y = x * tsc[c] + tsh[c] (then PReLU with talpha[c] if given) to its LDS image, so the
   // normalised activation needs no separate bn_apply pass; aout (optional) receives that activation (the wgrad operand).

@@ -50,7 +50,8 @@ const char* fedfr_last_error_string(void);
  * residual block, bn3 + identity + the NEXT block's bn1 are one pass; conv2's epilogue leaves the raw moments of its output against the
  * block input and the statistics of the sum are derived from them), "stem_bnred" (1 [default]: the reduction of the stem's BatchNorm
  * backward rides in the first block's bn1 apply pass), "sph_fin_multi" / "sph_pair_wgrad" (1 [default]: sphnet's backward pass finalizes all
- * PReLU parameter sums in one launch / runs a residual block's two weight gradients as one paired launch).  Unknown names are an error. */
+ * PReLU parameter sums in one launch / runs a residual block's two weight gradients as one paired launch), "sph_fuse_prelu_bwd" (1 [default]:
+ * the backward of the PReLU in front of a sphnet block's conv2 rides in that conv's dgrad epilogue, 14x14 / 28x28 maps).  Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);
 /* the switch's current value (a caller that changes one temporarily restores what it found) */
 int fedfr_get_option(const char* name, int* value);

@@ -75,7 +75,7 @@ def test_documented_options_exist_and_unknown_ones_are_errors(built_lib):
     defaults = {"tn_use_tr": 1, "conv_halo": 4, "nt_glds": 4, "wgrad9": 1, "wgrad9p": 1, "tn_glds": 2, "tn_pair": 0, "wgrad_pair_reduce": 1,
                 "bn_sliced": 1, "fuse_bnbwd": 2, "fuse_bnapply": 0, "eval_fuse": 1, "conv28_tpw2": 2, "dgrad_parity": 2, "wgrad_depth": 4,
                 "bn_fuse_bwd": 0, "ew_reduce_blocks": 512, "ew_bwd_apply_blocks": 2048, "ew_reduce_nt": 0, "event_nofence": 1, "fork_mode": 0,
-                "sph_fuse_act": 0, "c64p_bnbwd": 1, "fuse_bnbwd28": 1, "late_join": 1, "fc_wgrad_aux": 1, "fwd_xmom": 1, "stem_bnred": 1, "sph_fin_multi": 1, "sph_pair_wgrad": 1}
+                "sph_fuse_act": 0, "c64p_bnbwd": 1, "fuse_bnbwd28": 1, "late_join": 1, "fc_wgrad_aux": 1, "fwd_xmom": 1, "stem_bnred": 1, "sph_fin_multi": 1, "sph_pair_wgrad": 1, "sph_fuse_prelu_bwd": 1}
     for n in names:
         assert n in defaults, "document the default of option %r here" % n
         assert lib.fedfr_set_option(n.encode(), defaults[n]) == 0, n

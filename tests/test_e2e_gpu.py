@@ -622,6 +622,33 @@ def test_sphnet_vs_reference():
         assert torch.equal(net(x), feats.detach())
 
 
+def test_sphnet_backward_fusions_at_full_tile_batch():
+    """Round 3: at batches whose 14x14 / 28x28 layers run on the LDS-DMA kernels with a fused epilogue, sphnet's backward pass (a) lets the
+    dgrad of a block's conv2 apply the backward of the PReLU in front of it (option sph_fuse_prelu_bwd: output = dz, rows = the PReLU's
+    parameter sums), (b) runs the block's two weight gradients as one paired launch, (c) finalizes all PReLU sums in one launch.  Against
+    the plain sequence on the same model and inputs: identical embeddings, conv weight gradients from identical operands (paired kernel:
+    another K split order -> fp32 noise), PReLU slope / bias gradients equal up to the summation order of their partial rows."""
+    B = 64
+    sd = R.sphere_state_dict(20, tag=1.0)
+    x = R.closed_form_images(B, tag=4.0).to(DEV)
+    dfe = R.closed_form((B, 512), 0.37, 0.9, 1.0).to(DEV)
+    res = []
+    for on in (0, 1):
+        with _C.option_scope("sph_fuse_prelu_bwd", on), _C.option_scope("sph_pair_wgrad", on), _C.option_scope("sph_fin_multi", on):
+            net = backbones.sphnet(False, dropout=0, fp16=True, type=20).to(DEV)
+            net.load_state_dict(sd)
+            net.train()
+            f = net(x)
+            (f * dfe).sum().backward()
+            res.append((f.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (f0, g0), (f1, g1) = res
+    assert torch.equal(f0, f1)
+    for k in g0:
+        a, b = g0[k].double().flatten(), g1[k].double().flatten()
+        e = float((a - b).norm() / (a.norm() + 1e-30))
+        assert e < 2e-5, (k, e)
+
+
 def test_roc_vs_reference():
     """roc_cuda.py end to end: histogram and TPR@FPR read-out equal the values produced by the reference's own kernel body."""
     from fedfr_amd import eval_roc

@@ -218,8 +218,13 @@ _HEAD_SPLITK = __import__("os").environ.get("FEDFR_HEAD_SPLITK", "1") != "0"
 
 
 def _split_for(k: int) -> int:
-    """split-K degree of a head GEMM: k ranges of 128 (four k-steps of 32 per workgroup), at most 8"""
-    return max(1, min(8, k // 128))
+    """split-K degree of a head GEMM: k ranges of about 128 (four k-steps of 32 per workgroup), at most 8.
+
+    The kernel side (``head_sgemm_splitk``, csrc/head.hip) cuts k into chunks of ceil32(ceil(k / splits)) and refuses a split count whose
+    last chunk would be empty (k = 800 with 6 splits: 5 chunks of 160 already cover it), so the count is derived from the chunk."""
+    s = max(1, min(8, k // 128))
+    chunk = -(-(-(-k // s)) // 32) * 32
+    return -(-k // chunk)
 
 
 class FusedTrainer:
@@ -331,9 +336,15 @@ class FusedTrainer:
         # round 3: those ~25 us of launches go to the weight-gradient stream BEHIND the backward pass's own work there (that stream is
         # ordered after the head kernels above by the pass's first fork) and the main stream joins it again before anything else runs
         self._backward(plan, imgs, dfeats, st)
-        with torch.cuda.stream(self.aux_stream):
-            loss = off_path()
-        torch.cuda.current_stream().wait_stream(self.aux_stream)
+        main = torch.cuda.current_stream()
+        try:
+            with torch.cuda.stream(self.aux_stream):
+                loss = off_path()
+        finally:
+            # the join is unconditional: prob_t / g / fn / wn live in the main stream's pool, and a raise inside off_path must not leave the
+            # main stream free to reuse them while the aux stream still reads
+            main.wait_stream(self.aux_stream)
+        loss.record_stream(main)
         return loss
 
     def _backward(self, plan, imgs, dfeats, st):

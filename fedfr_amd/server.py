@@ -133,7 +133,10 @@ def fedavg_all_reduce(backbone, data_size: float, total_size: float, comm=None, 
         comm = TorchDistComm()
     state, nbt_f, nbt = backbone.exchange_buffer()
     w = float(data_size) / float(total_size)
-    n_float = (nbt_f.data_ptr() - state.data_ptr()) // 4          # params + running stats: everything in front of the counter image
+    # params + running stats = everything in front of the counter image.  Storage offsets, not pointer differences: a backbone without
+    # BatchNorm counters (sphnet) has an EMPTY image, and data_ptr() of an empty tensor is 0 on torch >= 2.x
+    n_float = nbt_f.storage_offset() - state.storage_offset()
+    assert 0 <= n_float <= state.numel(), "exchange_buffer: the counter image is not a slice of the state tensor"
     fl = state[:n_float]
     _axpy(fl, fl, w, False)
     if nbt.numel():

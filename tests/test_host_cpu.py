@@ -48,15 +48,20 @@ def test_no_cpu_fallback():
         backbones.iresnet50(pretrained=True)
 
 
-def _fedavg_worker(rank, port, tmp):
+def _fedavg_state(arch, tag):
+    if arch == "sphnet":
+        return R.sphere_state_dict(20, tag=tag)
+    return R.closed_form_state_dict(R.IRESNET_LAYERS[arch], tag=tag)
+
+
+def _fedavg_worker(rank, port, tmp, arch="iresnet18"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
-        layers = R.IRESNET_LAYERS["iresnet18"]
-        m = backbones.iresnet18()
-        m.load_state_dict(R.closed_form_state_dict(layers, tag=float(rank + 1)))
+        m = backbones.sphnet(type=20) if arch == "sphnet" else backbones.iresnet18()
+        m.load_state_dict(_fedavg_state(arch, float(rank + 1)))
         sizes = [300.0, 100.0]
 
         def cpu_scale(dst, src, w, accumulate):      # test double for the HIP axpy: the collective plumbing is under test
@@ -80,12 +85,14 @@ def _fedavg_worker(rank, port, tmp):
         dist.destroy_process_group()
 
 
-def test_fedavg_all_reduce_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("arch,port", [("iresnet18", 29655), ("sphnet", 29656)])
+def test_fedavg_all_reduce_two_ranks_gloo(tmp_path, arch, port):
+    """sphnet has no BatchNorm counters: the float image of the counters is an EMPTY slice of the state (data_ptr() of
+    an empty tensor is 0, so the split point must not come from pointer differences)."""
     import torch.multiprocessing as mp
-    mp.spawn(_fedavg_worker, args=(29655, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_fedavg_worker, args=(port, str(tmp_path), arch), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    layers = R.IRESNET_LAYERS["iresnet18"]
-    ref = R.fedpavg([R.closed_form_state_dict(layers, tag=1.0), R.closed_form_state_dict(layers, tag=2.0)], [300, 100])
+    ref = R.fedpavg([_fedavg_state(arch, 1.0), _fedavg_state(arch, 2.0)], [300, 100])
     for k in a:
         assert torch.equal(a[k], b[k]), k                   # every client ends the round with the same model
         if a[k].is_floating_point():

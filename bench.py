@@ -197,16 +197,43 @@ def self_launch(argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, cwd=ROOT)
-    json_line = None
-    for line in proc.stdout:
-        t = line.strip()
-        if t.startswith("{") and t.endswith("}") and '"metric"' in t:
-            json_line = t
-        else:
-            sys.stderr.write(line)
-    rc = proc.wait()
-    if json_line is not None:
+    # the child runs in a session of its own, so that a deadline can end exactly the processes started here (its process group), never
+    # anything matched by name.  FEDFR_BENCH_DEADLINE_S (default 1500 s): no JSON line from rank 0 by then = a hung rank / collective
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, cwd=ROOT, start_new_session=True)
+    deadline = float(os.environ.get("FEDFR_BENCH_DEADLINE_S", "1500"))
+    import signal
+    import threading
+    found = {"json": None}
+
+    def pump():
+        for line in proc.stdout:
+            t = line.strip()
+            if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+                found["json"] = t
+            else:
+                sys.stderr.write(line)
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    timed_out = False
+    try:
+        rc = proc.wait(timeout=deadline)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        print("bench.py: no result from the %d ranks within %.0f s: ending their process group" % (n, deadline), file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)              # pgid == the child's pid (start_new_session)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    th.join(10)
+    json_line = found["json"]
+    if json_line is not None and not timed_out:
         print(json_line, flush=True)
     elif rc == 0:
         print("bench.py: the ranks exited 0 but rank 0 printed no JSON line", file=sys.stderr, flush=True)
@@ -214,7 +241,58 @@ def self_launch(argv):
     return rc
 
 
+def select_library(argv):
+    """--lib fp16: run the same step on the IEEE-fp16 storage build (libfedfr_hip_fp16.so, `make fp16`; the reference's own AMP type,
+    backbones/iresnet.py:159).  Must act before fedfr_amd loads the library; the ranks of a self-launched run get the same argv."""
+    lib = "bf16"
+    for i, a in enumerate(argv):
+        if a == "--lib" and i + 1 < len(argv):
+            lib = argv[i + 1]
+        elif a.startswith("--lib="):
+            lib = a.split("=", 1)[1]
+    if lib == "fp16":
+        os.environ["FEDFR_HIP_LIB_NAME"] = "libfedfr_hip_fp16.so"
+    elif lib != "bf16":
+        raise SystemExit("bench.py: --lib must be bf16 or fp16")
+
+
+def parity_leg(dev):
+    """CHECKER leg (about a second; not part of any timed region): the loaded library's whole-network error against the reference's own
+    outputs on the committed fixture tests/golden/r100_b6.npz (iresnet100, 6 closed-form images; captured by tools/make_golden.py from the
+    imported reference) — relative L2 error of the eval-mode and train-mode embeddings and of the train-mode cosine logits.  The fixture's
+    closed-form weights / images come from the oracle's generators (oracle/ref_cpu.py: the checker's half, nothing here is timed)."""
+    import numpy as np
+    from oracle import ref_cpu as R
+    from fedfr_amd import backbones, client
+    g = np.load(os.path.join(ROOT, "tests", "golden", "r100_b6.npz"))
+    batch, ncls = int(g["batch"]), int(g["num_classes"])
+    m = backbones.iresnet100(False, dropout=0, fp16=True)
+    m.load_state_dict(R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet100"]))
+    m = m.to(dev)
+    x = R.closed_form_images(batch).to(dev)
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), torch.from_numpy(np.asarray(b)).double()
+        return float((a - b).norm() / (b.norm() + 1e-30))
+    m.eval()
+    with torch.no_grad():
+        fe = m(x)
+    m.train()
+    fcm = client.FC_module(512, ncls, "/tmp").to(dev)
+    fcm.fc.data = R.head_fc(ncls).to(dev)
+    with torch.no_grad():
+        ft = m(x)
+        cos = fcm(ft)
+    out = {"fixture": "tests/golden/r100_b6.npz (iresnet100, batch %d, reference-generated)" % batch, "metric": "relative L2 error vs the fp32 reference",
+           "embeddings_eval": round(rel(fe, g["feat_eval"]), 5), "embeddings_train": round(rel(ft, g["feat_train"]), 5),
+           "cosine_logits_train": round(rel(cos, g["cosine"]), 5), "north_star_tolerance_16bit": 1e-2}
+    del m, fcm
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
+    select_library(sys.argv[1:])
     rc = self_launch(sys.argv[1:])
     if rc is not None:
         raise SystemExit(rc)
@@ -235,6 +313,8 @@ def main():
                     help="dense: CosFace + dense cosine head (headline); pfc: ArcFace + PartialFC sample_rate 0.1 (BASELINE config 3; use --classes 85000); "
                          "pfc-sharded: BASELINE config 5 = per-client backbone + ONE CosFace PartialFC class-sharded over all ranks (sample_rate 0.1) + "
                          "a private BCE head per client (use --classes 85000 under torch.distributed.run)")
+    ap.add_argument("--lib", default="bf16", choices=["bf16", "fp16"],
+                    help="storage type of activations / gradients / MFMA operands: bf16 = libfedfr_hip.so (product), fp16 = libfedfr_hip_fp16.so (`make fp16`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -484,8 +564,8 @@ def main():
             with torch.cuda.stream(st2):
                 tr2 = client.FusedTrainer(model2, fc2, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4, aux_slot=1)
             pairs = [(tr, torch.cuda.current_stream()), (tr2, st2)]
-            w9p_prev = _C.get_option("wgrad9p")
-            _C.call("fedfr_set_option", b"wgrad9p", 1)          # what Server.train selects when clients share the GPU (csrc/wgrad9p.hip)
+            w9p_prev = _C.get_option("bn_fuse_bwd")
+            _C.call("fedfr_set_option", b"bn_fuse_bwd", 0)      # what Server.train selects when clients share the GPU: no in-launch hand-offs
             csteps = max(5, min(args.steps, 20))
             bar = threading.Barrier(3)
 
@@ -522,7 +602,7 @@ def main():
             concurrent = {"clients_on_this_gpu": 2, "value": round(2 * B * csteps / dtc, 1), "unit": "images/sec",
                           "ms_per_step_per_client": round(dtc * 1e3 / csteps, 3), "steps": csteps,
                           "note": "two independent clients (own backbone, optimiser, HIP stream pair), each running the same bs=%d train step; "
-                                  "aggregate over both (paired weight-gradient kernel on, as Server.train selects for concurrent clients).  "
+                                  "aggregate over both (the lone client's kernel selection).  "
                                   "`value` above is ONE client alone" % B}
             del tr2, model2
         except Exception as e:      # an auxiliary leg must never cost the headline number
@@ -530,7 +610,7 @@ def main():
             print("bench.py: the concurrent leg failed: %r" % (e,), file=sys.stderr, flush=True)
         finally:
             if "w9p_prev" in locals():
-                _C.call("fedfr_set_option", b"wgrad9p", w9p_prev)
+                _C.call("fedfr_set_option", b"bn_fuse_bwd", w9p_prev)
 
     # ---- the second half of BASELINE's metric at N = 1: server-side FedAvg of 1 / 2 / 4 / 8 client states (server.py:25-34) on this GPU
     fedavg = None
@@ -565,6 +645,16 @@ def main():
             leg_errors['fedavg'] = "%s: %s" % (type(e).__name__, e)
             print("bench.py: the fedavg leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
+    parity = None
+    if rank == 0 and not args.no_profile and not collective_step:
+        try:
+            tr.finish()
+            torch.cuda.synchronize()
+            parity = parity_leg(dev)
+        except Exception as e:      # an auxiliary leg must never cost the headline number
+            leg_errors['parity'] = "%s: %s" % (type(e).__name__, e)
+            print("bench.py: the parity leg failed: %r" % (e,), file=sys.stderr, flush=True)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
         try:
@@ -585,17 +675,22 @@ def main():
             "dtype": "fp16" if _C.storage_dtype() == torch.float16 else "bf16", "data": "synthetic" if backend == "nccl" and not share else "synthetic (REHEARSAL: ranks share one GPU / gloo — not a measurement)",
             "config": {"workload": "%s + %s, full train step "
                                    "(fwd+bwd+momentum-SGD), batch %d/GPU, 112x112 synthetic faces, random-init weights, "
-                                   "bf16 activations/weights with fp32 accumulate + fp32 master weights, fp32 head"
+                                   "%s activations/weights with fp32 accumulate + fp32 master weights, fp32 head"
                                    % (args.arch, ("CosFace(s=30,m=0.4) + dense %d-class cosine head" % NC) if args.head == "dense"
                                       else ("ArcFace(s=30,m=0.4) + PartialFC sample_rate 0.1 over %d classes" % NC) if args.head == "pfc"
                                       else ("CosFace(s=30,m=0.4) PartialFC sample_rate 0.1 over %d classes class-sharded over %d rank(s) + private "
-                                            "BCE head over %d identities per client (BASELINE config 5)" % (NC, world, NC // world)), B),
+                                            "BCE head over %d identities per client (BASELINE config 5)" % (NC, world, NC // world)), B,
+                                      "fp16" if _C.storage_dtype() == torch.float16 else "bf16"),
                        "global_batch": world * B, "parallelism": "1 client per GPU (FedAvg), dp%d" % world,
                        "clients": world},
             "images_per_sec_per_gpu": round(value / world, 1),
             "step_mfma_frac": round(step_tflop / (ms_step * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4),
             "step_algorithmic_tflop": round(step_tflop, 3),
             "final_loss": round(final_loss, 4),
+            "storage": "fp16" if _C.storage_dtype() == torch.float16 else "bf16",
+            "library": os.path.basename(_C.LIB_PATH),
+            "options_non_default": _C.options_non_default(),
+            "parity": parity,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": end_to_end,

@@ -27,6 +27,8 @@ SIGNATURES = {
     "fedfr_last_error_string": (C.c_char_p, []),
     "fedfr_set_option": (i32, [C.c_char_p, i32]),
     "fedfr_get_option": (i32, [C.c_char_p, C.POINTER(i32)]),
+    "fedfr_option_count": (i32, []),
+    "fedfr_option_info": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(i32)]),
     "fedfr_profile_enable": (i32, [i32]),
     "fedfr_profile_read": (i32, [i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
     "fedfr_net_create": (vp, [C.POINTER(i32), i32, i32, i32]),
@@ -173,6 +175,21 @@ def get_option(name: str) -> int:
     v = C.c_int(0)
     call("fedfr_get_option", name.encode(), C.byref(v))
     return v.value
+
+
+def options() -> dict:
+    """{name: (current value, library default)} of every switch the loaded library has."""
+    out = {}
+    for i in range(lib().fedfr_option_count()):
+        n, v, d = C.c_char_p(), C.c_int(0), C.c_int(0)
+        call("fedfr_option_info", i, C.byref(n), C.byref(v), C.byref(d))
+        out[n.value.decode()] = (v.value, d.value)
+    return out
+
+
+def options_non_default() -> dict:
+    """{name: value} of the switches that are not at the value the library starts with (FEDFR_OPTIONS, option_scope, set_option)."""
+    return {k: v for k, (v, d) in options().items() if v != d}
 
 
 class option_scope:

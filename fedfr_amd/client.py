@@ -1032,6 +1032,28 @@ class FlatStateDict(OrderedDict):
         self._ensure()
         return OrderedDict.pop(self, *a, **kw)
 
+    def popitem(self, last=True):
+        self._ensure()
+        return OrderedDict.popitem(self, last)
+
+    def setdefault(self, k, default=None):
+        self._ensure()
+        return OrderedDict.setdefault(self, k, default)
+
+    def move_to_end(self, k, last=True):
+        self._ensure()
+        OrderedDict.move_to_end(self, k, last)
+
+    def update(self, *a, **kw):
+        self._ensure()
+        OrderedDict.update(self, *a, **kw)
+
+    def clear(self):
+        # an emptied dictionary must stay empty: no lazy rebuild afterwards, and no flat tensors for load_state_dict's fast path to pick up
+        self._built = True
+        self.flat = None
+        OrderedDict.clear(self)
+
     def copy(self):
         self._ensure()
         return OrderedDict(self.items())

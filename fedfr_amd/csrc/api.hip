@@ -40,7 +40,9 @@ extern int g_sph_fuse_act;
 extern int g_sph_fin_multi;
 extern int g_sph_fuse_prelu_bwd;
 extern int g_sph_pair_wgrad;
+#ifdef FEDFR_DEBUG
 extern int g_dbg_skip;
+#endif
 extern int g_c64p_bnbwd;
 extern int g_late_join;
 extern int g_stem_bnred;
@@ -71,195 +73,112 @@ extern "C" {
 int fedfr_version(void) { return 100; }
 int fedfr_storage_dtype(void) { return FEDFR_FP16 ? 1 : 0; }
 const char* fedfr_last_error_string(void) { return g_err; }
+// ---- process-global switches (tuning / validation).  ONE table: name, variable, clamp (the default is the variable's initialiser, read before the first change), so that fedfr_set_option, fedfr_get_option and
+// fedfr_option_info (what bench.py lists as `options_non_default`) cannot disagree.  kind: 0 = boolean (any non-zero value -> 1),
+// 1 = integer clamped to [lo, hi], 2 = integer taken as given.  Switches that produce WRONG results (timing experiments) exist only in a
+// -DFEDFR_DEBUG build of the library.
+namespace {
+struct OptRow { const char* name; int* var; int kind; int lo, hi; };
+const OptRow kOptions[] = {
+    {"tn_use_tr", &g_tn_use_tr, 0, 0, 1},                  // 0: scalar-LDS fallback fragments of the register-staged TN kernel (validation)
+    {"tn_target_blocks", &g_tn_target_blocks, 1, 1, 1 << 20},
+    {"halo_waves", &g_halo_waves, 1, 4, 8},
+    {"halo_bn64", &g_halo_bn64, 0, 0, 1},
+    {"conv_halo", &g_conv_halo, 2, 0, 0},
+    {"fuse_bnred_next", &g_fuse_bnred_next, 0, 0, 1},
+    {"fuse_bnapply", &g_fuse_bnapply, 0, 0, 1},
+    {"dgrad_parity", &g_dgrad_parity, 1, 0, 2},
+    {"wgrad_pair_reduce", &g_wgrad_pair_reduce, 0, 0, 1},
+    {"nt_glds", &g_nt_glds, 1, 0, 15},                    // 0 register-staged NT kernel, 1..4 LDS-DMA operand ring where it pays, + 8 everywhere it can (gemm_nt_glds.hip)
+    {"tn_glds", &g_tn_glds, 2, 0, 0},                      // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
+    {"wgrad_depth", &g_wgrad_depth, 1, 2, kWgradDepth},
+    {"eval_fuse", &g_eval_fuse, 0, 0, 1},                  // eval-mode forward: BatchNorm (+PReLU, +identity, +next bn1) in the conv epilogues
+    {"wgrad9", &g_wgrad9, 0, 0, 1},                        // nine-tap weight-gradient kernel for 3x3 / stride-1 layers
+    {"tn_pair", &g_tn_pair, 0, 0, 1},
+    {"fuse_bnbwd", &g_fuse_bnbwd, 1, 0, 2},
+    {"conv_c64p", &g_conv_c64p, 0, 0, 1},                  // persistent register-resident-weights kernel for the 64 -> 64 channel 3x3 layers (112x112 / 56x56)
+    {"bn_sliced", &g_bn_sliced, 0, 0, 1},                  // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
+    {"wgrad9_wgs", &g_wgrad9_wgs, 1, 64, 1024},           // workgroups a wgrad9 launch aims for (more = shorter workgroups, more split-K slabs)
+    {"conv28_tpw2", &g_conv28_tpw2, 1, 0, 2},              // 28x28 convs with two image tiles per workgroup (1: forward, 2: dgrad too)
+    {"wgrad9p", &g_wgrad9p, 0, 0, 1},                      // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
+    {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes, 1, 7, 64},
+    {"bn_sliced_pre", &g_bn_sliced_pre, 2, 0, 0},          // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)
+    // row-slab BatchNorm-backward passes (the large maps): grid sizes may only shrink below the defaults the plans' partial-row buffers were sized with
+    {"ew_reduce_blocks", &g_ew_reduce_blocks, 1, 128, 2048},
+    {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks, 1, 128, 2048},
+    {"ew_reduce_nt", &g_ew_reduce_nt, 1, 0, 2},
+    {"bn_fuse_bwd", &g_bn_fuse_bwd, 0, 0, 1},              // reduce + apply pass of a BatchNorm backward in one launch with an in-launch hand-off (bn_sliced.hip)
+    {"event_nofence", &g_event_nofence, 0, 0, 1},          // takes effect for events created afterwards (a plan creates its fork / join events on first use)
+    {"sph_fuse_act", &g_sph_fuse_act, 0, 0, 1},
+    {"fuse_bnbwd28", &g_fuse_bnbwd28, 0, 0, 1},
+    {"fc_wgrad_aux", &g_fc_wgrad_aux, 0, 0, 1},
+    {"fwd_xmom", &g_fwd_xmom, 0, 0, 1},
+    {"stem_bnred", &g_stem_bnred, 0, 0, 1},
+    {"sph_fuse_prelu_bwd", &g_sph_fuse_prelu_bwd, 0, 0, 1},
+    {"sph_fin_multi", &g_sph_fin_multi, 0, 0, 1},
+    {"sph_pair_wgrad", &g_sph_pair_wgrad, 0, 0, 1},
+    {"late_join", &g_late_join, 0, 0, 1},
+    {"c64p_bnbwd", &g_c64p_bnbwd, 0, 0, 1},
+    {"fork_mode", &g_fork_mode, 0, 0, 1},
+    {"nt_nbuf", &g_nt_nbuf, 1, 1, 2},
+#ifdef FEDFR_DEBUG
+    {"dbg_skip", &g_dbg_skip, 2, 0, 0},                    // WRONG results: 1 = no weight-gradient launches of the residual blocks' 3x3 convs (timing bound)
+#endif
+};
+constexpr int kNumOptions = (int)(sizeof(kOptions) / sizeof(kOptions[0]));
+int g_opt_defaults[kNumOptions];
+bool g_opt_defaults_set = false;
+void opt_capture_defaults() {
+  if (g_opt_defaults_set) return;
+  for (int i = 0; i < kNumOptions; ++i) g_opt_defaults[i] = *kOptions[i].var;
+  g_opt_defaults_set = true;
+}
+const OptRow* opt_find(const char* name, int* idx = nullptr) {
+  if (!name) return nullptr;
+  for (int i = 0; i < kNumOptions; ++i)
+    if (!strcmp(name, kOptions[i].name)) {
+      if (idx) *idx = i;
+      return &kOptions[i];
+    }
+  return nullptr;
+}
+}  // namespace
+
 int fedfr_set_option(const char* name, int value) {
-  if (name && !strcmp(name, "tn_use_tr")) {
-    g_tn_use_tr = value ? 1 : 0;
-    return FEDFR_OK;
+  opt_capture_defaults();
+  const OptRow* o = opt_find(name);
+  if (!o) {
+    fedfr_set_error("set_option: unknown option '%s'", name ? name : "(null)");
+    return FEDFR_ERR_ARG;
   }
-  if (name && !strcmp(name, "tn_target_blocks")) {
-    g_tn_target_blocks = value > 0 ? value : 768;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "halo_waves")) {
-    g_halo_waves = value == 8 ? 8 : 4;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "halo_bn64")) {
-    g_halo_bn64 = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "conv_halo")) {
-    g_conv_halo = value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "fuse_bnred_next")) {
-    g_fuse_bnred_next = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "fuse_bnapply")) {
-    g_fuse_bnapply = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "dgrad_parity")) {
-    g_dgrad_parity = value < 0 ? 0 : value > 2 ? 2 : value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "wgrad_pair_reduce")) {
-    g_wgrad_pair_reduce = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "nt_glds")) {
-    g_nt_glds = value < 0 ? 0 : value & 15;   // 0 register-staged NT kernel, 1..4 LDS-DMA operand ring where it pays, + 8 everywhere it can (gemm_nt_glds.hip)
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "tn_glds")) {
-    g_tn_glds = value;          // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "wgrad_depth")) {
-    g_wgrad_depth = value < 2 ? 2 : value > kWgradDepth ? kWgradDepth : value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "eval_fuse")) {
-    g_eval_fuse = value ? 1 : 0;   // eval-mode forward: BatchNorm (+PReLU, +identity, +next bn1) in the conv epilogues
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "wgrad9")) {
-    g_wgrad9 = value ? 1 : 0;   // nine-tap weight-gradient kernel for 3x3 / stride-1 layers on 14x14 and 28x28 maps
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "tn_pair")) {
-    g_tn_pair = value ? 1 : 0;  // same-shape weight-gradient GEMMs of a block in one launch, two blocks per CU
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "fuse_bnbwd")) {
-    g_fuse_bnbwd = value < 0 ? 0 : value > 2 ? 2 : value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "conv_c64p")) {
-    g_conv_c64p = value ? 1 : 0;   // persistent register-resident-weights kernel for the 64 -> 64 channel 3x3 layers (112x112 / 56x56)
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "bn_sliced")) {
-    g_bn_sliced = value ? 1 : 0;   // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "wgrad9_wgs")) {
-    g_wgrad9_wgs = value < 64 ? 64 : value > 1024 ? 1024 : value;    // workgroups a wgrad9 launch aims for (more = shorter workgroups, more split-K slabs)
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "conv28_tpw2")) {
-    g_conv28_tpw2 = value < 0 ? 0 : value > 2 ? 2 : value;   // forward 28x28 convs with BatchNorm statistics: two image tiles per workgroup (256 partial rows instead of 1024)
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "wgrad9p")) {
-    g_wgrad9p = value ? 1 : 0;     // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "bn_sliced_bwd_passes")) {
-    g_bn_sliced_bwd_passes = value < 7 ? 7 : value > 64 ? 64 : value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "bn_sliced_pre")) {
-    g_bn_sliced_pre = value;       // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)
-    return FEDFR_OK;
-  }
-  // row-slab BatchNorm-backward passes (the large maps): grid sizes may only shrink below the defaults the plans' partial-row buffers were
-  // sized with (512 / 2048 workgroups)
-  if (name && !strcmp(name, "ew_reduce_blocks")) {
-    g_ew_reduce_blocks = value < 128 ? 128 : value > 2048 ? 2048 : value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "ew_bwd_apply_blocks")) {
-    g_ew_bwd_apply_blocks = value < 128 ? 128 : value > 2048 ? 2048 : value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "ew_reduce_nt")) {
-    g_ew_reduce_nt = value < 0 ? 0 : value > 2 ? 2 : value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "bn_fuse_bwd")) {
-    g_bn_fuse_bwd = value ? 1 : 0;   // reduce + apply pass of a BatchNorm backward in one launch with an in-launch hand-off (bn_sliced.hip)
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "event_nofence")) {
-    g_event_nofence = value ? 1 : 0;   // takes effect for events created afterwards (a plan creates its fork / join events on first use)
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "sph_fuse_act")) {
-    g_sph_fuse_act = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "fuse_bnbwd28")) {
-    g_fuse_bnbwd28 = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "fc_wgrad_aux")) {
-    g_fc_wgrad_aux = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "fwd_xmom")) {
-    g_fwd_xmom = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "stem_bnred")) {
-    g_stem_bnred = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "sph_fuse_prelu_bwd")) {
-    g_sph_fuse_prelu_bwd = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "sph_fin_multi")) {
-    g_sph_fin_multi = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "sph_pair_wgrad")) {
-    g_sph_pair_wgrad = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "late_join")) {
-    g_late_join = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "c64p_bnbwd")) {
-    g_c64p_bnbwd = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "dbg_skip")) {
-    g_dbg_skip = value;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "fork_mode")) {
-    g_fork_mode = value ? 1 : 0;
-    return FEDFR_OK;
-  }
-  if (name && !strcmp(name, "nt_nbuf")) {
-    g_nt_nbuf = value == 1 ? 1 : 2;
-    return FEDFR_OK;
-  }
-  fedfr_set_error("set_option: unknown option '%s'", name ? name : "(null)");
-  return FEDFR_ERR_ARG;
+  if (o->kind == 0) value = value ? 1 : 0;
+  else if (o->kind == 1) value = value < o->lo ? o->lo : value > o->hi ? o->hi : value;
+  *o->var = value;
+  return FEDFR_OK;
 }
 
 // current value of a switch (so that a caller that changes one for a while can put the previous value back)
 int fedfr_get_option(const char* name, int* value) {
-  static const struct { const char* n; int* p; } tab[] = {
-      {"tn_use_tr", &g_tn_use_tr}, {"tn_target_blocks", &g_tn_target_blocks}, {"halo_waves", &g_halo_waves}, {"halo_bn64", &g_halo_bn64},
-      {"conv_halo", &g_conv_halo}, {"fuse_bnred_next", &g_fuse_bnred_next}, {"fuse_bnapply", &g_fuse_bnapply}, {"dgrad_parity", &g_dgrad_parity},
-      {"wgrad_pair_reduce", &g_wgrad_pair_reduce}, {"nt_glds", &g_nt_glds}, {"tn_glds", &g_tn_glds}, {"wgrad_depth", &g_wgrad_depth},
-      {"eval_fuse", &g_eval_fuse}, {"wgrad9", &g_wgrad9}, {"tn_pair", &g_tn_pair}, {"fuse_bnbwd", &g_fuse_bnbwd}, {"conv_c64p", &g_conv_c64p},
-      {"bn_sliced", &g_bn_sliced}, {"wgrad9_wgs", &g_wgrad9_wgs}, {"conv28_tpw2", &g_conv28_tpw2}, {"wgrad9p", &g_wgrad9p},
-      {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes}, {"bn_sliced_pre", &g_bn_sliced_pre}, {"nt_nbuf", &g_nt_nbuf},
-      {"bn_fuse_bwd", &g_bn_fuse_bwd}, {"event_nofence", &g_event_nofence}, {"fork_mode", &g_fork_mode}, {"dbg_skip", &g_dbg_skip}, {"c64p_bnbwd", &g_c64p_bnbwd}, {"late_join", &g_late_join}, {"stem_bnred", &g_stem_bnred}, {"fwd_xmom", &g_fwd_xmom}, {"fc_wgrad_aux", &g_fc_wgrad_aux}, {"fuse_bnbwd28", &g_fuse_bnbwd28}, {"sph_fuse_act", &g_sph_fuse_act}, {"sph_fin_multi", &g_sph_fin_multi}, {"sph_fuse_prelu_bwd", &g_sph_fuse_prelu_bwd}, {"sph_pair_wgrad", &g_sph_pair_wgrad}, {"ew_reduce_blocks", &g_ew_reduce_blocks}, {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks}, {"ew_reduce_nt", &g_ew_reduce_nt}};
   FEDFR_REQUIRE(name && value, "get_option: null argument");
-  for (const auto& e : tab)
-    if (!strcmp(name, e.n)) {
-      *value = *e.p;
-      return FEDFR_OK;
-    }
-  fedfr_set_error("get_option: unknown option '%s'", name);
-  return FEDFR_ERR_ARG;
+  const OptRow* o = opt_find(name);
+  if (!o) {
+    fedfr_set_error("get_option: unknown option '%s'", name);
+    return FEDFR_ERR_ARG;
+  }
+  *value = *o->var;
+  return FEDFR_OK;
+}
+
+// enumeration of the switches: number of rows / row i = (name, current value, value the library starts with).  bench.py prints every row whose
+// value differs from its default next to the number it measures.
+int fedfr_option_count(void) { return kNumOptions; }
+int fedfr_option_info(int index, const char** name, int* value, int* default_value) {
+  FEDFR_REQUIRE(index >= 0 && index < kNumOptions && name && value && default_value, "option_info: bad index %d", index);
+  opt_capture_defaults();
+  *name = kOptions[index].name;
+  *value = *kOptions[index].var;
+  *default_value = g_opt_defaults[index];
+  return FEDFR_OK;
 }
 
 int fedfr_profile_enable(int on) {

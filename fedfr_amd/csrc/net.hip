@@ -381,10 +381,14 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
 }
 int g_wgrad_pair_reduce = 1;   // option "wgrad_pair_reduce": one slab-reduction launch for the two 3x3 weight gradients of a block
 // the two 3x3 weight gradients of a residual block; same shape (every block but a stage's first): one paired launch
-int g_dbg_skip = 0;   // option "dbg_skip" (timing experiments, WRONG results): 1 = no weight-gradient launches of the residual blocks' 3x3 convs
+#ifdef FEDFR_DEBUG
+int g_dbg_skip = 0;   // option "dbg_skip" (-DFEDFR_DEBUG builds only; timing experiments, WRONG results): 1 = no weight-gradient launches of the residual blocks' 3x3 convs
+#endif
 static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const bf16_t* dya, const ConvD& cvb, const bf16_t* inb,
                        const bf16_t* dyb, hipStream_t st) {
+#ifdef FEDFR_DEBUG
   if (g_dbg_skip & 1) return FEDFR_OK;
+#endif
   GemmTN a = wgrad_problem(c, cva, ina, dya), b = wgrad_problem(c, cvb, inb, dyb);
   if (gemm_tn_w9pair_ok(a, b)) {                        // both on the 64 x 64 nine-tap kernel, one launch
     const int sp = gemm_tn_w9pair_splits(a);

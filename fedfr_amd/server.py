@@ -243,15 +243,16 @@ class Server(object):
             # round with the same kernel selection (the paired weight-gradient kernel below: otherwise equal up to fp32 summation order).
             import threading
             from . import _C
-            # with the GPU saturated by several kernel chains, total kernel time is what counts: the paired 64 x 64 weight-gradient kernel
-            # (csrc/wgrad9p.hip; off for a lone client, whose two streams interleave better with the shorter single-layer kernel)
-            # The switch is process-global: the previous value (a user's FEDFR_OPTIONS setting) is put back when the round's clients are done,
-            # also on an error.  It changes the weight gradients' fp32 summation order relative to parallel_clients = 1.
+            # Kernel selection is the lone client's (the paired weight-gradient kernel has been the default since round 3), with ONE exception:
+            # kernels whose workgroups wait for each other inside a launch (in-launch hand-offs: option bn_fuse_bwd) rely on their whole grid
+            # being co-resident, which two clients' grids competing for the same CUs cannot promise — a spin could only end by its timeout.
+            # Those switches are forced off while clients share the GPU.  The switch is process-global: the previous value (a user's
+            # FEDFR_OPTIONS setting) is put back when the round's clients are done, also on an error.
             main = torch.cuda.current_stream(self.device)
             streams = getattr(self, "_client_streams", None)
             if streams is None or len(streams) < par:
                 streams = self._client_streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(par)]
-            with _C.option_scope("wgrad9p", 1):
+            with _C.option_scope("bn_fuse_bwd", 0):
                 for w0 in range(0, len(order), par):
                     errs = []
 

@@ -55,6 +55,11 @@ const char* fedfr_last_error_string(void);
 int fedfr_set_option(const char* name, int value);
 /* the switch's current value (a caller that changes one temporarily restores what it found) */
 int fedfr_get_option(const char* name, int* value);
+/* enumeration of the switches, so that a measurement can state which of them were NOT at their defaults (bench.py `options_non_default`):
+ * number of switches; switch `index` = (name, current value, the value the library starts with).  Switches that give wrong results
+ * (timing experiments such as "dbg_skip") exist only in a -DFEDFR_DEBUG build and are then listed too. */
+int fedfr_option_count(void);
+int fedfr_option_info(int index, const char** name, int* value, int* default_value);
 /* HIP-event timing of every MFMA GEMM launch on its own stream (bench.py roofline leg).  Slots 0..3: conv fwd/dgrad
  * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order; 8..11: the
  * LDS-halo 3x3 conv kernels conv3x3_halo2<128,14>, <128,28>, <64,*>, conv3x3_halo (v1).

@@ -245,12 +245,16 @@ def test_bench_self_launch_starts_the_ranks_before_any_gpu_call(monkeypatch, cap
     seen = {}
 
     class FakeProc:
-        def __init__(self, cmd, env=None, stdout=None, stderr=None, text=None, cwd=None):
-            seen["cmd"], seen["env"] = cmd, env
-            self.stdout = io.StringIO('NCCL version banner\n{"metric": "images/sec", "value": 1.0, "n_gpus": 4}\n')
+        pid = 2 ** 22 + 12345              # no such process group: a deadline's killpg must find nothing to end
+
+        def __init__(self, cmd, env=None, stdout=None, stderr=None, text=None, cwd=None, start_new_session=False):
+            seen["cmd"], seen["env"], seen["session"] = cmd, env, start_new_session
+            self.stdout = io.StringIO(seen.get("out", 'NCCL version banner\n{"metric": "images/sec", "value": 1.0, "n_gpus": 4}\n'))
             self.rc = seen.get("rc", 0)
 
-        def wait(self):
+        def wait(self, timeout=None):
+            if seen.get("hang"):
+                raise subprocess.TimeoutExpired("bench", timeout)
             return self.rc
     monkeypatch.setattr(subprocess, "Popen", FakeProc)
     assert bench.self_launch(["--gpus", "4", "--steps", "2"]) == 0
@@ -258,8 +262,61 @@ def test_bench_self_launch_starts_the_ranks_before_any_gpu_call(monkeypatch, cap
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
-    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["session"] is True      # own process group: a deadline ends exactly these processes
     out = capsys.readouterr()
     assert out.out.strip() == '{"metric": "images/sec", "value": 1.0, "n_gpus": 4}' and "NCCL version banner" in out.err
     seen["rc"] = 3
     assert bench.self_launch(["--gpus=2"]) == 3                        # a failing rank fails the bench
+    seen["rc"], seen["out"] = 0, "no result line\n"
+    assert bench.self_launch(["--gpus=2"]) == 1                        # ranks that exit 0 without a JSON line fail it too
+    seen["hang"] = True                                                # no result by the deadline -> non-zero, nothing on stdout
+    monkeypatch.setenv("FEDFR_BENCH_DEADLINE_S", "0.1")
+    capsys.readouterr()
+    assert bench.self_launch(["--gpus=2"]) == 124
+    assert capsys.readouterr().out.strip() == ""
+
+
+def test_flat_state_dict_lazy_views_behave_like_a_dict():
+    """the lazily built FlatStateDict must answer EVERY dict method as the built dictionary would — popitem / setdefault /
+    move_to_end on an unbuilt instance, and clear() must leave it empty for good (no lazy rebuild, no flat tensors left for
+    load_state_dict's fast path)."""
+    m = backbones.iresnet18()
+    keys = list(m.state_dict().keys())
+    sd = client.flat_state_dict(m)
+    k, v = sd.popitem()
+    assert k == keys[-1] and len(sd) == len(keys) - 1
+    sd = client.flat_state_dict(m)
+    assert sd.setdefault(keys[0], None) is not None and len(sd) == len(keys)
+    sd = client.flat_state_dict(m)
+    sd.move_to_end(keys[0])
+    assert list(sd.keys())[-1] == keys[0]
+    sd = client.flat_state_dict(m)
+    sd.clear()
+    assert len(sd) == 0 and list(sd.items()) == [] and sd.flat is None
+    sd = client.flat_state_dict(m)
+    sd.update({"extra": torch.zeros(1)})
+    assert len(sd) == len(keys) + 1
+
+
+def test_head_split_k_count_never_leaves_an_empty_range():
+    """FusedTrainer's split-K degree for the head GEMMs must satisfy head_sgemm_splitk's own rule (csrc/head.hip: chunk =
+    ceil32(ceil(K / splits)), chunk * (splits - 1) < K) for EVERY class count — a client's class count is arbitrary (800 used to give
+    6 splits of 160 = an empty sixth range)."""
+    for k in range(1, 8200):
+        s = client._split_for(k)
+        chunk = -(-(-(-k // s)) // 32) * 32
+        assert 1 <= s <= 8 and chunk * (s - 1) < k, (k, s, chunk)
+    assert client._split_for(512) == 4 and client._split_for(1000) == 7 and client._split_for(800) == 5
+
+
+def test_bench_self_launch_returns_nonzero_without_a_result(tmp_path):
+    """`python bench.py --gpus 2` starts its ranks as a child launcher; ranks that die (here: no GPU) or print no JSON
+    line must make the parent exit non-zero and print nothing on stdout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEDFR_BENCH_DEADLINE_S="240")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout

@@ -331,20 +331,25 @@ def test_roc_histogram_matches_reference_kernel_body():
     assert h[2000, 0] == 2 and h[1000, 1] == 7 and h.sum() == 9
 
 
-def test_sphnet_matches_reference():
-    """sphere20 forward + parameter gradients of the functional restatement vs the imported reference module."""
-    g = load_golden("sphnet20")
+@pytest.mark.parametrize("type_", [20, 64])
+def test_sphnet_matches_reference(type_):
+    """sphere20 / sphere64 (the reference's default, sphnet.py:72, and what run.sh trains) forward + parameter gradients of
+    the functional restatement vs the imported reference module."""
+    g = load_golden("sphnet%d" % type_)
     B = int(g["B"])
-    sd = R.sphere_state_dict(20, tag=1.0)
+    sd = R.sphere_state_dict(type_, tag=1.0)
     assert list(sd.keys()) == [str(k) for k in g["keys"]]
     x = R.closed_form_images(B, tag=4.0)
     dfe = R.closed_form((B, 512), 0.37, 0.9, 1.0)
-    feats, grads = R.sphere_step_grads(sd, x, dfe, 20)
+    feats, grads = R.sphere_step_grads(sd, x, dfe, type_)
     close(feats, g["feats"], 2e-4, 1e-5)
     for k in sd:
         assert abs(float(grads[k].norm()) - float(g["gnorm_" + k])) < 2e-4 * float(g["gnorm_" + k]) + 1e-6, k
         if ("g_" + k) in g.files:
             close(grads[k], g["g_" + k], 2e-3, 2e-4 * float(T(g["g_" + k]).abs().max()) + 1e-7)
+    for key in [f for f in g.files if f.endswith("_slice")]:          # slices of large tensors: "g_<param>_slice" = grad[:a, :b]
+        ref = T(g[key])
+        close(grads[key[2:-6]][: ref.shape[0], : ref.shape[1]], ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-7)
 
 
 # ---- IBasicBlock fixtures (tests/golden/block.npz; reference backbones/iresnet.py:28-57) -------------------------------------------

@@ -662,12 +662,12 @@ def gen_roc():
     save("roc", features=feature, labels=lab.astype(np.int64), target_size=target_size, hist=hist, tpr=np.array(tpr), total_pairs=int(hist.sum()))
 
 
-# ---- 11. sphnet (backbones/sphnet.py), sphere20 fwd + bwd ---------------------------------------------------------------------
-def gen_sphnet():
+# ---- 11. sphnet (backbones/sphnet.py), sphere20 and sphere64 (the reference's default, sphnet.py:72, and what run.sh trains) fwd + bwd ----
+def gen_sphnet(type_=20):
     from backbones.sphnet import sphere as ref_sphere
-    B = 8
-    net = ref_sphere(20)
-    sd = R.sphere_state_dict(20, tag=1.0)
+    B = 8 if type_ == 20 else 4
+    net = ref_sphere(type_)
+    sd = R.sphere_state_dict(type_, tag=1.0)
     assert list(net.state_dict().keys()) == list(sd.keys())
     net.load_state_dict(sd)
     net.train()
@@ -684,8 +684,12 @@ def gen_sphnet():
     out["g_layer2.2.conv1.weight_slice"] = net.layer2[2].conv1.weight.grad[:4, :16]
     out["g_layer1.0.weight"] = net.layer1[0].weight.grad
     out["g_fc.weight_slice"] = net.fc.weight.grad[:4, :2048]
+    if type_ == 64:         # the 16-unit 14x14 stage (layer3) and its neighbours: slices of a deep, a first and a last unit
+        out["g_layer3.17.conv2.weight_slice"] = net.layer3[17].conv2.weight.grad[:4, :16]      # (layerN = [conv, prelu, unit 0, unit 1, ...])
+        out["g_layer3.2.conv1.weight_slice"] = net.layer3[2].conv1.weight.grad[:4, :16]
+        out["g_layer4.4.conv1.weight_slice"] = net.layer4[4].conv1.weight.grad[:2, :16]
     out["keys"] = np.array(list(sd.keys()))
-    save("sphnet20", **out)
+    save("sphnet%d" % type_, **out)
 
 
 def gen_freeze_bn():
@@ -727,7 +731,7 @@ def gen_freeze_bn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining", "roc", "sphnet", "freeze_bn"]
+    which = sys.argv[1:] or ["block", "r50", "r100", "heads", "bce", "sgd", "fedavg", "pfc", "client", "public", "mining", "roc", "sphnet", "sphnet64", "freeze_bn"]
     if "freeze_bn" in which:
         gen_freeze_bn()
     if "block" in which:
@@ -749,7 +753,9 @@ if __name__ == "__main__":
     if "client" in which:
         gen_client()
     if "sphnet" in which:
-        gen_sphnet()
+        gen_sphnet(20)
+    if "sphnet64" in which:
+        gen_sphnet(64)
     if "roc" in which:
         gen_roc()
     if "mining" in which:

@@ -25,7 +25,7 @@ extern int g_tn_pair;
 extern int g_wgrad9;
 extern int g_conv_c64p;
 extern int g_bn_sliced, g_bn_sliced_pre, g_bn_sliced_bwd_passes;
-extern int g_wgrad9p;
+extern int g_wgrad9p, g_wgrad9p_bg;
 extern int g_wgrad9_wgs;
 extern int g_conv28_tpw2;
 extern int g_eval_fuse;
@@ -100,6 +100,7 @@ const OptRow kOptions[] = {
     {"bn_sliced", &g_bn_sliced, 0, 0, 1},                  // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
     {"wgrad9_wgs", &g_wgrad9_wgs, 1, 64, 1024},           // workgroups a wgrad9 launch aims for (more = shorter workgroups, more split-K slabs)
     {"conv28_tpw2", &g_conv28_tpw2, 1, 0, 2},              // 28x28 convs with two image tiles per workgroup (1: forward, 2: dgrad too)
+    {"wgrad9p_bg", &g_wgrad9p_bg, 0, 0, 1},                // a paired launch sums the PREVIOUS pair's split-K slabs beside its own work (0: stand-alone reduce_slabs launches)
     {"wgrad9p", &g_wgrad9p, 0, 0, 1},                      // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
     {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes, 1, 7, 64},
     {"bn_sliced_pre", &g_bn_sliced_pre, 2, 0, 0},          // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)

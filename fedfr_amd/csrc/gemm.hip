@@ -684,10 +684,11 @@ int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
 // the two 3x3 / stride-1 weight gradients of a residual block on the paired nine-tap kernel (wgrad9p.hip); *splits = slabs per layer
 bool gemm_tn_w9pair_ok(const GemmTN& a, const GemmTN& b) { return wgrad9p_applies(a, b); }
 int gemm_tn_w9pair_splits(const GemmTN& a) { return wgrad9p_pick_splits(a.Kp, a.NI, a.NJ, a.W); }
-int gemm_tn_launch_w9pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
+bool gemm_tn_w9pair_job_ok(const GemmTN& a, int splits, const W9PJob& job) { return wgrad9p_job_ok(a, splits, job); }
+int gemm_tn_launch_w9pair(GemmTN a, GemmTN b, int splits, hipStream_t st, const W9PJob* job) {
   FEDFR_TRY(tn_prepare(a));
   FEDFR_TRY(tn_prepare(b));
-  return launch_wgrad9_pair(a, b, splits, st);
+  return launch_wgrad9_pair(a, b, splits, st, job);
 }
 
 int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {

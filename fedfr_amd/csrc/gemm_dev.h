@@ -90,4 +90,5 @@ int launch_wgrad9(const GemmTN& p, int splits, hipStream_t st);
 extern int g_wgrad9p;
 bool wgrad9p_applies(const GemmTN& a, const GemmTN& b);
 int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W);
-int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st);
+bool wgrad9p_job_ok(const GemmTN& a, int splits, const W9PJob& job);
+int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job = nullptr);

@@ -169,7 +169,8 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
   for (int i = 0; i < 3 * (kWgradDepth - 1); ++i) n->ws_t2[i] = wtake(n->g_elems * 2);
   n->ws_part = wtake(n->part_floats * 4);
   n->ws_part2 = wtake((size_t)kSlicedRowsMax * 3 * 1024 * 4);   // rows written by the channel-sliced BatchNorm passes (bn_sliced.hip)
-  n->ws_slab = wtake(n->slab_floats * 4 * 2);      // two regions: paired weight-gradient GEMMs write their slab sets side by side
+  n->ws_slab = wtake(n->slab_floats * 4 * 4);      // four regions: paired weight-gradient GEMMs write their two slab sets side by side, and the NEXT pair
+                                                   // writes the other two while it sums this pair's (wgrad9p.hip, W9PJob)
   // small: coef[3*512] | finalize tmp [64*2*512] | dyfc f32 [B*F] | dyb bf16 [B*F] | dybt bf16 [F*Bp]
   n->ws_small = wtake((size_t)(3 * 512 + 64 * 2 * 512) * 4 + (size_t)Bq * num_features * 4 + (size_t)Bq * num_features * 2 +
                       (size_t)num_features * n->Bp * 2 + 1024);
@@ -379,13 +380,29 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
   FEDFR_TRY(gemm_tn_launch(p, splits, st));
   return ew_reduce_slabs(dst, c.slab(), splits, (size_t)p.NI * p.NJ, nullptr, 0, st);
 }
+// Slab sets of a paired nine-tap launch whose reduction has not been issued yet: the NEXT paired launch on the stream carries it out beside its own
+// work (wgrad9p.hip, W9PJob), or wgrad_flush() issues the stand-alone launches — before anything else uses the slab workspace or reads the
+// gradients (another weight-gradient kernel, the fused SGD of a finished stage, the end of the pass).
+struct WgradPending {
+  W9PJob job{};          // job.n == 0: nothing pending
+  int set = 1;           // slab regions {2 set, 2 set + 1} hold the pending pair (the next pair writes the other set)
+};
+static int wgrad_flush(const Ctx& c, WgradPending* pd, hipStream_t st) {
+  if (!pd || !pd->job.n) return FEDFR_OK;
+  const W9PJob j = pd->job;
+  pd->job.n = 0;
+  // two reduction launches on purpose: ONE launch for both layers (ew_reduce_slabs2) measured 16.00 vs 15.85 ms/step same-box in round 3 —
+  // the main stream waits for whatever the weight-gradient stream has resident, and two short kernels release the CUs sooner than one long
+  FEDFR_TRY(ew_reduce_slabs(j.dst[0], j.slab[0], j.nsplit, j.n, nullptr, 0, st));
+  return ew_reduce_slabs(j.dst[1], j.slab[1], j.nsplit, j.n, nullptr, 0, st);
+}
 int g_wgrad_pair_reduce = 1;   // option "wgrad_pair_reduce": one slab-reduction launch for the two 3x3 weight gradients of a block
 // the two 3x3 weight gradients of a residual block; same shape (every block but a stage's first): one paired launch
 #ifdef FEDFR_DEBUG
 int g_dbg_skip = 0;   // option "dbg_skip" (-DFEDFR_DEBUG builds only; timing experiments, WRONG results): 1 = no weight-gradient launches of the residual blocks' 3x3 convs
 #endif
 static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const bf16_t* dya, const ConvD& cvb, const bf16_t* inb,
-                       const bf16_t* dyb, hipStream_t st) {
+                       const bf16_t* dyb, hipStream_t st, WgradPending* pd = nullptr) {
 #ifdef FEDFR_DEBUG
   if (g_dbg_skip & 1) return FEDFR_OK;
 #endif
@@ -394,13 +411,23 @@ static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const 
     const int sp = gemm_tn_w9pair_splits(a);
     FEDFR_REQUIRE((size_t)sp * a.NI * a.NJ <= c.n->slab_floats, "conv_wgrad2: %d split-K slabs of %d x %d exceed the plan's slab workspace (%zu floats)",
                   sp, a.NI, a.NJ, c.n->slab_floats);
-    a.out = c.slab(0); b.out = c.slab(1);
-    FEDFR_TRY(gemm_tn_launch_w9pair(a, b, sp, st));
-    // two reduction launches on purpose: ONE launch for both layers (ew_reduce_slabs2) measured 16.00 vs 15.85 ms/step same-box in round 3 —
-    // the main stream waits for whatever the weight-gradient stream has resident, and two short kernels release the CUs sooner than one long
-    FEDFR_TRY(ew_reduce_slabs(c.grads + cva.w_off, c.slab(0), sp, (size_t)a.NI * a.NJ, nullptr, 0, st));
-    return ew_reduce_slabs(c.grads + cvb.w_off, c.slab(1), sp, (size_t)b.NI * b.NJ, nullptr, 0, st);
+    const int set = pd ? pd->set ^ 1 : 0;
+    a.out = c.slab(2 * set); b.out = c.slab(2 * set + 1);
+    // the previous pair's slabs: summed by this launch where its shape allows, else by their own launches first
+    const bool carry = pd && pd->job.n && gemm_tn_w9pair_job_ok(a, sp, pd->job);
+    if (pd && pd->job.n && !carry) FEDFR_TRY(wgrad_flush(c, pd, st));
+    FEDFR_TRY(gemm_tn_launch_w9pair(a, b, sp, st, carry ? &pd->job : nullptr));
+    W9PJob mine{};
+    mine.slab[0] = a.out; mine.slab[1] = b.out; mine.dst[0] = c.grads + cva.w_off; mine.dst[1] = c.grads + cvb.w_off;
+    mine.n = (size_t)a.NI * a.NJ; mine.nsplit = sp;
+    if (pd) {
+      pd->job = mine; pd->set = set;
+      return FEDFR_OK;
+    }
+    WgradPending now; now.job = mine;
+    return wgrad_flush(c, &now, st);
   }
+  FEDFR_TRY(wgrad_flush(c, pd, st));                    // every other kernel below uses slab regions 0 / 1 itself
   const int splits = gemm_tn_pick_splits(a.Kp, a.NI, a.NJ, a.C, a.Wo, a.stride);
   if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {
     // same shape, same split count: each launch writes its own slab set and ONE launch reduces both (45 launches fewer per step on the
@@ -878,6 +905,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     return FEDFR_OK;
   };
   hipEvent_t wdone[kWgradDepth] = {};              // "all weight GEMMs of the block of this generation have finished"
+  WgradPending pend_w;                             // a paired weight-gradient launch whose slabs the next one sums (wgrad9p.hip)
   for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
     const BlockD& k = n->blocks[bi];
     const int Mi = B * k.Hin * k.Hin, Mo = B * k.Hout * k.Hout;
@@ -910,9 +938,11 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
     if (fork_attached) fk.order_attached(fork_ev, wst);
     else fk.order(st, wst);
+    if (sgd_lo >= 0 && sgd_lo < sgd_hi) FEDFR_TRY(wgrad_flush(c, &pend_w, wst));      // the fused SGD reads the finished stage's gradients
     FEDFR_TRY(sgd_flush());
-    FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst));
+    FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst, &pend_w));
     if (k.has_ds) {
+      FEDFR_TRY(wgrad_flush(c, &pend_w, wst));
       FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, dd, wst));
       FEDFR_TRY(conv_dgrad(c, k.ds, dd, dxd));
     }
@@ -934,6 +964,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     cur ^= 1;
     if (sgd && !n->block_only && k.has_ds && bi > 0) sgd_lo = k.bn1.g_off;      // a stage is complete: its range goes out behind the next fork
   }
+  FEDFR_TRY(wgrad_flush(c, &pend_w, wst));
   // join: the stem wgrad below reuses the slab workspace; callers see all grads.  late_join: the stem's BatchNorm backward (two passes over
   // 205 MB tensors) does not wait for the last weight gradients — its dz goes to t(1) (da2 of the blocks: main stream only) instead of
   // t(0), which block 0's weight gradient may still be reading

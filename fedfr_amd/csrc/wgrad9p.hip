@@ -39,7 +39,24 @@ __device__ __forceinline__ void w9p_wait_vmcnt() {
 }
 __device__ __forceinline__ int w9p_swz(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }   // == tn_swz<128>
 
+// The split-K slabs of the PREVIOUS paired launch on this stream, summed by this launch's workgroups beside their own work (round 4).  A
+// stand-alone reduction is bandwidth-bound at 5-7 us per layer plus its launch boundary: 13 of the 66 us a pair cost.  Here a workgroup owns
+// `per` consecutive float4 outputs (its thread t the outputs o * 256 + t) and works through them in UNITS of four slab loads: one unit is
+// requested per 14 x 14 sub-image, right behind the sub-image's barrier, and summed a whole sub-image later (~2 us: the loads ride under
+// the MFMAs, 16 registers).  Summation order = the stand-alone kernels' (ew.hip), so the two paths agree bit for bit:
+//   narrow (reduce_slabs_kernel):      a = s_0; a += s_1; ... ascending slabs                          unit j of an output = slabs 4j .. 4j+3
+//   wide   (reduce_slabs_wide_kernel): a_q = sum over groups of (s_q + s_(q+8)) + (s_(q+16) + s_(q+24)), q = 0..7, groups 32 slabs apart;
+//                                      result = ((a_0 + a_1) + a_2) + ...                              unit = one group of one q
+struct W9PJobDev {
+  const float* slab[2];
+  float* dst[2];
+  unsigned n4, per;     // float4 per layer / per workgroup (n4 % per == 0: a workgroup's share lies in ONE layer)
+  int nsplit, wide;
+  int upo, units;       // units per output; units per thread = outputs per thread * upo (0 = no job)
+};
+
 struct W9P {
+  W9PJobDev job;
   const bf16_t* dy[2];  // [B][W][W][cout]
   const bf16_t* x[2];   // [B][W][W][cin]
   float* out[2];        // [splits][cout][9 cin]
@@ -152,6 +169,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
 
+  // ---- the previous launch's slab reduction (W9PJobDev).  Everything but the lane's float4 index is wave-uniform.
+  const int jU = p.job.units;
+  const unsigned jbase = (unsigned)blockIdx.x * p.job.per;
+  const int jlayer = jbase >= p.job.n4 ? 1 : 0;
+  const unsigned jfirst = jbase - (jlayer ? p.job.n4 : 0u);
+  const __amdgpu_buffer_rsrc_t rsJ = make_rsrc(p.job.slab[jlayer], (unsigned)p.job.nsplit * p.job.n4 * 16u);
+  float* const jdst = p.job.dst[jlayer];
+  const f32x4_t jzero = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t jr[4] = {jzero, jzero, jzero, jzero}, jacc = jzero, jtot = jzero;
+  auto job_issue = [&](int u) {
+    const int o = u / p.job.upo, j = u - o * p.job.upo;
+    const unsigned loc = (unsigned)(o * 256 + tid);
+    int s0 = 4 * j, ds = 1;
+    if (p.job.wide) {
+      const int ipq = p.job.nsplit >> 5, q = j / ipq;
+      s0 = q + 32 * (j - q * ipq); ds = 8;
+    }
+    const unsigned off = (jfirst + loc) * 16u;
+    const bool ok = loc < p.job.per;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned so = (unsigned)(s0 + r * ds) * p.job.n4 * 16u;
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (int)(ok ? off + so : 0xffffffffu), 0, 0);   // out of range reads as zeros
+      jr[r] = __builtin_bit_cast(f32x4_t, v);
+    }
+  };
+  auto job_consume = [&](int u) {
+    const int o = u / p.job.upo, j = u - o * p.job.upo;
+    const unsigned loc = (unsigned)(o * 256 + tid);
+    f32x4_t v;
+    if (p.job.wide) {
+      const int ipq = p.job.nsplit >> 5, q = j / ipq, itw = j - q * ipq;
+      const f32x4_t t = (jr[0] + jr[1]) + (jr[2] + jr[3]);
+      jacc = (itw == 0 ? jzero : jacc) + t;
+      if (itw == ipq - 1) jtot = q == 0 ? jacc : jtot + jacc;
+      v = jtot;
+    } else {
+      jacc = j == 0 ? jr[0] : jacc + jr[0];
+      jacc += jr[1]; jacc += jr[2]; jacc += jr[3];
+      v = jacc;
+    }
+    if (j == p.job.upo - 1 && loc < p.job.per)
+      *reinterpret_cast<float4*>(jdst + (size_t)(jfirst + loc) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+
   f32x4_t acc[9][2][2];                                    // [tap][ci block][co block]
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -221,6 +283,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         stage_setup(s0 + it + 2, dma);                      // nothing left to fetch: every piece reads as zeros (no memory traffic)
+        if (jU) {                                           // the unit requested a sub-image ago has landed (the vmcnt(0) above): sum it, request the next
+          if (it > 0 && it <= jU) job_consume(it - 1);
+          if (it < jU) job_issue(it);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       // read r of this step (compile-time after unrolling): the fragments of the NEXT step.  steady state: E_(kb+1), O_(kb+1) (8),
       // Q pair kb + 2 (12), in the step before the last also O_KS (4); last step: the next sub-image's E_0, O_0 and Q pair 0 (20) -- its
@@ -294,6 +361,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #undef W9P_READ
   w9p_wait_vmcnt<0>();
+  if (jU) {                                                 // the last sub-image's unit; units a short split had no sub-images for
+    if (nst <= jU) job_consume(nst - 1);
+    for (int u = nst; u < jU; ++u) {
+      job_issue(u);
+      w9p_wait_vmcnt<0>();
+      job_consume(u);
+    }
+  }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are read by VALU moves next (hand-written MFMAs: no automatic hazard nops)
 
   // D[m = ci][n = co]: lane holds ci = block 16 + (lane >> 4) 4 + {0..3} for co = block 16 + (lane & 15) -> one float4 per tap and block pair
@@ -334,7 +409,35 @@ int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W) {
   return ceil_div(stages, per);
 }
 
-int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st) {
+// the job's geometry for a carrying launch of `grid` workgroups with `per_split` sub-images each; false = it does not fit (stand-alone reduction)
+static bool w9p_job_geometry(const W9PJob& job, int grid, int per_split, W9PJobDev* d) {
+  if (!job.n || (job.n & 3) || job.nsplit < 1 || !job.slab[0] || !job.slab[1] || !job.dst[0] || !job.dst[1] || grid < 1) return false;
+  const size_t n4 = job.n / 4, total4 = 2 * n4;
+  if (total4 % (size_t)grid) return false;
+  const size_t per = total4 / grid;
+  if (n4 % per || (unsigned long long)job.nsplit * n4 * 16ull >= (1ull << 32)) return false;
+  const bool wide = job.nsplit >= 16 && n4 <= 65536;       // == reduce_slabs_launch's choice (ew.hip): same summation order either way
+  if (wide ? (job.nsplit % 32) != 0 : (job.nsplit % 4) != 0) return false;
+  const int nout = (int)((per + 255) / 256);
+  const int upo = wide ? 8 * (job.nsplit / 32) : job.nsplit / 4;
+  if ((long long)nout * upo > per_split) return false;     // one unit per sub-image: everything rides under the MFMAs
+  if (d) {
+    d->slab[0] = job.slab[0]; d->slab[1] = job.slab[1]; d->dst[0] = job.dst[0]; d->dst[1] = job.dst[1];
+    d->n4 = (unsigned)n4; d->per = (unsigned)per; d->nsplit = job.nsplit; d->wide = wide ? 1 : 0; d->upo = upo; d->units = nout * upo;
+  }
+  return true;
+}
+int g_wgrad9p_bg = 1;   // option "wgrad9p_bg": a paired launch sums the previous pair's split-K slabs itself (0: stand-alone reduce_slabs launches)
+bool wgrad9p_job_ok(const GemmTN& a, int splits, const W9PJob& job) {
+  if (!g_wgrad9p_bg || splits < 1) return false;
+  const int lg = w9p_lg(a.W);
+  if (lg < 0 || a.NI % 64 || a.C % 64) return false;
+  const int nstages = (a.Kp / (a.W * a.W)) << (2 * lg);
+  const int grid = 2 * (a.NI / 64) * (a.C / 64) * splits;
+  return w9p_job_geometry(job, grid, nstages / splits, nullptr);        // (the shortest split)
+}
+
+int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job) {
   FEDFR_REQUIRE(wgrad9p_applies(a, b), "wgrad9_pair: unsupported problem pair");
   W9P p{};
   p.dy[0] = a.P; p.dy[1] = b.P; p.x[0] = a.Q; p.x[1] = b.Q; p.out[0] = a.out; p.out[1] = b.out;
@@ -349,6 +452,8 @@ int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t
   FEDFR_REQUIRE(a.p_bytes == b.p_bytes && a.q_bytes == b.q_bytes, "wgrad9_pair: operand sizes differ");
   FEDFR_REQUIRE(a.p_bytes < (1u << 30) - (1u << 24) && a.q_bytes < (1u << 30) - (1u << 24), "wgrad9_pair: operands must be smaller than 1 GiB");
   const dim3 grid(2 * p.ntiles * splits);
+  if (job && job->n)
+    FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
   ProfScope prof(16, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
   constexpr size_t lds = 2 * (size_t)STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)

@@ -577,7 +577,8 @@ def test_sweeps_and_hard_negative_mining_vs_reference():
 
 # measured x 1.25 per type: (embeddings, gradient-norm median, gradient-norm max, direction median, direction max).  sphere64 stacks 29 residual units
 # (58 convs) of bf16 storage where sphere20 has 8
-SPH_TOL = {20: (2e-2, 1e-2, 0.12, 0.15, 0.4), 64: (2e-2, 1e-2, 0.12, 0.15, 0.4)}
+# measured (MI355X, round 4): sphere20 6.3e-3, 4.1e-3 / 5.8e-2, 0.106 / 0.160; sphere64 5.5e-3 (inside north_star's 1e-2), 5.8e-3 / 3.3e-2, 0.075 / 0.273
+SPH_TOL = {20: (2e-2, 1e-2, 0.12, 0.15, 0.4), 64: (7e-3, 7.5e-3, 4.2e-2, 0.095, 0.345)}
 
 
 @pytest.mark.parametrize("type_", [20, 64])
@@ -896,6 +897,10 @@ def test_full_size_step_invariants_r100_b128(monkeypatch, arch):
         assert abs(l2 - l0) <= 1e-6 * abs(l0), kw
         assert float((g2 - g0).norm()) <= 1e-4 * float(g0.norm()), (kw, float((g2 - g0).norm() / g0.norm()))
         assert torch.equal(f2, f0), kw
+    # (2b) round 4: a paired weight-gradient launch sums the PREVIOUS pair's split-K slabs beside its own work (csrc/wgrad9p.hip, W9PJob) in the
+    # stand-alone reduction kernels' own summation order: with the launches put back (wgrad9p_bg = 0) every gradient bit is the same
+    l3, g3, f3 = run(wgrad9p_bg=0)
+    assert l3 == l0 and torch.equal(g3, g0) and torch.equal(f3, f0)
     # (3)
     nbt = [v for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")]
     assert len(nbt) == {"iresnet100": 154, "iresnet50": 79}[arch] and len({int(v) for v in nbt}) == 1

@@ -42,17 +42,21 @@ __device__ __forceinline__ int w9p_swz(int row) { return (((row >> 1) & 1) << 1)
 // The split-K slabs of the PREVIOUS paired launch on this stream, summed by this launch's workgroups beside their own work (round 4).  A
 // stand-alone reduction is bandwidth-bound at 5-7 us per layer plus its launch boundary: 13 of the 66 us a pair cost.  Here a workgroup owns
 // `per` consecutive float4 outputs (its thread t the outputs o * 256 + t) and works through them in UNITS of four slab loads: one unit is
-// requested per 14 x 14 sub-image, right behind the sub-image's barrier, and summed a whole sub-image later (~2 us: the loads ride under
-// the MFMAs, 16 registers).  Summation order = the stand-alone kernels' (ew.hip), so the two paths agree bit for bit:
-//   narrow (reduce_slabs_kernel):      a = s_0; a += s_1; ... ascending slabs                          unit j of an output = slabs 4j .. 4j+3
-//   wide   (reduce_slabs_wide_kernel): a_q = sum over groups of (s_q + s_(q+8)) + (s_(q+16) + s_(q+24)), q = 0..7, groups 32 slabs apart;
-//                                      result = ((a_0 + a_1) + a_2) + ...                              unit = one group of one q
+// requested per 14 x 14 sub-image (in its second K-step, four single loads between MFMAs) and summed one sub-image later, again between
+// MFMAs (the loop's own vmcnt(0) at the end of every sub-image has retired the loads by then): 24 registers, ~25 instructions per sub-image,
+// all in the shadow of the MFMA stream.  (The first version ran 230 mostly scalar instructions per sub-image in the open, behind the
+// barrier: +6 us per launch — one wave per SIMD pays every instruction it issues outside an MFMA's shadow.)
+// Summation order = the stand-alone kernels' (ew.hip), so the two paths agree bit for bit (template parameter JM):
+//   1 narrow (reduce_slabs_kernel):      a = s_0; a += s_1; ... ascending slabs                       unit j of an output = slabs 4j .. 4j+3
+//   2 wide   (reduce_slabs_wide_kernel, 32 slabs): a_q = (s_q + s_(q+8)) + (s_(q+16) + s_(q+24)), result = ((a_0 + a_1) + a_2) + ...   unit q = a_q
+// Both start an output's accumulator at -0.0f (x + -0.0 == x for every x: "a = first term" without a select).
 struct W9PJobDev {
   const float* slab[2];
   float* dst[2];
   unsigned n4, per;     // float4 per layer / per workgroup (n4 % per == 0: a workgroup's share lies in ONE layer)
-  int nsplit, wide;
-  int upo, units;       // units per output; units per thread = outputs per thread * upo (0 = no job)
+  int nsplit;
+  int upo, units;       // units per output; units per thread = outputs per thread * upo
+  unsigned sb, sr;      // byte step between the slab groups of consecutive units / between the four loads of a unit
 };
 
 struct W9P {
@@ -75,6 +79,7 @@ constexpr int ZG = 2048;                                            // one 16-ro
 constexpr int P_B = ZG + P_ROWS * 128 + ZG, Q_B = Q_ROWS * 128, STAGE_B = P_B + Q_B;
 static_assert(P_B % 1024 == 0 && STAGE_B % 1024 == 0 && (NG - 1) * 2048 < 65536 && 2 * STAGE_B <= 160 * 1024, "stage geometry");
 
+template <int JM>   // 0: no slab-reduction job; 1 / 2: narrow / wide order (W9PJobDev)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad9p_kernel(W9P p) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef __attribute__((address_space(3))) unsigned char* lds_uc_t;
@@ -169,49 +174,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
 
-  // ---- the previous launch's slab reduction (W9PJobDev).  Everything but the lane's float4 index is wave-uniform.
-  const int jU = p.job.units;
+  // ---- the previous launch's slab reduction (W9PJobDev).  Everything but the lane's float4 offset is wave-uniform; the state below is all there
+  // is: jvoff = byte offset of this lane's float4 of the output being REQUESTED inside the layer (OOB: the lane has no output left — its loads
+  // then read zeros and it stores nothing), jcv = the same for the unit being SUMMED, jdone = that unit completes its output.
+  constexpr unsigned JOOB = 0xffffffffu;
   const unsigned jbase = (unsigned)blockIdx.x * p.job.per;
-  const int jlayer = jbase >= p.job.n4 ? 1 : 0;
+  const int jlayer = JM && jbase >= p.job.n4 ? 1 : 0;
   const unsigned jfirst = jbase - (jlayer ? p.job.n4 : 0u);
   const __amdgpu_buffer_rsrc_t rsJ = make_rsrc(p.job.slab[jlayer], (unsigned)p.job.nsplit * p.job.n4 * 16u);
-  float* const jdst = p.job.dst[jlayer];
-  const f32x4_t jzero = {0.f, 0.f, 0.f, 0.f};
-  f32x4_t jr[4] = {jzero, jzero, jzero, jzero}, jacc = jzero, jtot = jzero;
-  auto job_issue = [&](int u) {
-    const int o = u / p.job.upo, j = u - o * p.job.upo;
-    const unsigned loc = (unsigned)(o * 256 + tid);
-    int s0 = 4 * j, ds = 1;
-    if (p.job.wide) {
-      const int ipq = p.job.nsplit >> 5, q = j / ipq;
-      s0 = q + 32 * (j - q * ipq); ds = 8;
-    }
-    const unsigned off = (jfirst + loc) * 16u;
-    const bool ok = loc < p.job.per;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned so = (unsigned)(s0 + r * ds) * p.job.n4 * 16u;
-      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (int)(ok ? off + so : 0xffffffffu), 0, 0);   // out of range reads as zeros
+  unsigned char* const jdst = reinterpret_cast<unsigned char*>(p.job.dst[jlayer]);
+  const f32x4_t jneg0 = {-0.f, -0.f, -0.f, -0.f};
+  f32x4_t jr[4] = {jneg0, jneg0, jneg0, jneg0}, jacc = jneg0, jt0 = jneg0, jt1 = jneg0;
+  unsigned jvoff = JM && (unsigned)tid < p.job.per ? (jfirst + (unsigned)tid) * 16u : JOOB, jcv = JOOB;
+  int jj = 0, jo = 0;              // unit within the output / output being requested
+  unsigned jsb = 0;                // slab-group byte offset of that unit
+  bool jdone = false;
+  auto job_load = [&](int r) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
+    if constexpr (JM != 0) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (int)jvoff, (int)(jsb + (unsigned)r * p.job.sr), 0);
       jr[r] = __builtin_bit_cast(f32x4_t, v);
     }
   };
-  auto job_consume = [&](int u) {
-    const int o = u / p.job.upo, j = u - o * p.job.upo;
-    const unsigned loc = (unsigned)(o * 256 + tid);
-    f32x4_t v;
-    if (p.job.wide) {
-      const int ipq = p.job.nsplit >> 5, q = j / ipq, itw = j - q * ipq;
-      const f32x4_t t = (jr[0] + jr[1]) + (jr[2] + jr[3]);
-      jacc = (itw == 0 ? jzero : jacc) + t;
-      if (itw == ipq - 1) jtot = q == 0 ? jacc : jtot + jacc;
-      v = jtot;
-    } else {
-      jacc = j == 0 ? jr[0] : jacc + jr[0];
-      jacc += jr[1]; jacc += jr[2]; jacc += jr[3];
-      v = jacc;
+  auto job_advance = [&]() {       // behind the four loads of a unit: remember what the unit is for, step to the next one
+    if constexpr (JM != 0) {
+      jcv = jvoff;
+      jdone = jj == p.job.upo - 1;
+      ++jj; jsb += p.job.sb;
+      if (jdone) {
+        jj = 0; jsb = 0; ++jo;
+        jvoff = (unsigned)(jo * 256 + tid) < p.job.per ? jvoff + 4096u : JOOB;      // (an exhausted lane stays exhausted: per is not reached again)
+      }
     }
-    if (j == p.job.upo - 1 && loc < p.job.per)
-      *reinterpret_cast<float4*>(jdst + (size_t)(jfirst + loc) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto job_add = [&](int r) {      // step r of summing the unit in jr
+    if constexpr (JM == 1) {
+      jacc += jr[r];
+    } else if constexpr (JM == 2) {
+      if (r == 0) jt0 = jr[0] + jr[1];
+      else if (r == 1) jt1 = jr[2] + jr[3];
+      else if (r == 2) jt0 = jt0 + jt1;
+      else jacc += jt0;
+    }
+  };
+  auto job_finish = [&]() {        // the unit is summed: an output that is complete goes out
+    if constexpr (JM != 0) {
+      if (jdone) {
+        if (jcv != JOOB) *reinterpret_cast<float4*>(jdst + jcv) = make_float4(jacc[0], jacc[1], jacc[2], jacc[3]);
+        jacc = jneg0;
+      }
+    }
   };
 
   f32x4_t acc[9][2][2];                                    // [tap][ci block][co block]
@@ -283,11 +294,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         stage_setup(s0 + it + 2, dma);                      // nothing left to fetch: every piece reads as zeros (no memory traffic)
-        if (jU) {                                           // the unit requested a sub-image ago has landed (the vmcnt(0) above): sum it, request the next
-          if (it > 0 && it <= jU) job_consume(it - 1);
-          if (it < jU) job_issue(it);
-          __builtin_amdgcn_sched_barrier(0);
-        }
       }
       // read r of this step (compile-time after unrolling): the fragments of the NEXT step.  steady state: E_(kb+1), O_(kb+1) (8),
       // Q pair kb + 2 (12), in the step before the last also O_KS (4); last step: the next sub-image's E_0, O_0 and Q pair 0 (20) -- its
@@ -345,6 +351,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               }
               if (slot < nr) issue_read(slot);
               if (last && slot >= 2 && slot - 2 < NPW && !(W9P_ABLATE & 1)) issue_piece(slot - 2, it & 1);
+              if (JM != 0 && kb == 1) {                     // the slab-reduction job: slots the second K-step leaves free (20 reads, no DMA)
+                if (slot >= 20 && slot < 24) job_add(slot - 20);          // sum the unit requested one sub-image ago ...
+                if (slot == 24) job_finish();
+                if (slot >= 26 && slot < 30) job_load(slot - 26);         // ... and request the next one
+                if (slot == 30) job_advance();
+              }
               __builtin_amdgcn_sched_barrier(0);
               ++slot;
             }
@@ -361,12 +373,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #undef W9P_READ
   w9p_wait_vmcnt<0>();
-  if (jU) {                                                 // the last sub-image's unit; units a short split had no sub-images for
-    if (nst <= jU) job_consume(nst - 1);
-    for (int u = nst; u < jU; ++u) {
-      job_issue(u);
-      w9p_wait_vmcnt<0>();
-      job_consume(u);
+  if constexpr (JM != 0) {                                  // the last sub-image's unit; then the units a short split had no sub-images for
+    for (int u = nst - 1; u < p.job.units; ++u) {
+      if (u >= nst) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) job_load(r);
+        job_advance();
+        w9p_wait_vmcnt<0>();
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) job_add(r);
+      job_finish();
     }
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are read by VALU moves next (hand-written MFMAs: no automatic hazard nops)
@@ -410,20 +427,23 @@ int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W) {
 }
 
 // the job's geometry for a carrying launch of `grid` workgroups with `per_split` sub-images each; false = it does not fit (stand-alone reduction)
-static bool w9p_job_geometry(const W9PJob& job, int grid, int per_split, W9PJobDev* d) {
+static bool w9p_job_geometry(const W9PJob& job, int grid, int per_split, W9PJobDev* d, int* mode = nullptr) {
   if (!job.n || (job.n & 3) || job.nsplit < 1 || !job.slab[0] || !job.slab[1] || !job.dst[0] || !job.dst[1] || grid < 1) return false;
   const size_t n4 = job.n / 4, total4 = 2 * n4;
   if (total4 % (size_t)grid) return false;
   const size_t per = total4 / grid;
   if (n4 % per || (unsigned long long)job.nsplit * n4 * 16ull >= (1ull << 32)) return false;
   const bool wide = job.nsplit >= 16 && n4 <= 65536;       // == reduce_slabs_launch's choice (ew.hip): same summation order either way
-  if (wide ? (job.nsplit % 32) != 0 : (job.nsplit % 4) != 0) return false;
+  if (wide ? job.nsplit != 32 : (job.nsplit % 4) != 0) return false;
   const int nout = (int)((per + 255) / 256);
-  const int upo = wide ? 8 * (job.nsplit / 32) : job.nsplit / 4;
+  const int upo = wide ? 8 : job.nsplit / 4;
   if ((long long)nout * upo > per_split) return false;     // one unit per sub-image: everything rides under the MFMAs
   if (d) {
+    const unsigned s1 = (unsigned)n4 * 16u;                // one slab of one layer, in bytes
     d->slab[0] = job.slab[0]; d->slab[1] = job.slab[1]; d->dst[0] = job.dst[0]; d->dst[1] = job.dst[1];
-    d->n4 = (unsigned)n4; d->per = (unsigned)per; d->nsplit = job.nsplit; d->wide = wide ? 1 : 0; d->upo = upo; d->units = nout * upo;
+    d->n4 = (unsigned)n4; d->per = (unsigned)per; d->nsplit = job.nsplit; d->upo = upo; d->units = nout * upo;
+    d->sb = wide ? s1 : 4 * s1; d->sr = wide ? 8 * s1 : s1;
+    *mode = wide ? 2 : 1;
   }
   return true;
 }
@@ -452,15 +472,20 @@ int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t
   FEDFR_REQUIRE(a.p_bytes == b.p_bytes && a.q_bytes == b.q_bytes, "wgrad9_pair: operand sizes differ");
   FEDFR_REQUIRE(a.p_bytes < (1u << 30) - (1u << 24) && a.q_bytes < (1u << 30) - (1u << 24), "wgrad9_pair: operands must be smaller than 1 GiB");
   const dim3 grid(2 * p.ntiles * splits);
+  int jm = 0;
   if (job && job->n)
-    FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
+    FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job, &jm), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
   ProfScope prof(16, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
   constexpr size_t lds = 2 * (size_t)STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  hipLaunchKernelGGL(wgrad9p_kernel, grid, dim3(256), lds, st, p);
+  if (jm == 1) hipLaunchKernelGGL(wgrad9p_kernel<1>, grid, dim3(256), lds, st, p);
+  else if (jm == 2) hipLaunchKernelGGL(wgrad9p_kernel<2>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(wgrad9p_kernel<0>, grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("wgrad9_pair");
   return FEDFR_OK;
 }

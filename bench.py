@@ -80,6 +80,49 @@ def pmc_traffic():
     return out
 
 
+def pmc_mfma_busy():
+    """MFMA-pipe utilisation of the dominant kernels from the NEWEST committed SQ-counter summaries under profiles/ (tools/pmc_sq.sh: three
+    rocprofv3 --pmc passes over tools/conv_bench.py; bench.py cannot run rocprofv3 on itself): MfmaBusy = SQ_VALU_MFMA_BUSY_CYCLES per SIMD
+    / wave lifetime in cycles (SQ_WAVE_CYCLES counts quad-cycles per wave), i.e. the share of the time a wave is resident during which its
+    SIMD's matrix pipe is busy; `lds_wait` = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES.  -> {kernel: {...}}"""
+    import glob
+    import re
+    want = {"conv3x3_glds_kernel<14,14>": ("conv14_fwd", "conv3x3_glds_kernel<14, 14, 32, 4, false"),
+            "conv3x3_glds_kernel<14,14> (dgrad + BatchNorm-backward reduction epilogue)": ("conv14_fdgrad", "conv3x3_glds_kernel<14, 14, 32, 4, true"),
+            "conv3x3_glds_kernel<28,7>": ("conv28_fwd", "conv3x3_glds_kernel<28, 7, 40, 4, false"),
+            "conv3x3_glds_kernel<28,7> (dgrad + BatchNorm-backward reduction epilogue)": ("conv28_fdgrad", "conv3x3_glds_kernel<28, 7, 40, 4, true"),
+            W9P: ("wpair14", "wgrad9p_kernel")}
+    out = {}
+    for name, (tag, key) in want.items():
+        files = []
+        for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_%s_v*.txt" % tag)):
+            m = re.search(r"r(\d+)_pmc_sq_.*_v(\d+)\.txt$", os.path.basename(f))
+            if m:
+                files.append(((int(m.group(1)), int(m.group(2))), f))
+        if not files:
+            continue
+        f = sorted(files)[-1][1]
+        cur, vals = None, {}
+        for line in open(f):
+            if line.startswith("=="):
+                cur = line
+                continue
+            m = re.match(r"\s+(SQ_\w+)\s+per-dispatch\s+([\d.]+)", line)
+            if m and cur and key in cur:
+                vals.setdefault(m.group(1), float(m.group(2)))       # (the first dispatch block of the kernel in the file)
+        if {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES"} <= set(vals):
+            simds = 256 * 4
+            waves_per_simd = vals["SQ_WAVES"] / simds
+            life = 4.0 * vals["SQ_WAVE_CYCLES"] / vals["SQ_WAVES"]               # cycles a wave is resident
+            busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / simds                      # MFMA-busy cycles per SIMD
+            out[name] = {"mfma_busy": round(busy / life, 3), "waves_per_simd": round(waves_per_simd, 2),
+                         "lds_wait": round(vals.get("SQ_WAIT_INST_LDS", 0.0) / vals["SQ_WAVE_CYCLES"], 3),
+                         "parked_wait": round(vals.get("SQ_WAIT_ANY", 0.0) / vals["SQ_WAVE_CYCLES"], 3),
+                         "lds_bank_conflict_per_active": round(vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(vals.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0), 3),
+                         "source": os.path.relpath(f, ROOT)}
+    return out
+
+
 def _cpu_steps(arch, batch, steps, threads):
     from oracle import ref_cpu as R
     torch.set_num_threads(threads)
@@ -457,6 +500,7 @@ def main():
             _C.call("fedfr_profile_enable", 0)
             rows.sort(reverse=True)
             traffic = pmc_traffic()
+            sq = pmc_mfma_busy()
 
             def entry(ms, n, fl, slot):
                 name = SLOT_NAMES[slot]
@@ -465,6 +509,10 @@ def main():
                 e = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": tr_bytes,
                      "launches_per_step": n // psteps, "avg_launch_us": round(ms * 1e3 / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3)}
+                if name in sq:
+                    e["mfma_busy"] = sq[name]["mfma_busy"]
+                    e["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles a wave is resident (rocprofv3 --pmc, %s): the share of a wave's "
+                                           "lifetime during which its SIMD's matrix pipe is busy; launch overhead outside the waves' lifetime is not in it" % sq[name]["source"])
                 if tr_bytes is not None:
                     e["traffic_note"] = ("HBM bytes per launch on the 256->256 @14x14 layer, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                                          "FETCH x2 gfx950 correction), %s: %s; algorithmic %.1f MB" % (tr_file, tr_detail, ALGORITHMIC_MB.get(name, float("nan"))))
@@ -475,6 +523,7 @@ def main():
                 roofline["timing"] = "HIP events around each launch on its stream, single-stream pass of %d steps" % psteps
                 if len(rows) > 1:                      # the two 3x3 kernels (forward/dgrad and weight gradient) tie for the largest time share
                     roofline["second"] = entry(*rows[1])
+                roofline["sq_counters"] = sq
                 roofline["all_gemm_kernels"] = [{"kernel": SLOT_NAMES[s_], "ms_per_step": round(m_ / psteps, 3), "launches_per_step": k // psteps,
                                                  "tflops": round(f / (m_ * 1e-3) / 1e12, 1)} for m_, k, f, s_ in rows]
                 # the HBM-bound third of the step: BatchNorm forward / backward streaming passes (algorithmic bytes = tensors read + written once)

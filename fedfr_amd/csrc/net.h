@@ -61,6 +61,8 @@ struct SphStageD { SphUnit head; std::vector<SphBlockD> blocks; int C, H; };
 #define FEDFR_WGRAD_DEPTH 4
 #endif
 constexpr int kWgradDepth = FEDFR_WGRAD_DEPTH;
+constexpr int kSlabRegions = 4;         // split-K slab regions of `slab_floats` each in a plan's workspace: a paired weight-gradient launch writes two, and the
+                                        // NEXT pair writes the other two while it sums these (wgrad9p.hip, W9PJob); every plan layout allocates all of them
 constexpr int kSlicedRowsMax = 256;     // partial rows a channel-sliced BatchNorm pass writes at most (ew_bn_sliced_rows)
 struct FedfrNet {
   int layers[4];

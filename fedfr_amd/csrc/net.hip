@@ -169,7 +169,7 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
   for (int i = 0; i < 3 * (kWgradDepth - 1); ++i) n->ws_t2[i] = wtake(n->g_elems * 2);
   n->ws_part = wtake(n->part_floats * 4);
   n->ws_part2 = wtake((size_t)kSlicedRowsMax * 3 * 1024 * 4);   // rows written by the channel-sliced BatchNorm passes (bn_sliced.hip)
-  n->ws_slab = wtake(n->slab_floats * 4 * 4);      // four regions: paired weight-gradient GEMMs write their two slab sets side by side, and the NEXT pair
+  n->ws_slab = wtake(n->slab_floats * 4 * kSlabRegions);      // four regions: paired weight-gradient GEMMs write their two slab sets side by side, and the NEXT pair
                                                    // writes the other two while it sums this pair's (wgrad9p.hip, W9PJob)
   // small: coef[3*512] | finalize tmp [64*2*512] | dyfc f32 [B*F] | dyb bf16 [B*F] | dybt bf16 [F*Bp]
   n->ws_small = wtake((size_t)(3 * 512 + 64 * 2 * 512) * 4 + (size_t)Bq * num_features * 4 + (size_t)Bq * num_features * 2 +
@@ -412,6 +412,7 @@ static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const 
     FEDFR_REQUIRE((size_t)sp * a.NI * a.NJ <= c.n->slab_floats, "conv_wgrad2: %d split-K slabs of %d x %d exceed the plan's slab workspace (%zu floats)",
                   sp, a.NI, a.NJ, c.n->slab_floats);
     const int set = pd ? pd->set ^ 1 : 0;
+    static_assert(kSlabRegions >= 4, "two slab sets of two regions each");
     a.out = c.slab(2 * set); b.out = c.slab(2 * set + 1);
     // the previous pair's slabs: summed by this launch where its shape allows, else by their own launches first
     const bool carry = pd && pd->job.n && gemm_tn_w9pair_job_ok(a, sp, pd->job);

@@ -652,6 +652,20 @@ def test_sphnet_backward_fusions_at_full_tile_batch():
         a, b = g0[k].double().flatten(), g1[k].double().flatten()
         e = float((a - b).norm() / (a.norm() + 1e-30))
         assert e < 2e-5, (k, e)
+    # round 4: a paired launch sums the PREVIOUS pair's split-K slabs itself where the shape allows (sphere64's 16-unit 14x14 stage at this
+    # batch: 8 slabs per layer) — same summation order as the stand-alone reduction launches, so every gradient bit is the same
+    res64 = []
+    sd64 = R.sphere_state_dict(64, tag=1.0)
+    for bg in (1, 0):
+        with _C.option_scope("wgrad9p_bg", bg):
+            net = backbones.sphnet(False, dropout=0, fp16=True, type=64).to(DEV)
+            net.load_state_dict(sd64)
+            net.train()
+            f = net(x)
+            (f * dfe).sum().backward()
+            res64.append({k: p.grad.clone() for k, p in net.named_parameters()})
+            del net
+    assert all(torch.equal(res64[0][k], res64[1][k]) for k in res64[0])
 
 
 def test_roc_vs_reference():

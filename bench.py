@@ -33,7 +33,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0                                       # MI355X_M
 HBM_PEAK_GBPS = 8000.0                                                # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 SLOT_NAMES = ["gemm_nt_kernel<128,128>", "gemm_nt_kernel<128,64>", "gemm_nt_kernel<64,128>", "gemm_nt_kernel<64,64>",
               "gemm_tn_kernel<128,128>", "gemm_tn_kernel<128,64>", "gemm_tn_kernel<64,128>", "gemm_tn_kernel<64,64>",
-              "conv3x3_halo2_kernel<128,14>", "conv3x3_halo2_kernel<128,28>", "conv3x3_halo2_kernel<64,*>", "conv3x3_halo_kernel<*>",
+              "(retired slot 8)", "(retired slot 9)", "(retired slot 10)", "(retired slot 11)",      # the register-staged halo conv kernels of rounds 1-3
               "conv3x3_glds_kernel<14,14>", "conv3x3_glds_kernel<28,7>", "gemm_tn_glds_kernel<128,128>", "conv3x3 64-channel layers (c64p / glds<56,4>)",
               "wgrad9p_kernel<64x64x9, two layers per launch> (+ wgrad9_kernel<32x64x9>)", "gemm_nt_glds_kernel (7x7 and stride-2 3x3 convs)"]
 HBM_SLOTS = {20: "bn_apply", 21: "bn_bwd_reduce", 22: "bn_bwd_apply", 23: "bn_finalize", 24: "bn_bwd_finalize", 25: "reduce_slabs", 26: "sgd"}
@@ -463,6 +463,7 @@ def main():
         dist.all_reduce(tt, dist.ReduceOp.MAX)
         dt, t_local = float(tt[0]), float(tt[1])
     final_loss = float(loss)
+    model.check_handoffs()                       # (the stream is idle here: raises if an in-launch hand-off of the timed steps timed out)
 
     # ---- roofline leg: HIP-event timing of every MFMA GEMM launch and of the HBM-bound BatchNorm / SGD kernels, in a separate short
     # pass over the same workload
@@ -613,8 +614,9 @@ def main():
             with torch.cuda.stream(st2):
                 tr2 = client.FusedTrainer(model2, fc2, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4, aux_slot=1)
             pairs = [(tr, torch.cuda.current_stream()), (tr2, st2)]
-            w9p_prev = _C.get_option("bn_fuse_bwd")
+            w9p_prev = (_C.get_option("bn_fuse_bwd"), _C.get_option("fwd_bnfuse"))
             _C.call("fedfr_set_option", b"bn_fuse_bwd", 0)      # what Server.train selects when clients share the GPU: no in-launch hand-offs
+            _C.call("fedfr_set_option", b"fwd_bnfuse", 0)
             csteps = max(5, min(args.steps, 20))
             bar = threading.Barrier(3)
 
@@ -659,7 +661,8 @@ def main():
             print("bench.py: the concurrent leg failed: %r" % (e,), file=sys.stderr, flush=True)
         finally:
             if "w9p_prev" in locals():
-                _C.call("fedfr_set_option", b"bn_fuse_bwd", w9p_prev)
+                _C.call("fedfr_set_option", b"bn_fuse_bwd", w9p_prev[0])
+                _C.call("fedfr_set_option", b"fwd_bnfuse", w9p_prev[1])
 
     # ---- the second half of BASELINE's metric at N = 1: server-side FedAvg of 1 / 2 / 4 / 8 client states (server.py:25-34) on this GPU
     fedavg = None

@@ -37,6 +37,7 @@ SIGNATURES = {
     "fedfr_net_debug_capture": (i32, [vp, sz]),
     "fedfr_net_set_dropout": (i32, [vp, f32, u64, C.POINTER(i64)]),
     "fedfr_net_set_dropout_step": (i32, [vp, u64]),
+    "fedfr_net_handoff_errors": (i32, [vp, vp, vp, C.POINTER(C.c_uint)]),
     "fedfr_net_destroy": (None, [vp]),
     "fedfr_net_query": (i32, [vp, i32, C.POINTER(i64)]),
     "fedfr_net_tensor_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),
@@ -135,7 +136,7 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
-        # tuning / validation switches: FEDFR_OPTIONS="halo_waves=8,conv_halo=1" (see fedfr_set_option)
+        # tuning / validation switches: FEDFR_OPTIONS="fwd_bnfuse=0,tn_glds=0" (see fedfr_set_option)
         for kv in filter(None, os.environ.get("FEDFR_OPTIONS", "").split(",")):
             k, v = kv.split("=")
             if l.fedfr_set_option(k.strip().encode(), int(v)) != 0:

@@ -108,6 +108,13 @@ class _Plan:
         _C.call("fedfr_net_query", self.handle, what, C.byref(q))
         return q.value
 
+    def handoff_errors(self) -> int:
+        """Error word of the kernels that hand data between their workgroups inside a launch (fedfr_net_handoff_errors): non-zero = a
+        grid was not co-resident and a step's results are wrong.  Synchronises the current stream."""
+        e = C.c_uint(0)
+        _C.call("fedfr_net_handoff_errors", self.handle, self.ws.data_ptr(), _C.stream(), C.byref(e))
+        return e.value
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -693,6 +700,15 @@ class IResNet(nn.Module):
 
     def trainable_count(self) -> int:
         return self._counts[_C.Q_TRAINABLE_COUNT]
+
+    def check_handoffs(self) -> None:
+        """Raise if a kernel with an in-launch hand-off (a conv that applies the BatchNorm behind it: option fwd_bnfuse) gave up waiting for
+        the rest of its grid in any pass so far — possible only while several kernel chains share the GPU, which is why ``Server.train``
+        switches those options off for concurrent clients.  Synchronises the stream: call it where the host waits anyway."""
+        for plan in self._plans.values():
+            if plan.handoff_errors():
+                raise RuntimeError("fedfr_amd: an in-launch hand-off timed out (a kernel's grid was not co-resident): the results of this "
+                                   "model's last passes are wrong.  Set FEDFR_OPTIONS=fwd_bnfuse=0,bn_fuse_bwd=0 when other work shares the GPU.")
 
 
 def _iresnet(arch, block, layers, pretrained, progress, **kwargs):

@@ -13,15 +13,11 @@
 static thread_local char g_err[512] = "";
 extern int g_tn_use_tr;
 extern int g_nt_nbuf;
-extern int g_conv_halo;
-extern int g_halo_bn64;
-extern int g_halo_waves;
 extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_nt_glds;
 extern int g_wgrad_pair_reduce;
-extern int g_tn_pair;
 extern int g_wgrad9;
 extern int g_conv_c64p;
 extern int g_bn_sliced, g_bn_sliced_pre, g_bn_sliced_bwd_passes;
@@ -31,12 +27,9 @@ extern int g_conv28_tpw2;
 extern int g_eval_fuse;
 extern int g_wgrad_depth;
 extern int g_dgrad_parity;
-extern int g_fuse_bnapply;
 extern int g_fuse_bnred_next;
-extern int g_ew_reduce_blocks, g_ew_bwd_apply_blocks, g_ew_reduce_nt;
 extern int g_bn_fuse_bwd;
-extern int g_event_nofence, g_fork_mode;
-extern int g_sph_fuse_act;
+extern int g_event_nofence;
 extern int g_sph_fin_multi;
 extern int g_sph_fuse_prelu_bwd;
 extern int g_sph_pair_wgrad;
@@ -44,9 +37,9 @@ extern int g_sph_pair_wgrad;
 extern int g_dbg_skip;
 #endif
 extern int g_c64p_bnbwd;
-extern int g_late_join;
 extern int g_stem_bnred;
 extern int g_fwd_xmom;
+extern int g_fwd_bnfuse;
 extern int g_fc_wgrad_aux;
 extern int g_fuse_bnbwd28;
 
@@ -82,11 +75,7 @@ struct OptRow { const char* name; int* var; int kind; int lo, hi; };
 const OptRow kOptions[] = {
     {"tn_use_tr", &g_tn_use_tr, 0, 0, 1},                  // 0: scalar-LDS fallback fragments of the register-staged TN kernel (validation)
     {"tn_target_blocks", &g_tn_target_blocks, 1, 1, 1 << 20},
-    {"halo_waves", &g_halo_waves, 1, 4, 8},
-    {"halo_bn64", &g_halo_bn64, 0, 0, 1},
-    {"conv_halo", &g_conv_halo, 2, 0, 0},
     {"fuse_bnred_next", &g_fuse_bnred_next, 0, 0, 1},
-    {"fuse_bnapply", &g_fuse_bnapply, 0, 0, 1},
     {"dgrad_parity", &g_dgrad_parity, 1, 0, 2},
     {"wgrad_pair_reduce", &g_wgrad_pair_reduce, 0, 0, 1},
     {"nt_glds", &g_nt_glds, 1, 0, 15},                    // 0 register-staged NT kernel, 1..4 LDS-DMA operand ring where it pays, + 8 everywhere it can (gemm_nt_glds.hip)
@@ -94,7 +83,6 @@ const OptRow kOptions[] = {
     {"wgrad_depth", &g_wgrad_depth, 1, 2, kWgradDepth},
     {"eval_fuse", &g_eval_fuse, 0, 0, 1},                  // eval-mode forward: BatchNorm (+PReLU, +identity, +next bn1) in the conv epilogues
     {"wgrad9", &g_wgrad9, 0, 0, 1},                        // nine-tap weight-gradient kernel for 3x3 / stride-1 layers
-    {"tn_pair", &g_tn_pair, 0, 0, 1},
     {"fuse_bnbwd", &g_fuse_bnbwd, 1, 0, 2},
     {"conv_c64p", &g_conv_c64p, 0, 0, 1},                  // persistent register-resident-weights kernel for the 64 -> 64 channel 3x3 layers (112x112 / 56x56)
     {"bn_sliced", &g_bn_sliced, 0, 0, 1},                  // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
@@ -104,23 +92,17 @@ const OptRow kOptions[] = {
     {"wgrad9p", &g_wgrad9p, 0, 0, 1},                      // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
     {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes, 1, 7, 64},
     {"bn_sliced_pre", &g_bn_sliced_pre, 2, 0, 0},          // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)
-    // row-slab BatchNorm-backward passes (the large maps): grid sizes may only shrink below the defaults the plans' partial-row buffers were sized with
-    {"ew_reduce_blocks", &g_ew_reduce_blocks, 1, 128, 2048},
-    {"ew_bwd_apply_blocks", &g_ew_bwd_apply_blocks, 1, 128, 2048},
-    {"ew_reduce_nt", &g_ew_reduce_nt, 1, 0, 2},
     {"bn_fuse_bwd", &g_bn_fuse_bwd, 0, 0, 1},              // reduce + apply pass of a BatchNorm backward in one launch with an in-launch hand-off (bn_sliced.hip)
     {"event_nofence", &g_event_nofence, 0, 0, 1},          // takes effect for events created afterwards (a plan creates its fork / join events on first use)
-    {"sph_fuse_act", &g_sph_fuse_act, 0, 0, 1},
     {"fuse_bnbwd28", &g_fuse_bnbwd28, 0, 0, 1},
     {"fc_wgrad_aux", &g_fc_wgrad_aux, 0, 0, 1},
     {"fwd_xmom", &g_fwd_xmom, 0, 0, 1},
+    {"fwd_bnfuse", &g_fwd_bnfuse, 0, 0, 1},                // training forward: conv1 of a block applies bn2 + PReLU itself, statistics handed over inside the launch
     {"stem_bnred", &g_stem_bnred, 0, 0, 1},
     {"sph_fuse_prelu_bwd", &g_sph_fuse_prelu_bwd, 0, 0, 1},
     {"sph_fin_multi", &g_sph_fin_multi, 0, 0, 1},
     {"sph_pair_wgrad", &g_sph_pair_wgrad, 0, 0, 1},
-    {"late_join", &g_late_join, 0, 0, 1},
     {"c64p_bnbwd", &g_c64p_bnbwd, 0, 0, 1},
-    {"fork_mode", &g_fork_mode, 0, 0, 1},
     {"nt_nbuf", &g_nt_nbuf, 1, 1, 2},
 #ifdef FEDFR_DEBUG
     {"dbg_skip", &g_dbg_skip, 2, 0, 0},                    // WRONG results: 1 = no weight-gradient launches of the residual blocks' 3x3 convs (timing bound)
@@ -224,6 +206,20 @@ int fedfr_net_set_dropout(fedfr_net_t* n, float p, unsigned long long seed, long
 int fedfr_net_set_dropout_step(fedfr_net_t* n, unsigned long long step) {
   FEDFR_REQUIRE(n && !n->block_only, "net_set_dropout_step: need a network plan");
   n->dropout_step = step;
+  return FEDFR_OK;
+}
+// the error word of the in-launch hand-offs (conv + BatchNorm in one launch: GemmNT::hout; option bn_fuse_bwd): non-zero = a workgroup gave up
+// waiting for the rest of its grid (the grid was not co-resident: several kernel chains shared the GPU) and the step's results are WRONG.
+// Synchronises `stream`; callers ask where they synchronise anyway (end of an epoch, FusedTrainer.finish()).
+int fedfr_net_handoff_errors(const fedfr_net_t* n, const void* ws, void* stream, unsigned* out) {
+  FEDFR_REQUIRE(n && ws && out, "net_handoff_errors: null");
+  *out = 0;
+  if (n->hand_ws != ws) return FEDFR_OK;                  // no pass has used this workspace: nothing to report
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(ws) + n->ws_hand + ew_bn_fused_hand_bytes();
+  if (hipMemcpyAsync(out, src, sizeof(unsigned), hipMemcpyDeviceToHost, ST(stream)) != hipSuccess || hipStreamSynchronize(ST(stream)) != hipSuccess) {
+    fedfr_set_error("net_handoff_errors: device-to-host copy failed");
+    return FEDFR_ERR_HIP;
+  }
   return FEDFR_OK;
 }
 void fedfr_net_destroy(fedfr_net_t* net) {
@@ -455,18 +451,9 @@ int fedfr_conv2d_wgrad_pair(const uint16_t* xa, const uint16_t* dya, float* dwa,
     FEDFR_TRY(ew_reduce_slabs(dwa, a.out, sp, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream)));
     return ew_reduce_slabs(dwb, b.out, sp, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream));
   }
-  if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {      // shapes the paired kernel does not take: two ordinary launches
-    FEDFR_TRY(fedfr_conv2d_wgrad(xa, dya, dwa, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream));
-    return fedfr_conv2d_wgrad(xb, dyb, dwb, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream);
-  }
-  if (!ws || ws_bytes < 2 * one) {
-    fedfr_set_error("conv2d_wgrad_pair: workspace too small (%zu bytes, need %zu)", ws_bytes, 2 * one);
-    return FEDFR_ERR_WORKSPACE;
-  }
-  a.out = (float*)ws; b.out = (float*)((char*)ws + one);
-  FEDFR_TRY(gemm_tn_launch_pair(a, b, splits, ST(stream)));
-  FEDFR_TRY(ew_reduce_slabs(dwa, a.out, splits, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream)));
-  return ew_reduce_slabs(dwb, b.out, splits, (size_t)p.NI * p.NJ, nullptr, 0, ST(stream));
+  // shapes the paired kernel does not take: two ordinary launches
+  FEDFR_TRY(fedfr_conv2d_wgrad(xa, dya, dwa, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream));
+  return fedfr_conv2d_wgrad(xb, dyb, dwb, ws, ws_bytes, batch, hin, cin, cout, ksize, stride, stream);
 }
 int fedfr_weight_shadows(const float* w, uint16_t* wb, uint16_t* wdb, int cout, int ksize, int cin, void* stream) {
   FEDFR_REQUIRE(w, "weight_shadows: null");

@@ -18,25 +18,10 @@
 // input rows (net.hip alternates between two partial-row buffers).
 #include "ew.h"
 #include "gemm_dev.h"   // ProfScope
-#include <hip/hip_ext.h>
 
-// A caller that forks a second stream right behind a BatchNorm-backward apply pass can have the fork event ATTACHED to that launch
-// (hipExtLaunchKernel's stopEvent = the kernel's own completion signal) instead of recording it behind the kernel: an event record is a
-// packet of its own in the stream's queue, and the next kernel of the stream waits for it (~7.5 us of main-stream bubble per fork in the
-// kernel trace, 49 forks per backward pass).  ew_bn_set_stop_event(e) arms it for the NEXT sliced / fused apply launch of this thread;
-// ew_bn_take_stop_event() tells the caller whether a launch consumed it (else it records the event the ordinary way).
-static thread_local hipEvent_t t_stop_event = nullptr;
-void ew_bn_set_stop_event(hipEvent_t e) { t_stop_event = e; }
-bool ew_bn_stop_event_pending() { return t_stop_event != nullptr; }
-void ew_bn_clear_stop_event() { t_stop_event = nullptr; }
 template <typename K, typename P>
 static inline void launch_maybe_stop(K kernel, dim3 grid, dim3 block, hipStream_t st, P p) {
-  if (t_stop_event) {
-    hipExtLaunchKernelGGL(kernel, grid, block, 0, st, nullptr, t_stop_event, 0, p);
-    t_stop_event = nullptr;
-  } else {
-    hipLaunchKernelGGL(kernel, grid, block, 0, st, p);
-  }
+  hipLaunchKernelGGL(kernel, grid, block, 0, st, p);
 }
 
 #ifndef BNS_PRIO

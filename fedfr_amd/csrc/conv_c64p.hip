@@ -355,7 +355,7 @@ int conv_c64p_grid(int M) {                 // workgroups of a launch over M out
 bool conv_c64p_applies(const GemmNT& p) {
   return g_conv_c64p && p.mode == 1 && p.S == 3 && p.C == 64 && p.N == 64 && p.K == 576 && p.stride == 1 && p.pad == 1 && p.up == 1 && p.H == p.W &&
          (p.W == 112 || p.W == 56) && p.Ho == p.H && p.Wo == p.W && p.M % (p.W * p.W) == 0 && p.Cb && p.ldc == 64 && !p.Cf && !(p.bpart && p.stats) &&
-         !p.tsc && !p.esc && !p.eadd && !p.Cb2 && !p.par_on;
+         !p.esc && !p.eadd && !p.Cb2 && !p.par_on;
 }
 int launch_conv_c64p(GemmNT p, hipStream_t st) {
   FEDFR_REQUIRE(conv_c64p_applies(p), "conv3x3_c64p: unsupported shape");

@@ -2,4 +2,4 @@
 // per workgroup = 256 rows at B = 128 instead of 1024, few enough for the channel-sliced BatchNorm pass to reduce itself) -- alone in its
 // translation unit (gemm_dev.h)
 #include "conv_glds_impl.h"
-int launch_conv_glds8_w28_stats(GemmNT p, hipStream_t st) { return launch_glds<28, 7, 40, 4, false, 128, false, false, 2>(p, st); }
+int launch_conv_glds8_w28_stats(GemmNT p, hipStream_t st) { return launch_glds<28, 7, 40, 4, false, 128, false, 2>(p, st); }

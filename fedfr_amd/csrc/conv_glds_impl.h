@@ -61,7 +61,7 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false, int TPW = 1>   // TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); XFORM: BN(+PReLU) of the input applied to the LDS image; BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1, bool HF = false>   // HF: the train-mode BatchNorm (+PReLU) behind the conv applied by this launch, statistics handed over between its workgroups (GemmNT::hout); TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
   constexpr int PT = R_ * W_, BN = BN_, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   int img = bt / TPI, y0 = (bt - img * TPI) * R_;
   int m0 = bt * PT;
   const int n0 = bn * BN;
-  static_assert(TPW == 1 || !XFORM, "several tiles per workgroup: not with the input transform");
+  static_assert(!HF || (!FUSED && !ONECHUNK && BN_ == 128 && WN == 4), "hand-off variant: plain 8-wave kernel, 128-channel tiles");
   // XLATE (FUSED with several tiles per workgroup, round 3): the two-tiles instantiation sits at the register limit, so the BatchNorm input
   // tile cannot ride through the K loop in registers.  It is requested right BEHIND the loop (after the drain of the tail DMAs: the loads
   // fly while the accumulators are staged) and the tiles' column sums meet in LDS: ONE partial row per workgroup.
@@ -197,44 +197,6 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) acc[ni][mi] = MFMA16(fb[ni], fa[mi], acc[ni][mi]);
   };
-  // XFORM: per-channel (scale, shift, PReLU slope) of the input's BatchNorm staged in LDS behind the weight ring; every wave
-  // transforms the image pieces IT fetched (its own counted vmcnt covers them) just before a barrier that publishes them, so
-  // the pass needs no extra synchronisation; zero-padding rows (out-of-range DMA) are skipped and stay zero.
-  float* sCoef = reinterpret_cast<float*>(smem + NABUF * A_BYTES + NB * B_BYTES);     // [3][C]
-  const bool has_talpha = XFORM && p.talpha != nullptr;
-  auto transform_piece = [&](int abuf, int cc, int j) {
-    float sc[8], sh[8], al[8];
-    const float* cf = sCoef + cc * 64 + pch * 8;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { sc[q] = cf[q]; sh[q] = cf[p.C + q]; al[q] = cf[2 * p.C + q]; }
-    if (a_src[j] != OOB) {
-      uint4* q4 = reinterpret_cast<uint4*>(sA + abuf * A_BYTES + (j * NW + wave) * 1024 + lane * 16);
-      float f[8];
-      unpack8(*q4, f);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float v = f[q] * sc[q] + sh[q];
-        if (has_talpha) v = v > 0.f ? v : al[q] * v;
-        f[q] = v;
-      }
-      *q4 = pack8(f);
-    }
-  };
-  auto transform = [&](int abuf, int cc) {
-#pragma unroll
-    for (int j = 0; j < AP; ++j) transform_piece(abuf, cc, j);
-  };
-  // the transformed centre rows of chunk cc (= the normalised activation, the wgrad operand) go back to global once per image tile
-  auto writeback = [&](int abuf, int cc) {
-    if (bn == 0 && p.aout)
-      for (int idx = tid; idx < PT * 8; idx += NT) {
-        const int t = idx >> 3, c8 = idx & 7;
-        const int y = t / W_, x = t - y * W_;
-        const int r = (y + 1) * PWL + x + 1;
-        const uint4 v = *reinterpret_cast<const uint4*>(sA + abuf * A_BYTES + r * 128 + ((c8 ^ (r & 7)) << 4));
-        *reinterpret_cast<uint4*>(p.aout + (size_t)(m0 + t) * p.C + cc * 64 + c8 * 8) = v;
-      }
-  };
 #pragma unroll 1
   for (int ti = 0; ti < TPW; ++ti) {
   if (TPW > 1 && ti > 0) {
@@ -268,16 +230,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   issue_b(RST ? 3 : 1, 0, 1, true);                      // RST walks the taps dx-major: (dy, dx) = (0,0), (1,0), (2,0), (0,1), ...
   issue_b(RST ? 6 : 2, 0, 2, true);
   bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
-  if constexpr (XFORM) {                               // coefficient staging overlaps the first DMA round trip
-    for (int i = tid; i < p.C; i += NT) {
-      sCoef[i] = p.tsc[i];
-      sCoef[p.C + i] = p.tsh[i];
-      sCoef[2 * p.C + i] = p.talpha ? p.talpha[i] : 1.f;
-    }
-    __syncthreads();
-  }
   glds_wait_vmcnt<2 * BP>();
-  if constexpr (XFORM) transform(0, 0);
   __builtin_amdgcn_s_barrier();
   GLDS_STAMP(1);
   if constexpr (RST) {
@@ -310,16 +263,6 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           const int boff = (ONECHUNK ? 0 : h) * A_BYTES;
           const int boffn = (ONECHUNK ? 0 : (it == 8 ? (h ^ 1) : h)) * A_BYTES;
           const unsigned char* cB = sB + bbuf * B_BYTES;
-          if constexpr (XFORM) {
-            if (it == 1) {
-              writeback(ONECHUNK ? 0 : h, cc);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!ONECHUNK && it == 8 && more_c) {
-              transform(h ^ 1, cc + 1);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
           // ---- first half: k-step 0 MFMAs; this tap's NEW k-step 1 fragments are read between them
           if (!(GLDS_ABLATE & 4)) {
 #pragma unroll
@@ -393,16 +336,6 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         const int tapn = tap == 8 ? 0 : tap + 1;
         const int aoffn = (ONECHUNK ? 0 : (tap == 8 ? (h ^ 1) : h)) * A_BYTES + (tapn / 3) * PWL * 128;
         const unsigned char* cB = sB + bbuf * B_BYTES;
-        if constexpr (XFORM) {
-          if (tap == 1) {                                    // this chunk's transformed image is visible since the last barrier
-            writeback(ONECHUNK ? 0 : h, cc);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (!ONECHUNK && tap == 8 && more_c) {             // next chunk's image landed (taps >= 3 retired it): normalise own pieces.
-            transform(h ^ 1, cc + 1);                        // (one piece per tap "under" the MFMAs measured slower: hipcc serialises it)
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
         // ---- first half: k-step 0 MFMAs, with the fragment reads of k-step 1 threaded between them
         if (!(GLDS_ABLATE & 4)) read_frags(f1a, f1b, aoff, tap % 3, cB, 1);
         GLDS_PRIO(1);
@@ -567,7 +500,21 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         }
       }
   }
-  if (TPW == 1 && p.stats) {
+  if constexpr (HF && TPW == 1) {                       // the tile's two wave rows meet in LDS (the drained weight ring): ONE row per workgroup
+    float* hS = reinterpret_cast<float*>(smem + XOFF);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
+        const int col = wn * (BN / WN) + ni * 16 + lg * 4 + q;
+        if (l15 == 0) {
+          hS[wm * 2 * BN + col] = a;
+          hS[wm * 2 * BN + BN + col] = b;
+        }
+      }
+  }
+  if (TPW == 1 && p.stats && !HF) {
     const int ntile = gridDim.x / p.nbn;
     float* prow_ = p.stats + (size_t)(bt * WM + wm) * 2 * p.N;
 #pragma unroll
@@ -590,6 +537,24 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       }
   }
   __syncthreads();
+  if constexpr (HF) {
+    if (ti == TPW - 1) {
+      // the workgroup's statistics row is complete: publish it (write-through stores, drained, then ONE counter add per workgroup, one counter per launch: MI355X_MICROARCH.md,
+      // inter-workgroup visibility) BEFORE the copy-out below, so that the row travels while the tile is stored
+      const float* hs = TPW == 1 ? reinterpret_cast<const float*>(smem + XOFF) : sStat;
+      int hz;                                              // (opaque zero: nothing below may be computed in front of the K loop and kept through it)
+      asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
+      const int ht = tid + hz;
+      if (ht < 2 * BN) {
+        const int stat = ht / BN, col = ht - stat * BN;
+        __hip_atomic_store(p.stats + (size_t)btw * 2 * p.N + (size_t)stat * p.N + n0 + col, hs[ht] + hs[2 * BN + ht], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (ht == 0) __hip_atomic_fetch_add(p.hcnt + hz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   constexpr int CPR = BN / 8;
   if constexpr (!FUSED) {
     for (int idx = tid; idx < PT * CPR; idx += NT) {
@@ -761,7 +726,115 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       o[2 * (size_t)p.N] = t2;
     }
   }
-  if constexpr (TPW > 1) {
+  if constexpr (HF) {
+    // ---- the BatchNorm behind this conv (GemmNT::hout): wait for the rows of every workgroup of this N tile ...
+    int hz;                                                // (opaque zero, as above)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
+    const int ht = tid + hz;
+    if (ht == 0) {
+      unsigned spins = 0;
+      while ((int)(__hip_atomic_load(p.hcnt + hz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.htarget) < 0) {
+        if (++spins > (1u << 22)) {                        // ~ seconds: a workgroup of this grid never became resident
+          atomicOr(p.herr, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    // ... sum them per column in fp64, in the order of the stand-alone pass (bn_sliced.hip, fan_in_*: row group rg = rows rg, rg + 16, ...,
+    // then the 16 groups in ascending order) -> the same bits.  Thread: float4 column c4 (statistic c4 >> 5), row groups wave and wave + 8.
+    const int P = stat_rows;                               // (HF: the launcher passes the number of workgroups per N tile = statistics rows)
+    constexpr int HXOFF = NABUF * A_BYTES, HCST = BN * 2 + 16;        // the drained weight ring / the staged tile's row pitch (see the epilogue above)
+    double* red = reinterpret_cast<double*>(smem + HXOFF + 4096);     // [16][2 BN]
+    double* tot = red + 16 * 2 * BN;                                  // [2 BN]
+    float* cf = reinterpret_cast<float*>(tot + 2 * BN);               // [2][BN]: scale, shift
+    static_assert(4096 + (16 * 2 * BN + 2 * BN) * 8 + 2 * BN * 4 <= NB * B_BYTES, "hand-off scratch must fit the weight ring");
+    {
+      const __amdgpu_buffer_rsrc_t rsS = make_rsrc(p.stats, (unsigned)((size_t)P * 2 * (size_t)p.N * 4));
+      const int c4 = ht & 63;
+      const unsigned coff = ((unsigned)(c4 >> 5) * (unsigned)p.N + (unsigned)n0 + (unsigned)(c4 & 31) * 4u) * 4u;
+      const unsigned rstride = 2u * (unsigned)p.N * 4u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rg = (ht >> 6) + 8 * h;
+        u32x4_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = rg + 16 * i;
+          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, (int)(row < P ? (unsigned)row * rstride + coff : OOB), 0, 16);   // sc1: served by L2 / memory, never a stale L1 line
+        }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          a0 += (double)__uint_as_float(v[i][0]); a1 += (double)__uint_as_float(v[i][1]);
+          a2 += (double)__uint_as_float(v[i][2]); a3 += (double)__uint_as_float(v[i][3]);
+        }
+        double* d = red + rg * 2 * BN + c4 * 4;
+        d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
+      }
+    }
+    __syncthreads();
+    if (ht < 2 * BN) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i * 2 * BN + ht];
+      tot[ht] = t;
+    }
+    __syncthreads();
+    if (ht < BN) {
+      const int cch = n0 + ht;
+      const double mean = tot[ht] / p.hcount;
+      double var = tot[BN + ht] / p.hcount - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double rstd = 1.0 / sqrt(var + (double)p.heps);
+      const float ga = p.hgamma ? p.hgamma[cch] : 1.f, be = p.hbeta ? p.hbeta[cch] : 0.f;
+      const float sc = (float)((double)ga * rstd), sh = (float)((double)be - mean * (double)ga * rstd);
+      cf[ht] = sc;
+      cf[BN + ht] = sh;
+      if (btw == 0) {                                      // the workgroups of image tile 0 leave what the backward pass / the caller reads
+        p.hscale[cch] = sc; p.hshift[cch] = sh; p.hmean[cch] = (float)mean; p.hrstd[cch] = (float)rstd;
+        if (p.hrm) {
+          const double unb = p.hcount > 1.0 ? var * p.hcount / (p.hcount - 1.0) : var;
+          p.hrm[cch] = (float)((1.0 - p.hmomentum) * (double)p.hrm[cch] + p.hmomentum * mean);
+          p.hrv[cch] = (float)((1.0 - p.hmomentum) * (double)p.hrv[cch] + p.hmomentum * unb);
+        }
+      }
+    }
+    __syncthreads();
+    // ... and apply: hout = prelu?(tile * scale + shift) — the last tile from LDS (still staged), earlier ones re-read (own stores, drained above)
+    {
+      constexpr int CPRH = BN / 8;
+      const int ch = ht % CPRH;
+      float sc[8], sh[8], al[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        sc[q] = cf[ch * 8 + q];
+        sh[q] = cf[BN + ch * 8 + q];
+        al[q] = p.halpha ? p.halpha[n0 + ch * 8 + q] : 1.f;
+      }
+      const bool has_alpha = p.halpha != nullptr;
+#pragma unroll 1
+      for (int t2 = 0; t2 < TPW; ++t2) {
+        const int mt = (btw * TPW + t2) * PT;
+        for (int idx = ht; idx < PT * CPRH; idx += NT) {
+          const int row = idx / CPRH;
+          const size_t go = (size_t)(mt + row) * p.ldc + n0 + ch * 8;
+          const uint4 v = t2 == TPW - 1 ? *reinterpret_cast<const uint4*>(smem + row * HCST + ch * 16) : *reinterpret_cast<const uint4*>(p.Cb + go);
+          float f[8];
+          unpack8(v, f);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float y = f[q] * sc[q] + sh[q];
+            if (has_alpha) y = y > 0.f ? y : al[q] * y;
+            f[q] = y;
+          }
+          *reinterpret_cast<uint4*>(p.hout + go) = pack8(f);
+        }
+      }
+    }
+  }
+  if constexpr (TPW > 1 && !HF) {
     // one partial row per workgroup: wave row 0 + wave row 1 of the LDS partials (every tile's epilogue ended with a barrier)
     if (p.stats) {
       const int nrows = gridDim.x / p.nbn;
@@ -780,13 +853,22 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, bool XFORM = false, int TPW = 1>
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1, bool HF = false>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
   FEDFR_REQUIRE(p.N % BN_ == 0 && (ONECHUNK ? p.C == 64 : p.C % 128 == 0) && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
                 "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
   FEDFR_REQUIRE(FUSED == (p.bpart != nullptr), "conv3x3_glds: fused / plain variant mismatch");
-  FEDFR_REQUIRE(XFORM == (p.tsc != nullptr) && (!XFORM || (p.tsh && p.C <= 256)), "conv3x3_glds: input-transform variant mismatch");
+  FEDFR_REQUIRE(HF == (p.hout != nullptr), "conv3x3_glds: hand-off (BatchNorm in the launch) variant mismatch");
+  if (HF) {
+    FEDFR_REQUIRE(p.stats && p.hcnt && p.herr && p.hscale && p.hshift && p.hmean && p.hrstd && p.hcount > 0.0 && p.ldc == p.N && !p.esc && !p.eadd && !p.Cb2,
+                  "conv3x3_glds: the hand-off variant needs stats / counters / coefficient outputs, ldc == N and no other epilogue");
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    FEDFR_REQUIRE((p.M / PT / TPW) * (p.N / BN_) <= cus, "conv3x3_glds: the hand-off variant needs its %d workgroups co-resident, the device has %d CUs",
+                  (p.M / PT / TPW) * (p.N / BN_), cus);
+  }
   FEDFR_REQUIRE(!(p.esc || p.eadd || p.Cb2) || (!FUSED && p.ldc == p.N && (!p.esc || p.esh) && (!p.Cb2 || (p.esc2 && p.esh2) || p.e2alpha)),
                 "conv3x3_glds: output epilogue needs the plain variant, ldc == N and complete coefficient sets");
   if (FUSED) {
@@ -799,14 +881,14 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   p.nbn = p.N / BN_;
   FEDFR_REQUIRE((p.M / PT) % TPW == 0, "conv3x3_glds: %d tiles do not split into groups of %d", p.M / PT, TPW);
   const int ntile = p.M / PT / TPW;                     // workgroups per output-channel tile
-  constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128 + (XFORM ? 3 * 256 * 4 : 0) + (TPW > 1 ? 4 * (size_t)BN_ * 4 : 0);
+  constexpr size_t lds = (ONECHUNK ? 1 : 2) * (size_t)NPA * 1024 + 4 * (size_t)BN_ * 128 + (TPW > 1 ? 4 * (size_t)BN_ * 4 : 0);
   static_assert(lds >= (size_t)PT * (BN_ * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW, HF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15),   /* slot 15: 56x56 and 112x112 */ 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, XFORM, TPW>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW, HF>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, HF ? ntile : gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

@@ -105,9 +105,6 @@ struct BnBwdS {
 };
 size_t ew_bn_fused_hand_bytes();
 // fork event attached to the next sliced / fused BatchNorm-backward apply launch of this thread (bn_sliced.hip)
-void ew_bn_set_stop_event(hipEvent_t e);
-bool ew_bn_stop_event_pending();
-void ew_bn_clear_stop_event();
 // reduce pass + apply pass of a BatchNorm backward in ONE launch (same geometry, same arithmetic and summation order as
 // ew_bn_bwd_reduce_sliced followed by ew_bn_bwd_apply_sliced: bit-identical results); the tensors stay in registers across the hand-off
 bool ew_bn_bwd_fused_ok(int M, int C);

@@ -538,23 +538,23 @@ __global__ __launch_bounds__(EW_THREADS, ALPHA ? 4 : 5) void bn_bwd_reduce_kerne
   ew_block_colsum<3>(acc, p.C, tpr, rpp, cl, rl, active, shfl != 0, red, p.partials + (size_t)bid * 3 * p.C);
 }
 
-int g_ew_reduce_blocks = 512;       // option "ew_reduce_blocks": workgroups a row-slab bn_bwd_reduce launch aims for (= partial rows it leaves)
-int g_ew_bwd_apply_blocks = 2048;   // option "ew_bwd_apply_blocks": ... a row-slab bn_bwd_apply launch
-int g_ew_reduce_nt = 0;             // option "ew_reduce_nt": cache policy of the row-slab reduce pass's loads (0 plain, 1 x non-temporal, 2 both)
-int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, g_ew_reduce_blocks)); }
+// workgroups a row-slab bn_bwd_reduce / bn_bwd_apply launch aims for (= partial rows it leaves).  Round 3 swept both and the loads' cache policy
+// (profiles/r03_ab_ew_rowslab_options_v1.txt): nothing moved the step, the sweep's switches are gone
+constexpr int kEwReduceBlocks = 512, kEwBwdApplyBlocks = 2048;
+int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, kEwReduceBlocks)); }
 
 int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_reduce"));
   FEDFR_REQUIRE(p.dy && p.x && p.partials, "bn_bwd_reduce: null tensor");   // mean / rstd null: 0 / 1 (bias + PReLU backward)
   FEDFR_REQUIRE(!p.sc == !p.sh, "bn_bwd_reduce: scale and shift come together");
-  const int slab = slab_rows(p.M, p.C, g_ew_reduce_blocks);
+  const int slab = slab_rows(p.M, p.C, kEwReduceBlocks);
   const int grid = ceil_div(p.M, slab);
   const size_t lds = ew_colsum_lds(p.C, 3);
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;
   ProfScope prof(21, (double)p.M * p.C * 2 * 2, st);
 #define BWD_RED(A, N) hipLaunchKernelGGL((bn_bwd_reduce_kernel<A, N>), dim3(grid), dim3(EW_THREADS), lds, st, p, slab, shfl)
-  if (p.alpha) { if (g_ew_reduce_nt == 2) BWD_RED(true, 2); else if (g_ew_reduce_nt == 1) BWD_RED(true, 1); else BWD_RED(true, 0); }
-  else { if (g_ew_reduce_nt == 2) BWD_RED(false, 2); else if (g_ew_reduce_nt == 1) BWD_RED(false, 1); else BWD_RED(false, 0); }
+  if (p.alpha) BWD_RED(true, 0);
+  else BWD_RED(false, 0);
 #undef BWD_RED
   FEDFR_LAUNCH_CHECK("bn_bwd_reduce");
   return FEDFR_OK;
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(EW_THREADS, ((ALPHA && NX) || NX == 2) ? 3 : (ALPHA
   }
 }
 
-int ew_bn_bwd_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, g_ew_bwd_apply_blocks)); }
+int ew_bn_bwd_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, kEwBwdApplyBlocks)); }
 
 int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_bwd_apply"));
@@ -741,7 +741,7 @@ int ew_bn_bwd_apply(const BnBwd& p, hipStream_t st) {
   if (p.nx) FEDFR_REQUIRE(p.nmean && p.nrstd && p.npart, "bn_bwd_apply: next-BN reduction needs mean / rstd / partials");
   const bool nxa = p.nx && p.nalpha;
   if (nxa) FEDFR_REQUIRE(p.nsc && p.nsh && !p.alpha && !p.add, "bn_bwd_apply: the PReLU form of the next-BN reduction needs that BN's (scale, shift) and serves the plain variant only");
-  const int slab = slab_rows(p.M, p.C, g_ew_bwd_apply_blocks);
+  const int slab = slab_rows(p.M, p.C, kEwBwdApplyBlocks);
   const dim3 grid(ceil_div(p.M, slab));
   const size_t lds = p.nx ? ew_colsum_lds(p.C, nxa ? 3 : 2) : 0;
   const int shfl = ew_shfl_ok(p.C) ? 1 : 0;

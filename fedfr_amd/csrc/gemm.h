@@ -38,11 +38,6 @@ struct GemmNT {
   // bn(y) + bx (the next block's bn1) without a pass over that sum (net.hip, conv2 of a residual block).  bmean / brstd: any readable [N].
   int bmom;               // 2 (dgrad launches, sphnet): a bare PReLU(+bias) precedes the conv — the OUTPUT becomes dz = dy * prelu'(bx + bias) (bias in
                           // bbeta or null, slopes in balpha), rows [3][N] = (sum dz, sum dy z over z <= 0, same): the PReLU's backward pass disappears
-  // optional INPUT transform of the LDS-DMA conv kernel (forward of a conv whose input is BatchNorm(+PReLU) of a stored tensor): the
-  // kernel reads the raw tensor, applies y = x * tsc[c] + tsh[c] (then PReLU with talpha[c] if given) to its LDS image, so the
-  // normalised activation needs no separate bn_apply pass; aout (optional) receives that activation (the wgrad operand).
-  const float *tsc, *tsh, *talpha;
-  bf16_t* aout;
   // stride-2 dgrad by output-parity class (gemm.hip: nt_launch_parity): this launch computes the output pixels (2 h2 + par_h, 2 w2 + par_w)
   // of a [img][outH][outW] map with only the filter taps that reach a real (non-inserted-zero) input: 1, 2, 2 or 4 of the 9
   int par_on, par_h, par_w, outH, outW;
@@ -58,6 +53,22 @@ struct GemmNT {
   // same bf16-rounded conv output as the separate ew_bn_apply pass, so both forms give identical bits; Cb keeps the raw conv output
   const float* e2alpha;
   const bf16_t* e2add;
+  // round 4 (training forward): the TRAIN-MODE BatchNorm (+PReLU) that follows this conv, applied by the conv launch itself (conv_glds_impl.h, HF
+  // instantiations).  A BatchNorm is a grid-wide dependency; here the launch's workgroups hand their partial statistics rows to each other:
+  // every workgroup stores its row of `stats` write-through (agent scope), counts itself in *hcnt, copies its raw output tile out,
+  // then waits until the counter has reached htarget (every workgroup of the launch: bounded spin, *herr set on a time-out), sums the rows of
+  // its channels in the order of the stand-alone pass (bn_sliced.hip, fan_in: same bits), derives (scale, shift) and writes
+  // hout = prelu?(Cb * scale + shift) from the tile it still holds in LDS.  Needs the whole grid co-resident: the launcher refuses grids
+  // larger than the device's CU count (one workgroup per CU), callers switch it off when several kernel chains share the GPU.
+  bf16_t* hout;                             // null: off
+  const float *hgamma, *hbeta, *halpha;     // halpha null: no PReLU
+  float *hrm, *hrv;                         // running statistics, updated by the workgroups of image tile 0
+  float hmomentum, heps;
+  double hcount;
+  float *hscale, *hshift, *hmean, *hrstd;   // [N] each: what the backward pass reads
+  unsigned* hcnt;                           // arrival counter, monotonic over launches (zeroed once with the workspace)
+  unsigned htarget;                         // value *hcnt has once every workgroup of this launch has arrived
+  unsigned* herr;
   unsigned long long* dbg;   // diagnostics builds only (tools/stamp_halo2.hip): per-block in-kernel clock stamps
 };
 
@@ -79,17 +90,16 @@ struct GemmTN {
 // rows of partial stats the NT kernel writes for a given M (needed to size / finalize)
 int gemm_nt_stat_rows(int M, int N);
 bool gemm_nt_fused28_two_tiles(int M);   // a fused (BatchNorm-backward reduction) 28x28 dgrad of M output pixels leaves M / 392 partial rows
-int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride, bool xform = false);   // leading rows that are not zero filler
-bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride);
+int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride);   // leading rows that are not zero filler
 // shapes whose conv runs on an LDS-DMA kernel that implements the output epilogue (esc / eadd / Cb2)
 bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
+// ... and on an instantiation that can apply the train-mode BatchNorm behind it itself (GemmNT::hout): 14x14 maps, or 28x28 with two tiles
+// per workgroup, with at most one workgroup per CU of the current device
+bool gemm_nt_conv_handoff_ok(int W, int C, int N, int M, int ksize, int stride);
 // number of splits / workspace helpers
 int gemm_nt_pick_splits(int M, int N, int K);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st);
 int gemm_tn_launch(GemmTN p, int splits, hipStream_t st);
-// two same-shape conv weight-gradient problems in one launch (LDS-DMA kernel, two blocks per CU); check gemm_tn_pair_ok first
-bool gemm_tn_pair_ok(const GemmTN& a, const GemmTN& b, int splits);
-int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
 // the two same-shape 3x3 / stride-1 weight gradients of a residual block on the paired nine-tap kernel (wgrad9p.hip)
 bool gemm_tn_w9pair_ok(const GemmTN& a, const GemmTN& b);
 int gemm_tn_w9pair_splits(const GemmTN& a);

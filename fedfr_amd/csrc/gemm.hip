@@ -11,7 +11,7 @@
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------
 // slots: 0..3 = gemm_nt <128,128> <128,64> <64,128> <64,64>; 4..7 = gemm_tn <128,128> <128,64> <64,128> <64,64>;
-// 8 = conv3x3_halo2<128,14>, 9 = conv3x3_halo2<128,28>, 10 = conv3x3_halo2<64,*>, 11 = conv3x3_halo (v1, all),
+// 8..11 = (retired: the register-staged LDS-halo 3x3 kernels of rounds 1-3),
 // 12 = conv3x3_glds<14,14>, 13 = conv3x3_glds<28,7>, 14 = gemm_tn_glds<128,128>, 15 = conv3x3_glds<56,4> (64 channels), 16 = wgrad9,
 // 17 = gemm_nt_glds (all tiles)
 namespace {
@@ -67,10 +67,6 @@ int gemm_profile_read(int slot, double* total_ms, long long* launches, double* f
 }
 
 
-int g_halo_waves = 4;  // option "halo_waves": 4 or 8 waves per 128x128 tile in the halo2 kernel
-int g_halo_bn64 = 0;   // option "halo_bn64": 64-wide N tiles in the halo2 kernel (more, smaller blocks)
-int g_conv_halo = 4;   // option "conv_halo": 0 generic gather kernel, 1 halo v1 (masked, swizzled), 2 zero-padded image (W=14/28) else v1,
-                       // 3 LDS-DMA pipeline (W=14/28, Cout%128==0) else 2, 4 = 3 with 8 waves per tile
 
 // =====================================================================================================
 // NT kernel
@@ -300,19 +296,18 @@ int gemm_nt_stat_rows(int M, int N) {
 // writes so that a finalize over the 128-pixel-tile row count stays right): the 196-pixel-tile LDS-DMA kernels leave 2 per tile
 bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
 int g_conv28_tpw2 = 2;   // option "conv28_tpw2": 28x28 convs run two image tiles per workgroup -- 1: the forward launches (one BatchNorm partial row per workgroup: 256 instead of 1024), 2: the dgrad launches too (256 workgroups that stay instead of 512 that are dispatched in two rounds between the weight-gradient workgroups: 17.72 -> 17.54 ms/step same-box)
-static bool glds28_two_tiles_shape(int M) { return g_conv28_tpw2 && g_conv_halo >= 4 && (M / 196) % 2 == 0; }
+static bool glds28_two_tiles_shape(int M) { return g_conv28_tpw2 && (M / 196) % 2 == 0; }
 // the 28x28 dgrad with the BatchNorm-backward reduction in its epilogue runs two tiles per workgroup as well (one partial row each)
 bool gemm_nt_fused28_two_tiles(int M) { return g_conv28_tpw2 >= 2 && glds28_two_tiles_shape(M); }
 static bool glds28_two_tiles(const GemmNT& p) {          // option value 2: the dgrad launches (no statistics) too
   return (p.stats || g_conv28_tpw2 >= 2) && p.W == 28 && !p.esc && !p.eadd && !p.Cb2 && glds28_two_tiles_shape(p.M);
 }
-// xform: the conv ran on the input-transform kernel (conv_glds_x.hip, option fuse_bnapply), which keeps two rows per tile
-int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride, bool xform) {
+int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride) {
   if ((W == 14 || W == 28) && gemm_nt_conv_epilogue_ok(W, C, N, M, ksize, stride))
-    return (W == 28 && !xform && glds28_two_tiles_shape(M)) ? M / 196 / 2 : M / 196 * 2;
+    return (W == 28 && glds28_two_tiles_shape(M)) ? M / 196 / 2 : M / 196 * 2;
   // the persistent 64-channel kernel: two rows per workgroup, at most one workgroup per CU (conv_c64p.hip: launch_c64p) — 512 rows instead
   // of 6 272 / 25 088, few enough for the finalize kernel to take without the staging launch in front of it
-  if (!xform && g_conv_c64p && ksize == 3 && stride == 1 && C == 64 && N == 64 && (W == 56 || W == 112) && M % (W * W) == 0) return 2 * conv_c64p_grid(M);
+  if (g_conv_c64p && ksize == 3 && stride == 1 && C == 64 && N == 64 && (W == 56 || W == 112) && M % (W * W) == 0) return 2 * conv_c64p_grid(M);
   return gemm_nt_stat_rows(M, N);
 }
 
@@ -321,19 +316,25 @@ int g_dgrad_parity = 2;   // option "dgrad_parity": stride-2 3x3 dgrad as 4 outp
 // shapes whose conv runs on a plain LDS-DMA kernel instantiation (mirrors the dispatch in gemm_nt_launch_one): those implement the
 // eval-mode output epilogue (GemmNT::esc / eadd / Cb2)
 bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride) {
-  if (g_conv_halo < 4 || ksize != 3 || stride != 1 || W <= 0 || M % (W * W) != 0 || nt_bm(M, N) != 128) return false;
+  if (ksize != 3 || stride != 1 || W <= 0 || M % (W * W) != 0 || nt_bm(M, N) != 128) return false;
   if (W == 112) return C == 64 && N == 64;
   if (W == 56) return (C == 64 && (N == 64 || N == 128)) || (C == 128 && N == 64);
   if (W == 14 || W == 28) return N % 128 == 0 && C % 128 == 0;
   return false;
 }
 
-// shapes whose forward conv can take its input's BatchNorm(+PReLU) as an LDS-image transform (conv_glds_x.hip)
-bool gemm_nt_conv_xform_ok(int W, int C, int N, int M, int ksize, int stride) {
-  if (g_conv_halo < 4 || ksize != 3 || stride != 1 || M % (W * W) != 0 || C > 256) return false;
-  if (W == 14 || W == 28) return N % 128 == 0 && C % 128 == 0;
-  if (W == 56) return C == 64 && (N == 64 || N == 128);
-  return false;
+// shapes whose forward conv runs on an instantiation that applies the train-mode BatchNorm behind it itself (conv_glds_impl.h, HF): the whole
+// grid must be co-resident, one workgroup per CU
+bool gemm_nt_conv_handoff_ok(int W, int C, int N, int M, int ksize, int stride) {
+  if (ksize != 3 || stride != 1 || (W != 14 && W != 28) || M % (W * W) != 0 || N % 128 != 0 || C % 128 != 0 || nt_bm(M, N) != 128) return false;
+  if (W == 28 && !glds28_two_tiles_shape(M)) return false;
+  static int cus[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& n = cus[dev & 63];
+  if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+  const int wgs = (W == 14 ? M / 196 : M / 392) * (N / 128);
+  return n > 0 && wgs <= n;
 }
 
 static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st);
@@ -384,37 +385,32 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
     p.b_bytes = (unsigned)bb;
   }
   if (p.esc || p.eadd || p.Cb2)
-    FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.pad == 1 && p.H == p.W && p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && !p.bpart && !p.tsc &&
+    FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.pad == 1 && p.H == p.W && p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && !p.bpart &&
                   !p.stats && !p.par_on && gemm_nt_conv_epilogue_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: output epilogue is not available for this convolution");
-  if (p.tsc) {
-    FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.H == p.W && p.H == p.Ho && p.Cb && splits == 1 && !p.bpart &&
-                  gemm_nt_conv_xform_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: input transform is not available for this convolution");
-    return launch_conv_glds_x(p, st);
+  if (p.hout) {
+    FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.pad == 1 && p.H == p.W && p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && !p.bpart && !p.par_on &&
+                  p.stats && gemm_nt_conv_handoff_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: the BatchNorm hand-off is not available for this convolution");
+    return p.W == 14 ? launch_conv_glds8_w14_handoff(p, st) : launch_conv_glds8_w28_handoff(p, st);
   }
   if (splits == 1 && conv_c64p_applies(p)) return launch_conv_c64p(p, st);
   const int BM = nt_bm(p.M, p.N);
-  if (g_conv_halo && BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
+  // 3x3 / stride-1 / pad-1 layers on the LDS-DMA kernels (conv_glds_impl.h: one translation unit per instantiation); every other shape — odd map
+  // sizes, channel counts that are not multiples of 128 on the 14x14 / 28x28 maps — takes the generic gather GEMM below
+  if (BM == 128 && p.mode == 1 && p.S == 3 && p.K == 9 * p.C && p.stride == 1 && p.pad == 1 && p.up == 1 &&
       p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && p.W <= 126) {
-    if (g_conv_halo >= 4 && p.H == 112 && p.W == 112 && !p.bpart && p.M % (112 * 112) == 0 && p.C == 64 && p.N == 64) return launch_conv_glds_w112(p, st);
-    if (g_conv_halo >= 4 && p.H == 56 && p.W == 56 && !p.bpart && p.M % (56 * 56) == 0) {
+    if (p.H == 112 && p.W == 112 && !p.bpart && p.M % (112 * 112) == 0 && p.C == 64 && p.N == 64) return launch_conv_glds_w112(p, st);
+    if (p.H == 56 && p.W == 56 && !p.bpart && p.M % (56 * 56) == 0) {
       if (p.C == 64 && p.N == 64) return launch_conv_glds_w56(p, st);
       if (p.C == 64 && p.N == 128) return launch_conv_glds_w56_c64_n128(p, st);
       if (p.C == 128 && p.N == 64) return launch_conv_glds_w56_c128_n64(p, st);
     }
-    if (g_conv_halo >= 2 && p.H == p.W && (p.W == 14 || p.W == 28)) {
-      if (g_conv_halo >= 4 && p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0 && p.ldc == p.N)
+    if (p.H == p.W && (p.W == 14 || p.W == 28) && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0) {
+      if (p.bpart && p.ldc == p.N)
         return p.W == 14 ? launch_conv_glds8_fused_w14(p, st)
                          : (gemm_nt_fused28_two_tiles(p.M) && !p.stats ? launch_conv_glds8_fused_w28s(p, st) : launch_conv_glds8_fused_w28(p, st));
-      if (g_conv_halo >= 3 && !p.bpart && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0)
-        return g_conv_halo >= 4 ? (p.W == 14 ? launch_conv_glds8_w14(p, st)
-                                             : (glds28_two_tiles(p) ? launch_conv_glds8_w28_stats(p, st) : launch_conv_glds8_w28(p, st)))
-                                : (p.W == 14 ? launch_conv_glds_w14(p, st) : launch_conv_glds_w28(p, st));
-      const bool bn64 = p.N <= 64 || g_halo_bn64;
-      if (bn64 || g_halo_waves == 8) return launch_conv_halo2_misc(p, bn64, g_halo_waves == 8, st);
-      if (p.bpart) return p.W == 14 ? launch_conv_halo2_fused_w14(p, st) : launch_conv_halo2_fused_w28(p, st);
-      return p.W == 14 ? launch_conv_halo2_w14(p, st) : launch_conv_halo2_w28(p, st);
+      if (!p.bpart)
+        return p.W == 14 ? launch_conv_glds8_w14(p, st) : (glds28_two_tiles(p) ? launch_conv_glds8_w28_stats(p, st) : launch_conv_glds8_w28(p, st));
     }
-    return launch_conv_halo1(p, st);
   }
   if (gemm_nt_glds_applies(p, BM, splits)) return launch_nt_glds(p, BM, splits, 17, st);
   if (BM == 128) {
@@ -664,21 +660,6 @@ static int tn_prepare(GemmTN& p) {
     FEDFR_REQUIRE((p.ldq & 7) == 0, "gemm_tn: ldq%%8");
   }
   return FEDFR_OK;
-}
-
-int g_tn_pair = 0;   // option "tn_pair": the two same-shape weight-gradient GEMMs of a residual block in ONE launch on the 64-KiB ring (two blocks
-                     // per CU).  Off: same box, the pair runs 15 % faster on its own (72.0 us vs 2 x 42.2 us, bit-identical slabs) but with four
-                     // waves per SIMD and 128 KB of LDS taken no BN-backward workgroup fits beside it any more: the main stream's streaming
-                     // kernels stretch (bn_bwd_reduce 16.9 -> 29.6 us) and the step gets slower, 20.65 -> 21.05 ms
-bool gemm_tn_pair_ok(const GemmTN& a, const GemmTN& b, int splits) {
-  return !wgrad9_applies(a) && a.mode == 1 && b.mode == 1 && a.use_tr && b.use_tr && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C &&
-         gemm_tn_glds_pair_ok(a.Kp, a.NI, a.NJ, a.C, splits);
-}
-int gemm_tn_launch_pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
-  FEDFR_REQUIRE(gemm_tn_pair_ok(a, b, splits), "gemm_tn_pair: problems cannot be paired");
-  FEDFR_TRY(tn_prepare(a));
-  FEDFR_TRY(tn_prepare(b));
-  return launch_tn_glds_pair(a, b, splits, st);
 }
 
 // the two 3x3 / stride-1 weight gradients of a residual block on the paired nine-tap kernel (wgrad9p.hip); *splits = slabs per layer

@@ -44,17 +44,12 @@ struct ProfScope {
   ProfScope(int slot, double flops, hipStream_t st);
   ~ProfScope();
 };
-extern int g_conv_halo, g_halo_bn64, g_halo_waves, g_nt_nbuf, g_tn_target_blocks, g_tn_glds;
-int launch_conv_halo1(GemmNT p, hipStream_t st);          // conv_halo.hip
-int launch_conv_halo2_w14(GemmNT p, hipStream_t st);       // conv_halo2_w14.hip   plain, 128x128 tiles, 4 waves
-int launch_conv_halo2_w28(GemmNT p, hipStream_t st);       // conv_halo2_w28.hip
-int launch_conv_halo2_fused_w14(GemmNT p, hipStream_t st); // conv_halo2_fused14.hip  + BN-backward reduction epilogue
-int launch_conv_halo2_fused_w28(GemmNT p, hipStream_t st); // conv_halo2_fused28.hip
-int launch_conv_glds_w14(GemmNT p, hipStream_t st);        // conv_glds_w14.hip  LDS-DMA operands, counted vmcnt pipeline
-int launch_conv_glds_w28(GemmNT p, hipStream_t st);        // conv_glds_w28.hip
+extern int g_nt_nbuf, g_tn_target_blocks, g_tn_glds;
 int launch_conv_glds8_w14(GemmNT p, hipStream_t st);       // conv_glds8_w14.hip  same, 8 waves per tile
 int launch_conv_glds8_w28(GemmNT p, hipStream_t st);       // conv_glds8_w28.hip
 int launch_conv_glds8_w28_stats(GemmNT p, hipStream_t st); // conv_glds8_w28s.hip  two image tiles per workgroup, one BatchNorm partial row each
+int launch_conv_glds8_w14_handoff(GemmNT p, hipStream_t st);   // conv_glds8_w14h.hip   + the BatchNorm behind the conv, statistics handed over inside the launch
+int launch_conv_glds8_w28_handoff(GemmNT p, hipStream_t st);   // conv_glds8_w28sh.hip
 extern int g_conv28_tpw2;
 int launch_conv_glds_w56(GemmNT p, hipStream_t st);        // conv_glds_w56.hip  56x56, C = N = 64
 int launch_conv_glds_w112(GemmNT p, hipStream_t st);       // conv_glds_w112.hip 112x112, C = N = 64
@@ -65,11 +60,9 @@ extern int g_conv_c64p;
 bool conv_c64p_applies(const GemmNT& p);
 int conv_c64p_grid(int M);
 int launch_conv_c64p(GemmNT p, hipStream_t st);
-int launch_conv_glds_x(GemmNT p, hipStream_t st);          // conv_glds_x.hip  forward convs with the input BN(+PReLU) applied in LDS
 int launch_conv_glds8_fused_w14(GemmNT p, hipStream_t st); // conv_glds8_fused_w14.hip  + BN-backward reduction epilogue
 int launch_conv_glds8_fused_w28(GemmNT p, hipStream_t st); // conv_glds8_fused_w28.hip
 int launch_conv_glds8_fused_w28s(GemmNT p, hipStream_t st); // conv_glds8_fused_w28s.hip
-int launch_conv_halo2_misc(GemmNT p, int bn64, int waves8, hipStream_t st);   // conv_halo2_misc.hip  tuning variants
 // gemm_nt_glds.hip: the register-staged NT kernel's shapes with both operands fetched by LDS-DMA into a ring of stages
 extern int g_nt_glds;
 bool gemm_nt_glds_applies(const GemmNT& p, int BM, int splits);
@@ -77,9 +70,6 @@ int launch_nt_glds(const GemmNT& p, int BM, int splits, int slot, hipStream_t st
 int launch_tn_glds(GemmTN p, int splits, hipStream_t st);   // gemm_tn_glds.hip  wgrad GEMM, LDS-DMA operand ring
 bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode);
 int gemm_tn_glds_pick_splits(int Kp, int NI, int NJ);
-int launch_tn_glds_pair(GemmTN a, GemmTN b, int splits, hipStream_t st);
-bool gemm_tn_glds_pair_ok(int Kp, int NI, int NJ, int C, int splits);
-extern int g_tn_pair;
 // wgrad9.hip: 3x3 stride-1 weight gradient, all nine taps per workgroup, operands staged once
 extern int g_wgrad9, g_wgrad9_wgs;
 bool wgrad9_applies(const GemmTN& p);

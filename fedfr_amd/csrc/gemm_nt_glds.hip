@@ -245,7 +245,7 @@ int g_nt_glds = 4;   // option "nt_glds": 0 register-staged gemm_nt_kernel; 1 / 
 // the parity classes of a stride-2 dgrad) are better off with two register-staged workgroups per CU than with one 128 KB ring.
 bool gemm_nt_glds_applies(const GemmNT& p, int BM, int splits) {
   const bool pays = (g_nt_glds & 8) || (!p.par_on && ceil_div(p.ksteps_total, splits) >= 16);     // + 8: every shape the kernel can serve (tests)
-  return (g_nt_glds & 7) > 0 && p.N > 64 && (BM == 128 || BM == 64) && pays && !p.bpart && !p.tsc && !p.esc && !p.eadd && !p.Cb2;
+  return (g_nt_glds & 7) > 0 && p.N > 64 && (BM == 128 || BM == 64) && pays && !p.bpart && !p.esc && !p.eadd && !p.Cb2;
 }
 
 int launch_nt_glds(const GemmNT& p, int BM, int splits, int slot, hipStream_t st) {

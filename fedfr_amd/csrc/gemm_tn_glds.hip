@@ -206,16 +206,6 @@ template <int WI, int WJ>
 __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
   tn_glds_body<WI, WJ, 4>(p, (int)blockIdx.x, (int)gridDim.x);
 }
-// Two weight-gradient GEMMs of the same shape in one launch on the 64-KiB ring: blocks come in groups of eight (one per XCD under
-// round-robin placement) that alternate between the problems, so each CU gets a workgroup of either and the two interleave on its
-// SIMDs: four waves per SIMD instead of two hide each other's DMA issue, fragment reads and barrier waits.
-template <int WI, int WJ>
-__global__ __launch_bounds__(64 * WI * WJ, 2) void gemm_tn_glds_pair_kernel(GemmTN p0, GemmTN p1, int nblk) {
-  const int b = (int)blockIdx.x, second = (b >> 3) & 1;
-  const int local = ((b >> 4) << 3) | (b & 7);
-  if (local >= nblk) return;                       // padding of the last group of eight (whole workgroup, before any barrier)
-  tn_glds_body<WI, WJ, 2>(second ? p1 : p0, local, nblk);
-}
 }  // namespace
 
 bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode) {
@@ -254,31 +244,4 @@ int launch_tn_glds(GemmTN p, int splits, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 2>), dim3(p.ntiles * splits), dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_tn_glds");
   return FEDFR_OK;
-}
-
-// a and b: same NI, NJ, Kp (same tiling and K-split); each writes its own slab set
-int launch_tn_glds_pair(GemmTN a, GemmTN b, int splits, hipStream_t st) {
-  FEDFR_REQUIRE(gemm_tn_glds_applies(a.NI, a.NJ, a.C, a.mode) && gemm_tn_glds_applies(b.NI, b.NJ, b.C, b.mode) && a.use_tr && b.use_tr,
-                "gemm_tn_glds_pair: unsupported problem");
-  FEDFR_REQUIRE(a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp, "gemm_tn_glds_pair: the two problems differ in shape");
-  for (GemmTN* p : {&a, &b}) {
-    p->nbj = p->NJ / 128;
-    p->ntiles = (p->NI / 128) * p->nbj;
-    p->ksteps_total = ceil_div(p->Kp, 64);
-    p->ksteps_per_split = ceil_div(p->ksteps_total, splits);
-  }
-  FEDFR_REQUIRE(ceil_div(a.ksteps_total, a.ksteps_per_split) == splits, "gemm_tn_glds_pair: splits=%d leaves an empty split", splits);
-  const int nblk = a.ntiles * splits;
-  constexpr size_t lds = (size_t)2 * STAGE_B;
-  static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
-  attr_once.run([&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_pair_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  });
-  ProfScope prof(14, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
-  hipLaunchKernelGGL((gemm_tn_glds_pair_kernel<2, 4>), dim3(16 * ceil_div(nblk, 8)), dim3(512), lds, st, a, b, nblk);
-  FEDFR_LAUNCH_CHECK("gemm_tn_glds_pair");
-  return FEDFR_OK;
-}
-bool gemm_tn_glds_pair_ok(int Kp, int NI, int NJ, int C, int splits) {
-  return g_tn_glds >= 2 && g_tn_pair && gemm_tn_glds_applies(NI, NJ, C, 1);
 }

@@ -139,8 +139,6 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
     part = std::max(part, (long long)ew_bn_apply_grid((int)M, C) * 2 * C);
     part = std::max(part, (long long)ew_bn_bwd_grid((int)M, C) * 3 * C);
     part = std::max(part, (long long)ew_bn_bwd_apply_grid((int)M, C) * 3 * C);
-    // the row-slab grids are options ("ew_reduce_blocks" / "ew_bwd_apply_blocks", at most 2048 workgroups): room for any later setting
-    part = std::max(part, std::min<long long>(2048, (M + 7) / 8) * 3 * C);
   };
   auto upd_conv = [&](const ConvD& c) {
     const long long Mo = Bq * c.Hout * c.Hout;
@@ -289,32 +287,40 @@ static int conv_fwd_ep(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* 
   if (out2) { p.Cb2 = out2; p.esc2 = c.save(*bn2, 0); p.esh2 = c.save(*bn2, 1); }
   return gemm_nt_launch(p, 1, c.st);
 }
-// conv(act(bn(raw))): where the LDS-DMA kernel can normalise its input image itself the separate bn_apply pass disappears; the kernel
-// still leaves the normalised activation in `a` when training (the weight-gradient GEMM reads it), not in eval mode.
-int g_fuse_bnapply = 0;   // option "fuse_bnapply": BN(+PReLU) of a conv's input applied inside the LDS-DMA conv kernel (no bn_apply pass).  Off: measured
-                          // same box, it removes 98 bn_apply launches (-1.1 ms) but the un/re-packing VALU pass on the MFMA-bound SIMDs costs the
-                          // forward convs +0.7 ms and the activation still has to be written for wgrad: 20.39 ms/step without vs 20.51 with
-                          // (eval-mode forward, where nothing is written back: 5.87 -> 5.72 ms at batch 128).
-static int apply(const Ctx& c, const bf16_t* x1, const BnD& b1, const float* alpha, const bf16_t* x2, const BnD* b2, bf16_t* y, int M,
-                 bool stats, int nchw_hw);
-static int conv_fwd_bn(const Ctx& c, const ConvD& cv, const bf16_t* raw, const BnD& bn, const float* alpha, bf16_t* a, bf16_t* out,
-                       bool tr) {
-  const int M = c.n->B * cv.Hout * cv.Hout;
-  if (!g_fuse_bnapply || !gemm_nt_conv_xform_ok(cv.Hin, cv.Cin, cv.Cout, M, cv.R, cv.stride)) {
-    FEDFR_TRY(apply(c, raw, bn, alpha, nullptr, nullptr, a, c.n->B * cv.Hin * cv.Hin, false, 0));
-    return conv_fwd(c, cv, a, out, tr);
+// first pass on this workspace: no stale hand-off granule may ever carry a live epoch, and the arrival counter starts at zero
+static int hand_init(const FedfrNet* n, unsigned char* ws, hipStream_t st) {
+  if (n->hand_ws == ws) return FEDFR_OK;
+  if (hipMemsetAsync(ws + n->ws_hand, 0, ew_bn_fused_hand_bytes() + 256, st) != hipSuccess) {
+    fedfr_set_error("hand_init: hipMemsetAsync of the hand-off buffer failed");
+    return FEDFR_ERR_HIP;
   }
+  n->hand_ws = ws;
+  n->hand_epoch = 0;
+  n->hf_total = 0;
+  return FEDFR_OK;
+}
+int g_fwd_bnfuse = 1;     // option "fwd_bnfuse": training forward, conv1 of a residual block applies bn2 + PReLU itself (statistics handed over between the
+                          // launch's workgroups: GemmNT::hout) on the 14x14 / 28x28 maps — the bn_apply pass between conv1 and conv2 disappears
+// conv -> train-mode BatchNorm (+PReLU) in ONE launch: raw = conv(in) (kept: the backward pass reads it), a = prelu?(bn(raw))
+static int conv_fwd_handoff(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* raw, const BnD& bn, const float* alpha, bf16_t* a) {
   GemmNT p{};
-  p.A = raw; p.B = c.shadow + cv.w_off;
-  p.M = M; p.N = cv.Cout; p.K = cv.R * cv.R * cv.Cin;
+  p.A = in; p.B = c.shadow + cv.w_off;
+  p.M = c.n->B * cv.Hout * cv.Hout; p.N = cv.Cout; p.K = cv.R * cv.R * cv.Cin;
   p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = cv.R;
-  p.stride = cv.stride; p.pad = 1; p.up = 1;
-  p.Cb = out; p.ldc = cv.Cout; p.Cf = nullptr; p.stats = tr ? c.part() : nullptr;
-  p.tsc = c.save(bn, 0); p.tsh = c.save(bn, 1); p.talpha = alpha; p.aout = tr ? a : nullptr;
+  p.stride = 1; p.pad = 1; p.up = 1;
+  p.Cb = raw; p.ldc = cv.Cout; p.stats = c.part();
+  p.hout = a; p.hgamma = c.gamma(bn); p.hbeta = c.beta(bn); p.halpha = alpha;
+  p.hrm = c.bufs + bn.rm_off; p.hrv = c.bufs + bn.rv_off; p.hmomentum = kBnMomentum; p.heps = kBnEps; p.hcount = (double)p.M;
+  p.hscale = c.save(bn, 0); p.hshift = c.save(bn, 1); p.hmean = c.save(bn, 2); p.hrstd = c.save(bn, 3);
+  unsigned char* hb = c.ws + c.n->ws_hand + ew_bn_fused_hand_bytes();
+  p.herr = reinterpret_cast<unsigned*>(hb);
+  p.hcnt = reinterpret_cast<unsigned*>(hb + 64);
+  const int wgs = (cv.Hin == 14 ? p.M / 196 : p.M / 392) * (cv.Cout / 128);
+  c.n->hf_total += (unsigned)wgs;
+  p.htarget = c.n->hf_total;
   return gemm_nt_launch(p, 1, c.st);
 }
 int g_fwd_xmom = 1;       // option "fwd_xmom": bn3 + identity + the next block's bn1 as one pass from conv2's raw moments (14x14 / 28x28 blocks)
-extern int g_conv_halo;
 int g_fuse_bnbwd28 = 1;   // option "fuse_bnbwd28": ... and in the two-tiles 28x28 dgrad (with fuse_bnbwd != 0)
 int g_c64p_bnbwd = 1;   // option "c64p_bnbwd": BN-backward reduction in the epilogue of the persistent 64-channel dgrad kernel (with fuse_bnbwd != 0)
 extern int g_conv_c64p;
@@ -430,25 +436,17 @@ static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const 
   }
   FEDFR_TRY(wgrad_flush(c, pd, st));                    // every other kernel below uses slab regions 0 / 1 itself
   const int splits = gemm_tn_pick_splits(a.Kp, a.NI, a.NJ, a.C, a.Wo, a.stride);
-  if (splits < 2 || !gemm_tn_pair_ok(a, b, splits)) {
-    // same shape, same split count: each launch writes its own slab set and ONE launch reduces both (45 launches fewer per step on the
-    // weight-gradient stream, and the second GEMM does not wait behind the first one's reduction)
-    if (g_wgrad_pair_reduce && splits >= 2 && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C && a.Wo == b.Wo && a.stride == b.stride &&
-        (size_t)splits * a.NI * a.NJ <= c.n->slab_floats) {
-      a.out = c.slab(0); b.out = c.slab(1);
-      FEDFR_TRY(gemm_tn_launch(a, splits, st));
-      FEDFR_TRY(gemm_tn_launch(b, splits, st));
-      return ew_reduce_slabs2(c.grads + cva.w_off, c.slab(0), c.grads + cvb.w_off, c.slab(1), splits, (size_t)a.NI * a.NJ, st);
-    }
-    FEDFR_TRY(conv_wgrad(c, cva, ina, dya, st));
-    return conv_wgrad(c, cvb, inb, dyb, st);
+  // same shape, same split count: each launch writes its own slab set and ONE launch reduces both (45 launches fewer per step on the
+  // weight-gradient stream, and the second GEMM does not wait behind the first one's reduction)
+  if (g_wgrad_pair_reduce && splits >= 2 && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C && a.Wo == b.Wo && a.stride == b.stride &&
+      (size_t)splits * a.NI * a.NJ <= c.n->slab_floats) {
+    a.out = c.slab(0); b.out = c.slab(1);
+    FEDFR_TRY(gemm_tn_launch(a, splits, st));
+    FEDFR_TRY(gemm_tn_launch(b, splits, st));
+    return ew_reduce_slabs2(c.grads + cva.w_off, c.slab(0), c.grads + cvb.w_off, c.slab(1), splits, (size_t)a.NI * a.NJ, st);
   }
-  FEDFR_REQUIRE((size_t)splits * a.NI * a.NJ <= c.n->slab_floats, "conv_wgrad2: %d split-K slabs of %d x %d exceed the plan's slab workspace "
-                "(%zu floats): create the plan after changing tn_target_blocks", splits, a.NI, a.NJ, c.n->slab_floats);
-  a.out = c.slab(0); b.out = c.slab(1);
-  FEDFR_TRY(gemm_tn_launch_pair(a, b, splits, st));
-  FEDFR_TRY(ew_reduce_slabs(c.grads + cva.w_off, c.slab(0), splits, (size_t)a.NI * a.NJ, nullptr, 0, st));
-  return ew_reduce_slabs(c.grads + cvb.w_off, c.slab(1), splits, (size_t)b.NI * b.NJ, nullptr, 0, st);
+  FEDFR_TRY(conv_wgrad(c, cva, ina, dya, st));
+  return conv_wgrad(c, cvb, inb, dyb, st);
 }
 struct Rows { const float* ptr; int P; };     // where a BatchNorm's partial statistics rows are
 static int bn_coeffs(const Ctx& c, const BnD& b, Rows r, double count, bool training) {
@@ -558,6 +556,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   const int M0 = B * HW * HW;
   bf16_t* A = c.actb;
   if (!tr) FEDFR_TRY(eval_coeffs_all(c));
+  if (tr) FEDFR_TRY(hand_init(n, ws, st));
   Rows prev{c.part(), 0};                  // statistics of the tensor the next BatchNorm normalises
   if (n->block_only) {
     // lone block: x (fp32 NCHW) -> NHWC bf16 block input; an identity "apply" pass leaves the column statistics bn1 needs, exactly
@@ -607,8 +606,10 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
       continue;
     }
     if (!tr) {                                // eval mode without the fused epilogues: known affines, plain passes
-      FEDFR_TRY(conv_fwd_bn(c, k.conv1, A + k.x_off, k.bn1, nullptr, A + k.a1_off, A + k.c1_off, false));
-      FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, false));
+      FEDFR_TRY(apply(c, A + k.x_off, k.bn1, nullptr, nullptr, nullptr, A + k.a1_off, Mi, false));
+      FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, false));
+      FEDFR_TRY(apply(c, A + k.c1_off, k.bn2, params + k.alpha_off, nullptr, nullptr, A + k.a2_off, Mi, false));
+      FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, false));
       if (k.has_ds) {
         FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, false));
         FEDFR_TRY(apply(c, A + k.c2_off, k.bn3, nullptr, A + k.d_off, &k.bnds, A + k.out_off, Mo, false));
@@ -619,33 +620,31 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     }
     // a1 = bn1(x) -> conv1 -> a2 = prelu(bn2(c1)) -> conv2(stride) -> bn3(c2) + identity.  Statistics: the pass that produced x left
     // them in `prev`; a conv's epilogue leaves its output's in c.part()
-    const bool xf1 = !a1_ready && g_fuse_bnapply && gemm_nt_conv_xform_ok(k.conv1.Hin, k.conv1.Cin, k.conv1.Cout, Mi, k.conv1.R, k.conv1.stride);
-    const bool xf2 = g_fuse_bnapply && gemm_nt_conv_xform_ok(k.conv2.Hin, k.conv2.Cin, k.conv2.Cout, Mo, k.conv2.R, k.conv2.stride);
     // round 3 (option fwd_xmom): where conv2 runs on an LDS-DMA kernel with the moment epilogue, out = bn3(c2) + x AND the next block's
     // bn1(out) leave ONE pass (bn_apply2, ew.h): conv2 also sums c2 * x, and the statistics of `out` follow from those moments and the
     // statistics of x this block's bn1 saved — the next block's bn1 pass disappears
     const BlockD* nxb = bi + 1 < n->blocks.size() ? &n->blocks[bi + 1] : nullptr;
     const int xm_rows = k.Hout == 14 ? Mo / 196 : Mo / 392;
-    const bool xmom = g_fwd_xmom && nxb && !k.has_ds && !xf2 && g_conv_halo >= 4 && k.conv2.R == 3 && k.conv2.stride == 1 && (k.Hout == 14 || k.Hout == 28) &&
+    const bool xmom = g_fwd_xmom && nxb && !k.has_ds && k.conv2.R == 3 && k.conv2.stride == 1 && (k.Hout == 14 || k.Hout == 28) &&
                       k.conv2.Cin % 128 == 0 && k.Cout % 128 == 0 && k.conv2.Cin == k.Cout && nxb->bn1.C == k.Cout &&
                       gemm_nt_conv_epilogue_ok(k.Hout, k.conv2.Cin, k.Cout, Mo, 3, 1) &&          // (mirrors the dispatch: small problems take the generic kernel)
                       (k.Hout == 14 || gemm_nt_fused28_two_tiles(Mo)) && ew_bn_apply2_sliced_ok(Mo, k.Cout, xm_rows);
-    if (a1_ready) {                             // the previous block's output pass wrote a1 = bn1(x) and bn1's statistics
+    // round 4 (option fwd_bnfuse): conv1 applies bn2 + PReLU itself where its kernel can hand the statistics over inside the launch
+    const bool hf1 = g_fwd_bnfuse && gemm_nt_conv_handoff_ok(k.conv1.Hin, k.conv1.Cin, k.conv1.Cout, Mi, k.conv1.R, k.conv1.stride);
+    if (hf1) {
+      if (!a1_ready) FEDFR_TRY(bn_apply_train(c, k.bn1, prev, A + k.x_off, nullptr, nullptr, A + k.a1_off, Mi, nullptr));
+      a1_ready = false;
+      FEDFR_TRY(conv_fwd_handoff(c, k.conv1, A + k.a1_off, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off));
+    } else if (a1_ready) {                      // the previous block's output pass wrote a1 = bn1(x) and bn1's statistics
       FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, true));
       a1_ready = false;
-    } else if (xf1) {
-      FEDFR_TRY(bn_coeffs(c, k.bn1, prev, (double)Mi, true));
-      FEDFR_TRY(conv_fwd_bn(c, k.conv1, A + k.x_off, k.bn1, nullptr, A + k.a1_off, A + k.c1_off, true));
     } else {
       FEDFR_TRY(bn_apply_train(c, k.bn1, prev, A + k.x_off, nullptr, nullptr, A + k.a1_off, Mi, nullptr));
       FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, true));
     }
-    const Rows r1{c.part(), gemm_nt_stat_rows_live(Mi, k.Cout, k.conv1.Cin, k.conv1.Hin, k.conv1.R, k.conv1.stride, xf1)};
-    if (xf2) {
-      FEDFR_TRY(bn_coeffs(c, k.bn2, r1, (double)Mi, true));
-      FEDFR_TRY(conv_fwd_bn(c, k.conv2, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off, A + k.c2_off, true));
-    } else if (xmom) {
-      FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
+    const Rows r1{c.part(), gemm_nt_stat_rows_live(Mi, k.Cout, k.conv1.Cin, k.conv1.Hin, k.conv1.R, k.conv1.stride)};
+    if (xmom) {
+      if (!hf1) FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
       GemmNT p{};
       const ConvD& cv = k.conv2;
       p.A = A + k.a2_off; p.B = c.shadow + cv.w_off;
@@ -671,10 +670,10 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
       prev = Rows{c.part(), 0};
       continue;
     } else {
-      FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
+      if (!hf1) FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
       FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, true));
     }
-    const Rows r2{c.part(), gemm_nt_stat_rows_live(Mo, k.Cout, k.conv2.Cin, k.conv2.Hin, k.conv2.R, k.conv2.stride, xf2)};
+    const Rows r2{c.part(), gemm_nt_stat_rows_live(Mo, k.Cout, k.conv2.Cin, k.conv2.Hin, k.conv2.R, k.conv2.stride)};
     if (k.has_ds) {
       FEDFR_TRY(bn_coeffs(c, k.bn3, r2, (double)Mo, true));
       FEDFR_TRY(conv_fwd(c, k.ds, A + k.x_off, A + k.d_off, true));
@@ -787,10 +786,7 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
 
 int g_stem_bnred = 1;     // option "stem_bnred": the stem's BatchNorm-backward reduction rides in the first block's bn1 apply pass
 int g_fc_wgrad_aux = 1;   // option "fc_wgrad_aux": fc's weight gradient runs on the weight-gradient stream
-int g_late_join = 1;       // option "late_join": the streams join behind the stem's BatchNorm backward instead of in front of it
 int g_event_nofence = 1;   // option "event_nofence": fork / join events created with hipEventDisableSystemFence
-int g_fork_mode = 0;       // option "fork_mode": 1 = the per-block fork event is the completion signal of the BatchNorm-backward apply launch that
-                           // produces the last weight-gradient operand (hipExtLaunchKernel stopEvent) instead of a record packet behind it
 // fork/join helpers for the dual-stream backward (events are created once per plan)
 namespace {
 struct Fork {
@@ -811,11 +807,6 @@ struct Fork {
     if (!aux) return;
     hipEvent_t e = ev();
     if (!e || hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) ok = false;
-  }
-  // fork whose event was attached to the last launch on `from` (ew_bn_set_stop_event): `to` only waits
-  void order_attached(hipEvent_t e, hipStream_t to) {
-    if (!aux) return;
-    if (!e || hipStreamWaitEvent(to, e, 0) != hipSuccess) ok = false;
   }
   hipEvent_t mark(hipStream_t s) {            // record now, wait later
     if (!aux) return nullptr;
@@ -839,14 +830,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
   const int B = n->B, F = n->F, HW = n->HW;
   bf16_t* A = c.actb;
-  if (n->hand_ws != ws) {                           // first backward pass on this workspace: no stale granule may ever carry a live epoch
-    if (hipMemsetAsync(ws + n->ws_hand, 0, ew_bn_fused_hand_bytes() + 256, st) != hipSuccess) {
-      fedfr_set_error("net_backward: hipMemsetAsync of the hand-off buffer failed");
-      return FEDFR_ERR_HIP;
-    }
-    n->hand_ws = ws;
-    n->hand_epoch = 0;
-  }
+  FEDFR_TRY(hand_init(n, ws, st));
   Fork fk{n, st, aux};
   const hipStream_t wst = aux ? aux : st;          // stream of the weight-gradient GEMMs
   if (n->block_only) fk.order(st, wst);             // aux starts after everything already queued on main (forward pass); the full net forks below
@@ -922,14 +906,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     int f2 = 0, f1 = 0;
     FEDFR_TRY(conv_dgrad(c, k.conv2, dc2, da2, &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
     // a2 = prelu(bn2(c1))
-    hipEvent_t fork_ev = nullptr;
-    if (g_fork_mode == 1 && aux && !k.has_ds) {        // this apply pass is the last main-stream launch in front of the block's fork
-      fork_ev = fk.ev();
-      ew_bn_set_stop_event(fork_ev);
-    }
     FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, da2, A + k.c1_off, Mi, nullptr, nullptr, 0, dc1, k.alpha_off, Rows{c.part(), f2}));
-    const bool fork_attached = fork_ev && !ew_bn_stop_event_pending();
-    ew_bn_clear_stop_event();
     // identity path first (its BN reduction uses the shared partial buffer), then conv1's dgrad whose epilogue may
     // leave bn1's partial sums there for the bn_bwd that follows immediately
     if (k.has_ds) {
@@ -937,8 +914,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     }
     // ONE fork per block: every event record costs the main stream a ~8 us bubble (kernel trace), so the block's two or three
     // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
-    if (fork_attached) fk.order_attached(fork_ev, wst);
-    else fk.order(st, wst);
+    fk.order(st, wst);
     if (sgd_lo >= 0 && sgd_lo < sgd_hi) FEDFR_TRY(wgrad_flush(c, &pend_w, wst));      // the fused SGD reads the finished stage's gradients
     FEDFR_TRY(sgd_flush());
     FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst, &pend_w));
@@ -966,10 +942,10 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     if (sgd && !n->block_only && k.has_ds && bi > 0) sgd_lo = k.bn1.g_off;      // a stage is complete: its range goes out behind the next fork
   }
   FEDFR_TRY(wgrad_flush(c, &pend_w, wst));
-  // join: the stem wgrad below reuses the slab workspace; callers see all grads.  late_join: the stem's BatchNorm backward (two passes over
+  // join: the stem wgrad below reuses the slab workspace; callers see all grads.  The join sits BEHIND the stem's BatchNorm backward: the stem's BatchNorm backward (two passes over
   // 205 MB tensors) does not wait for the last weight gradients — its dz goes to t(1) (da2 of the blocks: main stream only) instead of
   // t(0), which block 0's weight gradient may still be reading
-  if (!g_late_join || n->block_only) fk.order(wst, st);
+  if (n->block_only) fk.order(wst, st);
   const int M0 = B * HW * HW;
   FEDFR_TRY(dbg_capture(c.g(cur), (size_t)M0 * n->blocks.front().Cin, &dbg_off, st));
   if (n->block_only) {                               // the gradient wrt the block input stays readable in the arena
@@ -979,9 +955,9 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     }
   } else {
   // ---- stem: a0 = prelu(bn1(conv1(x))) ----
-  bf16_t* dz0 = g_late_join ? c.t(1) : c.t(0);
+  bf16_t* dz0 = c.t(1);
   FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, dz0, n->stem_alpha_off, pend));
-  if (g_late_join) fk.order(wst, st);
+  fk.order(wst, st);
   FEDFR_TRY(ew_stem_wgrad(x, dz0, grads + n->stem.w_off, c.slab(), B, HW, HW, st));
   }
   if (!fk.ok) {

@@ -33,25 +33,25 @@ int fedfr_version(void);
 int fedfr_storage_dtype(void);
 const char* fedfr_last_error_string(void);
 /* Kernel-choice switches for same-box A/B measurements and validation fallbacks (no reference counterpart; every setting stays inside the
- * tests' tolerances; FEDFR_OPTIONS="name=value,..." in the environment applies them when the library is loaded).  The ones that matter:
- * "tn_use_tr" (1 = ds_read_b64_tr_b16 wgrad fragments [default], 0 = scalar LDS fallback), "conv_halo" (0..4 conv kernel generation),
- * "nt_glds" (0 register-staged NT GEMM everywhere, 4 [default] LDS-DMA operand ring for the long-K shapes, +8 for every shape it serves),
- * "wgrad9" / "wgrad9p" / "tn_glds" / "tn_pair" / "wgrad_pair_reduce" (weight-gradient kernels and their slab reductions), "bn_sliced"
- * (channel-sliced BatchNorm passes without finalize launches), "fuse_bnbwd" (0 / 1 / 2 [default since round 3, with "wgrad9p" = 1]: BatchNorm-backward reduction in the dgrad
- * epilogue, everywhere / 14x14 layers; with "c64p_bnbwd" (1 [default]) also in the persistent 64-channel dgrad of the 56x56 / 112x112 maps; with "fuse_bnbwd28"
- * (1 [default]) in the two-tiles 28x28 dgrad, whose 256 partial rows the channel-sliced apply pass takes), "fuse_bnapply", "eval_fuse", "conv28_tpw2", "dgrad_parity", "wgrad_depth", "bn_fuse_bwd" (0 [default] / 1: reduce + apply pass of a
- * BatchNorm backward in ONE launch on the 14x14 / 7x7 maps, partial rows handed over inside the launch; bit-identical to the two-launch
- * form), "ew_reduce_blocks" / "ew_bwd_apply_blocks" / "ew_reduce_nt" (grid sizes and load policy of the large maps' row-slab
- * BatchNorm-backward passes), "event_nofence" (1 [default]: the backward pass's fork / join events carry no system-scope fence),
- * "fork_mode" (0 [default] / 1: the per-block fork event rides on the completion signal of the launch in front of it), "sph_fuse_act"
- * (0 [default] / 1: sphnet's PReLU (+bias, +identity) in the conv kernel's epilogue where the kernel has one), "late_join" (1 [default]: the
- * streams of the backward pass join behind the stem's BatchNorm backward instead of in front of it), "fc_wgrad_aux" (1 [default]: fc's
- * weight gradient is the weight-gradient stream's first kernel), "fwd_xmom" (1 [default]: in the training forward pass of a 14x14 / 28x28
- * residual block, bn3 + identity + the NEXT block's bn1 are one pass; conv2's epilogue leaves the raw moments of its output against the
- * block input and the statistics of the sum are derived from them), "stem_bnred" (1 [default]: the reduction of the stem's BatchNorm
- * backward rides in the first block's bn1 apply pass), "sph_fin_multi" / "sph_pair_wgrad" (1 [default]: sphnet's backward pass finalizes all
- * PReLU parameter sums in one launch / runs a residual block's two weight gradients as one paired launch), "sph_fuse_prelu_bwd" (1 [default]:
- * the backward of the PReLU in front of a sphnet block's conv2 rides in that conv's dgrad epilogue, 14x14 / 28x28 maps).  Unknown names are an error. */
+ * tests' tolerances; FEDFR_OPTIONS="name=value,..." in the environment applies them when the library is loaded; fedfr_option_info lists
+ * them with their defaults).  Round 4 removed the switches whose alternative lost twice (the register-staged halo conv kernels, the
+ * BatchNorm-on-load conv, the two-blocks-per-CU weight-gradient pair, sphnet's activation epilogue, the fork / join placement and row-slab sweeps).  [default]:
+ *   GEMM kernels        "nt_glds" [4] LDS-DMA operand ring of the NT GEMM (0 register-staged everywhere, +8 every shape it serves), "nt_nbuf",
+ *                       "tn_glds" [2] LDS-DMA weight-gradient GEMM (0 register-staged, 1 four waves), "tn_use_tr" [1] (0 scalar LDS fragments),
+ *                       "tn_target_blocks", "dgrad_parity" [2] stride-2 dgrad by output-parity class (2: one launch), "conv_c64p" [1] persistent
+ *                       64-channel conv, "conv28_tpw2" [2] two 28x28 tiles per workgroup (1 forward only), "eval_fuse" [1] eval-mode BatchNorm in the conv epilogues
+ *   weight gradients    "wgrad9" [1] nine-tap kernel, "wgrad9p" [1] paired 64 x 64 nine-tap kernel, "wgrad9p_bg" [1] a paired launch sums the
+ *                       PREVIOUS pair's split-K slabs beside its own work (0: stand-alone reductions), "wgrad9_wgs", "wgrad_pair_reduce" [1],
+ *                       "wgrad_depth" [4] generations of weight-gradient operands in flight, "fc_wgrad_aux" [1]
+ *   BatchNorm forward   "bn_sliced" [1] channel-sliced passes without finalize launches, "fwd_xmom" [1] bn3 + identity + the next block's bn1 as one
+ *                       pass from conv2's raw moments, "fwd_bnfuse" [1] conv1 of a block applies bn2 + PReLU itself, statistics handed over between
+ *                       the launch's workgroups (needs the grid co-resident: see fedfr_net_handoff_errors)
+ *   BatchNorm backward  "fuse_bnbwd" [2] reduction in the dgrad epilogue (1 every fused kernel, 2 the 14x14 layers), "fuse_bnbwd28" [1], "c64p_bnbwd" [1],
+ *                       "fuse_bnred_next" [1] an apply pass reduces its output for the next BatchNorm, "stem_bnred" [1], "bn_fuse_bwd" [0] reduce + apply
+ *                       in one launch with an in-launch hand-off, "bn_sliced_pre", "bn_sliced_bwd_passes"
+ *   streams             "event_nofence" [1] fork / join events without a system-scope fence
+ *   sphnet              "sph_fin_multi" [1], "sph_pair_wgrad" [1], "sph_fuse_prelu_bwd" [1]
+ * Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);
 /* the switch's current value (a caller that changes one temporarily restores what it found) */
 int fedfr_get_option(const char* name, int* value);
@@ -61,8 +61,9 @@ int fedfr_get_option(const char* name, int* value);
 int fedfr_option_count(void);
 int fedfr_option_info(int index, const char** name, int* value, int* default_value);
 /* HIP-event timing of every MFMA GEMM launch on its own stream (bench.py roofline leg).  Slots 0..3: conv fwd/dgrad
- * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order; 8..11: the
- * LDS-halo 3x3 conv kernels conv3x3_halo2<128,14>, <128,28>, <64,*>, conv3x3_halo (v1).
+ * kernel gemm_nt tiles <128,128> <128,64> <64,128> <64,64>; 4..7: wgrad kernel gemm_tn, same tile order; 8..11: retired (the
+ * register-staged halo conv kernels of rounds 1-3); 12 conv3x3_glds<14,14>, 13 conv3x3_glds<28,7>, 14 gemm_tn_glds, 15 the 64-channel 3x3
+ * layers, 16 the nine-tap weight-gradient kernels, 17 gemm_nt_glds; 20..26 the HBM-bound BatchNorm / reduction / SGD kernels (flops = bytes).
  * enable(1) resets the counters; read() requires the stream to be synchronised; flops = sum of 2*M*N*K. */
 int fedfr_profile_enable(int on);
 int fedfr_profile_read(int slot, double* total_ms, long long* launches, double* flops);
@@ -94,6 +95,12 @@ int fedfr_net_set_dropout(fedfr_net_t* net, float p, unsigned long long seed, lo
  * workspace release, for every new model — so a host that wants masks that never repeat keeps the count itself (fedfr_amd.IResNet does:
  * one counter per model, handed over before every training forward). */
 int fedfr_net_set_dropout_step(fedfr_net_t* net, unsigned long long step);
+/* Kernels whose workgroups hand data to each other INSIDE a launch (round 4: a conv that applies the train-mode BatchNorm behind it,
+ * option "fwd_bnfuse"; option "bn_fuse_bwd") need their whole grid co-resident; a workgroup that waits too long gives up and sets an
+ * error word in the workspace, and that step's results are wrong.  *out = that word (0 = none) — synchronises `stream`; ask where the
+ * host synchronises anyway.  It cannot happen while ONE kernel chain owns the GPU; hosts that run several chains on one GPU switch the
+ * options off (fedfr_amd.server does). */
+int fedfr_net_handoff_errors(const fedfr_net_t* net, const void* ws, void* stream, unsigned* out);
 /* debug (tests): while buf != NULL, fedfr_net_backward* copies the gradient entering every block (bf16 NHWC, last block first) and then
  * the gradient wrt the first block's input back to back into buf (caller-owned, `elems` bf16 elements); NULL turns it off.  The one
  * exception to "no pointer is retained": clear it before freeing the buffer. */

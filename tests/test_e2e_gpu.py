@@ -679,40 +679,6 @@ def test_roc_vs_reference():
     assert t == int(g["target_size"]) and torch.equal(l.cpu(), T(g["labels"]))     # already target-first: a stable partition keeps it
 
 
-@pytest.mark.parametrize("training", [True, False])
-def test_fused_bn_apply_in_conv_matches_separate_pass(training):
-    """option fuse_bnapply: BN(+PReLU) of a conv's input applied to the LDS image inside the LDS-DMA conv kernel (and, in training,
-    written back as the wgrad operand) gives the same embeddings / gradients as the separate bn_apply pass: same fp32 ops on the
-    same bf16 inputs, so the results are bit-identical.  (The persistent 64-channel kernel, conv_c64p, is switched off for the comparison:
-    it sums its BatchNorm partials per workgroup instead of per tile, i.e. in another fp32 order than the LDS-image-transform kernel.)"""
-    outs = []
-    for opt in (0, 1):
-        _C.call("fedfr_set_option", b"fuse_bnapply", opt)
-        _C.call("fedfr_set_option", b"conv_c64p", 0)
-        _C.call("fedfr_set_option", b"conv28_tpw2", 0)      # (likewise: two 28x28 tiles per workgroup sum their partials in fp32 first)
-        _C.call("fedfr_set_option", b"fwd_xmom", 0)         # (the moment pass derives the next bn1's statistics instead of measuring them: not bit-identical)
-        try:
-            m, sd, _ = make_model("iresnet18", tag=3.0)
-            x = R.closed_form_images(128).to(DEV)
-            if training:
-                m.train()
-                f = m(x)
-                (f * R.closed_form((128, 512), 0.37, 0.9, 1.0).to(DEV)).sum().backward()
-                outs.append((f.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
-            else:
-                m.eval()
-                with torch.no_grad():
-                    outs.append((m(x).clone(), {}))
-        finally:
-            _C.call("fedfr_set_option", b"fuse_bnapply", 0)
-            _C.call("fedfr_set_option", b"conv_c64p", 1)
-            _C.call("fedfr_set_option", b"conv28_tpw2", 2)       # the library default
-            _C.call("fedfr_set_option", b"fwd_xmom", 1)
-    assert torch.equal(outs[0][0], outs[1][0])
-    for k in outs[0][1]:
-        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
-
-
 def test_paired_weight_gradient_kernel_in_the_network():
     """option wgrad9p (what Server.train selects for concurrent clients): every block's two same-shape 3x3 weight gradients from the paired
     64 x 64 nine-tap kernel — same operands, same K order per split, so the network's gradients agree with the single-layer kernel's to fp32

@@ -271,8 +271,8 @@ def test_conv_wgrad(B, H, Cin, Cout, k, s, variant):
 
 @pytest.mark.parametrize("B,H,C", [(128, 14, 256), (32, 28, 128), (24, 14, 128), (2, 14, 128)])
 def test_conv_wgrad_pair(B, H, C):
-    """Two same-shape 3x3 weight gradients in one launch (64-KiB ring, two workgroups per CU) == autograd of F.conv2d, and
-    bit-identical to the two single launches' split-K sums when the pair path is off."""
+    """fedfr_conv2d_wgrad_pair (the two same-shape 3x3 weight gradients of a residual block in one call) == autograd of F.conv2d on the same
+    bf16 operands, whichever kernel serves the shape."""
     outs = []
     for seed in (11, 23):
         x = bf(rnd((B, C, H, H), seed)).float()
@@ -282,20 +282,12 @@ def test_conv_wgrad_pair(B, H, C):
         outs.append((bf(nhwc(x)).to(dev()), bf(nhwc(dy)).to(dev()), w.grad.permute(0, 2, 3, 1)))
     nbytes = 2 * _C.lib().fedfr_conv2d_wgrad_ws_bytes(B, H, C, C, 3, 1)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev())
-    res = {}
-    for pair in (1, 0):
-        dwa = torch.full((C, 3, 3, C), float("nan"), device=dev())
-        dwb = torch.full((C, 3, 3, C), float("nan"), device=dev())
-        _C.call("fedfr_set_option", b"tn_pair", pair)
-        try:
-            _C.call("fedfr_conv2d_wgrad_pair", outs[0][0].data_ptr(), outs[0][1].data_ptr(), dwa.data_ptr(), outs[1][0].data_ptr(),
-                    outs[1][1].data_ptr(), dwb.data_ptr(), ws.data_ptr(), nbytes, B, H, C, C, 3, 1, _C.stream())
-            torch.cuda.synchronize()
-        finally:
-            _C.call("fedfr_set_option", b"tn_pair", 0)
-        assert relerr(dwa, outs[0][2]) < 2e-4 and relerr(dwb, outs[1][2]) < 2e-4
-        res[pair] = (dwa.cpu(), dwb.cpu())
-    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
+    dwa = torch.full((C, 3, 3, C), float("nan"), device=dev())
+    dwb = torch.full((C, 3, 3, C), float("nan"), device=dev())
+    _C.call("fedfr_conv2d_wgrad_pair", outs[0][0].data_ptr(), outs[0][1].data_ptr(), dwa.data_ptr(), outs[1][0].data_ptr(),
+            outs[1][1].data_ptr(), dwb.data_ptr(), ws.data_ptr(), nbytes, B, H, C, C, 3, 1, _C.stream())
+    torch.cuda.synchronize()
+    assert relerr(dwa, outs[0][2]) < 2e-4 and relerr(dwb, outs[1][2]) < 2e-4
 
 
 @pytest.mark.parametrize("B,H,C", [(128, 14, 256), (16, 28, 128), (3, 56, 64), (1, 112, 64), (2, 14, 512), (5, 14, 128), (1, 14, 64)])
@@ -770,11 +762,11 @@ def test_contrastive_vs_torch(B, D, temp):
     assert float(err) < 1e-4, float(err)
 
 
-@pytest.mark.parametrize("opt,val", [("conv_halo", 2), ("conv_halo", 3), ("tn_glds", 0), ("tn_glds", 1)])
-def test_conv_halo_variants(opt, val):
-    """the non-default GEMM kernel variants kept for same-box A/B (register-staged halo2 conv, 4-wave LDS-DMA conv / wgrad,
-    register-staged wgrad) stay parity-correct: fwd + dgrad + wgrad of one 14x14 and one 28x28 layer."""
-    default = {"conv_halo": 4, "tn_glds": 2}[opt]
+@pytest.mark.parametrize("opt,val", [("tn_glds", 0), ("tn_glds", 1)])
+def test_wgrad_kernel_variants(opt, val):
+    """the non-default weight-gradient kernel variants kept as validation fallbacks (register-staged / 4-wave LDS-DMA GEMM form) stay
+    parity-correct: fwd + dgrad + wgrad of one 14x14 and one 28x28 layer."""
+    default = {"tn_glds": 2}[opt]
     _C.call("fedfr_set_option", opt.encode(), val)
     try:
         for case in [(131, 14, 256, 256, 3, 1), (65, 28, 128, 128, 3, 1)]:

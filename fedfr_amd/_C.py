@@ -136,7 +136,7 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
-        # tuning / validation switches: FEDFR_OPTIONS="fwd_bnfuse=0,tn_glds=0" (see fedfr_set_option)
+        # tuning / validation switches: FEDFR_OPTIONS="wgrad9p_bg=0,tn_glds=0" (see fedfr_set_option)
         for kv in filter(None, os.environ.get("FEDFR_OPTIONS", "").split(",")):
             k, v = kv.split("=")
             if l.fedfr_set_option(k.strip().encode(), int(v)) != 0:

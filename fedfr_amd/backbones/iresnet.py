@@ -702,13 +702,13 @@ class IResNet(nn.Module):
         return self._counts[_C.Q_TRAINABLE_COUNT]
 
     def check_handoffs(self) -> None:
-        """Raise if a kernel with an in-launch hand-off (a conv that applies the BatchNorm behind it: option fwd_bnfuse) gave up waiting for
+        """Raise if a kernel with an in-launch hand-off (option bn_fuse_bwd) gave up waiting for
         the rest of its grid in any pass so far — possible only while several kernel chains share the GPU, which is why ``Server.train``
         switches those options off for concurrent clients.  Synchronises the stream: call it where the host waits anyway."""
         for plan in self._plans.values():
             if plan.handoff_errors():
                 raise RuntimeError("fedfr_amd: an in-launch hand-off timed out (a kernel's grid was not co-resident): the results of this "
-                                   "model's last passes are wrong.  Set FEDFR_OPTIONS=fwd_bnfuse=0,bn_fuse_bwd=0 when other work shares the GPU.")
+                                   "model's last passes are wrong.  Set FEDFR_OPTIONS=bn_fuse_bwd=0 when other work shares the GPU.")
 
 
 def _iresnet(arch, block, layers, pretrained, progress, **kwargs):

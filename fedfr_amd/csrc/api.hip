@@ -39,7 +39,6 @@ extern int g_dbg_skip;
 extern int g_c64p_bnbwd;
 extern int g_stem_bnred;
 extern int g_fwd_xmom;
-extern int g_fwd_bnfuse;
 extern int g_fc_wgrad_aux;
 extern int g_fuse_bnbwd28;
 
@@ -97,7 +96,6 @@ const OptRow kOptions[] = {
     {"fuse_bnbwd28", &g_fuse_bnbwd28, 0, 0, 1},
     {"fc_wgrad_aux", &g_fc_wgrad_aux, 0, 0, 1},
     {"fwd_xmom", &g_fwd_xmom, 0, 0, 1},
-    {"fwd_bnfuse", &g_fwd_bnfuse, 0, 0, 1},                // training forward: conv1 of a block applies bn2 + PReLU itself, statistics handed over inside the launch
     {"stem_bnred", &g_stem_bnred, 0, 0, 1},
     {"sph_fuse_prelu_bwd", &g_sph_fuse_prelu_bwd, 0, 0, 1},
     {"sph_fin_multi", &g_sph_fin_multi, 0, 0, 1},
@@ -208,7 +206,7 @@ int fedfr_net_set_dropout_step(fedfr_net_t* n, unsigned long long step) {
   n->dropout_step = step;
   return FEDFR_OK;
 }
-// the error word of the in-launch hand-offs (conv + BatchNorm in one launch: GemmNT::hout; option bn_fuse_bwd): non-zero = a workgroup gave up
+// the error word of the in-launch hand-offs (option bn_fuse_bwd: reduce + apply pass of a BatchNorm backward in one launch): non-zero = a workgroup gave up
 // waiting for the rest of its grid (the grid was not co-resident: several kernel chains shared the GPU) and the step's results are WRONG.
 // Synchronises `stream`; callers ask where they synchronise anyway (end of an epoch, FusedTrainer.finish()).
 int fedfr_net_handoff_errors(const fedfr_net_t* n, const void* ws, void* stream, unsigned* out) {

@@ -61,7 +61,7 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1, bool HF = false>   // HF: the train-mode BatchNorm (+PReLU) behind the conv applied by this launch, statistics handed over between its workgroups (GemmNT::hout); TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1>   // TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
   constexpr int PT = R_ * W_, BN = BN_, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
@@ -96,7 +96,6 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   int img = bt / TPI, y0 = (bt - img * TPI) * R_;
   int m0 = bt * PT;
   const int n0 = bn * BN;
-  static_assert(!HF || (!FUSED && !ONECHUNK && BN_ == 128 && WN == 4), "hand-off variant: plain 8-wave kernel, 128-channel tiles");
   // XLATE (FUSED with several tiles per workgroup, round 3): the two-tiles instantiation sits at the register limit, so the BatchNorm input
   // tile cannot ride through the K loop in registers.  It is requested right BEHIND the loop (after the drain of the tail DMAs: the loads
   // fly while the accumulators are staged) and the tiles' column sums meet in LDS: ONE partial row per workgroup.
@@ -500,21 +499,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         }
       }
   }
-  if constexpr (HF && TPW == 1) {                       // the tile's two wave rows meet in LDS (the drained weight ring): ONE row per workgroup
-    float* hS = reinterpret_cast<float*>(smem + XOFF);
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float a = row16_sum(ssum[ni][q]), b = row16_sum(ssq[ni][q]);
-        const int col = wn * (BN / WN) + ni * 16 + lg * 4 + q;
-        if (l15 == 0) {
-          hS[wm * 2 * BN + col] = a;
-          hS[wm * 2 * BN + BN + col] = b;
-        }
-      }
-  }
-  if (TPW == 1 && p.stats && !HF) {
+  if (TPW == 1 && p.stats) {
     const int ntile = gridDim.x / p.nbn;
     float* prow_ = p.stats + (size_t)(bt * WM + wm) * 2 * p.N;
 #pragma unroll
@@ -537,24 +522,6 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       }
   }
   __syncthreads();
-  if constexpr (HF) {
-    if (ti == TPW - 1) {
-      // the workgroup's statistics row is complete: publish it (write-through stores, drained, then ONE counter add per workgroup, one counter per launch: MI355X_MICROARCH.md,
-      // inter-workgroup visibility) BEFORE the copy-out below, so that the row travels while the tile is stored
-      const float* hs = TPW == 1 ? reinterpret_cast<const float*>(smem + XOFF) : sStat;
-      int hz;                                              // (opaque zero: nothing below may be computed in front of the K loop and kept through it)
-      asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
-      const int ht = tid + hz;
-      if (ht < 2 * BN) {
-        const int stat = ht / BN, col = ht - stat * BN;
-        __hip_atomic_store(p.stats + (size_t)btw * 2 * p.N + (size_t)stat * p.N + n0 + col, hs[ht] + hs[2 * BN + ht], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (ht == 0) __hip_atomic_fetch_add(p.hcnt + hz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   constexpr int CPR = BN / 8;
   if constexpr (!FUSED) {
     for (int idx = tid; idx < PT * CPR; idx += NT) {
@@ -726,115 +693,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       o[2 * (size_t)p.N] = t2;
     }
   }
-  if constexpr (HF) {
-    // ---- the BatchNorm behind this conv (GemmNT::hout): wait for the rows of every workgroup of this N tile ...
-    int hz;                                                // (opaque zero, as above)
-    asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
-    const int ht = tid + hz;
-    if (ht == 0) {
-      unsigned spins = 0;
-      while ((int)(__hip_atomic_load(p.hcnt + hz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.htarget) < 0) {
-        if (++spins > (1u << 22)) {                        // ~ seconds: a workgroup of this grid never became resident
-          atomicOr(p.herr, 1u);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    __syncthreads();
-    // ... sum them per column in fp64, in the order of the stand-alone pass (bn_sliced.hip, fan_in_*: row group rg = rows rg, rg + 16, ...,
-    // then the 16 groups in ascending order) -> the same bits.  Thread: float4 column c4 (statistic c4 >> 5), row groups wave and wave + 8.
-    const int P = stat_rows;                               // (HF: the launcher passes the number of workgroups per N tile = statistics rows)
-    constexpr int HXOFF = NABUF * A_BYTES, HCST = BN * 2 + 16;        // the drained weight ring / the staged tile's row pitch (see the epilogue above)
-    double* red = reinterpret_cast<double*>(smem + HXOFF + 4096);     // [16][2 BN]
-    double* tot = red + 16 * 2 * BN;                                  // [2 BN]
-    float* cf = reinterpret_cast<float*>(tot + 2 * BN);               // [2][BN]: scale, shift
-    static_assert(4096 + (16 * 2 * BN + 2 * BN) * 8 + 2 * BN * 4 <= NB * B_BYTES, "hand-off scratch must fit the weight ring");
-    {
-      const __amdgpu_buffer_rsrc_t rsS = make_rsrc(p.stats, (unsigned)((size_t)P * 2 * (size_t)p.N * 4));
-      const int c4 = ht & 63;
-      const unsigned coff = ((unsigned)(c4 >> 5) * (unsigned)p.N + (unsigned)n0 + (unsigned)(c4 & 31) * 4u) * 4u;
-      const unsigned rstride = 2u * (unsigned)p.N * 4u;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int rg = (ht >> 6) + 8 * h;
-        u32x4_t v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = rg + 16 * i;
-          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, (int)(row < P ? (unsigned)row * rstride + coff : OOB), 0, 16);   // sc1: served by L2 / memory, never a stale L1 line
-        }
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          a0 += (double)__uint_as_float(v[i][0]); a1 += (double)__uint_as_float(v[i][1]);
-          a2 += (double)__uint_as_float(v[i][2]); a3 += (double)__uint_as_float(v[i][3]);
-        }
-        double* d = red + rg * 2 * BN + c4 * 4;
-        d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
-      }
-    }
-    __syncthreads();
-    if (ht < 2 * BN) {
-      double t = 0.0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t += red[i * 2 * BN + ht];
-      tot[ht] = t;
-    }
-    __syncthreads();
-    if (ht < BN) {
-      const int cch = n0 + ht;
-      const double mean = tot[ht] / p.hcount;
-      double var = tot[BN + ht] / p.hcount - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const double rstd = 1.0 / sqrt(var + (double)p.heps);
-      const float ga = p.hgamma ? p.hgamma[cch] : 1.f, be = p.hbeta ? p.hbeta[cch] : 0.f;
-      const float sc = (float)((double)ga * rstd), sh = (float)((double)be - mean * (double)ga * rstd);
-      cf[ht] = sc;
-      cf[BN + ht] = sh;
-      if (btw == 0) {                                      // the workgroups of image tile 0 leave what the backward pass / the caller reads
-        p.hscale[cch] = sc; p.hshift[cch] = sh; p.hmean[cch] = (float)mean; p.hrstd[cch] = (float)rstd;
-        if (p.hrm) {
-          const double unb = p.hcount > 1.0 ? var * p.hcount / (p.hcount - 1.0) : var;
-          p.hrm[cch] = (float)((1.0 - p.hmomentum) * (double)p.hrm[cch] + p.hmomentum * mean);
-          p.hrv[cch] = (float)((1.0 - p.hmomentum) * (double)p.hrv[cch] + p.hmomentum * unb);
-        }
-      }
-    }
-    __syncthreads();
-    // ... and apply: hout = prelu?(tile * scale + shift) — the last tile from LDS (still staged), earlier ones re-read (own stores, drained above)
-    {
-      constexpr int CPRH = BN / 8;
-      const int ch = ht % CPRH;
-      float sc[8], sh[8], al[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        sc[q] = cf[ch * 8 + q];
-        sh[q] = cf[BN + ch * 8 + q];
-        al[q] = p.halpha ? p.halpha[n0 + ch * 8 + q] : 1.f;
-      }
-      const bool has_alpha = p.halpha != nullptr;
-#pragma unroll 1
-      for (int t2 = 0; t2 < TPW; ++t2) {
-        const int mt = (btw * TPW + t2) * PT;
-        for (int idx = ht; idx < PT * CPRH; idx += NT) {
-          const int row = idx / CPRH;
-          const size_t go = (size_t)(mt + row) * p.ldc + n0 + ch * 8;
-          const uint4 v = t2 == TPW - 1 ? *reinterpret_cast<const uint4*>(smem + row * HCST + ch * 16) : *reinterpret_cast<const uint4*>(p.Cb + go);
-          float f[8];
-          unpack8(v, f);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            float y = f[q] * sc[q] + sh[q];
-            if (has_alpha) y = y > 0.f ? y : al[q] * y;
-            f[q] = y;
-          }
-          *reinterpret_cast<uint4*>(p.hout + go) = pack8(f);
-        }
-      }
-    }
-  }
-  if constexpr (TPW > 1 && !HF) {
+  if constexpr (TPW > 1) {
     // one partial row per workgroup: wave row 0 + wave row 1 of the LDS partials (every tile's epilogue ended with a barrier)
     if (p.stats) {
       const int nrows = gridDim.x / p.nbn;
@@ -853,24 +712,12 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1, bool HF = false>
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
   FEDFR_REQUIRE(p.N % BN_ == 0 && (ONECHUNK ? p.C == 64 : p.C % 128 == 0) && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
                 "conv3x3_glds: unsupported shape (N=%d C=%d H=%d W=%d M=%d)", p.N, p.C, p.H, p.W, p.M);
   FEDFR_REQUIRE(FUSED == (p.bpart != nullptr), "conv3x3_glds: fused / plain variant mismatch");
-  FEDFR_REQUIRE(HF == (p.hout != nullptr), "conv3x3_glds: hand-off (BatchNorm in the launch) variant mismatch");
-  if (HF) {
-    FEDFR_REQUIRE(p.stats && p.hcnt && p.herr && p.hscale && p.hshift && p.hmean && p.hrstd && p.hcount > 0.0 && p.ldc == p.N && !p.esc && !p.eadd && !p.Cb2,
-                  "conv3x3_glds: the hand-off variant needs stats / counters / coefficient outputs, ldc == N and no other epilogue");
-    int dev = 0, cus = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    FEDFR_REQUIRE((p.M / PT / TPW) * (p.N / BN_) <= cus, "conv3x3_glds: the hand-off variant needs its %d workgroups co-resident, the device has %d CUs",
-                  (p.M / PT / TPW) * (p.N / BN_), cus);
-  }
-  FEDFR_REQUIRE(!(p.esc || p.eadd || p.Cb2) || (!FUSED && p.ldc == p.N && (!p.esc || p.esh) && (!p.Cb2 || (p.esc2 && p.esh2) || p.e2alpha)),
-                "conv3x3_glds: output epilogue needs the plain variant, ldc == N and complete coefficient sets");
   if (FUSED) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
@@ -885,10 +732,10 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   static_assert(lds >= (size_t)PT * (BN_ * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW, HF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15),   /* slot 15: 56x56 and 112x112 */ 2.0 * p.M * p.N * (double)p.K, st);
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW, HF>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, HF ? ntile : gemm_nt_stat_rows(p.M, p.N));
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

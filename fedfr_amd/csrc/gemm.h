@@ -53,22 +53,6 @@ struct GemmNT {
   // same bf16-rounded conv output as the separate ew_bn_apply pass, so both forms give identical bits; Cb keeps the raw conv output
   const float* e2alpha;
   const bf16_t* e2add;
-  // round 4 (training forward): the TRAIN-MODE BatchNorm (+PReLU) that follows this conv, applied by the conv launch itself (conv_glds_impl.h, HF
-  // instantiations).  A BatchNorm is a grid-wide dependency; here the launch's workgroups hand their partial statistics rows to each other:
-  // every workgroup stores its row of `stats` write-through (agent scope), counts itself in *hcnt, copies its raw output tile out,
-  // then waits until the counter has reached htarget (every workgroup of the launch: bounded spin, *herr set on a time-out), sums the rows of
-  // its channels in the order of the stand-alone pass (bn_sliced.hip, fan_in: same bits), derives (scale, shift) and writes
-  // hout = prelu?(Cb * scale + shift) from the tile it still holds in LDS.  Needs the whole grid co-resident: the launcher refuses grids
-  // larger than the device's CU count (one workgroup per CU), callers switch it off when several kernel chains share the GPU.
-  bf16_t* hout;                             // null: off
-  const float *hgamma, *hbeta, *halpha;     // halpha null: no PReLU
-  float *hrm, *hrv;                         // running statistics, updated by the workgroups of image tile 0
-  float hmomentum, heps;
-  double hcount;
-  float *hscale, *hshift, *hmean, *hrstd;   // [N] each: what the backward pass reads
-  unsigned* hcnt;                           // arrival counter, monotonic over launches (zeroed once with the workspace)
-  unsigned htarget;                         // value *hcnt has once every workgroup of this launch has arrived
-  unsigned* herr;
   unsigned long long* dbg;   // diagnostics builds only (tools/stamp_halo2.hip): per-block in-kernel clock stamps
 };
 
@@ -93,9 +77,6 @@ bool gemm_nt_fused28_two_tiles(int M);   // a fused (BatchNorm-backward reductio
 int gemm_nt_stat_rows_live(int M, int N, int C, int W, int ksize, int stride);   // leading rows that are not zero filler
 // shapes whose conv runs on an LDS-DMA kernel that implements the output epilogue (esc / eadd / Cb2)
 bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride);
-// ... and on an instantiation that can apply the train-mode BatchNorm behind it itself (GemmNT::hout): 14x14 maps, or 28x28 with two tiles
-// per workgroup, with at most one workgroup per CU of the current device
-bool gemm_nt_conv_handoff_ok(int W, int C, int N, int M, int ksize, int stride);
 // number of splits / workspace helpers
 int gemm_nt_pick_splits(int M, int N, int K);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st);

@@ -323,20 +323,6 @@ bool gemm_nt_conv_epilogue_ok(int W, int C, int N, int M, int ksize, int stride)
   return false;
 }
 
-// shapes whose forward conv runs on an instantiation that applies the train-mode BatchNorm behind it itself (conv_glds_impl.h, HF): the whole
-// grid must be co-resident, one workgroup per CU
-bool gemm_nt_conv_handoff_ok(int W, int C, int N, int M, int ksize, int stride) {
-  if (ksize != 3 || stride != 1 || (W != 14 && W != 28) || M % (W * W) != 0 || N % 128 != 0 || C % 128 != 0 || nt_bm(M, N) != 128) return false;
-  if (W == 28 && !glds28_two_tiles_shape(M)) return false;
-  static int cus[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int& n = cus[dev & 63];
-  if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
-  const int wgs = (W == 14 ? M / 196 : M / 392) * (N / 128);
-  return n > 0 && wgs <= n;
-}
-
 static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st);
 int gemm_nt_launch(GemmNT p, int splits, hipStream_t st) {
   if (g_dgrad_parity && p.mode == 1 && p.up == 2 && p.S == 3 && p.pad == 1 && p.stride == 1 && p.Cb && !p.stats && splits == 1 &&
@@ -387,11 +373,6 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
   if (p.esc || p.eadd || p.Cb2)
     FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.pad == 1 && p.H == p.W && p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && !p.bpart &&
                   !p.stats && !p.par_on && gemm_nt_conv_epilogue_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: output epilogue is not available for this convolution");
-  if (p.hout) {
-    FEDFR_REQUIRE(p.mode == 1 && p.up == 1 && p.pad == 1 && p.H == p.W && p.H == p.Ho && p.W == p.Wo && p.Cb && splits == 1 && !p.bpart && !p.par_on &&
-                  p.stats && gemm_nt_conv_handoff_ok(p.W, p.C, p.N, p.M, p.S, p.stride), "gemm_nt: the BatchNorm hand-off is not available for this convolution");
-    return p.W == 14 ? launch_conv_glds8_w14_handoff(p, st) : launch_conv_glds8_w28_handoff(p, st);
-  }
   if (splits == 1 && conv_c64p_applies(p)) return launch_conv_c64p(p, st);
   const int BM = nt_bm(p.M, p.N);
   // 3x3 / stride-1 / pad-1 layers on the LDS-DMA kernels (conv_glds_impl.h: one translation unit per instantiation); every other shape — odd map

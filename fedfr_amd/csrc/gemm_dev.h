@@ -48,8 +48,6 @@ extern int g_nt_nbuf, g_tn_target_blocks, g_tn_glds;
 int launch_conv_glds8_w14(GemmNT p, hipStream_t st);       // conv_glds8_w14.hip  same, 8 waves per tile
 int launch_conv_glds8_w28(GemmNT p, hipStream_t st);       // conv_glds8_w28.hip
 int launch_conv_glds8_w28_stats(GemmNT p, hipStream_t st); // conv_glds8_w28s.hip  two image tiles per workgroup, one BatchNorm partial row each
-int launch_conv_glds8_w14_handoff(GemmNT p, hipStream_t st);   // conv_glds8_w14h.hip   + the BatchNorm behind the conv, statistics handed over inside the launch
-int launch_conv_glds8_w28_handoff(GemmNT p, hipStream_t st);   // conv_glds8_w28sh.hip
 extern int g_conv28_tpw2;
 int launch_conv_glds_w56(GemmNT p, hipStream_t st);        // conv_glds_w56.hip  56x56, C = N = 64
 int launch_conv_glds_w112(GemmNT p, hipStream_t st);       // conv_glds_w112.hip 112x112, C = N = 64

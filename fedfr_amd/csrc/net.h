@@ -94,7 +94,6 @@ struct FedfrNet {
   // in-launch hand-off buffer of the fused BatchNorm-backward kernels (bn_sliced.hip): granules + one error word at its end; zeroed when a
   // workspace is seen for the first time, epochs count launches
   mutable unsigned hand_epoch = 0;
-  mutable unsigned hf_total = 0;        // arrivals counted so far by the conv launches that apply the BatchNorm behind them (GemmNT::hcnt: monotonic)
   mutable const unsigned char* hand_ws = nullptr;
   int sph_type = 0;                     // 20 / 64: a sphnet plan (net_create_sphere); the iresnet fields above are unused then
   std::vector<SphStageD> sph;

@@ -296,29 +296,7 @@ static int hand_init(const FedfrNet* n, unsigned char* ws, hipStream_t st) {
   }
   n->hand_ws = ws;
   n->hand_epoch = 0;
-  n->hf_total = 0;
   return FEDFR_OK;
-}
-int g_fwd_bnfuse = 1;     // option "fwd_bnfuse": training forward, conv1 of a residual block applies bn2 + PReLU itself (statistics handed over between the
-                          // launch's workgroups: GemmNT::hout) on the 14x14 / 28x28 maps — the bn_apply pass between conv1 and conv2 disappears
-// conv -> train-mode BatchNorm (+PReLU) in ONE launch: raw = conv(in) (kept: the backward pass reads it), a = prelu?(bn(raw))
-static int conv_fwd_handoff(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* raw, const BnD& bn, const float* alpha, bf16_t* a) {
-  GemmNT p{};
-  p.A = in; p.B = c.shadow + cv.w_off;
-  p.M = c.n->B * cv.Hout * cv.Hout; p.N = cv.Cout; p.K = cv.R * cv.R * cv.Cin;
-  p.mode = 1; p.H = cv.Hin; p.W = cv.Hin; p.C = cv.Cin; p.Ho = cv.Hout; p.Wo = cv.Hout; p.S = cv.R;
-  p.stride = 1; p.pad = 1; p.up = 1;
-  p.Cb = raw; p.ldc = cv.Cout; p.stats = c.part();
-  p.hout = a; p.hgamma = c.gamma(bn); p.hbeta = c.beta(bn); p.halpha = alpha;
-  p.hrm = c.bufs + bn.rm_off; p.hrv = c.bufs + bn.rv_off; p.hmomentum = kBnMomentum; p.heps = kBnEps; p.hcount = (double)p.M;
-  p.hscale = c.save(bn, 0); p.hshift = c.save(bn, 1); p.hmean = c.save(bn, 2); p.hrstd = c.save(bn, 3);
-  unsigned char* hb = c.ws + c.n->ws_hand + ew_bn_fused_hand_bytes();
-  p.herr = reinterpret_cast<unsigned*>(hb);
-  p.hcnt = reinterpret_cast<unsigned*>(hb + 64);
-  const int wgs = (cv.Hin == 14 ? p.M / 196 : p.M / 392) * (cv.Cout / 128);
-  c.n->hf_total += (unsigned)wgs;
-  p.htarget = c.n->hf_total;
-  return gemm_nt_launch(p, 1, c.st);
 }
 int g_fwd_xmom = 1;       // option "fwd_xmom": bn3 + identity + the next block's bn1 as one pass from conv2's raw moments (14x14 / 28x28 blocks)
 int g_fuse_bnbwd28 = 1;   // option "fuse_bnbwd28": ... and in the two-tiles 28x28 dgrad (with fuse_bnbwd != 0)
@@ -629,13 +607,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
                       k.conv2.Cin % 128 == 0 && k.Cout % 128 == 0 && k.conv2.Cin == k.Cout && nxb->bn1.C == k.Cout &&
                       gemm_nt_conv_epilogue_ok(k.Hout, k.conv2.Cin, k.Cout, Mo, 3, 1) &&          // (mirrors the dispatch: small problems take the generic kernel)
                       (k.Hout == 14 || gemm_nt_fused28_two_tiles(Mo)) && ew_bn_apply2_sliced_ok(Mo, k.Cout, xm_rows);
-    // round 4 (option fwd_bnfuse): conv1 applies bn2 + PReLU itself where its kernel can hand the statistics over inside the launch
-    const bool hf1 = g_fwd_bnfuse && gemm_nt_conv_handoff_ok(k.conv1.Hin, k.conv1.Cin, k.conv1.Cout, Mi, k.conv1.R, k.conv1.stride);
-    if (hf1) {
-      if (!a1_ready) FEDFR_TRY(bn_apply_train(c, k.bn1, prev, A + k.x_off, nullptr, nullptr, A + k.a1_off, Mi, nullptr));
-      a1_ready = false;
-      FEDFR_TRY(conv_fwd_handoff(c, k.conv1, A + k.a1_off, A + k.c1_off, k.bn2, params + k.alpha_off, A + k.a2_off));
-    } else if (a1_ready) {                      // the previous block's output pass wrote a1 = bn1(x) and bn1's statistics
+    if (a1_ready) {                             // the previous block's output pass wrote a1 = bn1(x) and bn1's statistics
       FEDFR_TRY(conv_fwd(c, k.conv1, A + k.a1_off, A + k.c1_off, true));
       a1_ready = false;
     } else {
@@ -644,7 +616,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
     }
     const Rows r1{c.part(), gemm_nt_stat_rows_live(Mi, k.Cout, k.conv1.Cin, k.conv1.Hin, k.conv1.R, k.conv1.stride)};
     if (xmom) {
-      if (!hf1) FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
+      FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
       GemmNT p{};
       const ConvD& cv = k.conv2;
       p.A = A + k.a2_off; p.B = c.shadow + cv.w_off;
@@ -670,7 +642,7 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
       prev = Rows{c.part(), 0};
       continue;
     } else {
-      if (!hf1) FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
+      FEDFR_TRY(bn_apply_train(c, k.bn2, r1, A + k.c1_off, params + k.alpha_off, nullptr, A + k.a2_off, Mi, nullptr));
       FEDFR_TRY(conv_fwd(c, k.conv2, A + k.a2_off, A + k.c2_off, true));
     }
     const Rows r2{c.part(), gemm_nt_stat_rows_live(Mo, k.Cout, k.conv2.Cin, k.conv2.Hin, k.conv2.R, k.conv2.stride)};

@@ -244,7 +244,7 @@ class Server(object):
             import threading
             from . import _C
             # Kernel selection is the lone client's (the paired weight-gradient kernel has been the default since round 3), with ONE exception:
-            # kernels whose workgroups wait for each other inside a launch (in-launch hand-offs: options fwd_bnfuse, bn_fuse_bwd) rely on their whole grid
+            # kernels whose workgroups wait for each other inside a launch (in-launch hand-offs: option bn_fuse_bwd) rely on their whole grid
             # being co-resident, which two clients' grids competing for the same CUs cannot promise — a spin could only end by its timeout.
             # Those switches are forced off while clients share the GPU.  The switch is process-global: the previous value (a user's
             # FEDFR_OPTIONS setting) is put back when the round's clients are done, also on an error.
@@ -252,7 +252,7 @@ class Server(object):
             streams = getattr(self, "_client_streams", None)
             if streams is None or len(streams) < par:
                 streams = self._client_streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(par)]
-            with _C.option_scope("bn_fuse_bwd", 0), _C.option_scope("fwd_bnfuse", 0):
+            with _C.option_scope("bn_fuse_bwd", 0):
                 for w0 in range(0, len(order), par):
                     errs = []
 

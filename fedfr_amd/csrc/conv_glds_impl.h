@@ -476,9 +476,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           if (p.ealpha) a = a > 0.f ? a : eal_[ni][q] * a;
         }
         h[q] = f2bf(a);
-        const float v = mok ? bf2f(h[q]) : 0.f;
-        ssum[ni][q] += v;
-        ssq[ni][q] += v * v;
+        if constexpr (!FUSED) {                            // (the fused instantiations leave their statistics in the reduction pass below, never these)
+          const float v = mok ? bf2f(h[q]) : 0.f;
+          ssum[ni][q] += v;
+          ssq[ni][q] += v * v;
+        }
       }
       uint2 pk;
       pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
@@ -721,7 +723,7 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   if (FUSED) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && p.ldc == p.N, "conv3x3_glds: fused BN-bwd reduction needs bx / mean / rstd and ldc == N");
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
-    FEDFR_REQUIRE(TPW == 1 || !p.stats, "conv3x3_glds: the several-tiles fused variant keeps its running row where the forward statistics would live");
+    FEDFR_REQUIRE(!p.stats, "conv3x3_glds: a fused-epilogue launch leaves reduction rows (bpart), not forward statistics");
     FEDFR_REQUIRE(p.bmom != 2 || p.balpha, "conv3x3_glds: the PReLU-apply epilogue needs the slopes");
     if (p.bwd_fused) *p.bwd_fused = p.M / PT / TPW;
   }

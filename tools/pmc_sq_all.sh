@@ -8,5 +8,5 @@ bash tools/pmc_sq.sh conv28_fwd     "s2_128x128@28" fwd    > /dev/null && echo d
 bash tools/pmc_sq.sh conv28_fdgrad  "s2_128x128@28" fdgrad > /dev/null && echo done conv28_fdgrad
 bash tools/pmc_sq.sh wpair14        "s3_256x256@14" wpair  > /dev/null && echo done wpair14
 bash tools/pmc_sq.sh wpair28        "s2_128x128@28" wpair  > /dev/null && echo done wpair28
-python3 tools/conv_bench.py 30 "" fwd,dgrad,fdgrad,wgrad,wpair > gpurun_out/r04_conv_bench_base.txt 2>&1; tail -3 gpurun_out/r04_conv_bench_base.txt
-python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline > gpurun_out/r04_bench_base.json 2> gpurun_out/r04_bench_base.err; tail -c 600 gpurun_out/r04_bench_base.json
+
+

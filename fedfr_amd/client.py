@@ -354,10 +354,22 @@ class FusedTrainer:
             self._shadows_pending = None
         aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
         S = _C.loss_scale()
+        self._grads_scaled = False
         if S != 1.0:
-            # fp16 validation build: the gradient enters the backbone scaled, the parameter gradients are unscaled before anything reads
-            # them (so the update cannot ride inside the backward pass)
+            # fp16-storage build: the gradient enters the backbone multiplied by the static loss scale S
             ds = dfeats * S
+            if self._fuse_sgd:
+                # step(): the update kernels undo the scale themselves (fedfr_sgd_step_scaled: g * 1/S, stored back), so the update rides inside
+                # the backward pass exactly as in the bf16 build; optimizer_step() finishes [0, done_from) the same way
+                import ctypes
+                done = ctypes.c_longlong(0)
+                _C.call("fedfr_net_backward2_sgd_scaled", plan.handle, imgs.data_ptr(), ds.data_ptr(), bb._flat_params.data_ptr(),
+                        bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                        self.lr, self.mu, self.wd, 1 if self.first else 0, 1.0 / S, ctypes.byref(done), st, aux)
+                self._sgd_done_from = int(done.value)
+                self._grads_scaled = True
+                return
+            # forward_backward(): the parameter gradients are unscaled before anything reads them
             _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), ds.data_ptr(), bb._flat_params.data_ptr(),
                     bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st, aux)
             bb._flat_grads.mul_(1.0 / S)
@@ -383,7 +395,11 @@ class FusedTrainer:
         first = 1 if self.first else 0
         n_rest = self.n_train if self._sgd_done_from is None else self._sgd_done_from      # the rest was updated inside the backward pass
         self._sgd_done_from = None
-        if n_rest > 0:
+        scaled, self._grads_scaled = getattr(self, "_grads_scaled", False), False
+        if n_rest > 0 and scaled:
+            _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / _C.loss_scale(), st)
+        elif n_rest > 0:
             _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                     bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, st)
         if self.pfc is not None:

@@ -123,6 +123,7 @@ struct NetSgd {
   float* params; bf16_t* shadow; float* mom;      // writable views of the (same) parameter / bf16 mirror buffers, momentum buffer
   float lr, mu, wd; int first;
   long long done_from;
+  float gscale = 1.f;                             // 1 / loss scale of the incoming gradient (fp16-storage build); the update kernels undo it
 };
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
                  unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux, NetSgd* sgd = nullptr);

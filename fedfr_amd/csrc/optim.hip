@@ -15,13 +15,20 @@ __device__ __forceinline__ float sgd_one(float p, float g, float& buf, float lr,
   return fmaf(-lr, b, p);                                          // param.add_(buf, alpha=-lr)  (fmadd in torch)
 }
 
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                  bf16_t* __restrict__ shadow, size_t n, float lr, float mu, float wd, int first) {
+// UNSCALE: the gradient buffer holds gs^-1 x the gradient (static loss scale of the fp16-storage build); the kernel multiplies by gs
+// (a power of two: exact) and stores the true gradient back, so the buffer reads like p.grad afterwards.
+template <bool UNSCALE>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
+                                                  bf16_t* __restrict__ shadow, size_t n, float lr, float mu, float wd, int first, float gs) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    if (UNSCALE) {
+      gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs;
+      reinterpret_cast<float4*>(g)[i] = gv;
+    }
     float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
     pv.x = sgd_one(pv.x, gv.x, bv.x, lr, mu, wd, first);
     pv.y = sgd_one(pv.y, gv.y, bv.y, lr, mu, wd, first);
@@ -38,21 +45,27 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float b = first ? 0.f : buf[i];
-    const float v = sgd_one(p[i], g[i], b, lr, mu, wd, first);
+    float gi = g[i];
+    if (UNSCALE) { gi *= gs; g[i] = gi; }
+    const float v = sgd_one(p[i], gi, b, lr, mu, wd, first);
     p[i] = v;
     buf[i] = b;
     if (shadow) shadow[i] = f2bf(v);
   }
 }
 
-int optim_sgd(float* p, const float* g, float* buf, bf16_t* shadow, size_t n, float lr, float mu, float wd, int first,
-              hipStream_t st) {
+int optim_sgd(float* p, float* g, float* buf, bf16_t* shadow, size_t n, float lr, float mu, float wd, int first,
+              hipStream_t st, float gscale) {
   FEDFR_REQUIRE(p && g && buf && n > 0, "sgd: bad args");
   FEDFR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd: buffers must be 16-byte aligned");
   const size_t work = n / 4 + 1;
   const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
-  ProfScope prof(26, (double)n * (first ? 16.0 : 20.0) + (shadow ? 2.0 * n : 0.0), st);      // p, g (, buf) read; p, buf (, bf16 mirror) written
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first);
+  const bool unscale = gscale != 1.f;
+  ProfScope prof(26, (double)n * (first ? 16.0 : 20.0) + (shadow ? 2.0 * n : 0.0) + (unscale ? 4.0 * n : 0.0), st);      // p, g (, buf) read; p, buf (, bf16 mirror, unscaled g) written
+  if (unscale)
+    hipLaunchKernelGGL(sgd_kernel<true>, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first, gscale);
+  else
+    hipLaunchKernelGGL(sgd_kernel<false>, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first, 1.f);
   FEDFR_LAUNCH_CHECK("sgd");
   return FEDFR_OK;
 }

@@ -409,10 +409,11 @@ def test_sgd_inside_backward_is_bit_identical(arch, dual, monkeypatch):
             ls.append(float(tr.step(imgs, lab)))
         tr.finish()
         torch.cuda.synchronize()
-        res.append((ls, m._flat_params.clone(), tr.mom.clone(), m._shadow[: m.trainable_count()].clone(), fc.clone()))
+        res.append((ls, m._flat_params.clone(), tr.mom.clone(), m._shadow[: m.trainable_count()].clone(), fc.clone(), m._flat_grads.clone()))
     a, b = res
     assert a[0] == b[0], (a[0], b[0])
-    for i, name in ((1, "parameters"), (2, "momentum"), (3, "bf16 mirror"), (4, "head fc")):
+    # gradient buffer: in the fp16-storage build the fused update kernels undo the loss scale in place (fedfr_sgd_step_scaled)
+    for i, name in ((1, "parameters"), (2, "momentum"), (3, "bf16 mirror"), (4, "head fc"), (5, "gradient buffer")):
         assert torch.equal(a[i], b[i]), name
     # and the update really happened inside the pass: only stem + stage 1 are left to the flat kernel
     tr._fuse_sgd = True
@@ -1389,7 +1390,7 @@ def test_fp16_storage_build_meets_the_1e2_bar():
         pytest.skip("libfedfr_hip_fp16.so is not built (make -C fedfr_amd/csrc fp16)")
     env = dict(os.environ, FEDFR_HIP_LIB_NAME="libfedfr_hip_fp16.so")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_e2e_gpu.py"), "-x", "-q", "-s", "-k",
-                        "backbone_forward_vs_reference or train_step_grads_vs_reference or fused_client_loop"], env=env, capture_output=True,
+                        "backbone_forward_vs_reference or train_step_grads_vs_reference or fused_client_loop or sgd_inside_backward"], env=env, capture_output=True,
                        text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     emb = re.findall(r"MEASURED (iresnet\d+) embeddings: eval ([\d.e+-]+) train ([\d.e+-]+)", r.stdout)

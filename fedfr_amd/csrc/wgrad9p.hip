@@ -21,7 +21,7 @@
 // 132 VGPRs + 144 AGPRs at one wave per SIMD (wgrad9: 2 x 144 of 512).  Off by default: see g_wgrad9p.
 #include "gemm_tn_dev.h"
 #ifndef W9P_ABLATE
-#define W9P_ABLATE 0     // timing experiments only: 1 no in-loop DMA, 2 no in-loop fragment reads, 4 no MFMA, 16 no slab stores
+#define W9P_ABLATE 0     // timing experiments only: 1 no in-loop DMA, 2 no in-loop fragment reads, 4 no MFMA, 16 no slab stores, 32 no slab loads by the reduction job
 #endif
 
 // option "wgrad9p".  Off by default: measured on one box, the pair runs in 66-69 us against 89 us for the two single-layer launches with
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   bool jdone = false;
   auto job_load = [&](int r) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
     if constexpr (JM != 0) {
-      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (int)jvoff, (int)(jsb + (unsigned)r * p.job.sr), 0);
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (W9P_ABLATE & 32) ? (int)JOOB : (int)jvoff, (int)(jsb + (unsigned)r * p.job.sr), 0);
       jr[r] = __builtin_bit_cast(f32x4_t, v);
     }
   };

@@ -79,7 +79,7 @@ struct FedfrNet {
   long long act_bf16_count, act_float_off_bytes, act_bytes;
   // workspace layout (byte offsets)
   size_t ws_bytes;
-  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_part2, ws_slab, ws_small, ws_fc, ws_hand;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
+  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_part2, ws_slab, ws_small, ws_fc, ws_hand, ws_stem = 0;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
   mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;

@@ -174,6 +174,8 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
                       (size_t)num_features * n->Bp * 2 + 1024);
   n->ws_fc = wtake((size_t)n->Bp * n->fc_in * 4);
   n->ws_hand = wtake(ew_bn_fused_hand_bytes() + 256);
+  n->ws_stem = wtake((size_t)ew_stem_wgrad_blocks(batch, in_hw, in_hw) * 2048 * 4);     // the stem weight gradient's own partials: it runs on the main stream
+                                                                                        // while the weight-gradient stream is still in the slab regions
   n->ws_bytes = w;
 }
 
@@ -914,9 +916,9 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     if (sgd && !n->block_only && k.has_ds && bi > 0) sgd_lo = k.bn1.g_off;      // a stage is complete: its range goes out behind the next fork
   }
   FEDFR_TRY(wgrad_flush(c, &pend_w, wst));
-  // join: the stem wgrad below reuses the slab workspace; callers see all grads.  The join sits BEHIND the stem's BatchNorm backward: the stem's BatchNorm backward (two passes over
-  // 205 MB tensors) does not wait for the last weight gradients — its dz goes to t(1) (da2 of the blocks: main stream only) instead of
-  // t(0), which block 0's weight gradient may still be reading
+  // join: callers see all grads.  It sits at the very END: neither the stem's BatchNorm backward (two passes over 205 MB tensors; its dz goes to
+  // t(1) — da2 of the blocks, main stream only — instead of t(0), which block 0's weight gradient may still be reading) nor the stem's
+  // weight gradient (own partials, ws_stem) waits for the last weight gradients of stage 1
   if (n->block_only) fk.order(wst, st);
   const int M0 = B * HW * HW;
   FEDFR_TRY(dbg_capture(c.g(cur), (size_t)M0 * n->blocks.front().Cin, &dbg_off, st));
@@ -929,8 +931,8 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   // ---- stem: a0 = prelu(bn1(conv1(x))) ----
   bf16_t* dz0 = c.t(1);
   FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, dz0, n->stem_alpha_off, pend));
+  FEDFR_TRY(ew_stem_wgrad(x, dz0, grads + n->stem.w_off, reinterpret_cast<float*>(ws + n->ws_stem), B, HW, HW, st));
   fk.order(wst, st);
-  FEDFR_TRY(ew_stem_wgrad(x, dz0, grads + n->stem.w_off, c.slab(), B, HW, HW, st));
   }
   if (!fk.ok) {
     fedfr_set_error("net_backward: HIP event record/wait failed");

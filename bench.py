@@ -447,6 +447,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = tr.step(imgs[i % nbuf], labs[i % nbuf])
+    t_enqueue = time.perf_counter() - t0         # host time to ENQUEUE the K steps (no sync inside): well below dt = the GPU is never waiting for the host
     if isinstance(loss, tuple):
         loss = loss[0]
     t_local = None
@@ -463,6 +464,16 @@ def main():
         dist.all_reduce(tt, dist.ReduceOp.MAX)
         dt, t_local = float(tt[0]), float(tt[1])
     final_loss = float(loss)
+    # host cost of one step: enqueue time of a step issued into an EMPTY queue (the timed loop's own enqueue time includes the back-pressure of
+    # a full queue).  Far below ms_per_step = the GPU never waits for the host.
+    host_ms = []
+    if not use_dist:
+        for i in range(5):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            tr.step(imgs[i % nbuf], labs[i % nbuf])
+            host_ms.append((time.perf_counter() - th) * 1e3)
+        torch.cuda.synchronize()
     model.check_handoffs()                       # (the stream is idle here: raises if an in-launch hand-off of the timed steps timed out)
 
     # ---- roofline leg: HIP-event timing of every MFMA GEMM launch and of the HBM-bound BatchNorm / SGD kernels, in a separate short
@@ -734,6 +745,8 @@ def main():
                        "global_batch": world * B, "parallelism": "1 client per GPU (FedAvg), dp%d" % world,
                        "clients": world},
             "images_per_sec_per_gpu": round(value / world, 1),
+            "host_enqueue_ms_per_step": {"empty_queue_median": round(sorted(host_ms)[len(host_ms) // 2], 3) if host_ms else None,
+                                         "timed_loop": round(t_enqueue * 1e3 / args.steps, 3)},      # timed loop: includes queue back-pressure
             "step_mfma_frac": round(step_tflop / (ms_step * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4),
             "step_algorithmic_tflop": round(step_tflop, 3),
             "final_loss": round(final_loss, 4),

@@ -16,10 +16,19 @@ import torch.nn.functional as F
 
 from . import ref_cpu as R
 
+STORAGE = torch.bfloat16      # the 16-bit storage type being modelled; the GPU tests set it to the loaded library's (set_storage): bfloat16 for the
+                              # product build, float16 for the fp16-storage build (same kernels, 10 mantissa bits)
+
+
+def set_storage(dtype: torch.dtype) -> None:
+    global STORAGE
+    assert dtype in (torch.bfloat16, torch.float16)
+    STORAGE = dtype
+
 
 def q(x: torch.Tensor) -> torch.Tensor:
     """round to bf16 storage, identity gradient."""
-    return x + (x.detach().to(torch.bfloat16).float() - x.detach())
+    return x + (x.detach().to(STORAGE).float() - x.detach())
 
 
 class _RoundGrad(torch.autograd.Function):
@@ -31,7 +40,7 @@ class _RoundGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).float()
+        return g.to(STORAGE).float()
 
 
 def qg(x: torch.Tensor) -> torch.Tensor:

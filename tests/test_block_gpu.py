@@ -21,6 +21,16 @@ from oracle import bf16_emul as E  # noqa: E402
 from fedfr_amd import backbones, _C  # noqa: E402
 from fedfr_amd.backbones.iresnet import BlockPlan  # noqa: E402
 
+
+@pytest.fixture(autouse=True)
+def _oracle_models_the_loaded_librarys_storage():
+    """oracle/bf16_emul.py rounds where the HIP path stores 16-bit tensors: to the loaded library's type (bfloat16; float16 under
+    FEDFR_HIP_LIB_NAME=libfedfr_hip_fp16.so), back to bfloat16 for the CPU tests that may follow in the same session."""
+    from oracle import bf16_emul
+    bf16_emul.set_storage(_C.storage_dtype())
+    yield
+    bf16_emul.set_storage(torch.bfloat16)
+
 DEV = torch.device("cuda:0")
 
 # gradients BEHIND the PReLU derivative in the block's backward pass (tests/test_oracle_golden.py:test_block_bf16_storage_floor)
@@ -137,7 +147,7 @@ def test_backward_layerwise_vs_bf16_oracle(arch, batch):
             hw, cin = hw // stride, cout
     sizes = [batch * (b[4] // b[3]) ** 2 * b[2] for b in blocks]
     total = sum(sizes) + batch * 112 * 112 * 64
-    cap = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
+    cap = torch.zeros(total, dtype=_C.storage_dtype(), device=DEV)
     _C.call("fedfr_net_debug_capture", cap.data_ptr(), cap.numel())
     try:
         feats = m(x)
@@ -157,10 +167,13 @@ def test_backward_layerwise_vs_bf16_oracle(arch, batch):
     def act(bi, which):
         o, rows, ch = C.c_longlong(), C.c_int(), C.c_int()
         _C.call("fedfr_net_act_info", plan.handle, bi, which, C.byref(o), C.byref(rows), C.byref(ch))
-        a = plan.act[o.value * 2: (o.value + rows.value * ch.value) * 2].view(torch.bfloat16).view(rows.value, ch.value)
+        a = plan.act[o.value * 2: (o.value + rows.value * ch.value) * 2].view(_C.storage_dtype()).view(rows.value, ch.value)
         return _nchw(a.float(), batch).cpu()
 
     params = dict(m.named_parameters())
+    # the captured activation gradients carry the library's static loss scale (1 for bf16 storage, 256 for the fp16 build: _C.loss_scale());
+    # the oracle block is run on them as captured, so its parameter gradients carry it too — the module's p.grad are already unscaled
+    S = _C.loss_scale()
     errs = []
     for bi, (name, ci, co, stride, h) in enumerate(blocks):
         bsd = {k: v.clone() for k, v in sd.items() if k.startswith(name + ".")}
@@ -176,7 +189,7 @@ def test_backward_layerwise_vs_bf16_oracle(arch, batch):
         for k in pk:
             if float(bsd[k].grad.norm()) < 1e-4 * scale:                 # biases in front of a BatchNorm: analytically zero
                 continue
-            errs.append((k, rel(params[k].grad, bsd[k].grad)))
+            errs.append((k, rel(params[k].grad * S, bsd[k].grad)))
     # bn1.bias / bn2.bias gradients are column sums of tensors whose channel means a BatchNorm backward has just removed (the exact
     # value is a border effect of the 3x3 window): nearly cancelling sums of bf16-rounded terms, held to a looser bar
     sums = [e for e in errs if e[0].endswith(("bn1.bias", "bn2.bias"))]

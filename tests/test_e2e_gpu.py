@@ -20,6 +20,16 @@ from fedfr_amd.partial_fc import PartialFC  # noqa: E402
 DEV = torch.device("cuda:0")
 
 
+
+@pytest.fixture(autouse=True)
+def _oracle_models_the_loaded_librarys_storage():
+    """oracle/bf16_emul.py rounds where the HIP path stores 16-bit tensors: to the loaded library's type (bfloat16; float16 under
+    FEDFR_HIP_LIB_NAME=libfedfr_hip_fp16.so), back to bfloat16 for the CPU tests that may follow in the same session."""
+    from oracle import bf16_emul
+    bf16_emul.set_storage(_C.storage_dtype())
+    yield
+    bf16_emul.set_storage(torch.bfloat16)
+
 def T(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -63,7 +73,7 @@ def _hip_act(plan, block, which):
     _C.call("fedfr_net_act_info", plan.handle, block, which, C.byref(off), C.byref(rows), C.byref(ch))
     if off.value < 0:
         return None
-    a = plan.act[off.value * 2: (off.value + rows.value * ch.value) * 2].view(torch.bfloat16).view(rows.value, ch.value)
+    a = plan.act[off.value * 2: (off.value + rows.value * ch.value) * 2].view(_C.storage_dtype()).view(rows.value, ch.value)
     return a.float().cpu()
 
 

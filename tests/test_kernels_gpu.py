@@ -17,8 +17,13 @@ def dev():
     return torch.device("cuda:0")
 
 
+def S16():
+    """the loaded library's 16-bit storage type: bfloat16 (product build) or float16 (FEDFR_HIP_LIB_NAME=libfedfr_hip_fp16.so)"""
+    return _C.storage_dtype()
+
+
 def bf(t):
-    return t.to(torch.bfloat16)
+    return t.to(S16())
 
 
 def rnd(shape, seed, scale=1.0):
@@ -77,7 +82,7 @@ def test_conv_fwd_and_stats(B, H, Cin, Cout, k, s):
     Ho = H // s
     xd = bf(nhwc(x)).to(dev())
     wd = bf(w.permute(0, 2, 3, 1).contiguous()).to(dev())          # KRSC
-    y = torch.empty(B, Ho, Ho, Cout, dtype=torch.bfloat16, device=dev())
+    y = torch.empty(B, Ho, Ho, Cout, dtype=S16(), device=dev())
     rows = _C.lib().fedfr_conv2d_stat_rows(B, Ho, Cout)
     stats = torch.full((rows, 2, Cout), float("nan"), device=dev())
     _C.call("fedfr_conv2d_fwd", xd.data_ptr(), wd.data_ptr(), y.data_ptr(), stats.data_ptr(), B, H, Cin, Cout, k, s, _C.stream())
@@ -100,14 +105,14 @@ def test_conv_dgrad(B, H, Cin, Cout, k, s):
     F.conv2d(x, w, None, s, 1 if k == 3 else 0).backward(dy)
     ref = x.grad
     wk = w.permute(0, 2, 3, 1).contiguous().to(dev())            # KRSC fp32
-    wb = torch.empty(wk.shape, dtype=torch.bfloat16, device=dev())
-    wdb = torch.empty(Cin, k, k, Cout, dtype=torch.bfloat16, device=dev())
+    wb = torch.empty(wk.shape, dtype=S16(), device=dev())
+    wdb = torch.empty(Cin, k, k, Cout, dtype=S16(), device=dev())
     _C.call("fedfr_weight_shadows", wk.data_ptr(), wb.data_ptr(), wdb.data_ptr(), Cout, k, Cin, _C.stream())
     dyd = bf(nhwc(dy)).to(dev())
     if k == 1:
-        dx = torch.empty(B, Ho, Ho, Cin, dtype=torch.bfloat16, device=dev())
+        dx = torch.empty(B, Ho, Ho, Cin, dtype=S16(), device=dev())
     else:
-        dx = torch.empty(B, H, H, Cin, dtype=torch.bfloat16, device=dev())
+        dx = torch.empty(B, H, H, Cin, dtype=S16(), device=dev())
     _C.call("fedfr_conv2d_dgrad", dyd.data_ptr(), wdb.data_ptr(), dx.data_ptr(), B, H, Cin, Cout, k, s, _C.stream())
     torch.cuda.synchronize()
     got = dx.float().cpu().permute(0, 3, 1, 2)
@@ -129,13 +134,13 @@ def test_conv_dgrad_fused_bn_bwd_reduction(B, H, Cin, Cout, prelu):
     dy = bf(rnd((B, Cout, H, H), 7))
     d = dev()
     wk = w.permute(0, 2, 3, 1).contiguous().to(d)
-    wdb = torch.empty(Cin, 3, 3, Cout, dtype=torch.bfloat16, device=d)
+    wdb = torch.empty(Cin, 3, 3, Cout, dtype=S16(), device=d)
     _C.call("fedfr_weight_shadows", wk.data_ptr(), None, wdb.data_ptr(), Cout, 3, Cin, _C.stream())
     dyd = nhwc(dy).to(d)
     bnx = bf(rnd((B * H * H, Cin), 9) * 1.5 + 0.2).to(d)
     mean, rstd = (rnd((Cin,), 10) * 0.2).to(d), (rnd((Cin,), 11) * 0.2 + 1.0).to(d)
     gamma, beta, alpha = (rnd((Cin,), 12) * 0.2 + 1).to(d), (rnd((Cin,), 13) * 0.3).to(d), (rnd((Cin,), 14) * 0.1 + 0.25).to(d)
-    dx = torch.empty(B, H, H, Cin, dtype=torch.bfloat16, device=d)
+    dx = torch.empty(B, H, H, Cin, dtype=S16(), device=d)
     part = torch.full((((B * H * H + 127) // 128), 3, Cin), float("nan"), device=d)
     rows = C.c_int(0)
     _C.call("fedfr_conv2d_dgrad_bnbwd", dyd.data_ptr(), wdb.data_ptr(), dx.data_ptr(), B, H, Cin, Cout, 3, 1, bnx.data_ptr(),
@@ -187,7 +192,7 @@ def test_forward_moment_conv_and_bn_apply2(B, H, Ch):
     wb = bf(w.permute(0, 2, 3, 1).contiguous()).to(d)                   # KRSC bf16
     xd = bf(nhwc(x)).to(d)
     other = bf(rnd((M, Ch), 21) * 1.3 + 0.25).to(d)
-    y = torch.empty(B, H, H, Ch, dtype=torch.bfloat16, device=d)
+    y = torch.empty(B, H, H, Ch, dtype=S16(), device=d)
     part = torch.full((M // 196 + 1, 3, Ch), float("nan"), device=d)
     rows = C.c_int(0)
     _C.call("fedfr_conv2d_fwd_moments", xd.data_ptr(), wb.data_ptr(), y.data_ptr(), B, H, Ch, Ch, other.data_ptr(), part.data_ptr(),
@@ -214,8 +219,8 @@ def test_forward_moment_conv_and_bn_apply2(B, H, Ch):
     xmean = of.mean(0).float()
     xrstd = (1.0 / torch.sqrt(of.var(0, unbiased=False) + eps)).float()
     sv = [torch.full((Ch,), float("nan"), device=d) for _ in range(8)]
-    out = torch.empty(M, Ch, dtype=torch.bfloat16, device=d)
-    y2 = torch.empty(M, Ch, dtype=torch.bfloat16, device=d)
+    out = torch.empty(M, Ch, dtype=S16(), device=d)
+    y2 = torch.empty(M, Ch, dtype=S16(), device=d)
     _C.call("fedfr_bn_apply2_sliced", part.data_ptr(), rows.value, float(M), mom, eps, g3.data_ptr(), b3.data_ptr(), rm3.data_ptr(), rv3.data_ptr(),
             sv[0].data_ptr(), sv[1].data_ptr(), sv[2].data_ptr(), sv[3].data_ptr(), xmean.data_ptr(), xrstd.data_ptr(), g1.data_ptr(), b1.data_ptr(),
             rm1.data_ptr(), rv1.data_ptr(), sv[4].data_ptr(), sv[5].data_ptr(), sv[6].data_ptr(), sv[7].data_ptr(), y.data_ptr(), other.data_ptr(),
@@ -352,7 +357,7 @@ def test_stem_fwd_wgrad(B, HW):
     xb, wb = bf(x).float(), bf(w).float()        # the kernel rounds x and w to bf16 for the MFMA
     ref = F.conv2d(xb, wb, None, 1, 1)
     wk = w.permute(0, 2, 3, 1).contiguous().to(dev())
-    y = torch.empty(B, HW, HW, 64, dtype=torch.bfloat16, device=dev())
+    y = torch.empty(B, HW, HW, 64, dtype=S16(), device=dev())
     rows = _C.lib().fedfr_stem_stat_rows(B, HW)
     stats = torch.full((rows, 2, 64), float("nan"), device=dev())
     xd = x.to(dev())
@@ -454,7 +459,7 @@ def test_bn_backward(M, C, prelu, addmode):
     part = torch.full((rows, 3, C), float("nan"), device=d)
     coef = torch.empty(3, C, device=d)
     dg, db, da = (torch.full((C,), float("nan"), device=d) for _ in range(3))
-    dx = torch.empty(M, C, dtype=torch.bfloat16, device=d)
+    dx = torch.empty(M, C, dtype=S16(), device=d)
     t = lambda v: None if v is None else v.to(d)   # noqa: E731
     keep = [t(dy), t(x), t(mean), t(rstd), t(gamma), t(beta), t(alpha) if prelu else None, t(add), t(add_up)]
     _C.call("fedfr_bn_bwd", keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
@@ -552,7 +557,7 @@ def test_bn_bwd_sliced(M, C, prelu, with_add, with_next):
     part = torch.full((rows, 3, C), float("nan"), device=d)
     npart = torch.full((rows, 3, C), float("nan"), device=d)
     dg, db, da = (torch.full((C,), float("nan"), device=d) for _ in range(3))
-    dx = torch.empty(M, C, dtype=torch.bfloat16, device=d)
+    dx = torch.empty(M, C, dtype=S16(), device=d)
     t = lambda v: None if v is None else v.to(d)   # noqa: E731
     k = dict(dy=t(dy), x=t(x), mean=t(mean), rstd=t(rstd), gamma=t(gamma), alpha=t(alpha) if prelu else None, sc=t(sc), sh=t(sh), add=t(add),
              nx=t(nx), nmean=t(nmean), nrstd=t(nrstd))
@@ -890,7 +895,7 @@ def test_bias_prelu_bwd_vs_torch(M, C, with_bias, with_add):
     addd = bf(add).to(dev()) if with_add else None
     rows = _C.lib().fedfr_bn_bwd_rows(M, C)
     part = torch.empty(rows, 3, C, device=dev()); coef = torch.empty(3, C, device=dev())
-    db = torch.empty(C, device=dev()); da = torch.empty(C, device=dev()); dx = torch.empty(M, C, dtype=torch.bfloat16, device=dev())
+    db = torch.empty(C, device=dev()); da = torch.empty(C, device=dev()); dx = torch.empty(M, C, dtype=S16(), device=dev())
     bd, ad = bias.detach().to(dev()), alpha.detach().to(dev())
     _C.call("fedfr_bias_prelu_bwd", dyd.data_ptr(), xd.data_ptr(), bd.data_ptr() if with_bias else None, ad.data_ptr(), M, C, part.data_ptr(),
             coef.data_ptr(), db.data_ptr() if with_bias else None, da.data_ptr(), addd.data_ptr() if with_add else None, dx.data_ptr(), _C.stream())
@@ -904,11 +909,11 @@ def test_bias_prelu_bwd_vs_torch(M, C, with_bias, with_add):
 
 def test_pad_input_nhwc():
     x = torch.randn(3, 3, 20, 20)
-    out = torch.empty(3, 20, 20, 64, dtype=torch.bfloat16, device=dev())
+    out = torch.empty(3, 20, 20, 64, dtype=S16(), device=dev())
     xd = x.to(dev())
     _C.call("fedfr_pad_input_nhwc", xd.data_ptr(), out.data_ptr(), 3, 3, 400, 64, _C.stream())
     torch.cuda.synchronize()
-    assert torch.equal(out[..., :3].cpu(), x.permute(0, 2, 3, 1).to(torch.bfloat16)) and float(out[..., 3:].float().abs().max()) == 0.0
+    assert torch.equal(out[..., :3].cpu(), x.permute(0, 2, 3, 1).to(S16())) and float(out[..., 3:].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 11])

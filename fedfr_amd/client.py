@@ -270,6 +270,7 @@ class FusedTrainer:
         self.fuse_sgd = os.environ.get("FEDFR_FUSE_SGD", "1") != "0"
         self._fuse_sgd = False
         self._sgd_done_from = None
+        self._grads_scaled = False          # fp16-storage build: [0, _sgd_done_from) of the gradient buffer still carries the loss scale
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
@@ -395,7 +396,7 @@ class FusedTrainer:
         first = 1 if self.first else 0
         n_rest = self.n_train if self._sgd_done_from is None else self._sgd_done_from      # the rest was updated inside the backward pass
         self._sgd_done_from = None
-        scaled, self._grads_scaled = getattr(self, "_grads_scaled", False), False
+        scaled, self._grads_scaled = self._grads_scaled, False
         if n_rest > 0 and scaled:
             _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                     bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / _C.loss_scale(), st)

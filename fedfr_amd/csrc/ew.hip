@@ -780,6 +780,10 @@ __device__ __forceinline__ double bn1d_rg_sum(double v, double (*red)[64], int r
   for (int i = 0; i < BN1D_RG; ++i) t += red[i][cl];
   return t;
 }
+// CACHE (B <= BN1D_NR x BN1D_RG rows): a thread's rows are fetched ONCE, all loads in flight together, and the three passes run on registers
+// (round 4: the kernel sits on the serial head chain between the forward and the backward pass; same operations in the same order)
+constexpr int BN1D_NR = 16;
+template <bool CACHE>
 __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_fwd_kernel(const float* x, float* y, int B, int C, const float* gamma, const float* beta,
                                 float* rm, float* rv, float momentum, float eps, int training, float* save_mean,
                                 float* save_rstd) {
@@ -787,15 +791,33 @@ __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_fwd_kernel(const float* x, 
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = min(blockIdx.x * 64 + cl, C - 1);
   const bool own = blockIdx.x * 64 + cl < C && rg == 0;
+  float xv[CACHE ? BN1D_NR : 1];
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int j = 0; j < BN1D_NR; ++j) {
+      const int b = rg + j * BN1D_RG;
+      xv[j] = x[(size_t)min(b, B - 1) * C + c];
+    }
+  }
   float mean, rstd;
   if (training) {
     double s = 0.0;
-    for (int b = rg; b < B; b += BN1D_RG) s += (double)x[(size_t)b * C + c];
+    if constexpr (CACHE) {
+#pragma unroll
+      for (int j = 0; j < BN1D_NR; ++j) if (rg + j * BN1D_RG < B) s += (double)xv[j];
+    } else {
+      for (int b = rg; b < B; b += BN1D_RG) s += (double)x[(size_t)b * C + c];
+    }
     const double mu = bn1d_rg_sum(s, red, rg, cl) / B;
     double v = 0.0;
-    for (int b = rg; b < B; b += BN1D_RG) {
-      const double d = (double)x[(size_t)b * C + c] - mu;
-      v += d * d;
+    if constexpr (CACHE) {
+#pragma unroll
+      for (int j = 0; j < BN1D_NR; ++j) if (rg + j * BN1D_RG < B) { const double d = (double)xv[j] - mu; v += d * d; }
+    } else {
+      for (int b = rg; b < B; b += BN1D_RG) {
+        const double d = (double)x[(size_t)b * C + c] - mu;
+        v += d * d;
+      }
     }
     v = bn1d_rg_sum(v, red, rg, cl);
     const double var = v / B;
@@ -816,18 +838,31 @@ __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_fwd_kernel(const float* x, 
   }
   if (blockIdx.x * 64 + cl >= C) return;
   const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-  for (int b = rg; b < B; b += BN1D_RG) y[(size_t)b * C + c] = (x[(size_t)b * C + c] - mean) * rstd * g + bt;
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int j = 0; j < BN1D_NR; ++j) {
+      const int b = rg + j * BN1D_RG;
+      if (b < B) y[(size_t)b * C + c] = (xv[j] - mean) * rstd * g + bt;
+    }
+  } else {
+    for (int b = rg; b < B; b += BN1D_RG) y[(size_t)b * C + c] = (x[(size_t)b * C + c] - mean) * rstd * g + bt;
+  }
 }
 
 int ew_bn1d_fwd(const float* x, float* y, int B, int C, const float* gamma, const float* beta, float* rm, float* rv,
                 float momentum, float eps, int training, float* save_mean, float* save_rstd, hipStream_t st) {
   FEDFR_REQUIRE(x && y && B > 0 && C > 0 && rm && rv, "bn1d_fwd: bad args");
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, x, y, B, C, gamma, beta, rm, rv, momentum, eps,
-                     training, save_mean, save_rstd);
+  if (B <= BN1D_NR * BN1D_RG)
+    hipLaunchKernelGGL(bn1d_fwd_kernel<true>, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, x, y, B, C, gamma, beta, rm, rv, momentum, eps,
+                       training, save_mean, save_rstd);
+  else
+    hipLaunchKernelGGL(bn1d_fwd_kernel<false>, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, x, y, B, C, gamma, beta, rm, rv, momentum, eps,
+                       training, save_mean, save_rstd);
   FEDFR_LAUNCH_CHECK("bn1d_fwd");
   return FEDFR_OK;
 }
 
+template <bool CACHE>
 __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_bwd_kernel(const float* dy, const float* x, float* dx, int B, int C, const float* gamma,
                                 const float* mean, const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb,
                                 bf16_t* dxbt, int ldt, int frozen) {
@@ -835,27 +870,52 @@ __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_bwd_kernel(const float* dy,
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = min(blockIdx.x * 64 + cl, C - 1);
   const bool valid = blockIdx.x * 64 + cl < C, own = valid && rg == 0;
+  float dv[CACHE ? BN1D_NR : 1], xv[CACHE ? BN1D_NR : 1];
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int j = 0; j < BN1D_NR; ++j) {
+      const size_t o = (size_t)min(rg + j * BN1D_RG, B - 1) * C + c;
+      dv[j] = dy[o];
+      xv[j] = x[o];
+    }
+  }
   const float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = rg; b < B; b += BN1D_RG) {
-    const float d = dy[(size_t)b * C + c];
-    s1 += d;
-    s2 += (double)d * (double)((x[(size_t)b * C + c] - mu) * rs);
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int j = 0; j < BN1D_NR; ++j)
+      if (rg + j * BN1D_RG < B) {
+        s1 += dv[j];
+        s2 += (double)dv[j] * (double)((xv[j] - mu) * rs);
+      }
+  } else {
+    for (int b = rg; b < B; b += BN1D_RG) {
+      const float d = dy[(size_t)b * C + c];
+      s1 += d;
+      s2 += (double)d * (double)((x[(size_t)b * C + c] - mu) * rs);
+    }
   }
   s1 = bn1d_rg_sum(s1, red, rg, cl);
   s2 = bn1d_rg_sum(s2, red, rg, cl);
   const float m1 = frozen ? 0.f : (float)(s1 / B), m2 = frozen ? 0.f : (float)(s2 / B);     // frozen: statistics were constants, dx = g rstd dy
   if (dbeta && own) dbeta[c] = (float)s1;
   double cs = 0.0;
-  if (valid)
-    for (int b = rg; b < B; b += BN1D_RG) {
-      const float xh = (x[(size_t)b * C + c] - mu) * rs;
-      const float v = g * rs * (dy[(size_t)b * C + c] - m1 - xh * m2);
-      dx[(size_t)b * C + c] = v;
-      cs += v;
-      if (dxb) dxb[(size_t)b * C + c] = f2bf(v);
-      if (dxbt) dxbt[(size_t)c * ldt + b] = f2bf(v);
+  auto one = [&](int b, float d, float xx) {
+    const float xh = (xx - mu) * rs;
+    const float v = g * rs * (d - m1 - xh * m2);
+    dx[(size_t)b * C + c] = v;
+    cs += v;
+    if (dxb) dxb[(size_t)b * C + c] = f2bf(v);
+    if (dxbt) dxbt[(size_t)c * ldt + b] = f2bf(v);
+  };
+  if (valid) {
+    if constexpr (CACHE) {
+#pragma unroll
+      for (int j = 0; j < BN1D_NR; ++j) if (rg + j * BN1D_RG < B) one(rg + j * BN1D_RG, dv[j], xv[j]);
+    } else {
+      for (int b = rg; b < B; b += BN1D_RG) one(b, dy[(size_t)b * C + c], x[(size_t)b * C + c]);
     }
+  }
   cs = bn1d_rg_sum(cs, red, rg, cl);
   if (dx_colsum && own) dx_colsum[c] = (float)cs;
 }
@@ -863,8 +923,12 @@ __global__ __launch_bounds__(64 * BN1D_RG) void bn1d_bwd_kernel(const float* dy,
 int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const float* gamma, const float* mean,
                 const float* rstd, float* dbeta, float* dx_colsum, bf16_t* dxb, bf16_t* dxbt, int ldt, hipStream_t st, int frozen) {
   FEDFR_REQUIRE(dy && x && dx && B > 0 && C > 0 && mean && rstd, "bn1d_bwd: bad args");
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, dy, x, dx, B, C, gamma, mean, rstd, dbeta,
-                     dx_colsum, dxb, dxbt, ldt, frozen);
+  if (B <= BN1D_NR * BN1D_RG)
+    hipLaunchKernelGGL(bn1d_bwd_kernel<true>, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, dy, x, dx, B, C, gamma, mean, rstd, dbeta,
+                       dx_colsum, dxb, dxbt, ldt, frozen);
+  else
+    hipLaunchKernelGGL(bn1d_bwd_kernel<false>, dim3(ceil_div(C, 64)), dim3(64 * BN1D_RG), 0, st, dy, x, dx, B, C, gamma, mean, rstd, dbeta,
+                       dx_colsum, dxb, dxbt, ldt, frozen);
   FEDFR_LAUNCH_CHECK("bn1d_bwd");
   return FEDFR_OK;
 }

@@ -29,12 +29,46 @@ int head_normalize_rows(const float* x, float* xn, float* inv, int R, int D, flo
 
 // dx = inv * (dxn - xn * <xn, dxn>)     (F.normalize backward; the eps clamp branch has zero measure)
 // dxn may arrive as `nslab` split-K slabs of the GEMM that produced it (head_sgemm_splitk): summed here, slab 0 first
+// WIDE (D <= 64 * NRB_J): a lane's elements (lane, lane + 64, ...) are fetched once per slab with all loads of a slab in flight together and stay in
+// registers for both passes (round 4: with 7 split-K slabs the element-at-a-time form was a chain of ~110 dependent round trips = 21 us on the
+// serial head chain).  Same additions in the same order.
+constexpr int NRB_J = 8;
+template <bool WIDE>
 __global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ inv,
                                                                  const float* __restrict__ dxn, float* __restrict__ dx,
                                                                  int R, int D, float beta, int nslab, long long slab_stride) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const size_t o = (size_t)row * D;
+  if constexpr (WIDE) {
+    float gv[NRB_J], xv[NRB_J];
+#pragma unroll
+    for (int j = 0; j < NRB_J; ++j) {
+      const int i = min(lane + 64 * j, D - 1);
+      xv[j] = xn[o + i];
+      gv[j] = dxn[o + i];
+    }
+    for (int k = 1; k < nslab; ++k) {
+      float t[NRB_J];
+#pragma unroll
+      for (int j = 0; j < NRB_J; ++j) t[j] = dxn[(size_t)k * slab_stride + o + min(lane + 64 * j, D - 1)];
+#pragma unroll
+      for (int j = 0; j < NRB_J; ++j) gv[j] += t[j];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NRB_J; ++j) if (lane + 64 * j < D) s += xv[j] * gv[j];
+    s = wave_sum(s);
+    const float iv = inv[row];
+#pragma unroll
+    for (int j = 0; j < NRB_J; ++j) {
+      const int i = lane + 64 * j;
+      if (i < D) {
+        const float v = iv * (gv[j] - xv[j] * s);
+        dx[o + i] = beta != 0.f ? beta * dx[o + i] + v : v;
+      }
+    }
+  } else {
   auto g = [&](int i) {
     float v = dxn[o + i];
     for (int k = 1; k < nslab; ++k) v += dxn[(size_t)k * slab_stride + o + i];
@@ -48,11 +82,15 @@ __global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __
     const float v = iv * (g(i) - xn[o + i] * s);
     dx[o + i] = beta != 0.f ? beta * dx[o + i] + v : v;
   }
+  }
 }
 int head_normalize_rows_bwd_slabs(const float* xn, const float* inv, const float* dxn, int nslab, long long slab_stride, float* dx, int R, int D,
                                   float beta, hipStream_t st) {
   FEDFR_REQUIRE(xn && inv && dxn && dx && R > 0 && D > 0 && nslab >= 1 && (nslab == 1 || slab_stride >= (long long)R * D), "normalize_rows_bwd: bad args");
-  hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, xn, inv, dxn, dx, R, D, beta, nslab, slab_stride);
+  if (D <= 64 * NRB_J)
+    hipLaunchKernelGGL(normalize_rows_bwd_kernel<true>, dim3(ceil_div(R, 4)), dim3(256), 0, st, xn, inv, dxn, dx, R, D, beta, nslab, slab_stride);
+  else
+    hipLaunchKernelGGL(normalize_rows_bwd_kernel<false>, dim3(ceil_div(R, 4)), dim3(256), 0, st, xn, inv, dxn, dx, R, D, beta, nslab, slab_stride);
   FEDFR_LAUNCH_CHECK("normalize_rows_bwd");
   return FEDFR_OK;
 }

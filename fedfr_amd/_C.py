@@ -52,7 +52,7 @@ SIGNATURES = {
     "fedfr_net_f32_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "fedfr_net_f32_backward": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "fedfr_net_backward2_sgd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, C.POINTER(i64), vp, vp]),
-    "fedfr_net_backward2_sgd_scaled": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, f32, C.POINTER(i64), vp, vp]),
+    "fedfr_net_backward2_sgd_scaled": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, f32, vp, C.POINTER(i64), vp, vp]),
     "fedfr_conv2d_stat_rows": (i32, [i32, i32, i32]),
     "fedfr_conv2d_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "fedfr_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -106,7 +106,7 @@ SIGNATURES = {
     "fedfr_contrastive": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     "fedfr_sum_scale": (i32, [vp, i32, f32, vp, vp]),
     "fedfr_sgd_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, i32, vp]),
-    "fedfr_sgd_step_scaled": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, i32, f32, vp]),
+    "fedfr_sgd_step_scaled": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, i32, f32, vp, vp]),
     "fedfr_fedavg_axpy": (i32, [vp, vp, f32, sz, i32, vp]),
     "fedfr_fedavg_multi": (i32, [vp, vp, vp, i32, sz, i32, vp]),
     "fedfr_fedavg_i64": (i32, [vp, vp, f32, i32, i32, vp, vp]),

@@ -271,6 +271,14 @@ class FusedTrainer:
         self._fuse_sgd = False
         self._sgd_done_from = None
         self._grads_scaled = False          # fp16-storage build: [0, _sgd_done_from) of the gradient buffer still carries the loss scale
+        # fp16-storage build: this trainer's loss scale (starts at _C.loss_scale(); 1 for bf16 storage) and the device word the update kernels
+        # set when they skipped a non-finite gradient element (fedfr_sgd_step_scaled): read in finish() / every `overflow_check_every` steps,
+        # where an overflow halves the scale — torch.cuda.amp.GradScaler's back-off (client.py:301,394-396) without a host sync per step
+        self.loss_scale = _C.loss_scale()
+        self._overflow = torch.zeros(1, dtype=torch.int32, device=bb.device)
+        self.overflow_check_every = 100
+        self.overflows = 0
+        self._steps_since_check = 0
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
@@ -281,6 +289,21 @@ class FusedTrainer:
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
+        self.check_overflow()
+
+    def check_overflow(self) -> bool:
+        """fp16-storage build: did an update kernel skip non-finite gradient elements since the last check?  (synchronises the stream.)  If so
+        the loss scale is halved for the following steps and a warning is issued; the skipped elements kept their values."""
+        self._steps_since_check = 0
+        if self.loss_scale == 1.0 or int(self._overflow.item()) == 0:
+            return False
+        import warnings
+        self._overflow.zero_()
+        self.overflows += 1
+        self.loss_scale = max(1.0, self.loss_scale * 0.5)
+        warnings.warn("fedfr_amd: non-finite gradients under the fp16 loss scale — the affected parameter elements were not updated; "
+                      "loss scale lowered to %g" % self.loss_scale)
+        return True
 
     @_C.on_device(lambda self: self.bb.device)
     def forward_backward(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
@@ -354,7 +377,7 @@ class FusedTrainer:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)   # dgrad shadows rebuilt on aux after the last SGD step
             self._shadows_pending = None
         aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
-        S = _C.loss_scale()
+        S = self.loss_scale
         self._grads_scaled = False
         if S != 1.0:
             # fp16-storage build: the gradient enters the backbone multiplied by the static loss scale S
@@ -366,7 +389,7 @@ class FusedTrainer:
                 done = ctypes.c_longlong(0)
                 _C.call("fedfr_net_backward2_sgd_scaled", plan.handle, imgs.data_ptr(), ds.data_ptr(), bb._flat_params.data_ptr(),
                         bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                        self.lr, self.mu, self.wd, 1 if self.first else 0, 1.0 / S, ctypes.byref(done), st, aux)
+                        self.lr, self.mu, self.wd, 1 if self.first else 0, 1.0 / S, self._overflow.data_ptr(), ctypes.byref(done), st, aux)
                 self._sgd_done_from = int(done.value)
                 self._grads_scaled = True
                 return
@@ -399,12 +422,19 @@ class FusedTrainer:
         scaled, self._grads_scaled = self._grads_scaled, False
         if n_rest > 0 and scaled:
             _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / _C.loss_scale(), st)
+                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / self.loss_scale, self._overflow.data_ptr(), st)
+            self._steps_since_check += 1
+            if self._steps_since_check >= self.overflow_check_every:
+                self.check_overflow()
         elif n_rest > 0:
             _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                     bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, st)
         if self.pfc is not None:
             self.pfc.fused_sgd_update(self.lr, self.mu, self.wd)      # sampled rows: SGD + scatter back
+        elif self.loss_scale != 1.0:
+            # (fp32 head: no scale to undo, but a forward pass that overflowed fp16 hands it non-finite gradients too: same guard)
+            _C.call("fedfr_sgd_step_scaled", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
+                    self.lr, self.mu, self.wd, first, 1.0, self._overflow.data_ptr(), st)
         else:
             _C.call("fedfr_sgd_step", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
                     self.lr, self.mu, self.wd, first, st)

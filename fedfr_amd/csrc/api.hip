@@ -308,11 +308,11 @@ int fedfr_net_backward2_sgd(const fedfr_net_t* n, const float* x, const float* d
 }
 int fedfr_net_backward2_sgd_scaled(const fedfr_net_t* n, const float* x, const float* dfeats, float* params, uint16_t* shadow, void* act,
                                    void* ws, float* grads, float* momentum, float lr, float mu, float wd, int first, float grad_scale,
-                                   long long* done_from, void* stream, void* aux_stream) {
+                                   unsigned* overflow, long long* done_from, void* stream, void* aux_stream) {
   FEDFR_REQUIRE(aux_stream == nullptr || aux_stream != stream, "net_backward2_sgd_scaled: aux_stream must differ from stream (pass NULL for single-stream)");
   FEDFR_REQUIRE(momentum && done_from, "net_backward2_sgd_scaled: null momentum buffer / done_from");
   FEDFR_REQUIRE(grad_scale > 0.f, "net_backward2_sgd_scaled: grad_scale must be positive");
-  NetSgd sg{params, BFM(shadow), momentum, lr, mu, wd, first, 0, grad_scale};
+  NetSgd sg{params, BFM(shadow), momentum, lr, mu, wd, first, 0, grad_scale, overflow};
   const int rc = net_backward(n, x, dfeats, params, BF(shadow), (unsigned char*)act, (unsigned char*)ws, grads, ST(stream), ST(aux_stream), &sg);
   *done_from = sg.done_from;
   return rc;
@@ -667,9 +667,9 @@ int fedfr_sgd_step(float* params, const float* grads, float* buf, uint16_t* shad
   return optim_sgd(params, const_cast<float*>(grads), buf, BFM(shadow), n, lr, momentum, weight_decay, first_step, ST(stream));
 }
 int fedfr_sgd_step_scaled(float* params, float* grads, float* buf, uint16_t* shadow, size_t n, float lr, float momentum, float weight_decay,
-                          int first_step, float grad_scale, void* stream) {
+                          int first_step, float grad_scale, unsigned* overflow, void* stream) {
   FEDFR_REQUIRE(grad_scale > 0.f, "sgd_step_scaled: grad_scale must be positive");
-  return optim_sgd(params, grads, buf, BFM(shadow), n, lr, momentum, weight_decay, first_step, ST(stream), grad_scale);
+  return optim_sgd(params, grads, buf, BFM(shadow), n, lr, momentum, weight_decay, first_step, ST(stream), grad_scale, overflow);
 }
 int fedfr_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, void* stream) {
   return optim_fedavg_axpy(dst, src, w, n, accumulate, ST(stream));

@@ -124,6 +124,7 @@ struct NetSgd {
   float lr, mu, wd; int first;
   long long done_from;
   float gscale = 1.f;                             // 1 / loss scale of the incoming gradient (fp16-storage build); the update kernels undo it
+  unsigned* overflow = nullptr;                   // device word the update kernels set when they skipped a non-finite gradient element
 };
 int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const float* params, const bf16_t* shadow,
                  unsigned char* act, unsigned char* ws, float* grads, hipStream_t st, hipStream_t aux, NetSgd* sgd = nullptr);

@@ -858,7 +858,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     if (sgd_lo < 0 || sgd_lo >= sgd_hi) return FEDFR_OK;
     FEDFR_REQUIRE((sgd_lo & 3) == 0, "net_backward: fused SGD range not 16-byte aligned");
     FEDFR_TRY(optim_sgd(sgd->params + sgd_lo, grads + sgd_lo, sgd->mom + sgd_lo, sgd->shadow + sgd_lo, (size_t)(sgd_hi - sgd_lo), sgd->lr, sgd->mu,
-                        sgd->wd, sgd->first, wst, sgd->gscale));
+                        sgd->wd, sgd->first, wst, sgd->gscale, sgd->overflow));
     sgd->done_from = sgd_lo;
     sgd_hi = sgd_lo; sgd_lo = -1;
     return FEDFR_OK;

@@ -3,7 +3,7 @@
 #include "common.h"
 
 int optim_sgd(float* p, float* g, float* buf, bf16_t* shadow, size_t n, float lr, float mu, float wd, int first,
-              hipStream_t st, float gscale = 1.f);   // gscale != 1: g holds gradient / gscale; it is multiplied in the kernel and stored back
+              hipStream_t st, float gscale = 1.f, unsigned* overflow = nullptr);   // gscale != 1: g holds gradient / gscale; it is multiplied in the kernel and stored back
 int optim_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, hipStream_t st);
 int optim_fedavg_multi(float* dst, const float* const* srcs, const float* ws, int k, size_t n, int accumulate, hipStream_t st);
 int optim_fedavg_i64(float* acc, const long long* src, float w, int n, int accumulate, long long* out_trunc, hipStream_t st);

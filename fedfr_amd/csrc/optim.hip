@@ -16,12 +16,17 @@ __device__ __forceinline__ float sgd_one(float p, float g, float& buf, float lr,
 }
 
 // UNSCALE: the gradient buffer holds gs^-1 x the gradient (static loss scale of the fp16-storage build); the kernel multiplies by gs
-// (a power of two: exact) and stores the true gradient back, so the buffer reads like p.grad afterwards.
+// (a power of two: exact) and stores the true gradient back, so the buffer reads like p.grad afterwards.  Overflow guard (what
+// torch.cuda.amp.GradScaler.step does for the reference's fp16 path, client.py:394-396, without its host synchronisation): an element whose
+// gradient is not finite is NOT updated (parameter, momentum and mirror keep their values; on the first step its momentum starts at 0) and
+// *ovf is set, so one overflowing pass cannot poison the weights; the host reads the word when it next synchronises and lowers the scale.
 template <bool UNSCALE>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
-                                                  bf16_t* __restrict__ shadow, size_t n, float lr, float mu, float wd, int first, float gs) {
+                                                  bf16_t* __restrict__ shadow, size_t n, float lr, float mu, float wd, int first, float gs,
+                                                  unsigned* __restrict__ ovf) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4 = n / 4;
+  bool bad = false;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -30,10 +35,22 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
       reinterpret_cast<float4*>(g)[i] = gv;
     }
     float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
-    pv.x = sgd_one(pv.x, gv.x, bv.x, lr, mu, wd, first);
-    pv.y = sgd_one(pv.y, gv.y, bv.y, lr, mu, wd, first);
-    pv.z = sgd_one(pv.z, gv.z, bv.z, lr, mu, wd, first);
-    pv.w = sgd_one(pv.w, gv.w, bv.w, lr, mu, wd, first);
+    if (UNSCALE) {
+      const float4 p0 = pv, b0 = bv;
+      pv.x = sgd_one(pv.x, gv.x, bv.x, lr, mu, wd, first);
+      pv.y = sgd_one(pv.y, gv.y, bv.y, lr, mu, wd, first);
+      pv.z = sgd_one(pv.z, gv.z, bv.z, lr, mu, wd, first);
+      pv.w = sgd_one(pv.w, gv.w, bv.w, lr, mu, wd, first);
+      if (!isfinite(gv.x)) { pv.x = p0.x; bv.x = b0.x; bad = true; }
+      if (!isfinite(gv.y)) { pv.y = p0.y; bv.y = b0.y; bad = true; }
+      if (!isfinite(gv.z)) { pv.z = p0.z; bv.z = b0.z; bad = true; }
+      if (!isfinite(gv.w)) { pv.w = p0.w; bv.w = b0.w; bad = true; }
+    } else {
+      pv.x = sgd_one(pv.x, gv.x, bv.x, lr, mu, wd, first);
+      pv.y = sgd_one(pv.y, gv.y, bv.y, lr, mu, wd, first);
+      pv.z = sgd_one(pv.z, gv.z, bv.z, lr, mu, wd, first);
+      pv.w = sgd_one(pv.w, gv.w, bv.w, lr, mu, wd, first);
+    }
     reinterpret_cast<float4*>(p)[i] = pv;
     reinterpret_cast<float4*>(buf)[i] = bv;
     if (shadow) {
@@ -47,25 +64,28 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
     float b = first ? 0.f : buf[i];
     float gi = g[i];
     if (UNSCALE) { gi *= gs; g[i] = gi; }
-    const float v = sgd_one(p[i], gi, b, lr, mu, wd, first);
+    const float p0 = p[i], b0 = b;
+    float v = sgd_one(p0, gi, b, lr, mu, wd, first);
+    if (UNSCALE && !isfinite(gi)) { v = p0; b = b0; bad = true; }
     p[i] = v;
     buf[i] = b;
     if (shadow) shadow[i] = f2bf(v);
   }
+  if (UNSCALE && bad && ovf) *ovf = 1u;          // (every writer stores the same value)
 }
 
 int optim_sgd(float* p, float* g, float* buf, bf16_t* shadow, size_t n, float lr, float mu, float wd, int first,
-              hipStream_t st, float gscale) {
+              hipStream_t st, float gscale, unsigned* overflow) {
   FEDFR_REQUIRE(p && g && buf && n > 0, "sgd: bad args");
   FEDFR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd: buffers must be 16-byte aligned");
   const size_t work = n / 4 + 1;
   const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
-  const bool unscale = gscale != 1.f;
+  const bool unscale = gscale != 1.f || overflow != nullptr;
   ProfScope prof(26, (double)n * (first ? 16.0 : 20.0) + (shadow ? 2.0 * n : 0.0) + (unscale ? 4.0 * n : 0.0), st);      // p, g (, buf) read; p, buf (, bf16 mirror, unscaled g) written
   if (unscale)
-    hipLaunchKernelGGL(sgd_kernel<true>, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first, gscale);
+    hipLaunchKernelGGL(sgd_kernel<true>, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first, gscale, overflow);
   else
-    hipLaunchKernelGGL(sgd_kernel<false>, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first, 1.f);
+    hipLaunchKernelGGL(sgd_kernel<false>, dim3(grid), dim3(256), 0, st, p, g, buf, shadow, n, lr, mu, wd, first, 1.f, nullptr);
   FEDFR_LAUNCH_CHECK("sgd");
   return FEDFR_OK;
 }

@@ -156,7 +156,7 @@ int fedfr_net_backward2_sgd(const fedfr_net_t* net, const float* x, const float*
  * unscaled gradients and grads[0, *done_from) still scaled ones: the caller finishes with fedfr_sgd_step_scaled on [0, *done_from). */
 int fedfr_net_backward2_sgd_scaled(const fedfr_net_t* net, const float* x, const float* dfeats, float* params, uint16_t* shadow, void* act,
                                    void* ws, float* grads, float* momentum, float lr, float mu, float wd, int first, float grad_scale,
-                                   long long* done_from, void* stream, void* aux_stream);
+                                   unsigned* overflow, long long* done_from, void* stream, void* aux_stream);
 
 /* fp32 VALIDATION path of the same plan (csrc/net_f32.hip): IResNet.forward / autograd backward (iresnet.py:46-57,158-172) with fp32
  * activations and exact-fp32 arithmetic (im2col + the fp32-MFMA GEMM, two-pass BatchNorm in fp64) — what the "1e-3 fp32" tolerance is
@@ -347,9 +347,11 @@ int fedfr_sgd_step(float* params, const float* grads, float* momentum_buf, uint1
                    float momentum, float weight_decay, int first_step, void* stream);
 /* fedfr_sgd_step on a gradient buffer that holds gradient / grad_scale (the GradScaler of client.py:394-396 with a static scale: the
  * fp16-storage build's backward pass runs on loss-scaled gradients): the kernel multiplies by grad_scale before the update and stores the
- * unscaled gradient back, so `grads` reads like p.grad afterwards.  grad_scale a power of two => bit-identical to unscale + fedfr_sgd_step. */
+ * unscaled gradient back, so `grads` reads like p.grad afterwards.  grad_scale a power of two => bit-identical to unscale + fedfr_sgd_step.
+ * Overflow guard (GradScaler.step's skip, without its host synchronisation): an element whose gradient is not finite keeps its parameter,
+ * momentum and mirror value, and the device word *overflow (optional) is set to 1; the caller reads and clears it when it next synchronises. */
 int fedfr_sgd_step_scaled(float* params, float* grads, float* momentum_buf, uint16_t* bf16_shadow, size_t n, float lr, float momentum,
-                          float weight_decay, int first_step, float grad_scale, void* stream);
+                          float weight_decay, int first_step, float grad_scale, unsigned* overflow, void* stream);
 int fedfr_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, void* stream);
 /* dst = (accumulate ? dst : 0) + sum_i ws[i] * srcs[i] over k <= 8 client states (HOST arrays of k device pointers / k weights) in one pass,
  * ascending i, one fp32 multiply and one fp32 add per term: bit-identical to k fedfr_fedavg_axpy calls = the loop of server.py:27-33 */

@@ -1385,6 +1385,35 @@ def test_sphnet_trains_through_the_fused_trainer_like_iresnet():
     assert rel(m2.state_dict()["layer3.2.conv1.weight"], 0.5 * (s0["layer3.2.conv1.weight"] + s1["layer3.2.conv1.weight"])) < 1e-6
 
 
+def test_fp16_overflow_guard_keeps_the_weights_finite():
+    """fp16-storage build only: an absurd loss scale overflows every fp16 gradient of the backbone.  The update kernels skip the non-finite
+    elements (fedfr_sgd_step_scaled), so parameters / momentum / mirrors stay finite; finish() reports the overflow and halves the trainer's
+    scale; with a sane scale the same trainer trains on."""
+    if _C.storage_dtype() != torch.float16:
+        pytest.skip("loss scaling exists in the fp16-storage build only (FEDFR_HIP_LIB_NAME=libfedfr_hip_fp16.so)")
+    B, C = 8, 40
+    m, sd, layers = make_model("iresnet18", tag=5.0)
+    fc = R.head_fc(C).to(DEV)
+    tr = client.FusedTrainer(m, fc, "CosFace", 30.0, 0.4, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    before = m._flat_params.clone()
+    tr.loss_scale = 2.0 ** 60
+    imgs, lab = R.closed_form_images(B, tag=0.0).to(DEV), R.closed_form_labels(B, C, tag=0).to(DEV)
+    tr.step(imgs, lab)
+    with pytest.warns(UserWarning, match="non-finite gradients"):
+        tr.finish()
+    assert tr.overflows == 1 and tr.loss_scale == 2.0 ** 59
+    assert bool(torch.isfinite(m._flat_params).all()) and bool(torch.isfinite(tr.mom).all())
+    nt = m.trainable_count()
+    skipped = float((m._flat_params[:nt] == before[:nt]).float().mean())
+    assert skipped > 0.5, skipped                                # (almost) every backbone gradient overflowed: those elements were not touched
+    tr.loss_scale = 256.0
+    mid = m._flat_params.clone()
+    ls = [float(tr.step(imgs, lab)) for _ in range(3)]
+    tr.finish()
+    assert tr.overflows == 1 and all(np.isfinite(ls)) and bool(torch.isfinite(m._flat_params).all())
+    assert float((m._flat_params[:nt] != mid[:nt]).float().mean()) > 0.9          # ... and now it trains
+
+
 def test_fp16_storage_build_meets_the_1e2_bar():
     """VERDICT r2 missing #4: the library built on IEEE fp16 storage (`make fp16` -> libfedfr_hip_fp16.so; csrc/common.h FEDFR_FP16: the
     reference's own AMP type, backbones/iresnet.py:159; same kernels, same MFMA rate, 10 mantissa bits instead of 7, static loss scale on
@@ -1400,7 +1429,7 @@ def test_fp16_storage_build_meets_the_1e2_bar():
         pytest.skip("libfedfr_hip_fp16.so is not built (make -C fedfr_amd/csrc fp16)")
     env = dict(os.environ, FEDFR_HIP_LIB_NAME="libfedfr_hip_fp16.so")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_e2e_gpu.py"), "-x", "-q", "-s", "-k",
-                        "backbone_forward_vs_reference or train_step_grads_vs_reference or fused_client_loop or sgd_inside_backward"], env=env, capture_output=True,
+                        "backbone_forward_vs_reference or train_step_grads_vs_reference or fused_client_loop or sgd_inside_backward or fp16_overflow_guard"], env=env, capture_output=True,
                        text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     emb = re.findall(r"MEASURED (iresnet\d+) embeddings: eval ([\d.e+-]+) train ([\d.e+-]+)", r.stdout)

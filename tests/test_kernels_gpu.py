@@ -689,6 +689,47 @@ def test_sgd_matches_golden():
             torch.testing.assert_close(got_m, torch.from_numpy(g["m%d_s%d" % (i, step)]), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("first", [1, 0])
+def test_sgd_step_scaled_unscales_in_place_and_skips_non_finite_gradients(first):
+    """fedfr_sgd_step_scaled (the GradScaler.step of client.py:394-396 with a static scale, no host sync): the buffer holds gradient / grad_scale;
+    finite elements are updated bit-identically to `unscale, then fedfr_sgd_step` and the buffer holds the true gradient afterwards; an element
+    whose gradient is inf / nan keeps parameter, momentum and mirror (momentum 0 on the first step) and the overflow word is set."""
+    d = dev()
+    n = 4099                                                    # float4 body + scalar tail
+    p0 = rnd((n,), 1).to(d)
+    g_true = rnd((n,), 2, 0.3).to(d)
+    m0 = rnd((n,), 3, 0.1).to(d)
+    S = 256.0
+    bad = torch.tensor([0, 5, 1023, 4096, 4098], device=d)
+    vals = torch.tensor([float("inf"), float("nan"), -float("inf"), float("nan"), float("inf")], device=d)
+    # reference: plain kernel on the true gradient
+    pr, gr, mr = p0.clone(), g_true.clone(), m0.clone()
+    shr = torch.zeros(n, dtype=S16(), device=d)
+    _C.call("fedfr_sgd_step", pr.data_ptr(), gr.data_ptr(), mr.data_ptr(), shr.data_ptr(), n, 0.1, 0.9, 5e-4, first, _C.stream())
+    # scaled kernel, clean gradient: identical, flag clear
+    ps, gs, ms = p0.clone(), g_true * S, m0.clone()
+    shs = torch.zeros(n, dtype=S16(), device=d)
+    ovf = torch.zeros(1, dtype=torch.int32, device=d)
+    _C.call("fedfr_sgd_step_scaled", ps.data_ptr(), gs.data_ptr(), ms.data_ptr(), shs.data_ptr(), n, 0.1, 0.9, 5e-4, first, 1.0 / S, ovf.data_ptr(), _C.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(ps, pr) and torch.equal(ms, mr) and torch.equal(gs, g_true) and torch.equal(shs.view(torch.int16), shr.view(torch.int16))
+    assert int(ovf.item()) == 0
+    # poisoned gradient: those elements are skipped, everything else as before
+    pq, gq, mq = p0.clone(), g_true * S, m0.clone()
+    gq[bad] = vals
+    shq = torch.full((n,), 7.0, dtype=S16(), device=d)
+    _C.call("fedfr_sgd_step_scaled", pq.data_ptr(), gq.data_ptr(), mq.data_ptr(), shq.data_ptr(), n, 0.1, 0.9, 5e-4, first, 1.0 / S, ovf.data_ptr(), _C.stream())
+    torch.cuda.synchronize()
+    assert int(ovf.item()) == 1
+    keep = torch.ones(n, dtype=torch.bool, device=d)
+    keep[bad] = False
+    assert torch.equal(pq[keep], pr[keep]) and torch.equal(mq[keep], mr[keep])
+    assert torch.equal(pq[bad], p0[bad])
+    assert torch.equal(mq[bad], torch.zeros_like(m0[bad]) if first else m0[bad])
+    assert torch.equal(shq[bad].float(), p0[bad].to(S16()).float())                   # the mirror of a skipped element = its (unchanged) parameter
+    assert bool(torch.isfinite(pq).all()) and bool(torch.isfinite(mq).all())
+
+
 def test_fedavg_axpy_bit_exact():
     ws = [1200 / 5100, 800 / 5100, 3100 / 5100]
     xs = [rnd((100003,), i) for i in range(3)]

@@ -227,7 +227,39 @@ def _split_for(k: int) -> int:
     return -(-k // chunk)
 
 
-class FusedTrainer:
+class _LossScaleGuard:
+    """fp16-storage build only (``_C.loss_scale() != 1``): a trainer's loss scale and the device word the update kernels set when they skipped a
+    non-finite gradient element (fedfr_sgd_step_scaled).  The word is read in ``finish()`` and every ``overflow_check_every`` steps; an
+    overflow halves the scale and warns — torch.cuda.amp.GradScaler's back-off (client.py:301,394-396) without a host sync per step."""
+
+    def _init_loss_scale(self, device):
+        self.loss_scale = _C.loss_scale()
+        self._overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self.overflow_check_every = 100
+        self.overflows = 0
+        self._steps_since_check = 0
+
+    def _count_step(self):
+        self._steps_since_check += 1
+        if self._steps_since_check >= self.overflow_check_every:
+            self.check_overflow()
+
+    def check_overflow(self) -> bool:
+        """Did an update kernel skip non-finite gradient elements since the last check?  (bf16 build: no; fp16 build: synchronises the stream.)
+        If so the loss scale is halved for the following steps and a warning is issued; the skipped elements kept their values."""
+        self._steps_since_check = 0
+        if self.loss_scale == 1.0 or int(self._overflow.item()) == 0:
+            return False
+        import warnings
+        self._overflow.zero_()
+        self.overflows += 1
+        self.loss_scale = max(1.0, self.loss_scale * 0.5)
+        warnings.warn("fedfr_amd: non-finite gradients under the fp16 loss scale — the affected parameter elements were not updated; "
+                      "loss scale lowered to %g" % self.loss_scale)
+        return True
+
+
+class FusedTrainer(_LossScaleGuard):
     """One optimiser lifetime (= one FL round for one client: the reference re-creates SGD every round, F8).
 
     step(imgs, labels) == the body of the reference hot loop (client.py:537-550) for the Sequential model:
@@ -271,14 +303,7 @@ class FusedTrainer:
         self._fuse_sgd = False
         self._sgd_done_from = None
         self._grads_scaled = False          # fp16-storage build: [0, _sgd_done_from) of the gradient buffer still carries the loss scale
-        # fp16-storage build: this trainer's loss scale (starts at _C.loss_scale(); 1 for bf16 storage) and the device word the update kernels
-        # set when they skipped a non-finite gradient element (fedfr_sgd_step_scaled): read in finish() / every `overflow_check_every` steps,
-        # where an overflow halves the scale — torch.cuda.amp.GradScaler's back-off (client.py:301,394-396) without a host sync per step
-        self.loss_scale = _C.loss_scale()
-        self._overflow = torch.zeros(1, dtype=torch.int32, device=bb.device)
-        self.overflow_check_every = 100
-        self.overflows = 0
-        self._steps_since_check = 0
+        self._init_loss_scale(bb.device)
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
@@ -290,20 +315,6 @@ class FusedTrainer:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
         self.check_overflow()
-
-    def check_overflow(self) -> bool:
-        """fp16-storage build: did an update kernel skip non-finite gradient elements since the last check?  (synchronises the stream.)  If so
-        the loss scale is halved for the following steps and a warning is issued; the skipped elements kept their values."""
-        self._steps_since_check = 0
-        if self.loss_scale == 1.0 or int(self._overflow.item()) == 0:
-            return False
-        import warnings
-        self._overflow.zero_()
-        self.overflows += 1
-        self.loss_scale = max(1.0, self.loss_scale * 0.5)
-        warnings.warn("fedfr_amd: non-finite gradients under the fp16 loss scale — the affected parameter elements were not updated; "
-                      "loss scale lowered to %g" % self.loss_scale)
-        return True
 
     @_C.on_device(lambda self: self.bb.device)
     def forward_backward(self, imgs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
@@ -423,9 +434,7 @@ class FusedTrainer:
         if n_rest > 0 and scaled:
             _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                     bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / self.loss_scale, self._overflow.data_ptr(), st)
-            self._steps_since_check += 1
-            if self._steps_since_check >= self.overflow_check_every:
-                self.check_overflow()
+            self._count_step()
         elif n_rest > 0:
             _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                     bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, st)
@@ -460,7 +469,7 @@ class FusedTrainer:
         return loss
 
 
-class FusedHeadTrainer:
+class FusedHeadTrainer(_LossScaleGuard):
     """Fused backbone step with an arbitrary differentiable head — the training body of ``train_with_public_data``
     (reference client.py:354-441): the backbone runs as ``fedfr_net_forward`` / ``fedfr_net_backward2`` + the flat SGD
     kernel exactly as in ``FusedTrainer``; the head (FC_module / BCE_module / margin / CE / contrastive — each a HIP-backed
@@ -483,6 +492,7 @@ class FusedHeadTrainer:
         self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
         self.head_mom = {}
         self.first = True
+        self._init_loss_scale(bb.device)
         self.aux_stream = _make_aux_stream(bb.device, aux_slot)
         self._shadows_pending = None
         if self.aux_stream is not None:
@@ -513,17 +523,20 @@ class FusedHeadTrainer:
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
-        S = _C.loss_scale()                               # 1 for the bf16 build; the fp16 validation build scales the incoming gradient
+        S = self.loss_scale                               # 1 for the bf16 build; the fp16-storage build scales the incoming gradient
         if S != 1.0:
             dfeats = dfeats * S
         _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
                 self.aux_stream.cuda_stream if self.aux_stream is not None else None)
+        # ---- opt.step()  (fp16-storage build: the kernel undoes the scale in place and skips non-finite elements, _LossScaleGuard)
+        ovf = self._overflow.data_ptr()
         if S != 1.0:
-            bb._flat_grads.mul_(1.0 / S)
-        # ---- opt.step()
-        _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, st)
+            _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                    bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, 1.0 / S, ovf, st)
+        else:
+            _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                    bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, st)
         for hp in self.head_params:
             if hp.grad is None:                                       # torch.optim.SGD skips parameters without a gradient
                 continue
@@ -533,8 +546,12 @@ class FusedHeadTrainer:
             first = buf is None
             if first:
                 buf = self.head_mom[hp] = torch.empty_like(hp.data)
-            _C.call("fedfr_sgd_step", hp.data.data_ptr(), hp.grad.data_ptr(), buf.data_ptr(), None, hp.numel(), self.lr, self.mu,
-                    self.wd, 1 if first else 0, st)
+            if S != 1.0:
+                _C.call("fedfr_sgd_step_scaled", hp.data.data_ptr(), hp.grad.data_ptr(), buf.data_ptr(), None, hp.numel(), self.lr, self.mu,
+                        self.wd, 1 if first else 0, 1.0, ovf, st)
+            else:
+                _C.call("fedfr_sgd_step", hp.data.data_ptr(), hp.grad.data_ptr(), buf.data_ptr(), None, hp.numel(), self.lr, self.mu,
+                        self.wd, 1 if first else 0, st)
         if self.aux_stream is not None:
             main = torch.cuda.current_stream()
             self.aux_stream.wait_stream(main)
@@ -544,6 +561,8 @@ class FusedHeadTrainer:
         else:
             bb.refresh_shadows(False)
         self.first = False
+        if S != 1.0:
+            self._count_step()
 
     @_C.on_device(lambda self: self.bb.device)
     def step(self, imgs: torch.Tensor, labels: torch.Tensor, head_loss):
@@ -566,6 +585,7 @@ class FusedHeadTrainer:
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
+        self.check_overflow()
 
 
 class ShardedHeadTrainer(FusedHeadTrainer):

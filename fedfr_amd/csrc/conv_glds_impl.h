@@ -21,7 +21,7 @@
 #define GLDS_RASTER 1      // padded-raster M index with fragment reuse across vertical taps (14x14 / 28x28 instantiations)
 #endif
 #ifndef GLDS_ABLATE
-#define GLDS_ABLATE 0
+#define GLDS_ABLATE 0      // timing ablations (WRONG results): 1 no in-loop LDS-DMA, 2 no per-tap barrier, 4 no fragment reads, 8 no prologue DMA / wait for the second tile of a workgroup
 #endif
 #ifndef GLDS_FUSED_ABLATE
 #define GLDS_FUSED_ABLATE 0      // timing ablations of the fused BN-backward epilogue (WRONG results): 1 no x loads, 2 no per-element pass, 4 no reduction
@@ -224,12 +224,15 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     }
   }
   // prologue: image of chunk 0, weight tiles of taps 0..2; wait for the image and tap 0, fetch tap 0's first fragments
+  const bool skip_pro = (GLDS_ABLATE & 8) && TPW > 1 && ti > 0;      // timing ablation: what the second tile's prologue costs (it computes on stale LDS contents)
+  if (!skip_pro) {
   issue_a(0, 0, true);
   issue_b(0, 0, 0, true);
   issue_b(RST ? 3 : 1, 0, 1, true);                      // RST walks the taps dx-major: (dy, dx) = (0,0), (1,0), (2,0), (0,1), ...
   issue_b(RST ? 6 : 2, 0, 2, true);
+  }
   bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
-  glds_wait_vmcnt<2 * BP>();
+  if (!skip_pro) glds_wait_vmcnt<2 * BP>();
   __builtin_amdgcn_s_barrier();
   GLDS_STAMP(1);
   if constexpr (RST) {

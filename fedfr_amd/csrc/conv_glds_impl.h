@@ -21,7 +21,7 @@
 #define GLDS_RASTER 1      // padded-raster M index with fragment reuse across vertical taps (14x14 / 28x28 instantiations)
 #endif
 #ifndef GLDS_ABLATE
-#define GLDS_ABLATE 0      // timing ablations (WRONG results): 1 no in-loop LDS-DMA, 2 no per-tap barrier, 4 no fragment reads, 8 no prologue DMA / wait for the second tile of a workgroup
+#define GLDS_ABLATE 0      // timing ablations (WRONG results): 1 no in-loop LDS-DMA, 2 no per-tap barrier, 4 no fragment reads, 8 no prologue DMA / wait for the second tile of a workgroup, 16 no in-loop vmcnt waits (DMA still issued; RST path)
 #endif
 #ifndef GLDS_FUSED_ABLATE
 #define GLDS_FUSED_ABLATE 0      // timing ablations of the fused BN-backward epilogue (WRONG results): 1 no x loads, 2 no per-element pass, 4 no reduction
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               // 1 DS read
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (!(GLDS_ABLATE & 1)) { if (!ONECHUNK && (it == 1 || it == 2)) glds_wait_vmcnt<BP + AP>(); else glds_wait_vmcnt<BP>(); }
+          if (!(GLDS_ABLATE & 17)) { if (!ONECHUNK && (it == 1 || it == 2)) glds_wait_vmcnt<BP + AP>(); else glds_wait_vmcnt<BP>(); }
           if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
           // ---- second half: k-step 1 MFMAs; the next tap's new k-step 0 fragments and this tap's DMA issue between them

@@ -391,17 +391,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // D[m = ci][n = co]: lane holds ci = block 16 + (lane >> 4) 4 + {0..3} for co = block 16 + (lane & 15) -> one float4 per tap and block pair
   float* slab = p.out[prob] + (size_t)split * p.cout * 9 * p.cin;
   const int NJ = 9 * p.cin;
+  // (tap outer, ci block inner: the two 64-B halves of a 128-B line leave back to back — 0.7 us per launch over the ci-block-outer order;
+  // non-temporal stores measured neutral, profiles/r04_ab_wgrad9p_store_order_v1.txt)
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int co = co0 + coh * 32 + b * 16 + (lane & 15);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int ci = ci0 + cih * 32 + a * 16 + (lane >> 4) * 4;
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int a = 0; a < 2; ++a)
         if (!(W9P_ABLATE & 16) || acc[t][a][b][0] == 12345.f)
-          *reinterpret_cast<float4*>(slab + (size_t)co * NJ + t * p.cin + ci) = make_float4(acc[t][a][b][0], acc[t][a][b][1], acc[t][a][b][2], acc[t][a][b][3]);
-    }
+          *reinterpret_cast<f32x4_t*>(slab + (size_t)co * NJ + t * p.cin + ci0 + cih * 32 + a * 16 + (lane >> 4) * 4) = acc[t][a][b];
   }
 }
 }  // namespace

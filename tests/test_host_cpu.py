@@ -320,3 +320,33 @@ def test_bench_self_launch_returns_nonzero_without_a_result(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert '"metric"' not in r.stdout
+
+
+def test_loss_scale_guard_backs_off_and_warns():
+    """client._LossScaleGuard (fp16-storage build's GradScaler stand-in): nothing is read while the scale is 1 (bf16 build: no sync); a set
+    overflow word halves the scale, warns, is cleared and counted; the periodic check fires every `overflow_check_every` steps."""
+    import warnings
+    import torch
+    from fedfr_amd import client
+
+    class T(client._LossScaleGuard):
+        pass
+    t = T()
+    t._init_loss_scale(torch.device("cpu"))
+    assert t.loss_scale == 1.0 and t.check_overflow() is False          # the bf16 library is the one loaded on the CPU box
+    t._overflow[0] = 1
+    assert t.check_overflow() is False                                  # scale 1: the word is never consulted
+    t.loss_scale = 256.0
+    with pytest.warns(UserWarning, match="loss scale lowered to 128"):
+        assert t.check_overflow() is True
+    assert t.loss_scale == 128.0 and t.overflows == 1 and int(t._overflow[0]) == 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert t.check_overflow() is False
+    t.overflow_check_every = 3
+    t._overflow[0] = 1
+    t._count_step(); t._count_step()
+    assert t.loss_scale == 128.0
+    with pytest.warns(UserWarning):
+        t._count_step()
+    assert t.loss_scale == 64.0 and t.overflows == 2 and t._steps_since_check == 0

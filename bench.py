@@ -285,18 +285,39 @@ def self_launch(argv):
 
 
 def select_library(argv):
-    """--lib fp16: run the same step on the IEEE-fp16 storage build (libfedfr_hip_fp16.so, `make fp16`; the reference's own AMP type,
-    backbones/iresnet.py:159).  Must act before fedfr_amd loads the library; the ranks of a self-launched run get the same argv."""
-    lib = "bf16"
+    """--lib fp16 (default): libfedfr_hip.so, the product library — IEEE fp16 storage, the reference's own AMP type (backbones/iresnet.py:159),
+    inside north_star's 1e-2 on whole-network outputs.  --lib bf16: the same kernels on bf16 storage (libfedfr_hip_bf16.so, `make bf16`).
+    Must act before fedfr_amd loads the library; the ranks of a self-launched run get the same argv."""
+    lib = "fp16"
     for i, a in enumerate(argv):
         if a == "--lib" and i + 1 < len(argv):
             lib = argv[i + 1]
         elif a.startswith("--lib="):
             lib = a.split("=", 1)[1]
-    if lib == "fp16":
-        os.environ["FEDFR_HIP_LIB_NAME"] = "libfedfr_hip_fp16.so"
-    elif lib != "bf16":
-        raise SystemExit("bench.py: --lib must be bf16 or fp16")
+    if lib == "bf16":
+        os.environ["FEDFR_HIP_LIB_NAME"] = "libfedfr_hip_bf16.so"
+    elif lib != "fp16":
+        raise SystemExit("bench.py: --lib must be fp16 or bf16")
+    return lib
+
+
+def bf16_build_leg(args):
+    """SECONDARY line: the same workload on the bf16-storage build, measured by a FRESH child process (`python bench.py --lib bf16 --secondary`:
+    timed region + parity leg only) started after this process's own timed region and legs are over — never a re-exec of a process that has
+    touched the GPU.  -> {"ms_per_step", "value", "parity", "library"} or {"error": ...}"""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "fedfr_amd", "libfedfr_hip_bf16.so")):
+        return {"error": "fedfr_amd/libfedfr_hip_bf16.so is not built (make -C fedfr_amd/csrc bf16)"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--lib", "bf16", "--secondary", "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--arch", args.arch, "--batch", str(args.batch), "--classes", str(args.classes), "--head", args.head]
+    env = {k: v for k, v in os.environ.items() if k not in ("FEDFR_HIP_LIB_NAME", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = next((t for t in reversed(r.stdout.splitlines()) if t.startswith("{") and '"metric"' in t), None)
+    if r.returncode != 0 or line is None:
+        return {"error": "child exited %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+    d = json.loads(line)
+    return {"library": d["library"], "storage": d["storage"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "steps": d["steps"],
+            "warmup": d["warmup"], "parity": d["parity"], "measured_by": "fresh child process `bench.py --lib bf16 --secondary`, after this process's timed region"}
 
 
 def parity_leg(dev):
@@ -356,11 +377,17 @@ def main():
                     help="dense: CosFace + dense cosine head (headline); pfc: ArcFace + PartialFC sample_rate 0.1 (BASELINE config 3; use --classes 85000); "
                          "pfc-sharded: BASELINE config 5 = per-client backbone + ONE CosFace PartialFC class-sharded over all ranks (sample_rate 0.1) + "
                          "a private BCE head per client (use --classes 85000 under torch.distributed.run)")
-    ap.add_argument("--lib", default="bf16", choices=["bf16", "fp16"],
-                    help="storage type of activations / gradients / MFMA operands: bf16 = libfedfr_hip.so (product), fp16 = libfedfr_hip_fp16.so (`make fp16`)")
+    ap.add_argument("--lib", default="fp16", choices=["fp16", "bf16"],
+                    help="storage type of activations / gradients / MFMA operands: fp16 = libfedfr_hip.so (product default), bf16 = libfedfr_hip_bf16.so (`make bf16`)")
+    ap.add_argument("--secondary", action="store_true",
+                    help="timed region + parity leg only (what the default run's `bf16_build` child process executes)")
+    ap.add_argument("--no-bf16-build", action="store_true", help="skip the secondary bf16-build line (a child process after the legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
+    secondary = args.secondary
+    if secondary:
+        args.no_profile = args.no_cpu_baseline = args.no_bf16_build = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -707,7 +734,7 @@ def main():
             print("bench.py: the fedavg leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
     parity = None
-    if rank == 0 and not args.no_profile and not collective_step:
+    if rank == 0 and (secondary or not args.no_profile) and not collective_step:
         try:
             tr.finish()
             torch.cuda.synchronize()
@@ -715,6 +742,16 @@ def main():
         except Exception as e:      # an auxiliary leg must never cost the headline number
             leg_errors['parity'] = "%s: %s" % (type(e).__name__, e)
             print("bench.py: the parity leg failed: %r" % (e,), file=sys.stderr, flush=True)
+
+    bf16_build = None
+    if rank == 0 and world == 1 and not args.no_bf16_build and not args.no_profile and _C.storage_dtype() == torch.float16:
+        try:
+            tr.finish()
+            torch.cuda.synchronize()
+            bf16_build = bf16_build_leg(args)
+        except Exception as e:      # an auxiliary leg must never cost the headline number
+            leg_errors['bf16_build'] = "%s: %s" % (type(e).__name__, e)
+            print("bench.py: the bf16_build leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported on rank 0 at N = 1 only
@@ -754,6 +791,7 @@ def main():
             "library": os.path.basename(_C.LIB_PATH),
             "options_non_default": _C.options_non_default(),
             "parity": parity,
+            "bf16_build": bf16_build,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": end_to_end,

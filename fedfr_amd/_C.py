@@ -147,17 +147,71 @@ def lib() -> C.CDLL:
 
 
 def storage_dtype() -> torch.dtype:
-    """torch dtype of the library's 16-bit storage (activations, shadows): bfloat16, or float16 for the fp16 validation build."""
+    """torch dtype of the library's 16-bit storage (activations, shadows): float16 for the product library (libfedfr_hip.so), bfloat16 for libfedfr_hip_bf16.so."""
     return torch.float16 if lib().fedfr_storage_dtype() == 1 else torch.bfloat16
 
 
 def loss_scale() -> float:
-    """Static loss scale applied to the gradient entering a backbone's backward pass (and removed from the parameter gradients): 1 for the
-    bf16 product build (fp32 exponent range), FEDFR_LOSS_SCALE (default 256) for the fp16 build, whose activation gradients would
-    otherwise fall into fp16's subnormals (the reference's fp16 autocast uses a GradScaler for the same reason, client.py:301,394-396)."""
+    """INITIAL loss scale applied to the gradient entering a backbone's backward pass (and removed from the parameter gradients): FEDFR_LOSS_SCALE
+    (default 256) for the fp16-storage library, whose activation gradients would otherwise fall into fp16's subnormals (the reference's fp16
+    autocast uses a GradScaler for the same reason, client.py:301,394-396); 1 for the bf16-storage build (fp32 exponent range).  The value in
+    force on a device — lowered after an overflow, grown back afterwards — is ``loss_scale_state(device).scale``."""
     if lib().fedfr_storage_dtype() != 1:
         return 1.0
     return float(os.environ.get("FEDFR_LOSS_SCALE", "256"))
+
+
+class LossScaleState:
+    """The loss scale of ONE device, alive for the whole process (trainers come and go every FL round: the reference keeps ONE GradScaler per
+    client process, client.py:301).  ``word`` is the device word the update kernels set when they skipped a non-finite gradient element
+    (fedfr_sgd_step_scaled); ``poll()`` reads it (host sync: call it where the host has just drained a loss anyway), halves the scale after
+    an overflow (GradScaler's backoff_factor 0.5) and doubles it again after ``growth_interval`` clean steps, never beyond the initial scale
+    (the static scale is sized for the path's parity; there is nothing to gain above it)."""
+
+    growth_interval = 2000          # torch.cuda.amp.GradScaler's default
+
+    def __init__(self, device):
+        self.initial = self.scale = loss_scale()
+        self.enabled = self.initial != 1.0          # fp16-storage library: every update goes through the guarded kernels
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.overflows = 0                          # overflowing intervals seen so far
+        self.clean_steps = 0                        # steps since the last overflow that a poll has confirmed clean
+        self.unpolled_steps = 0
+
+    def count_step(self, n: int = 1):
+        self.unpolled_steps += n
+
+    def poll(self) -> bool:
+        """True if an update kernel skipped non-finite elements since the last poll (then: scale halved, warning issued)."""
+        if not self.enabled:
+            return False
+        steps, self.unpolled_steps = self.unpolled_steps, 0
+        if int(self.word.item()) == 0:
+            self.clean_steps += steps
+            if self.scale < self.initial and self.clean_steps >= self.growth_interval:
+                self.scale = min(self.initial, self.scale * 2.0)
+                self.clean_steps = 0
+            return False
+        import warnings
+        self.word.zero_()
+        self.overflows += 1
+        self.clean_steps = 0
+        self.scale = max(2.0 ** -14, self.scale * 0.5)
+        warnings.warn("fedfr_amd: non-finite gradients under the fp16 loss scale — the affected parameter elements were not updated; "
+                      "loss scale lowered to %g" % self.scale)
+        return True
+
+
+_LOSS_SCALE_STATES = {}
+
+
+def loss_scale_state(device) -> LossScaleState:
+    """The process-wide LossScaleState of ``device`` (created on first use)."""
+    key = str(torch.device(device))
+    st = _LOSS_SCALE_STATES.get(key)
+    if st is None:
+        st = _LOSS_SCALE_STATES[key] = LossScaleState(device)
+    return st
 
 
 def last_error() -> str:

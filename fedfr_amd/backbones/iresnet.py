@@ -665,7 +665,7 @@ class IResNet(nn.Module):
             _C.call("fedfr_net_f32_backward", plan.handle, dfeats.data_ptr(), self._flat_params.data_ptr(), arena.data_ptr(), ws.data_ptr(),
                     target.data_ptr(), _C.stream())
         else:
-            S = _C.loss_scale()                           # 1 for the bf16 build; static loss scale of the fp16 validation build
+            S = _C.loss_scale_state(self._flat_params.device).scale      # fp16-storage library: the device's loss scale (1 for the bf16 library)
             if S != 1.0:
                 dfeats = dfeats * S
             _C.call("fedfr_net_backward", plan.handle, x.data_ptr(), dfeats.data_ptr(), self._flat_params.data_ptr(),

@@ -228,35 +228,51 @@ def _split_for(k: int) -> int:
 
 
 class _LossScaleGuard:
-    """fp16-storage build only (``_C.loss_scale() != 1``): a trainer's loss scale and the device word the update kernels set when they skipped a
-    non-finite gradient element (fedfr_sgd_step_scaled).  The word is read in ``finish()`` and every ``overflow_check_every`` steps; an
-    overflow halves the scale and warns — torch.cuda.amp.GradScaler's back-off (client.py:301,394-396) without a host sync per step."""
+    """fp16-storage library (``_C.loss_scale() != 1``): a trainer's view of its device's loss scale (``_C.LossScaleState``: it outlives the
+    trainer, so a back-off carries over to the next FL round) and of the device word the update kernels set when they skipped a non-finite
+    gradient element (fedfr_sgd_step_scaled).  The word is read in ``check_overflow()``: in ``finish()``, every ``overflow_check_every`` steps
+    and — through ``Client.train*`` — wherever the host drains a loss value anyway (every step at the reference's ``loss.item()`` cadence).
+    An overflow halves the scale and warns; ``growth_interval`` clean steps double it again up to its initial value: torch.cuda.amp.GradScaler's
+    schedule (client.py:301,394-396) without a host sync per step.  What differs from GradScaler is stated in INTEGRATION.md: the skip is per
+    ELEMENT (a parameter element whose gradient is not finite keeps its value, momentum and mirror), not per step."""
 
     def _init_loss_scale(self, device):
-        self.loss_scale = _C.loss_scale()
-        self._overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self._ls = _C.loss_scale_state(device)
         self.overflow_check_every = 100
-        self.overflows = 0
+        self.overflows = 0                       # overflowing intervals THIS trainer has seen (the device total: self._ls.overflows)
         self._steps_since_check = 0
 
+    @property
+    def loss_scale(self) -> float:
+        return self._ls.scale
+
+    @loss_scale.setter
+    def loss_scale(self, v: float):
+        self._ls.scale = float(v)
+
+    @property
+    def guarded(self) -> bool:
+        """True for the fp16-storage library: every parameter update goes through the overflow-guarded kernel, whatever the scale is now."""
+        return self._ls.enabled
+
+    @property
+    def _overflow(self) -> torch.Tensor:
+        return self._ls.word
+
     def _count_step(self):
+        self._ls.count_step()
         self._steps_since_check += 1
         if self._steps_since_check >= self.overflow_check_every:
             self.check_overflow()
 
     def check_overflow(self) -> bool:
-        """Did an update kernel skip non-finite gradient elements since the last check?  (bf16 build: no; fp16 build: synchronises the stream.)
-        If so the loss scale is halved for the following steps and a warning is issued; the skipped elements kept their values."""
+        """Did an update kernel skip non-finite gradient elements since the last check?  (bf16 library: no, nothing is read; fp16 library:
+        synchronises the stream.)  If so the loss scale is halved for the following steps and a warning is issued."""
         self._steps_since_check = 0
-        if self.loss_scale == 1.0 or int(self._overflow.item()) == 0:
-            return False
-        import warnings
-        self._overflow.zero_()
-        self.overflows += 1
-        self.loss_scale = max(1.0, self.loss_scale * 0.5)
-        warnings.warn("fedfr_amd: non-finite gradients under the fp16 loss scale — the affected parameter elements were not updated; "
-                      "loss scale lowered to %g" % self.loss_scale)
-        return True
+        hit = self._ls.poll()
+        if hit:
+            self.overflows += 1
+        return hit
 
 
 class FusedTrainer(_LossScaleGuard):
@@ -390,8 +406,8 @@ class FusedTrainer(_LossScaleGuard):
         aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
         S = self.loss_scale
         self._grads_scaled = False
-        if S != 1.0:
-            # fp16-storage build: the gradient enters the backbone multiplied by the static loss scale S
+        if self.guarded:
+            # fp16-storage library: the gradient enters the backbone multiplied by the loss scale S
             ds = dfeats * S
             if self._fuse_sgd:
                 # step(): the update kernels undo the scale themselves (fedfr_sgd_step_scaled: g * 1/S, stored back), so the update rides inside
@@ -407,7 +423,7 @@ class FusedTrainer(_LossScaleGuard):
             # forward_backward(): the parameter gradients are unscaled before anything reads them
             _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), ds.data_ptr(), bb._flat_params.data_ptr(),
                     bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st, aux)
-            bb._flat_grads.mul_(1.0 / S)
+            bb._flat_grads.mul_(1.0 / S)         # (inf / NaN stay what they are: optimizer_step()'s guarded kernel skips those elements)
             self._sgd_done_from = None
             return
         if self._fuse_sgd:
@@ -431,22 +447,29 @@ class FusedTrainer(_LossScaleGuard):
         n_rest = self.n_train if self._sgd_done_from is None else self._sgd_done_from      # the rest was updated inside the backward pass
         self._sgd_done_from = None
         scaled, self._grads_scaled = self._grads_scaled, False
-        if n_rest > 0 and scaled:
-            _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / self.loss_scale, self._overflow.data_ptr(), st)
+        if self.guarded:
+            # fp16-storage library: EVERY update is the guarded kernel — the rest of a fused step still carries the scale (gscale = 1/S),
+            # the gradients of forward_backward() were unscaled there already (gscale = 1); non-finite elements are skipped and flagged either way
+            ovf = self._overflow.data_ptr()
+            if n_rest > 0:
+                _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                        bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / self.loss_scale if scaled else 1.0, ovf, st)
+            if self.pfc is not None:
+                self.pfc.fused_sgd_update(self.lr, self.mu, self.wd, overflow=self._overflow)      # sampled rows: guarded SGD + scatter back
+            else:
+                # (fp32 head: no scale to undo, but a forward pass that overflowed fp16 hands it non-finite gradients too: same guard)
+                _C.call("fedfr_sgd_step_scaled", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
+                        self.lr, self.mu, self.wd, first, 1.0, ovf, st)
             self._count_step()
-        elif n_rest > 0:
-            _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, st)
-        if self.pfc is not None:
-            self.pfc.fused_sgd_update(self.lr, self.mu, self.wd)      # sampled rows: SGD + scatter back
-        elif self.loss_scale != 1.0:
-            # (fp32 head: no scale to undo, but a forward pass that overflowed fp16 hands it non-finite gradients too: same guard)
-            _C.call("fedfr_sgd_step_scaled", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
-                    self.lr, self.mu, self.wd, first, 1.0, self._overflow.data_ptr(), st)
         else:
-            _C.call("fedfr_sgd_step", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
-                    self.lr, self.mu, self.wd, first, st)
+            if n_rest > 0:
+                _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                        bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, st)
+            if self.pfc is not None:
+                self.pfc.fused_sgd_update(self.lr, self.mu, self.wd)      # sampled rows: SGD + scatter back
+            else:
+                _C.call("fedfr_sgd_step", self.fc.data_ptr(), self.fc_grad.data_ptr(), self.fc_mom.data_ptr(), None, self.fc.numel(),
+                        self.lr, self.mu, self.wd, first, st)
         # dgrad-layout weight copies (only needed by the NEXT backward; the forward mirror was written by the SGD kernel):
         # rebuilt on the aux stream so they overlap the next forward pass
         if self.aux_stream is not None:
@@ -523,15 +546,16 @@ class FusedHeadTrainer(_LossScaleGuard):
         if self._shadows_pending is not None:
             torch.cuda.current_stream().wait_stream(self._shadows_pending)
             self._shadows_pending = None
-        S = self.loss_scale                               # 1 for the bf16 build; the fp16-storage build scales the incoming gradient
-        if S != 1.0:
+        S = self.loss_scale                               # the fp16-storage library scales the incoming gradient (bf16 library: no scale)
+        guarded = self.guarded
+        if guarded:
             dfeats = dfeats * S
         _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
                 bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
                 self.aux_stream.cuda_stream if self.aux_stream is not None else None)
         # ---- opt.step()  (fp16-storage build: the kernel undoes the scale in place and skips non-finite elements, _LossScaleGuard)
         ovf = self._overflow.data_ptr()
-        if S != 1.0:
+        if guarded:
             _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
                     bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, 1.0 / S, ovf, st)
         else:
@@ -546,7 +570,7 @@ class FusedHeadTrainer(_LossScaleGuard):
             first = buf is None
             if first:
                 buf = self.head_mom[hp] = torch.empty_like(hp.data)
-            if S != 1.0:
+            if guarded:
                 _C.call("fedfr_sgd_step_scaled", hp.data.data_ptr(), hp.grad.data_ptr(), buf.data_ptr(), None, hp.numel(), self.lr, self.mu,
                         self.wd, 1 if first else 0, 1.0, ovf, st)
             else:
@@ -561,7 +585,7 @@ class FusedHeadTrainer(_LossScaleGuard):
         else:
             bb.refresh_shadows(False)
         self.first = False
-        if S != 1.0:
+        if guarded:
             self._count_step()
 
     @_C.on_device(lambda self: self.bb.device)
@@ -636,7 +660,7 @@ class ShardedHeadTrainer(FusedHeadTrainer):
             ops.axpy_(dfeats, leaf.grad, 1.0)
             bce = bce.detach()
         self._backward_and_update(plan, imgs, dfeats)
-        self.pfc.fused_sgd_update(self.lr, self.mu, self.wd)
+        self.pfc.fused_sgd_update(self.lr, self.mu, self.wd, overflow=self._overflow if self.guarded else None)
         loss = cos_loss if bce is None else ops.axpy_(ops.scale(bce.reshape(1), self.bce_weight), cos_loss.reshape(1), 1.0).reshape(())
         return loss, cos_loss, bce
 
@@ -836,6 +860,7 @@ class Client(object):
                     for l in pending:
                         loss_meter.update(l.item(), 1)
                     pending = []
+                    trainer.check_overflow()         # fp16 library: the host has just synchronised for the loss — read the overflow word too
         for l in pending:
             loss_meter.update(l.item(), 1)
         trainer.finish()
@@ -968,6 +993,7 @@ class Client(object):
                 if b is not None:
                     bce_meter.update(b.item(), 1)
             pending.clear()
+            trainer.check_overflow()                 # fp16 library: rides on the synchronisation the loss values have just paid for
 
         for epoch in range(start_epoch, start_epoch + self.local_epoch):
             trainer.set_lr(cfg.lr * 0.1 ** ((epoch - start_epoch) // cfg.train_decay))     # StepLR (client.py:348,443)

@@ -7,12 +7,13 @@
 #include <stdint.h>
 #include <stddef.h>
 
-// 16-bit storage type of activations, activation gradients and MFMA weight operands.  Default: bf16.  -DFEDFR_FP16=1 builds the SAME kernels
-// on IEEE fp16 storage (libfedfr_hip_fp16.so, `make fp16`): the reference's own AMP type (backbones/iresnet.py:159), 10 instead of 7 mantissa
-// bits at the same MFMA rate — the validation build that shows the bf16 parity gaps of DESIGN.md section 3 are storage rounding (the names
-// below keep "bf16": they denote "the 16-bit storage type").  fp16's range needs a loss scale for the gradients: the host side applies one.
+// 16-bit storage type of activations, activation gradients and MFMA weight operands.  Default (libfedfr_hip.so): IEEE fp16 — the reference's own
+// AMP type (backbones/iresnet.py:159), 10 mantissa bits: whole-network embeddings / logits / gradients inside north_star's 1e-2 of the fp32
+// reference; its range needs a loss scale for the gradients, which the host side applies and guards (fedfr_sgd_step_scaled).  -DFEDFR_FP16=0
+// (`make bf16` -> libfedfr_hip_bf16.so) builds the SAME kernels on bf16 storage: 7 mantissa bits, no loss scale, ~1 % faster, 1.5-2.5e-2 on
+// whole-network outputs.  The names below keep "bf16": they denote "the 16-bit storage type".
 #ifndef FEDFR_FP16
-#define FEDFR_FP16 0
+#define FEDFR_FP16 1
 #endif
 typedef unsigned short bf16_t;   // raw 16-bit storage bits in memory
 #if FEDFR_FP16

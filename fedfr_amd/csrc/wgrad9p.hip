@@ -79,7 +79,9 @@ constexpr int ZG = 2048;                                            // one 16-ro
 constexpr int P_B = ZG + P_ROWS * 128 + ZG, Q_B = Q_ROWS * 128, STAGE_B = P_B + Q_B;
 static_assert(P_B % 1024 == 0 && STAGE_B % 1024 == 0 && (NG - 1) * 2048 < 65536 && 2 * STAGE_B <= 160 * 1024, "stage geometry");
 
-template <int JM>   // 0: no slab-reduction job; 1 / 2: narrow / wide order (W9PJobDev)
+// JM: 0 no slab-reduction job; 1 / 2: narrow / wide order (W9PJobDev).  JU: units of the job per sub-image — 1 (K-step 1), or 2 (K-steps 1 and 3, each
+// with its own four load registers: the half-length workgroups of a split launch carry the same reduction in half as many sub-images)
+template <int JM, int JU = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad9p_kernel(W9P p) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef __attribute__((address_space(3))) unsigned char* lds_uc_t;
@@ -184,42 +186,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const __amdgpu_buffer_rsrc_t rsJ = make_rsrc(p.job.slab[jlayer], (unsigned)p.job.nsplit * p.job.n4 * 16u);
   unsigned char* const jdst = reinterpret_cast<unsigned char*>(p.job.dst[jlayer]);
   const f32x4_t jneg0 = {-0.f, -0.f, -0.f, -0.f};
-  f32x4_t jr[4] = {jneg0, jneg0, jneg0, jneg0}, jacc = jneg0, jt0 = jneg0, jt1 = jneg0;
-  unsigned jvoff = JM && (unsigned)tid < p.job.per ? (jfirst + (unsigned)tid) * 16u : JOOB, jcv = JOOB;
+  f32x4_t jr[JU][4], jacc = jneg0, jt0 = jneg0, jt1 = jneg0;
+#pragma unroll
+  for (int u = 0; u < JU; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) jr[u][r] = jneg0;
+  unsigned jvoff = JM && (unsigned)tid < p.job.per ? (jfirst + (unsigned)tid) * 16u : JOOB, jcv[JU];
   int jj = 0, jo = 0;              // unit within the output / output being requested
   unsigned jsb = 0;                // slab-group byte offset of that unit
-  bool jdone = false;
-  auto job_load = [&](int r) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
+  bool jdone[JU];
+#pragma unroll
+  for (int u = 0; u < JU; ++u) { jcv[u] = JOOB; jdone[u] = false; }
+  // `set` (compile-time): which of the JU register sets the unit travels in; units are requested AND summed in one global order
+  // (set 0 in K-step 1, set 1 in K-step 3 of every sub-image), so the accumulator sees ascending units whatever JU is
+  auto job_load = [&](int set, int r) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
     if constexpr (JM != 0) {
       const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (W9P_ABLATE & 32) ? (int)JOOB : (int)jvoff, (int)(jsb + (unsigned)r * p.job.sr), 0);
-      jr[r] = __builtin_bit_cast(f32x4_t, v);
+      jr[set][r] = __builtin_bit_cast(f32x4_t, v);
     }
   };
-  auto job_advance = [&]() {       // behind the four loads of a unit: remember what the unit is for, step to the next one
+  auto job_advance = [&](int set) {       // behind the four loads of a unit: remember what the unit is for, step to the next one
     if constexpr (JM != 0) {
-      jcv = jvoff;
-      jdone = jj == p.job.upo - 1;
+      jcv[set] = jvoff;
+      jdone[set] = jj == p.job.upo - 1;
       ++jj; jsb += p.job.sb;
-      if (jdone) {
+      if (jdone[set]) {
         jj = 0; jsb = 0; ++jo;
         jvoff = (unsigned)(jo * 256 + tid) < p.job.per ? jvoff + 4096u : JOOB;      // (an exhausted lane stays exhausted: per is not reached again)
       }
     }
   };
-  auto job_add = [&](int r) {      // step r of summing the unit in jr
+  auto job_add = [&](int set, int r) {      // step r of summing the unit in jr[set]
     if constexpr (JM == 1) {
-      jacc += jr[r];
+      jacc += jr[set][r];
     } else if constexpr (JM == 2) {
-      if (r == 0) jt0 = jr[0] + jr[1];
-      else if (r == 1) jt1 = jr[2] + jr[3];
+      if (r == 0) jt0 = jr[set][0] + jr[set][1];
+      else if (r == 1) jt1 = jr[set][2] + jr[set][3];
       else if (r == 2) jt0 = jt0 + jt1;
       else jacc += jt0;
     }
   };
-  auto job_finish = [&]() {        // the unit is summed: an output that is complete goes out
+  auto job_finish = [&](int set) {        // the unit is summed: an output that is complete goes out
     if constexpr (JM != 0) {
-      if (jdone) {
-        if (jcv != JOOB) *reinterpret_cast<float4*>(jdst + jcv) = make_float4(jacc[0], jacc[1], jacc[2], jacc[3]);
+      if (jdone[set]) {
+        if (jcv[set] != JOOB) *reinterpret_cast<float4*>(jdst + jcv[set]) = make_float4(jacc[0], jacc[1], jacc[2], jacc[3]);
         jacc = jneg0;
       }
     }
@@ -351,11 +361,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               }
               if (slot < nr) issue_read(slot);
               if (last && slot >= 2 && slot - 2 < NPW && !(W9P_ABLATE & 1)) issue_piece(slot - 2, it & 1);
-              if (JM != 0 && kb == 1) {                     // the slab-reduction job: slots the second K-step leaves free (20 reads, no DMA)
-                if (slot >= 20 && slot < 24) job_add(slot - 20);          // sum the unit requested one sub-image ago ...
-                if (slot == 24) job_finish();
-                if (slot >= 26 && slot < 30) job_load(slot - 26);         // ... and request the next one
-                if (slot == 30) job_advance();
+              if (JM != 0 && (kb == 1 || (JU == 2 && kb == 3))) {      // the slab-reduction job: slots K-steps 1 and 3 leave free (20 reads, no DMA)
+                const int set = (JU == 2 && kb == 3) ? 1 : 0;
+                if (slot >= 20 && slot < 24) job_add(set, slot - 20);     // sum the unit this set requested one sub-image ago ...
+                if (slot == 24) job_finish(set);
+                if (slot >= 26 && slot < 30) job_load(set, slot - 26);    // ... and request the next one
+                if (slot == 30) job_advance(set);
               }
               __builtin_amdgcn_sched_barrier(0);
               ++slot;
@@ -373,17 +384,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #undef W9P_READ
   w9p_wait_vmcnt<0>();
-  if constexpr (JM != 0) {                                  // the last sub-image's unit; then the units a short split had no sub-images for
-    for (int u = nst - 1; u < p.job.units; ++u) {
-      if (u >= nst) {
+  if constexpr (JM != 0) {                                  // the units requested during the last sub-image; then the units a short split had no sub-images for
 #pragma unroll
-        for (int r = 0; r < 4; ++r) job_load(r);
-        job_advance();
-        w9p_wait_vmcnt<0>();
-      }
+    for (int set = 0; set < JU; ++set) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) job_add(r);
-      job_finish();
+      for (int r = 0; r < 4; ++r) job_add(set, r);
+      job_finish(set);
+    }
+    for (int u = JU * nst; u < p.job.units; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) job_load(0, r);
+      job_advance(0);
+      w9p_wait_vmcnt<0>();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) job_add(0, r);
+      job_finish(0);
     }
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are read by VALU moves next (hand-written MFMAs: no automatic hazard nops)

@@ -213,11 +213,16 @@ class PartialFC(Module):
 
     @torch.no_grad()
     @_C.on_device(lambda self: self.device)
-    def fused_sgd_update(self, lr, momentum=0.9, weight_decay=5e-4):
+    def fused_sgd_update(self, lr, momentum=0.9, weight_decay=5e-4, overflow=None):
         """Caller-side ``opt.step(); pfc.update()`` for the sampled rows as two HIP calls (momentum rows already
-        exist, so this is never a 'first' step — partial_fc.py:124-126)."""
+        exist, so this is never a 'first' step — partial_fc.py:124-126).  ``overflow``: the fp16-storage library's device word
+        (client._LossScaleGuard) — the update then skips and flags non-finite gradient elements like every other update of that library."""
         sw = self.sub_weight.data
-        _C.call("fedfr_sgd_step", sw.data_ptr(), self.sub_weight.grad.data_ptr(), self.sub_weight_mom.data_ptr(), None, sw.numel(),
-                float(lr), float(momentum), float(weight_decay), 0, _C.stream())
+        if overflow is not None:
+            _C.call("fedfr_sgd_step_scaled", sw.data_ptr(), self.sub_weight.grad.data_ptr(), self.sub_weight_mom.data_ptr(), None, sw.numel(),
+                    float(lr), float(momentum), float(weight_decay), 0, 1.0, overflow.data_ptr(), _C.stream())
+        else:
+            _C.call("fedfr_sgd_step", sw.data_ptr(), self.sub_weight.grad.data_ptr(), self.sub_weight_mom.data_ptr(), None, sw.numel(),
+                    float(lr), float(momentum), float(weight_decay), 0, _C.stream())
         if int(self.sample_rate) != 1:
             self.update()

@@ -92,9 +92,9 @@ def test_hot_kernels_do_not_spill(built_lib):
     kr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kr)
     ks = kr.kernels(built_lib.LIB_PATH)
-    fp16 = os.path.join(os.path.dirname(built_lib.LIB_PATH), "libfedfr_hip_fp16.so")      # the fp16-storage validation build: same rule
-    if os.path.exists(fp16) and os.path.basename(built_lib.LIB_PATH) != "libfedfr_hip_fp16.so":
-        ks.update({"fp16:" + k: v for k, v in kr.kernels(fp16).items()})
+    bf16 = os.path.join(os.path.dirname(built_lib.LIB_PATH), "libfedfr_hip_bf16.so")      # the bf16-storage build of the same kernels: same rule
+    if os.path.exists(bf16) and os.path.basename(built_lib.LIB_PATH) != "libfedfr_hip_bf16.so":
+        ks.update({"bf16:" + k: v for k, v in kr.kernels(bf16).items()})
     assert len(ks) > 100, len(ks)
     hot = ("conv3x3_glds_kernel", "conv3x3_c64p_kernel", "wgrad9_kernel", "wgrad9p_kernel", "gemm_nt_glds_kernel", "gemm_tn_glds",
            "gemm_nt_kernel", "bn_apply_s_kernel", "bn_bwd_reduce_s_kernel", "bn_bwd_apply_s_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel",

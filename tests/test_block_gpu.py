@@ -6,7 +6,10 @@
   parameter gradients) against the bf16-storage oracle's autograd, each block fed with the HIP block input and the HIP gradient
   entering it, so rounding flips do not compound.  The backward twin of test_forward_layerwise_vs_bf16_oracle (test_e2e_gpu.py).
 
-Tolerances are the measured values x 1.25 (DESIGN.md section 3 has the table); north_star's bf16 bar is 1e-2.
+Tolerances: on the product library (fp16 storage) everything in front of the PReLU kink — and, for the slope-1 fixtures, EVERYTHING — is asserted
+at north_star's 1e-2 itself; the gradients behind the kink at the stated exception (tests/test_e2e_gpu.py docstring: a rounding of the PReLU's
+input flips the derivative of the elements next to zero, relative L2 ~ sqrt(flipped fraction)).  The bf16 bounds (second argument of T16) serve
+the child-process subset on libfedfr_hip_bf16.so (round 4's measurements x 1.25).
 """
 import numpy as np
 import pytest
@@ -24,14 +27,21 @@ from fedfr_amd.backbones.iresnet import BlockPlan  # noqa: E402
 
 @pytest.fixture(autouse=True)
 def _oracle_models_the_loaded_librarys_storage():
-    """oracle/bf16_emul.py rounds where the HIP path stores 16-bit tensors: to the loaded library's type (bfloat16; float16 under
-    FEDFR_HIP_LIB_NAME=libfedfr_hip_fp16.so), back to bfloat16 for the CPU tests that may follow in the same session."""
+    """oracle/bf16_emul.py rounds where the HIP path stores 16-bit tensors: to the loaded library's type (float16; bfloat16 under
+    FEDFR_HIP_LIB_NAME=libfedfr_hip_bf16.so), back to bfloat16 for the CPU tests that may follow in the same session."""
     from oracle import bf16_emul
     bf16_emul.set_storage(_C.storage_dtype())
     yield
     bf16_emul.set_storage(torch.bfloat16)
 
 DEV = torch.device("cuda:0")
+SPEC = 1e-2                 # north_star: outputs within 1e-2 of the reference for 16-bit storage
+
+
+def T16(fp16_bound, bf16_bound):
+    """The bound an assertion uses on the loaded library: the product library stores fp16; libfedfr_hip_bf16.so runs the child-process subset."""
+    return fp16_bound if _C.storage_dtype() == torch.float16 else bf16_bound
+
 
 # gradients BEHIND the PReLU derivative in the block's backward pass (tests/test_oracle_golden.py:test_block_bf16_storage_floor)
 POST_MASK = ("dx", "g_bn1.weight", "g_bn1.bias", "g_conv1.weight", "g_bn2.bias")
@@ -87,15 +97,17 @@ def test_block_vs_reference(name, dual_stream):
             assert float(v.abs().max()) < 1e-3 * gmax, k
     front = {k: e for k, e in errs.items() if k not in POST_MASK}
     behind = {k: e for k, e in errs.items() if k in POST_MASK}
-    assert max(front.values()) < 7.5e-3, front                   # measured <= 5.95e-3 on all seven fixtures; north_star: 1e-2
+    assert max(front.values()) < T16(SPEC, 7.5e-3), front        # fp16 measured <= 1.1e-3, bf16 <= 5.95e-3 on all seven fixtures; north_star: 1e-2
     # bn1.bias / bn2.bias gradients are column sums of a tensor whose channel means the BatchNorm behind it has just removed: the exact
     # value is a border effect of the 3x3 window, i.e. a nearly cancelling sum of bf16-rounded terms (measured 1.0e-2 on the slope-1 blocks)
     sums = {k: e for k, e in behind.items() if k in ("g_bn1.bias", "g_bn2.bias")}
     rest = {k: e for k, e in behind.items() if k not in sums}
     print("block %s dual=%d: front %.2e (%s); behind the PReLU kink %.2e (%s), cancelling sums %.2e" %
           (name, dual_stream, max(front.values()), max(front, key=front.get), max(rest.values()), max(rest, key=rest.get), max(sums.values())))
-    assert max(rest.values()) < (7.5e-3 if lin else 4e-2), rest              # slope 1: inside north_star's 1e-2 like everything else
-    assert max(sums.values()) < (1.35e-2 if lin else 7.5e-2), sums           # measured 1.06e-2 / 5.9e-2
+    # slope 1: inside north_star's 1e-2 like everything else (fp16: 6.5e-4, sums 1.4e-3).  With the kink: fp16 measured <= 1.7e-2 / sums 2.5e-2,
+    # bf16 <= 3.6e-2 / 5.9e-2 — the exception class
+    assert max(rest.values()) < (T16(SPEC, 7.5e-3) if lin else T16(3e-2, 4e-2)), rest
+    assert max(sums.values()) < (T16(SPEC, 1.35e-2) if lin else T16(5e-2, 7.5e-2)), sums
     # BN buffers after one training forward (momentum 0.1, unbiased running variance) and the batch counters
     out = plan.state_dict()
     for k, v in out.items():
@@ -112,8 +124,8 @@ def test_block_vs_reference(name, dual_stream):
     esum = {k: e for k, e in emu.items() if k in ("g_bn1.bias", "g_bn2.bias")}       # the nearly cancelling column sums (see above)
     erest = {k: e for k, e in emu.items() if k not in esum}
     print("   vs bf16 oracle: worst %.2e %s; cancelling sums %.2e" % (max(erest.values()), max(erest, key=erest.get), max(esum.values())))
-    assert max(erest.values()) < 6e-3, erest                     # measured <= 4.6e-3
-    assert max(esum.values()) < 1.9e-2, esum                     # measured <= 1.5e-2
+    assert max(erest.values()) < T16(2e-3, 6e-3), erest          # kernel vs storage-emulating oracle: fp16 measured <= 6.0e-4, bf16 <= 4.6e-3
+    assert max(esum.values()) < T16(SPEC, 1.9e-2), esum          # fp16 measured <= 1.9e-3, bf16 <= 1.5e-2
     assert float(np.median(list(emu.values()))) < 4e-3, emu
 
 
@@ -203,6 +215,7 @@ def test_backward_layerwise_vs_bf16_oracle(arch, batch):
     # (bn1.weight, conv1.weight) of ONE block: both read the gradient behind that block's PReLU, where a bf16 rounding that lands on the
     # other side of the kink changes the derivative of an element by (1 - slope); which block draws the outlier moves with the last
     # fp32 bits of the BatchNorm coefficients (summation order), its size does not
-    assert worst[1] < 7.2e-3, worst
-    assert worst_sum[1] < 2.5e-2, worst_sum             # measured <= 1.9e-2
-    assert np.median(vals) < 1.3e-3, np.median(vals)    # measured 0.5e-3 / 1.0e-3 / 0.9e-3
+    # fp16 (product library): worst 8.6e-4 / 2.4e-3 / 5.9e-3, sums <= 8.6e-3, median 1.9e-4: everything inside north_star's 1e-2
+    assert worst[1] < T16(SPEC, 7.2e-3), worst
+    assert worst_sum[1] < T16(SPEC, 2.5e-2), worst_sum  # bf16 measured <= 1.9e-2
+    assert np.median(vals) < T16(5e-4, 1.3e-3), np.median(vals)    # fp16 measured 1.9e-4; bf16 0.5e-3 / 1.0e-3 / 0.9e-3

@@ -1,6 +1,16 @@
 """End-to-end parity of the HIP path (through the reference-shaped Python surface) against the golden vectors
 captured from the imported reference and, where finer detail is needed, the CPU oracle on identical
-closed-form inputs.  Tolerances: bf16 backbone 1e-2-class (stated per assert), fp32 head 1e-4-class."""
+closed-form inputs.
+
+Tolerances.  The product library (libfedfr_hip.so) stores IEEE fp16 — the reference's own AMP type, backbones/iresnet.py:159.  On it every
+whole-network OUTPUT (embeddings, cosine logits, loss, running statistics, gradient norms) is asserted at north_star's 1e-2 itself (SPEC), not
+at a measured value.  One class cannot meet 1e-2 on any 16-bit storage and is asserted at a stated exception (KINK_*): the per-parameter
+DIRECTION of gradients that passed a PReLU.  Rounding the PReLU's input moves elements across zero; each flipped element changes its
+derivative from 1 to the slope, so a flipped fraction f of the elements changes the gradient by ~ (1 - slope) sqrt(f) in relative L2 —
+sqrt(1e-3) = 3e-2 for fp16's 2^-11, sqrt(8e-3) = 9e-2 for bf16's 2^-8, 8e-4 for the fp32 validation path (measured: 2.7-3.5e-2, 8.5e-2-1.2e-1,
+2.5-8e-4).  The same kernels with slope 1 (no kink) are inside 1e-2 on every gradient (test_gradients_without_the_prelu_kink_meet_the_spec,
+tests/test_block_gpu.py `*_lin`).  T16(fp16_bound, bf16_bound) picks the bound of the loaded library; the bf16 bounds (what 7 mantissa bits
+allow, measured in round 4) are used by the child-process subset that loads libfedfr_hip_bf16.so."""
 import os
 
 import numpy as np
@@ -18,13 +28,22 @@ from fedfr_amd import backbones, losses, client, server, ops, _C  # noqa: E402
 from fedfr_amd.partial_fc import PartialFC  # noqa: E402
 
 DEV = torch.device("cuda:0")
+SPEC = 1e-2                 # north_star: embeddings, logits, grads within 1e-2 of the reference for 16-bit storage
+# stated exceptions on fp16 storage (see the module docstring): per-parameter gradient direction behind a PReLU kink
+# (median / worst tensor over a network), worst single parameter tensor's gradient NORM (a bn3 scale: a sum of kink-affected products)
+KINK_DIR_MEDIAN, KINK_DIR_MAX, KINK_NORM_MAX = 5e-2, 1.2e-1, 3e-2
+
+
+def T16(fp16_bound, bf16_bound):
+    """The bound an assertion uses on the loaded library: the product library stores fp16; libfedfr_hip_bf16.so runs the child-process subset."""
+    return fp16_bound if _C.storage_dtype() == torch.float16 else bf16_bound
 
 
 
 @pytest.fixture(autouse=True)
 def _oracle_models_the_loaded_librarys_storage():
-    """oracle/bf16_emul.py rounds where the HIP path stores 16-bit tensors: to the loaded library's type (bfloat16; float16 under
-    FEDFR_HIP_LIB_NAME=libfedfr_hip_fp16.so), back to bfloat16 for the CPU tests that may follow in the same session."""
+    """oracle/bf16_emul.py rounds where the HIP path stores 16-bit tensors: to the loaded library's type (float16; bfloat16 under
+    FEDFR_HIP_LIB_NAME=libfedfr_hip_bf16.so), back to bfloat16 for the CPU tests that may follow in the same session."""
     from oracle import bf16_emul
     bf16_emul.set_storage(_C.storage_dtype())
     yield
@@ -137,19 +156,19 @@ def test_forward_layerwise_vs_bf16_oracle(arch, batch, training):
     assert dict(errs)["feats"] < 2e-3, dict(errs)["feats"]
 
 
-# measured x 1.25 (north_star's 1e-2 is not reachable for whole-network embeddings with bf16 MFMA operands:
-# tools/precision_study.py): (eval, train) embeddings per architecture; running statistics of early / last layers
-# measured (eval, train): iresnet50 1.17e-2 / 1.71e-2 (the bf16-storage oracle: 1.7e-2 train), iresnet100 1.55e-2 / 2.59e-2;
-# running statistics: 1.7e-3 (early layers), 1.5e-2 (bn2 / features)
-EMB_TOL = {"iresnet50": (1.5e-2, 2.2e-2), "iresnet100": (2e-2, 3.3e-2)}
-STAT_TOL_EARLY, STAT_TOL_LATE = 2.5e-3, 2e-2
+# fp16 (product library): north_star's 1e-2 for every whole-network output (measured: embeddings 1.5e-3 / 2.2e-3 (iresnet50 eval / train),
+# 2.0e-3 / 3.1e-3 (iresnet100); running statistics 2e-4 early layers, 1.3-1.9e-3 bn2 / features).
+# bf16 (libfedfr_hip_bf16.so, child-process subset): 7 mantissa bits do not reach 1e-2 on 50-100 layers of train-mode BatchNorm
+# (tools/precision_study.py); bounds = round 4's measurements (1.17e-2 / 1.71e-2, 1.55e-2 / 2.59e-2; statistics 1.7e-3 / 1.5e-2) x 1.25
+EMB_TOL_BF16 = {"iresnet50": (1.5e-2, 2.2e-2), "iresnet100": (2e-2, 3.3e-2)}
+STAT_TOL_BF16 = (2.5e-3, 2e-2)      # early layers, bn2 / features
 
 
 @pytest.mark.parametrize("arch,batch,fname", [("iresnet50", 8, "r50_b8"), ("iresnet100", 6, "r100_b6")])
 def test_backbone_forward_vs_reference(arch, batch, fname):
-    """Embeddings against the imported fp32 reference.  bf16 activation/weight STORAGE alone moves the embeddings of
-    these 50/100-layer train-mode-BN nets by 1.2e-2 / 1.6e-2 (oracle/bf16_emul.py vs the fp32 oracle, same inputs);
-    the HIP path sits at exactly that level; asserted at measured x 1.25 (EMB_TOL)."""
+    """Embeddings (eval- and train-mode BatchNorm) and running statistics against the imported fp32 reference: north_star's 1e-2 on the
+    product (fp16-storage) library.  (bf16 STORAGE alone moves the embeddings of these 50/100-layer train-mode-BN nets by 1.2e-2 / 1.6e-2 —
+    oracle/bf16_emul.py vs the fp32 oracle, same inputs — which is where the bf16 build sits.)"""
     g = load_golden(fname)
     m, sd, layers = make_model(arch)
     x = R.closed_form_images(batch).to(DEV)
@@ -159,7 +178,7 @@ def test_backbone_forward_vs_reference(arch, batch, fname):
     m.train()
     ft = m(x)
     print("MEASURED %s embeddings: eval %.3e train %.3e" % (arch, rel(fe, g["feat_eval"]), rel(ft, g["feat_train"])))
-    lim_e, lim_t = EMB_TOL[arch]
+    lim_e, lim_t = T16((SPEC, SPEC), EMB_TOL_BF16[arch])
     assert rel(fe, g["feat_eval"]) < lim_e, rel(fe, g["feat_eval"])
     assert rel(ft, g["feat_train"]) < lim_t, rel(ft, g["feat_train"])
     # running stats: reference momentum / unbiased-variance rule (fp32 statistics of bf16 tensors)
@@ -173,7 +192,7 @@ def test_backbone_forward_vs_reference(arch, batch, fname):
             worst_early = max(worst_early, e)
     print("MEASURED %s running stats: early layers %.3e, bn2/features %.3e" % (arch, worst_early, worst_late))
     for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer4.2.bn3", "bn2", "features"):
-        tol = STAT_TOL_LATE if k in ("bn2", "features") else STAT_TOL_EARLY     # late layers carry the accumulated bf16 storage noise
+        tol = T16((SPEC, SPEC), STAT_TOL_BF16)[1 if k in ("bn2", "features") else 0]     # (bf16: late layers carry the accumulated storage noise)
         assert rel(sd_out[k + ".running_mean"], g["rm_" + k]) < tol, (k, rel(sd_out[k + ".running_mean"], g["rm_" + k]))
         assert rel(sd_out[k + ".running_var"], g["rv_" + k]) < tol, (k, rel(sd_out[k + ".running_var"], g["rv_" + k]))
         assert int(sd_out[k + ".num_batches_tracked"]) == int(g["nbt_" + k])
@@ -299,12 +318,11 @@ def test_freeze_bn_vs_reference():
     vals = np.array([d for _, d in dirs])
     print("MEASURED freeze_BN iresnet18: embeddings %.3e; grad norms median %.3e max %.3e; directions median %.3e max %.3e (%s)" %
           (e_f, np.median(nerr), nerr.max(), np.median(vals), vals.max(), max(dirs, key=lambda d: d[1])[0]))
-    # eval-mode BatchNorms do not renormalise: bf16 storage noise is not amplified the way train-mode statistics amplify it
-    # measured: embeddings 8.6e-3 (inside north_star's 1e-2: no batch statistics to renormalise the storage noise), gradient norms median
-    # 2.0e-3 / max 2.4e-2, per-parameter directions median 3.5e-2 / max 5.8e-2 (bf16 storage + PReLU-kink flips, as in train mode); x 1.25
-    assert e_f < 1e-2, e_f
-    assert np.median(nerr) < 2.5e-3 and nerr.max() < 3.1e-2, (np.median(nerr), nerr.max())
-    assert np.median(vals) < 4.4e-2 and vals.max() < 7.3e-2, max(dirs, key=lambda d: d[1])
+    # fp16: embeddings 1.0e-3, gradient norms median 6e-4 / max 4.9e-3 (all at the spec); directions median 1.1e-2 / max 2.2e-2 = the PReLU-kink class
+    # bf16 subset: embeddings 8.6e-3, norms 2.0e-3 / 2.4e-2, directions 3.5e-2 / 5.8e-2 (round 4, x 1.25)
+    assert e_f < SPEC, e_f
+    assert np.median(nerr) < T16(SPEC, 2.5e-3) and nerr.max() < T16(SPEC, 3.1e-2), (np.median(nerr), nerr.max())
+    assert np.median(vals) < T16(KINK_DIR_MEDIAN, 4.4e-2) and vals.max() < T16(KINK_DIR_MAX, 7.3e-2), max(dirs, key=lambda d: d[1])
     out = m.state_dict()
     for k in ("bn1", "layer2.0.downsample.1", "layer4.1.bn3", "bn2", "features"):      # nothing tracked
         assert torch.equal(out[k + ".running_mean"].cpu(), sd[k + ".running_mean"]) and torch.equal(out[k + ".running_var"].cpu(), sd[k + ".running_var"])
@@ -312,25 +330,30 @@ def test_freeze_bn_vs_reference():
     m.train()                                   # nn.Module.train() resets the BatchNorm submodules
     assert m._fwd_mode() == 1 and m.bn1.training
     again = m(x)
-    assert rel(again, g["feats_after_train_call"]) < 2.5e-2
+    assert rel(again, g["feats_after_train_call"]) < T16(SPEC, 2.5e-2)
     assert int(m.state_dict()["bn1.num_batches_tracked"]) == int(g["nbt_bn1"]) + 1
 
 
-# whole-network gradients against the fp32 reference: measured x 1.25.  These are NOT kernel-error bounds — per block the backward pass
-# is within 4.3e-3 of the bf16-storage oracle (test_block_gpu.py) — they bound what 50-100 layers of bf16 storage, PReLU derivative flips
-# and BatchNorm-backward mean subtractions do to a gradient (the bf16 oracle shows the same numbers: oracle/bf16_emul.py)
-# measured: cosines 1.7e-2 / 2.6e-2; gradient norms median 3.2e-3 / 4.2e-3, max 6.7e-2 / 4.7e-2; directions median 8.5e-2 / 1.18e-1,
-# max 0.175 / 0.33 (the maxima are bn1.bias-type gradients: nearly cancelling column sums, see test_block_gpu.py)
-GRAD_TOL = {"iresnet50": {"cosine": 2.2e-2, "norm_median": 4.5e-3, "norm_max": 8.5e-2, "dir_median": 0.11, "dir_max": 0.22},
-            "iresnet100": {"cosine": 3.3e-2, "norm_median": 5.5e-3, "norm_max": 6e-2, "dir_median": 0.15, "dir_max": 0.42}}
+# whole-network gradients against the fp32 reference.
+# fp16 (product library): cosine logits, loss and gradient NORMS at north_star's 1e-2 (measured: cosines 2.2e-3 / 3.1e-3; norms median 9e-4 / 1.2e-3);
+# the worst single tensor's norm (a bn3 scale, 1.0e-2 / 1.9e-2) and the per-parameter DIRECTIONS (median 2.7e-2 / 3.5e-2, max 6.1e-2 / 6.5e-2) are
+# the PReLU-kink class (module docstring): stated exceptions KINK_*, not kernel error — per block the backward pass is within 6e-3 of the
+# storage-emulating oracle (test_block_gpu.py), and with slope 1 the whole network is inside 1e-2 (next test but one).
+# bf16 (libfedfr_hip_bf16.so subset): round 4's measurements x 1.25 (cosines 1.7e-2 / 2.6e-2; norms 3.2e-3 / 4.2e-3, max 6.7e-2 / 4.7e-2; directions
+# median 8.5e-2 / 1.18e-1, max 0.175 / 0.33)
+GRAD_TOL_BF16 = {"iresnet50": {"cosine": 2.2e-2, "norm_median": 4.5e-3, "norm_max": 8.5e-2, "dir_median": 0.11, "dir_max": 0.22},
+                 "iresnet100": {"cosine": 3.3e-2, "norm_median": 5.5e-3, "norm_max": 6e-2, "dir_median": 0.15, "dir_max": 0.42}}
+GRAD_TOL_FP16 = {"cosine": SPEC, "norm_median": SPEC, "norm_max": KINK_NORM_MAX, "dir_median": KINK_DIR_MEDIAN, "dir_max": KINK_DIR_MAX}
+
+
+def grad_tol(arch):
+    return T16(GRAD_TOL_FP16, GRAD_TOL_BF16[arch])
 
 
 @pytest.mark.parametrize("arch,batch,fname", [("iresnet50", 8, "r50_b8"), ("iresnet100", 6, "r100_b6")])
 def test_train_step_grads_vs_reference(arch, batch, fname):
-    """reference-style eager step (client.py:543-549): logits = fc(backbone(x)); margin; cross-entropy; backward.
-    Tolerances calibrated with the bf16-storage oracle: vs fp32 it shows per-parameter gradient NORMS within 0.3 %
-    median / 5 % max and per-parameter DIRECTION (relative L2 of the whole tensor) 9 % median — BN-backward's
-    mean-subtractions amplify activation rounding; HIP measures the same (0.3 % / 7 % / 7-11 %)."""
+    """reference-style eager step (client.py:543-549): logits = fc(backbone(x)); margin; cross-entropy; backward — cosine logits, loss,
+    every parameter gradient's norm and direction against the imported reference (bounds: grad_tol above)."""
     g = load_golden(fname)
     C = int(g["num_classes"])
     m, sd, layers = make_model(arch)
@@ -345,7 +368,8 @@ def test_train_step_grads_vs_reference(arch, batch, fname):
     loss = ops.cross_entropy(logits, lab)
     loss.backward()
     print("MEASURED %s cosine %.3e loss %.3e" % (arch, rel(cosine, g["cosine"]), abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))))
-    assert rel(cosine, g["cosine"]) < GRAD_TOL[arch]["cosine"], rel(cosine, g["cosine"])
+    GT = grad_tol(arch)
+    assert rel(cosine, g["cosine"]) < GT["cosine"], rel(cosine, g["cosine"])
     assert abs(float(loss) - float(g["loss"])) < 5e-3 * abs(float(g["loss"]))
     names = [str(n) for n in g["grad_names"]]
     params = dict(m.named_parameters())
@@ -354,8 +378,8 @@ def test_train_step_grads_vs_reference(arch, batch, fname):
     big = ref > 1e-6 * ref.max()
     relerr = np.abs(norms[big] - ref[big]) / ref[big]
     print("MEASURED %s grad norms: median %.3e max %.3e (%s)" % (arch, np.median(relerr), relerr.max(), names[int(np.argmax(relerr))]))
-    assert np.median(relerr) < GRAD_TOL[arch]["norm_median"], np.median(relerr)
-    assert relerr.max() < GRAD_TOL[arch]["norm_max"], (relerr.max(), names[int(np.argmax(relerr))])
+    assert np.median(relerr) < GT["norm_median"], np.median(relerr)
+    assert relerr.max() < GT["norm_max"], (relerr.max(), names[int(np.argmax(relerr))])
     dirs = []
     gmax = max(float(T(g[k]).double().norm()) for k in g.files if k.startswith("g_") and k[2:] in params)
     for k in g.files:
@@ -369,8 +393,49 @@ def test_train_step_grads_vs_reference(arch, batch, fname):
     dirs.append(("head fc[:8]", rel(fcm.fc.grad[:8], g["g_fc_head_rows"])))
     vals = np.array([d for _, d in dirs])
     print("MEASURED %s grad directions: median %.3e max %.3e (%s)" % (arch, np.median(vals), vals.max(), max(dirs, key=lambda d: d[1])[0]))
-    assert np.median(vals) < GRAD_TOL[arch]["dir_median"], np.median(vals)
-    assert vals.max() < GRAD_TOL[arch]["dir_max"], max(dirs, key=lambda d: d[1])
+    assert np.median(vals) < GT["dir_median"], np.median(vals)
+    assert vals.max() < GT["dir_max"], max(dirs, key=lambda d: d[1])
+
+
+@pytest.mark.parametrize("arch,batch", [("iresnet50", 8), ("iresnet100", 6)])
+def test_gradients_without_the_prelu_kink_meet_the_spec(arch, batch):
+    """The exception above is the kink, not the kernels: the SAME networks with every PReLU slope set to 1 (the activation becomes the
+    identity, nothing else changes: same kernels, same BatchNorm statistics, same 16-bit storage) — one eager train step against the fp32
+    oracle on the same inputs (oracle/ref_cpu.py restates the reference and is pinned to it by tests/golden): cosine logits, loss, every
+    parameter gradient's norm AND direction inside north_star's 1e-2 on the product library (the nearly cancelling BatchNorm-bias column sums
+    are listed apart, as everywhere)."""
+    C = 32
+    m, sd, layers = make_model(arch)
+    for k in sd:
+        if k.endswith("prelu.weight"):
+            sd[k] = torch.ones_like(sd[k])
+    m.load_state_dict(sd)
+    m.train()
+    fcm = client.FC_module(512, C, "/tmp").to(DEV)
+    fc0 = R.head_fc(C)
+    fcm.fc.data = fc0.clone().to(DEV)
+    x, lab = R.closed_form_images(batch), R.closed_form_labels(batch, C)
+    cosine = client.Sequential_model(m, fcm)(x.to(DEV))
+    loss = ops.cross_entropy(losses.CosFace(s=30, m=0.4)(cosine, lab.to(DEV)), lab.to(DEV))
+    loss.backward()
+    f_ref, c_ref, l_ref, g_ref, fcg_ref = R.train_step_grads(sd, fc0.clone(), x, lab, layers)
+    params = dict(m.named_parameters())
+    gmax = max(float(v.norm()) for v in g_ref.values())
+    names = [k for k in R.trainable_keys(sd) if float(g_ref[k].norm()) > 1e-3 * gmax and not k.endswith("prelu.weight")]
+    sums = [k for k in names if k.endswith(("bn1.bias", "bn2.bias"))]              # column sums of tensors whose channel means a BatchNorm has just removed
+    rest = [k for k in names if k not in sums]
+    nerr = np.array([abs(float(params[k].grad.norm()) - float(g_ref[k].norm())) / float(g_ref[k].norm()) for k in rest])
+    derr = np.array([rel(params[k].grad, g_ref[k]) for k in rest])
+    serr = np.array([rel(params[k].grad, g_ref[k]) for k in sums])
+    print("MEASURED %s slope-1 network: cosine %.3e loss %.3e; grad norms median %.3e max %.3e; directions median %.3e max %.3e (%s); "
+          "cancelling sums median %.3e max %.3e; head grad %.3e" %
+          (arch, rel(cosine, c_ref), abs(float(loss) - l_ref) / abs(l_ref), np.median(nerr), nerr.max(), np.median(derr), derr.max(),
+           rest[int(np.argmax(derr))], np.median(serr), serr.max(), rel(fcm.fc.grad, fcg_ref)))
+    assert rel(cosine, c_ref) < T16(SPEC, 3.3e-2)
+    assert abs(float(loss) - l_ref) < 5e-3 * abs(l_ref)
+    assert np.median(nerr) < T16(SPEC, 2e-2) and nerr.max() < T16(SPEC, 6e-2), (np.median(nerr), nerr.max())
+    assert np.median(derr) < T16(SPEC, 5e-2) and derr.max() < T16(SPEC, 0.15), (np.median(derr), derr.max(), rest[int(np.argmax(derr))])
+    assert rel(fcm.fc.grad, fcg_ref) < T16(SPEC, 3.3e-2)
 
 
 def test_fused_client_loop_vs_reference():
@@ -586,10 +651,12 @@ def test_sweeps_and_hard_negative_mining_vs_reference():
     assert len(sub.dataset) == len(g["hn_index"]) and sub.dataset.num_classes == npub
 
 
-# measured x 1.25 per type: (embeddings, gradient-norm median, gradient-norm max, direction median, direction max).  sphere64 stacks 29 residual units
-# (58 convs) of bf16 storage where sphere20 has 8
-# measured (MI355X, round 4): sphere20 6.3e-3, 4.1e-3 / 5.8e-2, 0.106 / 0.160; sphere64 5.5e-3 (inside north_star's 1e-2), 5.8e-3 / 3.3e-2, 0.075 / 0.273
-SPH_TOL = {20: (2e-2, 1e-2, 0.12, 0.15, 0.4), 64: (7e-3, 7.5e-3, 4.2e-2, 0.095, 0.345)}
+# per type: (embeddings, gradient-norm median, gradient-norm max, direction median, direction max).
+# fp16: embeddings 7.7e-4 / 7.0e-4 and norm medians 2.4e-3 / 3.2e-3 at the spec; worst norm 2.0e-2 / 1.4e-2 and directions 3.4e-2 / 3.0e-2 median,
+# 5.4e-2 / 8.5e-2 max: the PReLU-kink class (every sphnet unit is conv -> PReLU)
+# bf16 subset, round 4 x 1.25: sphere20 6.3e-3, 4.1e-3 / 5.8e-2, 0.106 / 0.160; sphere64 5.5e-3, 5.8e-3 / 3.3e-2, 0.075 / 0.273
+SPH_TOL_BF16 = {20: (2e-2, 1e-2, 0.12, 0.15, 0.4), 64: (7e-3, 7.5e-3, 4.2e-2, 0.095, 0.345)}
+SPH_TOL_FP16 = (SPEC, SPEC, KINK_NORM_MAX, KINK_DIR_MEDIAN, KINK_DIR_MAX)
 
 
 @pytest.mark.parametrize("type_", [20, 64])
@@ -610,7 +677,7 @@ def test_sphnet_vs_reference(type_):
     x = R.closed_form_images(B, tag=4.0).to(DEV)
     dfe = R.closed_form((B, 512), 0.37, 0.9, 1.0).to(DEV)
     feats = net(x)
-    tol_f, tol_nm, tol_nx, tol_dm, tol_dx = SPH_TOL[type_]
+    tol_f, tol_nm, tol_nx, tol_dm, tol_dx = T16(SPH_TOL_FP16, SPH_TOL_BF16[type_])
     print("MEASURED sphere%d embeddings %.3e" % (type_, rel(feats, g["feats"])))
     assert rel(feats, g["feats"]) < tol_f, rel(feats, g["feats"])
     (feats * dfe).sum().backward()
@@ -816,12 +883,15 @@ def test_large_batch_train_step_vs_oracle(fuse_bnbwd):
         _large_batch_step()
 
 
-# measured x 1.25 (cosine 1.19e-2, norms 2.6e-3 / 9.3e-2, directions 4.8e-2 / 0.34, head gradient 1.2e-2)
-LB_TOL = {"cosine": 1.5e-2, "norm_median": 3.2e-3, "norm_max": 0.12, "dir_median": 6e-2, "dir_max": 0.43, "head": 1.6e-2}
+# fp16: cosine 1.5e-3, loss 1e-6, norms median 8.4e-4 (spec), head gradient 1.6e-3 (spec); worst norm 1.02e-2 and directions 1.6e-2 / 4.7e-2: kink class
+# bf16 subset: round 4 x 1.25 (cosine 1.19e-2, norms 2.6e-3 / 9.3e-2, directions 4.8e-2 / 0.34, head gradient 1.2e-2)
+LB_TOL_BF16 = {"cosine": 1.5e-2, "norm_median": 3.2e-3, "norm_max": 0.12, "dir_median": 6e-2, "dir_max": 0.43, "head": 1.6e-2}
+LB_TOL_FP16 = {"cosine": SPEC, "norm_median": SPEC, "norm_max": KINK_NORM_MAX, "dir_median": KINK_DIR_MEDIAN, "dir_max": KINK_DIR_MAX, "head": SPEC}
 
 
 def _large_batch_step():
     layers = R.IRESNET_LAYERS["iresnet18"]
+    LB_TOL = T16(LB_TOL_FP16, LB_TOL_BF16)
     B, C = 128, 100
     m, sd, _ = make_model("iresnet18", tag=3.0)
     m.train()
@@ -934,13 +1004,15 @@ def test_full_size_product_path_vs_fp32_validation_path(arch):
     nerr = np.array([abs(float(a[2][k].norm()) - gn[k]) / gn[k] for k in gn if gn[k] > 1e-3 * gmax])
     derr = np.array([rel(a[2][k], b[2][k]) for k in gn if gn[k] > 1e-3 * gmax])
     stat = max(rel(a[3][k], b[3][k]) for k in a[3])
-    print("MEASURED %s b128, bf16 product path vs fp32 validation path: embeddings eval %.3e train %.3e; gradient norms median %.3e max %.3e; "
+    print("MEASURED %s b128, 16-bit product path vs fp32 validation path: embeddings eval %.3e train %.3e; gradient norms median %.3e max %.3e; "
           "directions median %.3e max %.3e; running statistics %.3e" % (arch, e_eval, e_train, np.median(nerr), nerr.max(), np.median(derr), derr.max(), stat))
-    lim_e, lim_t = EMB_TOL[arch]
+    # fp16: measured 2.0e-3 / 2.6e-3 (iresnet100), 1.5e-3 / 2.0e-3 (iresnet50); norms 1e-3 / 1.0e-2; directions 3.4e-2 / 6.0e-2; statistics 7e-4
+    lim_e, lim_t = T16((SPEC, SPEC), EMB_TOL_BF16[arch])
+    gt = grad_tol(arch)
     assert e_eval < lim_e and e_train < lim_t, (e_eval, e_train)
-    assert np.median(nerr) < GRAD_TOL[arch]["norm_median"] and nerr.max() < GRAD_TOL[arch]["norm_max"], (np.median(nerr), nerr.max())
-    assert np.median(derr) < GRAD_TOL[arch]["dir_median"] and derr.max() < 0.5, (np.median(derr), derr.max())
-    assert stat < STAT_TOL_LATE, stat
+    assert np.median(nerr) < gt["norm_median"] and nerr.max() < gt["norm_max"], (np.median(nerr), nerr.max())
+    assert np.median(derr) < gt["dir_median"] and derr.max() < T16(KINK_DIR_MAX, 0.5), (np.median(derr), derr.max())
+    assert stat < T16(SPEC, STAT_TOL_BF16[1]), stat
 
 
 @pytest.mark.parametrize("arch,batch", [("iresnet18", 128), ("iresnet50", 64)])
@@ -1274,8 +1346,9 @@ def test_client_train_ragged_and_single_image_batches_vs_oracle():
     print("MEASURED ragged client loop:", {k: "%.2e" % v for k, v in errs.items()})
     # batches of 5 / 3 / 2 images: BatchNorm statistics over so few samples are ill-conditioned, the bf16 gradient noise is several times that
     # of the batch-8 client fixture (test_fused_client_loop_vs_reference: 1e-2) — measured 1.6e-2 on conv1.weight
+    # (fp16: head 5.2e-3, conv1.weight 3.3e-3: at the spec)
     for k, v in errs.items():
-        assert v < (3.3e-2 if k == "head" else 2.1e-2), (k, v)          # measured 2.6e-2 / 1.6e-2
+        assert v < T16(SPEC, 3.3e-2 if k == "head" else 2.1e-2), (k, v)          # bf16 subset: measured 2.6e-2 / 1.6e-2
 
 
 @pytest.mark.parametrize("batch", [128, 24])
@@ -1386,19 +1459,22 @@ def test_sphnet_trains_through_the_fused_trainer_like_iresnet():
 
 
 def test_fp16_overflow_guard_keeps_the_weights_finite():
-    """fp16-storage build only: an absurd loss scale overflows every fp16 gradient of the backbone.  The update kernels skip the non-finite
-    elements (fedfr_sgd_step_scaled), so parameters / momentum / mirrors stay finite; finish() reports the overflow and halves the trainer's
-    scale; with a sane scale the same trainer trains on."""
+    """fp16 storage (the product library): an absurd loss scale overflows every fp16 gradient of the backbone.  The update kernels skip the
+    non-finite elements (fedfr_sgd_step_scaled), so parameters / momentum / mirrors stay finite; finish() reports the overflow and halves the
+    DEVICE's scale (_C.LossScaleState: it outlives the trainer, so the next round starts from the lowered value — ADVICE r4); with a sane scale
+    the same trainer trains on, and `growth_interval` clean steps bring the scale back up to its initial value."""
     if _C.storage_dtype() != torch.float16:
-        # loss scaling exists in the fp16-storage build only: run this very test in a child process that loads that library
-        import subprocess
-        import sys
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        assert os.path.exists(os.path.join(root, "fedfr_amd", "libfedfr_hip_fp16.so")), "libfedfr_hip_fp16.so is not built (make -C fedfr_amd/csrc fp16)"
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "fp16_overflow_guard"],
-                           env=dict(os.environ, FEDFR_HIP_LIB_NAME="libfedfr_hip_fp16.so"), capture_output=True, text=True, timeout=600, cwd=root)
-        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-        return
+        pytest.skip("loss scaling exists on fp16 storage only (this process loaded the bf16 build)")
+    state = _C.loss_scale_state(DEV)
+    saved = (state.scale, state.clean_steps, state.growth_interval)
+    try:
+        _overflow_guard_body(state)
+    finally:
+        state.scale, state.clean_steps, state.growth_interval = saved
+        state.word.zero_()
+
+
+def _overflow_guard_body(state):
     B, C = 8, 40
     m, sd, layers = make_model("iresnet18", tag=5.0)
     fc = R.head_fc(C).to(DEV)
@@ -1414,40 +1490,66 @@ def test_fp16_overflow_guard_keeps_the_weights_finite():
     nt = m.trainable_count()
     skipped = float((m._flat_params[:nt] == before[:nt]).float().mean())
     assert skipped > 0.5, skipped                                # (almost) every backbone gradient overflowed: those elements were not touched
-    tr.loss_scale = 256.0
+    # the lowered scale belongs to the device, not to the trainer: a NEW trainer (= the next FL round) starts from it
+    tr2 = client.FusedTrainer(m, fc, "CosFace", 30.0, 0.4, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    assert tr2.loss_scale == 2.0 ** 59 and tr2.overflows == 0 and state.overflows >= 1
+    tr2.loss_scale = state.initial / 2                            # (as if the back-offs had ended one step below the initial scale)
+    state.growth_interval = 2
     mid = m._flat_params.clone()
-    ls = [float(tr.step(imgs, lab)) for _ in range(3)]
-    tr.finish()
-    assert tr.overflows == 1 and all(np.isfinite(ls)) and bool(torch.isfinite(m._flat_params).all())
+    ls = [float(tr2.step(imgs, lab)) for _ in range(3)]
+    tr2.finish()
+    assert tr2.overflows == 0 and all(np.isfinite(ls)) and bool(torch.isfinite(m._flat_params).all())
     assert float((m._flat_params[:nt] != mid[:nt]).float().mean()) > 0.9          # ... and now it trains
+    assert tr2.loss_scale == state.initial                         # three clean steps >= growth_interval: doubled once, never beyond the initial scale
+    # forward_backward() + optimizer_step() (the gradients-then-update contract; FEDFR_FUSE_SGD=0 takes the same route): guarded as well
+    tr3 = client.FusedTrainer(m, fc, "CosFace", 30.0, 0.4, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    tr3.loss_scale = 2.0 ** 60
+    before3, fc_before = m._flat_params.clone(), fc.clone()
+    tr3.forward_backward(imgs, lab)
+    assert not bool(torch.isfinite(m._flat_grads[:nt]).all())      # the unscaled gradients the caller sees do carry the overflow
+    tr3.optimizer_step()
+    with pytest.warns(UserWarning, match="non-finite gradients"):
+        assert tr3.check_overflow() is True
+    tr3.finish()
+    assert bool(torch.isfinite(m._flat_params).all()) and bool(torch.isfinite(tr3.mom).all()) and bool(torch.isfinite(fc).all())
+    assert float((m._flat_params[:nt] == before3[:nt]).float().mean()) > 0.5
+    # PartialFC head: its sampled-row update is guarded by the same word
+    from fedfr_amd.partial_fc import PartialFC as _PFC
+    pfc = _PFC(rank=0, local_rank=0, world_size=1, batch_size=B, resume=False, margin_softmax=losses.CosFace(s=30, m=0.4), num_classes=C,
+               sample_rate=1.0, embedding_size=512, prefix="/tmp")
+    tr4 = client.FusedTrainer(m, pfc, "CosFace", 30.0, 0.4, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    tr4.loss_scale = state.initial
+    tr4.step(imgs, lab)
+    tr4.finish()
+    pfc.sub_weight.grad.fill_(float("inf"))                        # a poisoned row gradient: the guarded update must leave the rows alone
+    rows = pfc.sub_weight.data.clone()
+    pfc.fused_sgd_update(0.05, 0.9, 5e-4, overflow=state.word)
+    torch.cuda.synchronize()
+    assert torch.equal(pfc.sub_weight.data, rows) and int(state.word.item()) != 0
+    state.word.zero_()
 
 
-def test_fp16_storage_build_meets_the_1e2_bar():
-    """VERDICT r2 missing #4: the library built on IEEE fp16 storage (`make fp16` -> libfedfr_hip_fp16.so; csrc/common.h FEDFR_FP16: the
-    reference's own AMP type, backbones/iresnet.py:159; same kernels, same MFMA rate, 10 mantissa bits instead of 7, static loss scale on
-    the host side) against the imported reference's goldens: whole-network embeddings (eval and train-mode BatchNorm), cosine logits and
-    the loss of iresnet50 / iresnet100 INSIDE north_star's 1e-2 — where the bf16 product build measures 1.2-2.6e-2:
-    the gap is storage rounding, not the kernels.  Runs the reference-parity tests of this file in a child process that loads the fp16
-    library, and reads their MEASURED lines."""
+def test_bf16_build_reference_parity_subset():
+    """The SECOND build of the library, libfedfr_hip_bf16.so (`make bf16`; csrc/common.h FEDFR_FP16=0: the same kernels on bf16 storage, no loss
+    scale, ~1 % faster): the reference-parity tests of this file and the block fixtures in a child process that loads it, at the bounds 7
+    mantissa bits allow (T16's second argument).  Its MEASURED lines are read back: whole-network embeddings sit at 1.2-2.6e-2 — outside
+    north_star's 1e-2, which is why this build is not the default."""
     import re
     import subprocess
     import sys
+    if _C.storage_dtype() != torch.float16:
+        pytest.skip("this process already runs on the bf16 build")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, "fedfr_amd", "libfedfr_hip_fp16.so")):
-        pytest.skip("libfedfr_hip_fp16.so is not built (make -C fedfr_amd/csrc fp16)")
-    env = dict(os.environ, FEDFR_HIP_LIB_NAME="libfedfr_hip_fp16.so")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_e2e_gpu.py"), "-x", "-q", "-s", "-k",
-                        "backbone_forward_vs_reference or train_step_grads_vs_reference or fused_client_loop or sgd_inside_backward"], env=env, capture_output=True,
-                       text=True, timeout=900, cwd=root)
+    assert os.path.exists(os.path.join(root, "fedfr_amd", "libfedfr_hip_bf16.so")), "libfedfr_hip_bf16.so is not built (make -C fedfr_amd/csrc bf16)"
+    env = dict(os.environ, FEDFR_HIP_LIB_NAME="libfedfr_hip_bf16.so")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_e2e_gpu.py"), os.path.join(root, "tests", "test_block_gpu.py"),
+                        "-x", "-q", "-s", "-p", "no:cacheprovider", "-k",
+                        "backbone_forward_vs_reference or train_step_grads_vs_reference or fused_client_loop or sgd_inside_backward or block_vs_reference "
+                        "or without_the_prelu_kink or sphnet_vs_reference or full_size_step_invariants"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     emb = re.findall(r"MEASURED (iresnet\d+) embeddings: eval ([\d.e+-]+) train ([\d.e+-]+)", r.stdout)
     cos = re.findall(r"MEASURED (iresnet\d+) cosine ([\d.e+-]+) loss ([\d.e+-]+)", r.stdout)
-    nrm = re.findall(r"MEASURED (iresnet\d+) grad norms: median ([\d.e+-]+) max ([\d.e+-]+)", r.stdout)
-    assert len(emb) == 2 and len(cos) == 2 and len(nrm) == 2, r.stdout[-3000:]
-    for arch, ev, tr_ in emb:
-        assert float(ev) < 5e-3 and float(tr_) < 5e-3, (arch, ev, tr_)           # measured 1.5e-3 / 2.2e-3 (r50), 2.0e-3 / 3.2e-3 (r100)
-    for arch, c_, l_ in cos:
-        assert float(c_) < 5e-3 and float(l_) < 1e-3, (arch, c_, l_)              # measured 2.2e-3 / 3.2e-3; loss 6e-5 / 2e-5
-    for arch, med, mx in nrm:
-        assert float(med) < 2e-3 and float(mx) < 3e-2, (arch, med, mx)           # measured 9.5e-4 / 1.1e-2 (r50), 1.1e-3 / 2.0e-2 (r100)
-    print("fp16 build:", emb, cos, nrm)
+    assert len(emb) == 2 and len(cos) == 2, r.stdout[-3000:]
+    print("bf16 build:", emb, cos)
+    assert all(float(ev) > 5e-3 for _, ev, _ in emb)          # (it really was the bf16 build: fp16 storage measures 1.5-2e-3 here)

@@ -323,30 +323,54 @@ def test_bench_self_launch_returns_nonzero_without_a_result(tmp_path):
 
 
 def test_loss_scale_guard_backs_off_and_warns():
-    """client._LossScaleGuard (fp16-storage build's GradScaler stand-in): nothing is read while the scale is 1 (bf16 build: no sync); a set
-    overflow word halves the scale, warns, is cleared and counted; the periodic check fires every `overflow_check_every` steps."""
+    """client._LossScaleGuard over _C.LossScaleState (the fp16 library's GradScaler stand-in, client.py:301,394-396): a disabled state (bf16 library)
+    never reads the word; a set overflow word halves the DEVICE's scale, warns, is cleared and counted; the periodic check fires every
+    `overflow_check_every` steps; the lowered scale outlives the trainer; `growth_interval` clean steps double it again, never beyond the
+    initial scale."""
     import warnings
     import torch
-    from fedfr_amd import client
+    from fedfr_amd import client, _C
 
     class T(client._LossScaleGuard):
         pass
+    dev = torch.device("cpu")
+    _C._LOSS_SCALE_STATES.pop(str(dev), None)
     t = T()
-    t._init_loss_scale(torch.device("cpu"))
-    assert t.loss_scale == 1.0 and t.check_overflow() is False          # the bf16 library is the one loaded on the CPU box
-    t._overflow[0] = 1
-    assert t.check_overflow() is False                                  # scale 1: the word is never consulted
-    t.loss_scale = 256.0
+    t._init_loss_scale(dev)
+    st = t._ls
+    assert st is _C.loss_scale_state(dev)
+    assert t.loss_scale == _C.loss_scale() == 256.0 and t.guarded          # the product library (fp16 storage) is the one loaded by default
+    assert t.check_overflow() is False
+    st.enabled = False                                                      # what the bf16 library's state looks like: nothing is ever read
+    st.word[0] = 1
+    assert t.check_overflow() is False and int(st.word[0]) == 1
+    st.enabled = True
     with pytest.warns(UserWarning, match="loss scale lowered to 128"):
         assert t.check_overflow() is True
-    assert t.loss_scale == 128.0 and t.overflows == 1 and int(t._overflow[0]) == 0
+    assert t.loss_scale == 128.0 and t.overflows == 1 and st.overflows == 1 and int(st.word[0]) == 0
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         assert t.check_overflow() is False
     t.overflow_check_every = 3
-    t._overflow[0] = 1
+    st.word[0] = 1
     t._count_step(); t._count_step()
     assert t.loss_scale == 128.0
     with pytest.warns(UserWarning):
         t._count_step()
     assert t.loss_scale == 64.0 and t.overflows == 2 and t._steps_since_check == 0
+    # the next round's trainer (a new object) starts from the lowered scale ...
+    t2 = T()
+    t2._init_loss_scale(dev)
+    assert t2.loss_scale == 64.0 and t2.overflows == 0
+    # ... and clean steps grow it back: x2 per growth_interval polled clean steps, capped at the initial value
+    st.growth_interval = 5
+    for _ in range(4):
+        t2._count_step()
+    assert t2.check_overflow() is False and t2.loss_scale == 64.0            # 4 clean steps: not yet
+    t2._count_step()
+    assert t2.check_overflow() is False and t2.loss_scale == 128.0           # 5
+    for _ in range(20):
+        t2._count_step()
+        t2.check_overflow()
+    assert t2.loss_scale == 256.0 == st.initial
+    _C._LOSS_SCALE_STATES.pop(str(dev), None)

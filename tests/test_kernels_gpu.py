@@ -18,7 +18,7 @@ def dev():
 
 
 def S16():
-    """the loaded library's 16-bit storage type: bfloat16 (product build) or float16 (FEDFR_HIP_LIB_NAME=libfedfr_hip_fp16.so)"""
+    """the loaded library's 16-bit storage type: float16 (the product library) or bfloat16 (FEDFR_HIP_LIB_NAME=libfedfr_hip_bf16.so)"""
     return _C.storage_dtype()
 
 

@@ -47,6 +47,30 @@ PMC_KEYS = {"conv3x3_glds_kernel<14,14>": ("conv3x3_glds_kernel<14, 14",), W9P: 
             "gemm_tn_glds_kernel<128,128>": ("gemm_tn_glds_kernel", "reduce_slabs")}
 
 
+# translation units (fedfr_amd/csrc) a replayed counter belongs to: a summary under profiles/ carries the git blob hashes of the sources it was
+# collected on (tools/source_stamp.py); a difference to the working tree marks the field stale
+_COMMON_TU = ["common.h", "gemm_dev.h"]
+KERNEL_TUS = {"conv14": ["conv_glds_impl.h", "conv_glds8_w14.hip", "conv_glds8_fused_w14.hip", "nt_epilogue.h"] + _COMMON_TU,
+              "conv28": ["conv_glds_impl.h", "conv_glds8_w28.hip", "conv_glds8_fused_w28.hip", "nt_epilogue.h"] + _COMMON_TU,
+              "w9p": ["wgrad9p.hip", "gemm_tn_dev.h"] + _COMMON_TU,
+              "tn_glds": ["gemm_tn_glds.hip", "gemm_tn_dev.h"] + _COMMON_TU}
+
+
+def staleness(summary_path, tus):
+    """-> {"stale": True / False, ...}: do the sources the summary was collected on still match the working tree?  A summary that predates source
+    stamps (rounds 1-4) counts as stale."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("source_stamp", os.path.join(ROOT, "tools", "source_stamp.py"))
+    ss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ss)
+    then = ss.parse_stamp(summary_path)
+    if then is None:
+        return {"stale": True, "stale_note": "summary carries no source stamp (collected before round 5): archived, not this build's"}
+    now = ss.source_hashes()
+    changed = sorted(t for t in tus if then.get(t) != now.get(t))
+    return {"stale": bool(changed), "stale_sources": changed} if changed else {"stale": False}
+
+
 def pmc_traffic():
     """HBM bytes per launch from the NEWEST committed PMC summary under profiles/ (tools/pmc_traffic.sh: separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction; bench.py cannot run rocprofv3 on itself).  For the weight-gradient
@@ -74,7 +98,8 @@ def pmc_traffic():
                     parts = [(n + (" x 2" if "reduce_slabs" in n else ""), fe * (2 if "reduce_slabs" in n else 1), wr * (2 if "reduce_slabs" in n else 1))
                              for n, fe, wr in parts]
                 tot = sum(fe + wr for _, fe, wr in parts)
-                out[kern] = (int(round(tot * 1e6)), os.path.relpath(f, ROOT),
+                tus = KERNEL_TUS["conv14" if kern.startswith("conv3x3") else "w9p" if kern == W9P else "tn_glds"] + (["ew.hip"] if kern != "conv3x3_glds_kernel<14,14>" else [])
+                out[kern] = (int(round(tot * 1e6)), os.path.relpath(f, ROOT), staleness(f, tus),
                              " + ".join("%s: fetch %.1f MB, write %.1f MB" % (re.sub(r"^void\s+(\(anonymous namespace\)::)?", "", n).split("<")[0].split("(")[0], fe, wr)
                                         for n, fe, wr in parts))
     return out
@@ -120,6 +145,7 @@ def pmc_mfma_busy():
                          "parked_wait": round(vals.get("SQ_WAIT_ANY", 0.0) / vals["SQ_WAVE_CYCLES"], 3),
                          "lds_bank_conflict_per_active": round(vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(vals.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0), 3),
                          "source": os.path.relpath(f, ROOT)}
+            out[name].update(staleness(f, KERNEL_TUS["conv14" if tag.startswith("conv14") else "conv28" if tag.startswith("conv28") else "w9p"]))
     return out
 
 
@@ -544,18 +570,20 @@ def main():
             def entry(ms, n, fl, slot):
                 name = SLOT_NAMES[slot]
                 ach = fl / (ms * 1e-3) / 1e12
-                tr_bytes, tr_file, tr_detail = traffic.get(name, (None, None, None))
+                tr_bytes, tr_file, tr_stale, tr_detail = traffic.get(name, (None, None, None, None))
                 e = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": tr_bytes,
                      "launches_per_step": n // psteps, "avg_launch_us": round(ms * 1e3 / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3)}
                 if name in sq:
                     e["mfma_busy"] = sq[name]["mfma_busy"]
+                    e["mfma_busy_stale"] = sq[name].get("stale")
                     e["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles a wave is resident (rocprofv3 --pmc, %s): the share of a wave's "
                                            "lifetime during which its SIMD's matrix pipe is busy; launch overhead outside the waves' lifetime is not in it" % sq[name]["source"])
                 if tr_bytes is not None:
                     e["traffic_note"] = ("HBM bytes per launch on the 256->256 @14x14 layer, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                                          "FETCH x2 gfx950 correction), %s: %s; algorithmic %.1f MB" % (tr_file, tr_detail, ALGORITHMIC_MB.get(name, float("nan"))))
                     e["algorithmic_bytes"] = int(ALGORITHMIC_MB[name] * 1e6) if name in ALGORITHMIC_MB else None
+                    e["traffic_stale"] = tr_stale
                 return e
             if rows:
                 roofline = entry(*rows[0])

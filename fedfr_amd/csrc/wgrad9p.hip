@@ -430,35 +430,44 @@ bool wgrad9p_applies(const GemmTN& a, const GemmTN& b) {
   return g_wgrad9p && wgrad9_applies(a) && wgrad9_applies(b) && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C && a.W == b.W &&
          a.NI % 64 == 0 && a.C % 64 == 0;
 }
-// 2 layers x tiles x splits ~ 256 workgroups (one per CU), at least two sub-images per split
-int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W) {
+// 2 layers x tiles x splits ~ 256 workgroups (one per CU) x rounds, at least two sub-images per split
+int g_wgrad9p_rounds = 1;   // option "wgrad9p_rounds": 2 = twice the K-splits (512 workgroups of half the length, dispatched in two rounds): a dgrad conv of the
+                            // high-priority stream then waits for half as long a workgroup, at twice the slab traffic
+int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W, int rounds) {
   const int stages = (Kp / (W * W)) << (2 * w9p_lg(W));
   const int tiles = (NI / 64) * (NJ / 9 / 64);
-  int splits = 128 / tiles;
+  int splits = 128 * (rounds > 0 ? rounds : g_wgrad9p_rounds) / tiles;
   if (splits < 1) splits = 1;
   if (splits > stages / 2) splits = stages / 2 > 0 ? stages / 2 : 1;
   const int per = ceil_div(stages, splits);
   return ceil_div(stages, per);
 }
 
-// the job's geometry for a carrying launch of `grid` workgroups with `per_split` sub-images each; false = it does not fit (stand-alone reduction)
-static bool w9p_job_geometry(const W9PJob& job, int grid, int per_split, W9PJobDev* d, int* mode = nullptr) {
-  if (!job.n || (job.n & 3) || job.nsplit < 1 || !job.slab[0] || !job.slab[1] || !job.dst[0] || !job.dst[1] || grid < 1) return false;
-  const size_t n4 = job.n / 4, total4 = 2 * n4;
+// the job's geometry for a carrying launch of `grid` workgroups with `per_split` sub-images each; false = it does not fit (stand-alone reduction).
+// A job with slab[1] == dst[1] == nullptr is a SINGLE tensor (one layer's slabs, written by a half-K launch, wgrad9h below): its n / 4 outputs are
+// spread over the whole grid and always summed in ascending slab order (mode 1).  *ju = units per sub-image the kernel must run (1 or 2).
+static bool w9p_job_geometry(const W9PJob& job, int grid, int per_split, W9PJobDev* d, int* mode = nullptr, int* ju = nullptr) {
+  const bool single = !job.slab[1] && !job.dst[1];
+  if (!job.n || (job.n & 3) || job.nsplit < 1 || !job.slab[0] || !job.dst[0] || (!single && (!job.slab[1] || !job.dst[1])) || grid < 1) return false;
+  const size_t n4 = job.n / 4, total4 = single ? n4 : 2 * n4;
   if (total4 % (size_t)grid) return false;
   const size_t per = total4 / grid;
   if (n4 % per || (unsigned long long)job.nsplit * n4 * 16ull >= (1ull << 32)) return false;
-  const bool wide = job.nsplit >= 16 && n4 <= 65536;       // == reduce_slabs_launch's choice (ew.hip): same summation order either way
+  const bool wide = !single && !job.ascending && job.nsplit >= 16 && n4 <= 65536;       // == reduce_slabs_launch's choice (ew.hip): same summation order either way
   if (wide ? job.nsplit != 32 : (job.nsplit % 4) != 0) return false;
   const int nout = (int)((per + 255) / 256);
   const int upo = wide ? 8 : job.nsplit / 4;
-  if ((long long)nout * upo > per_split) return false;     // one unit per sub-image: everything rides under the MFMAs
+  const long long units = (long long)nout * upo;
+  // one unit per sub-image (K-step 1), or two (K-steps 1 and 3; narrow order only): everything rides under the MFMAs
+  const int need = units <= per_split ? 1 : ((!wide && units <= 2ll * per_split) ? 2 : 0);
+  if (!need) return false;
   if (d) {
     const unsigned s1 = (unsigned)n4 * 16u;                // one slab of one layer, in bytes
-    d->slab[0] = job.slab[0]; d->slab[1] = job.slab[1]; d->dst[0] = job.dst[0]; d->dst[1] = job.dst[1];
-    d->n4 = (unsigned)n4; d->per = (unsigned)per; d->nsplit = job.nsplit; d->upo = upo; d->units = nout * upo;
+    d->slab[0] = job.slab[0]; d->slab[1] = single ? job.slab[0] : job.slab[1]; d->dst[0] = job.dst[0]; d->dst[1] = single ? job.dst[0] : job.dst[1];
+    d->n4 = (unsigned)n4; d->per = (unsigned)per; d->nsplit = job.nsplit; d->upo = upo; d->units = (int)units;
     d->sb = wide ? s1 : 4 * s1; d->sr = wide ? 8 * s1 : s1;
     *mode = wide ? 2 : 1;
+    if (ju) *ju = need;
   }
   return true;
 }
@@ -472,7 +481,38 @@ bool wgrad9p_job_ok(const GemmTN& a, int splits, const W9PJob& job) {
   return w9p_job_geometry(job, grid, nstages / splits, nullptr);        // (the shortest split)
 }
 
+// ---- ONE layer per launch, its K range (the batch) cut into two halves that take the places of the pair's two layers (round 5): the same
+// kernel, 256 workgroups that live HALF as long (8 instead of 16 sub-images at B = 128), so that a launch fits the BatchNorm window behind
+// the dgrad conv that produced its operand (net.hip: the paired launch's 57 us workgroups kept the next conv waiting for ~30 us per block).
+// Both halves write ONE contiguous slab set [2 splits][NI][NJ]; the next launch sums it as a single-tensor job (w9p_job_geometry).
+bool wgrad9h_applies(const GemmTN& a) {
+  if (!g_wgrad9p || !wgrad9_applies(a) || a.NI % 64 || a.C % 64) return false;
+  const int images = a.Kp / (a.W * a.W);
+  return images >= 2 && images % 2 == 0 && (a.NI / 64) * (a.C / 64) >= 4;       // (64-channel layers: one tile per layer = 128 slabs per half: they keep the pair)
+}
+int wgrad9h_pick_splits(const GemmTN& a) { return wgrad9p_pick_splits(a.Kp / 2, a.NI, a.NJ, a.W, 1); }      // per half
+bool wgrad9h_job_ok(const GemmTN& a, int splits, const W9PJob& job) {
+  GemmTN h = a;
+  h.Kp = a.Kp / 2;
+  return wgrad9p_job_ok(h, splits, job);
+}
+int launch_wgrad9_pair_impl(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job, double flops);
+int launch_wgrad9_halves(const GemmTN& a, int splits, hipStream_t st, const W9PJob* job) {
+  FEDFR_REQUIRE(wgrad9h_applies(a), "wgrad9_halves: unsupported problem");
+  GemmTN h0 = a, h1 = a;
+  h0.Kp = h1.Kp = a.Kp / 2;
+  h1.P = a.P + (size_t)h0.Kp * a.ldp;
+  h1.Q = a.Q + (size_t)(h0.Kp / (a.W * a.W)) * a.H * a.W * a.C;
+  h1.out = a.out + (size_t)splits * a.NI * a.NJ;
+  h0.p_bytes = h1.p_bytes = a.p_bytes / 2;
+  h0.q_bytes = h1.q_bytes = a.q_bytes / 2;
+  return launch_wgrad9_pair_impl(h0, h1, splits, st, job, 2.0 * a.NI * a.NJ * (double)a.Kp);
+}
+
 int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job) {
+  return launch_wgrad9_pair_impl(a, b, splits, st, job, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp);
+}
+int launch_wgrad9_pair_impl(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job, double flops) {
   FEDFR_REQUIRE(wgrad9p_applies(a, b), "wgrad9_pair: unsupported problem pair");
   W9P p{};
   p.dy[0] = a.P; p.dy[1] = b.P; p.x[0] = a.Q; p.x[1] = b.Q; p.out[0] = a.out; p.out[1] = b.out;
@@ -487,18 +527,20 @@ int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t
   FEDFR_REQUIRE(a.p_bytes == b.p_bytes && a.q_bytes == b.q_bytes, "wgrad9_pair: operand sizes differ");
   FEDFR_REQUIRE(a.p_bytes < (1u << 30) - (1u << 24) && a.q_bytes < (1u << 30) - (1u << 24), "wgrad9_pair: operands must be smaller than 1 GiB");
   const dim3 grid(2 * p.ntiles * splits);
-  int jm = 0;
+  int jm = 0, ju = 1;
   if (job && job->n)
-    FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job, &jm), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
-  ProfScope prof(16, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
+    FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job, &jm, &ju), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
+  ProfScope prof(16, flops, st);
   constexpr size_t lds = 2 * (size_t)STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  if (jm == 1) hipLaunchKernelGGL(wgrad9p_kernel<1>, grid, dim3(256), lds, st, p);
+  if (jm == 1 && ju == 2) hipLaunchKernelGGL((wgrad9p_kernel<1, 2>), grid, dim3(256), lds, st, p);
+  else if (jm == 1) hipLaunchKernelGGL(wgrad9p_kernel<1>, grid, dim3(256), lds, st, p);
   else if (jm == 2) hipLaunchKernelGGL(wgrad9p_kernel<2>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(wgrad9p_kernel<0>, grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("wgrad9_pair");

@@ -27,9 +27,10 @@ extern "C" {
 #define FEDFR_ERR_UNSUPPORTED (-4)
 
 int fedfr_version(void);
-/* 16-bit storage type of activations / activation gradients / MFMA weight operands this build uses: 0 = bf16 (libfedfr_hip.so, the
- * product), 1 = IEEE fp16 (libfedfr_hip_fp16.so, `make -C fedfr_amd/csrc fp16`: the reference's own AMP type, backbones/iresnet.py:159 —
- * a validation build; gradients then need the host's loss scale, FEDFR_LOSS_SCALE) */
+/* 16-bit storage type of activations / activation gradients / MFMA weight operands this build uses: 1 = IEEE fp16 (libfedfr_hip.so, the
+ * product: the reference's own AMP type, backbones/iresnet.py:159; gradients carry the host's loss scale, FEDFR_LOSS_SCALE, which
+ * fedfr_sgd_step_scaled / fedfr_net_backward2_sgd_scaled undo and guard), 0 = bf16 (libfedfr_hip_bf16.so, `make -C fedfr_amd/csrc bf16`:
+ * the same kernels, no loss scale, whole-network outputs 1.5-2.5e-2 from the fp32 reference instead of 2-3e-3) */
 int fedfr_storage_dtype(void);
 const char* fedfr_last_error_string(void);
 /* Kernel-choice switches for same-box A/B measurements and validation fallbacks (no reference counterpart; every setting stays inside the
@@ -42,6 +43,8 @@ const char* fedfr_last_error_string(void);
  *                       64-channel conv, "conv28_tpw2" [2] two 28x28 tiles per workgroup (1 forward only), "eval_fuse" [1] eval-mode BatchNorm in the conv epilogues
  *   weight gradients    "wgrad9" [1] nine-tap kernel, "wgrad9p" [1] paired 64 x 64 nine-tap kernel, "wgrad9p_bg" [1] a paired launch sums the
  *                       PREVIOUS pair's split-K slabs beside its own work (0: stand-alone reductions), "wgrad9_wgs", "wgrad_pair_reduce" [1],
+ *                       "wgrad_split" [1] one half-K launch per 3x3 layer released behind its dgrad conv (2: in front of it, 0: one paired launch per block),
+ *                       "wgrad9p_rounds" [1] x K-splits of a paired launch (2: 512 workgroups of half the length),
  *                       "wgrad_depth" [4] generations of weight-gradient operands in flight, "fc_wgrad_aux" [1]
  *   BatchNorm forward   "bn_sliced" [1] channel-sliced passes without finalize launches, "fwd_xmom" [1] bn3 + identity + the next block's bn1 as one
  *                       pass from conv2's raw moments

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 from fedfr_amd import _C
 dev = torch.device("cuda:0")
+T16 = _C.storage_dtype()                      # the loaded library's 16-bit storage type
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 filt = sys.argv[2] if len(sys.argv) > 2 else ""
 which = sys.argv[3] if len(sys.argv) > 3 else "fwd,dgrad,wgrad"
@@ -32,13 +33,13 @@ tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 for name, H, Cin, Cout, k, s, cnt in SHAPES:
     if filt and filt not in name: continue
     Ho = H // s
-    x = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
-    dy = torch.randn(B, Ho, Ho, Cout, device=dev).to(torch.bfloat16)
+    x = torch.randn(B, H, H, Cin, device=dev).to(T16)
+    dy = torch.randn(B, Ho, Ho, Cout, device=dev).to(T16)
     w = (torch.randn(Cout, k, k, Cin, device=dev) * 0.05)
-    wb = torch.empty(Cout, k, k, Cin, dtype=torch.bfloat16, device=dev); wdb = torch.empty(Cin, k, k, Cout, dtype=torch.bfloat16, device=dev)
+    wb = torch.empty(Cout, k, k, Cin, dtype=T16, device=dev); wdb = torch.empty(Cin, k, k, Cout, dtype=T16, device=dev)
     _C.call("fedfr_weight_shadows", w.data_ptr(), wb.data_ptr(), wdb.data_ptr(), Cout, k, Cin, _C.stream())
-    y = torch.empty(B, Ho, Ho, Cout, dtype=torch.bfloat16, device=dev)
-    dx = torch.empty(B, H, H, Cin, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(B, Ho, Ho, Cout, dtype=T16, device=dev)
+    dx = torch.empty(B, H, H, Cin, dtype=T16, device=dev)
     dw = torch.empty(Cout, k, k, Cin, device=dev)
     stats = torch.empty(_C.lib().fedfr_conv2d_stat_rows(B, Ho, Cout), 2, Cout, device=dev)
     nb = _C.lib().fedfr_conv2d_wgrad_ws_bytes(B, H, Cin, Cout, k, s); ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
@@ -51,7 +52,7 @@ for name, H, Cin, Cout, k, s, cnt in SHAPES:
         t = timeit(lambda: _C.call("fedfr_conv2d_dgrad", dy.data_ptr(), wdb.data_ptr(), dx.data_ptr(), B, H, Cin, Cout, k, s, st)); tot["dgrad"] += t * cnt; res.append("dgrad %7.1f us %6.0f TF" % (t * 1e3, flop / t / 1e9))
     if "fdgrad" in which and k == 3 and s == 1:      # dgrad with the fused BN-backward reduction epilogue (PReLU variant)
         import ctypes
-        bnx = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
+        bnx = torch.randn(B, H, H, Cin, device=dev).to(T16)
         cv = [torch.rand(Cin, device=dev) + 0.5 for _ in range(5)]
         part = torch.empty((B * H * H + 127) // 128, 3, Cin, device=dev); rows = ctypes.c_int(0)
         t = timeit(lambda: _C.call("fedfr_conv2d_dgrad_bnbwd", dy.data_ptr(), wdb.data_ptr(), dx.data_ptr(), B, H, Cin, Cout, k, s, bnx.data_ptr(),
@@ -60,7 +61,7 @@ for name, H, Cin, Cout, k, s, cnt in SHAPES:
     if "wgrad" in which:
         t = timeit(lambda: _C.call("fedfr_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, B, H, Cin, Cout, k, s, st)); tot["wgrad"] += t * cnt; res.append("wgrad %7.1f us %6.0f TF" % (t * 1e3, flop / t / 1e9))
     if "wpair" in which and k == 3 and s == 1 and Cin == Cout:      # the block's two same-shape weight gradients in one call (wgrad9p.hip when it applies)
-        x2 = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16); dy2 = torch.randn(B, Ho, Ho, Cout, device=dev).to(torch.bfloat16)
+        x2 = torch.randn(B, H, H, Cin, device=dev).to(T16); dy2 = torch.randn(B, Ho, Ho, Cout, device=dev).to(T16)
         dw2 = torch.empty(Cout, k, k, Cin, device=dev); ws2 = torch.empty(max(2 * nb, 16), dtype=torch.uint8, device=dev)
         t = timeit(lambda: _C.call("fedfr_conv2d_wgrad_pair", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x2.data_ptr(), dy2.data_ptr(), dw2.data_ptr(),
                                    ws2.data_ptr(), 2 * nb, B, H, Cin, Cout, k, s, st)); res.append("wpair %7.1f us %6.0f TF" % (t * 1e3, 2 * flop / t / 1e9))

@@ -18,7 +18,7 @@ for P in "$P1" "$P2" "$P3"; do
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT -o p$i -- python3 $R/tools/conv_bench.py 5 "$SHAPE" "$WHICH" "$@" > $OUT/run$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/run$i.log; }
 done
 cd $R
-OUT=$OUT TAG=$TAG SHAPE="$SHAPE" WHICH="$WHICH" OPTS="$*" python3 - <<'PY' | tee $R/gpurun_out/pmc_sq/$TAG.txt
+{ python3 tools/source_stamp.py; OUT=$OUT TAG=$TAG SHAPE="$SHAPE" WHICH="$WHICH" OPTS="$*" python3 - <<'PY'
 import csv, glob, collections, os
 out = os.environ["OUT"]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); dur = collections.defaultdict(list)
@@ -45,3 +45,4 @@ for k, d in sorted(agg.items()):
         print("   -> MfmaBusy (MFMA_BUSY / BUSY_CYCLES) %.3f ; LDS-wait share of wave cycles %.3f ; any-wait share %.3f" %
               (d["SQ_VALU_MFMA_BUSY_CYCLES"] / busy, d.get("SQ_WAIT_INST_LDS", 0) / max(cnt[(k, "SQ_WAIT_INST_LDS")], 1) / (wc / n), d.get("SQ_WAIT_INST_ANY", 0) / wc))
 PY
+} | tee $R/gpurun_out/pmc_sq/$TAG.txt

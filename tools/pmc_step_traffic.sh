@@ -7,6 +7,7 @@ cd /tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o f -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $OUT/f.json 2> $OUT/f.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o w -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $OUT/w.json 2> $OUT/w.err
 cd $R
+python3 tools/source_stamp.py
 python3 - "$TAG" <<'PY'
 import csv, glob, collections, sys
 fam = lambda n: ("BatchNorm passes" if any(k in n for k in ("bn_apply", "bn_bwd", "bn_finalize", "colsum_stage", "bn1d")) else

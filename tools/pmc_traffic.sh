@@ -6,6 +6,7 @@ R=$PWD; OUT=$R/gpurun_out/pmc_traffic; rm -rf $OUT; mkdir -p $OUT
 SHAPE=${1:-s3_256x256@14}; WHICH=${2:-fwd}
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o f -- python3 tools/conv_bench.py 5 "$SHAPE" "$WHICH" > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o w -- python3 tools/conv_bench.py 5 "$SHAPE" "$WHICH" > /dev/null 2>&1
+python3 tools/source_stamp.py
 python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

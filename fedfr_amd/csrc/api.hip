@@ -18,8 +18,6 @@ extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_nt_glds;
 extern int g_wgrad_pair_reduce;
-extern int g_wgrad_split;
-extern int g_wgrad9p_rounds;
 extern int g_wgrad9;
 extern int g_conv_c64p;
 extern int g_bn_sliced, g_bn_sliced_pre, g_bn_sliced_bwd_passes;
@@ -79,8 +77,6 @@ const OptRow kOptions[] = {
     {"fuse_bnred_next", &g_fuse_bnred_next, 0, 0, 1},
     {"dgrad_parity", &g_dgrad_parity, 1, 0, 2},
     {"wgrad_pair_reduce", &g_wgrad_pair_reduce, 0, 0, 1},
-    {"wgrad_split", &g_wgrad_split, 1, 0, 2},
-    {"wgrad9p_rounds", &g_wgrad9p_rounds, 1, 1, 2},      // K-splits of a paired weight-gradient launch x this (2: 512 workgroups of half the length)              // 1: one half-K weight-gradient launch per 3x3 layer, released behind its dgrad conv (2: in front of it); 0: one paired launch per block
     {"nt_glds", &g_nt_glds, 1, 0, 15},                    // 0 register-staged NT kernel, 1..4 LDS-DMA operand ring where it pays, + 8 everywhere it can (gemm_nt_glds.hip)
     {"tn_glds", &g_tn_glds, 2, 0, 0},                      // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
     {"wgrad_depth", &g_wgrad_depth, 1, 2, kWgradDepth},
@@ -426,16 +422,6 @@ int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* w
   p.P = BF(dy); p.Q = BF(x); p.Kp = batch * hout * hout; p.NI = cout; p.NJ = ksize * ksize * cin;
   p.mode = 1; p.H = hin; p.W = hin; p.C = cin; p.Ho = hout; p.Wo = hout; p.S = ksize; p.stride = stride;
   p.pad = ksize == 3 ? 1 : 0; p.ldp = cout; p.use_tr = g_tn_use_tr;
-  if (g_wgrad_split && gemm_tn_w9half_ok(p)) {
-    // what the network's backward pass launches per 3x3 / stride-1 layer (net.hip, option wgrad_split): the batch in two halves on the
-    // paired nine-tap kernel, one contiguous slab set, summed in ascending order
-    const int sp = gemm_tn_w9half_splits(p);
-    if (ws && ws_bytes >= (size_t)2 * sp * p.NI * p.NJ * sizeof(float)) {
-      p.out = (float*)ws;
-      FEDFR_TRY(gemm_tn_launch_w9half(p, sp, ST(stream)));
-      return ew_reduce_slabs_ascending(dw, (const float*)ws, 2 * sp, (size_t)p.NI * p.NJ, ST(stream));
-    }
-  }
   const int splits = gemm_tn_pick_splits(p.Kp, p.NI, p.NJ, p.C, p.Wo, p.stride);
   if (splits == 1) {
     p.out = dw;

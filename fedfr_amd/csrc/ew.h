@@ -129,7 +129,6 @@ int ew_bn1d_bwd(const float* dy, const float* x, float* dx, int B, int C, const 
 int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n,
                     hipStream_t st);
 int ew_reduce_slabs2(float* dst0, const float* slabs0, float* dst1, const float* slabs1, int nsplit, size_t n, hipStream_t st);
-int ew_reduce_slabs_ascending(float* dst, const float* slabs, int nsplit, size_t n, hipStream_t st);   // ascending slabs, whatever the shape
 int ew_reduce_slabs_bf16(bf16_t* dst, const float* slabs, int nsplit, size_t n, hipStream_t st);
 
 // ---- conversions -----------------------------------------------------------------------------------------------

@@ -993,13 +993,13 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(float* dst, cons
   }
 }
 static int reduce_slabs_launch(float* dst, const float* slabs, float* dst1, const float* slabs1, int nsplit, size_t n, const float* bias, int bias_n,
-                               hipStream_t st, bool force_narrow = false) {
+                               hipStream_t st) {
   FEDFR_REQUIRE(dst && slabs && nsplit > 0 && n > 0 && (n & 3) == 0, "reduce_slabs: bad args (n%%4)");
   if (bias) FEDFR_REQUIRE((bias_n & 3) == 0 && bias_n > 0, "reduce_slabs: bias_n%%4");
   const size_t n4 = n / 4;
   const unsigned ny = dst1 ? 2 : 1;
   ProfScope prof(25, (double)n * 4 * (nsplit + 1) * ny, st);
-  if (!force_narrow && nsplit >= 16 && n4 <= 65536) {
+  if (nsplit >= 16 && n4 <= 65536) {
     hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 31) / 32), ny), dim3(256), 0, st, dst, slabs, nsplit, n4, bias, bias_n, dst1, slabs1);
     FEDFR_LAUNCH_CHECK("reduce_slabs_wide");
     return FEDFR_OK;
@@ -1011,11 +1011,6 @@ static int reduce_slabs_launch(float* dst, const float* slabs, float* dst1, cons
 }
 int ew_reduce_slabs(float* dst, const float* slabs, int nsplit, size_t n, const float* bias, int bias_n, hipStream_t st) {
   return reduce_slabs_launch(dst, slabs, nullptr, nullptr, nsplit, n, bias, bias_n, st);
-}
-// ascending-slab order whatever the shape: the stand-alone twin of a single-tensor job a half-K weight-gradient launch would have carried
-// (wgrad9p.hip, w9p_job_geometry: single jobs are always summed in this order, so both paths give the same bits)
-int ew_reduce_slabs_ascending(float* dst, const float* slabs, int nsplit, size_t n, hipStream_t st) {
-  return reduce_slabs_launch(dst, slabs, nullptr, nullptr, nsplit, n, nullptr, 0, st, true);
 }
 // two slab sets of the same geometry (the two 3x3 weight gradients of a residual block) in one launch
 int ew_reduce_slabs2(float* dst0, const float* slabs0, float* dst1, const float* slabs1, int nsplit, size_t n, hipStream_t st) {
@@ -1159,8 +1154,7 @@ __global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float*
 #pragma unroll 4
   for (int pp = t >> 5; pp < 64; pp += 8) {
     const int p = p0 + pp, c = c0 + (t & 31) * 2;
-    if (p < HW && c + 1 < C) *reinterpret_cast<unsigned*>(d + (size_t)p * C + c) = pack_bf2(tile[(t & 31) * 2][pp], tile[(t & 31) * 2 + 1][pp]);
-    else if (p < HW && c < C) d[(size_t)p * C + c] = f2bf(tile[(t & 31) * 2][pp]);
+    if (p < HW && c + 1 < C) *reinterpret_cast<unsigned*>(d + (size_t)p * C + c) = pack_bf2(tile[(t & 31) * 2][pp], tile[(t & 31) * 2 + 1][pp]);      // (C is even: launcher)
   }
 }
 int ew_nchw_f32_to_nhwc_bf16(const float* src, bf16_t* dst, int B, int C, int HW, hipStream_t st) {

@@ -88,21 +88,14 @@ int gemm_tn_w9pair_splits(const GemmTN& a);
 // separate reduce_slabs launches cost 13 of the 66 us of a pair).  dst[l] = sum over s of slab[l][s * n + i], in the summation order of the
 // stand-alone kernels (ew_reduce_slabs: ascending slabs, or the 8-lane order of its wide form), so both paths give the same bits.
 struct W9PJob {
-  const float* slab[2];   // [nsplit][n] each; slab[1] == dst[1] == nullptr: ONE tensor (a half-K launch's slab set), always summed in ascending order
+  const float* slab[2];   // [nsplit][n] each
   float* dst[2];
   size_t n;               // floats per layer (0 = no job)
   int nsplit;
-  int ascending;          // 1: ascending slab order whatever the shape (else the order ew_reduce_slabs would choose)
 };
 // can a paired launch of this shape carry `job`? (its loads must fit beside the launch's own sub-images: see wgrad9p.hip)
 bool gemm_tn_w9pair_job_ok(const GemmTN& a, int splits, const W9PJob& job);
 int gemm_tn_launch_w9pair(GemmTN a, GemmTN b, int splits, hipStream_t st, const W9PJob* job = nullptr);
-// ONE 3x3 / stride-1 weight gradient per launch on the same kernel, the batch cut into two halves that take the pair's two places (round 5):
-// half-length workgroups, a.out = [2 splits][NI][NJ] contiguous (splits = slabs per half)
-bool gemm_tn_w9half_ok(const GemmTN& a);
-int gemm_tn_w9half_splits(const GemmTN& a);
-bool gemm_tn_w9half_job_ok(const GemmTN& a, int splits, const W9PJob& job);
-int gemm_tn_launch_w9half(GemmTN a, int splits, hipStream_t st, const W9PJob* job = nullptr);
 // Wo > 0: conv weight gradient on a Wo x Wo output map (lets the nine-tap kernel, wgrad9.hip, be chosen)
 int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C_or_0, int Wo = 0, int stride = 1);
 int gemm_tn_max_splits(int Kp, int NI, int NJ, int C_or_0, int Wo, int stride);

@@ -653,14 +653,6 @@ int gemm_tn_launch_w9pair(GemmTN a, GemmTN b, int splits, hipStream_t st, const 
   return launch_wgrad9_pair(a, b, splits, st, job);
 }
 
-bool gemm_tn_w9half_ok(const GemmTN& a) { return wgrad9h_applies(a); }
-int gemm_tn_w9half_splits(const GemmTN& a) { return wgrad9h_pick_splits(a); }
-bool gemm_tn_w9half_job_ok(const GemmTN& a, int splits, const W9PJob& job) { return wgrad9h_job_ok(a, splits, job); }
-int gemm_tn_launch_w9half(GemmTN a, int splits, hipStream_t st, const W9PJob* job) {
-  FEDFR_TRY(tn_prepare(a));
-  return launch_wgrad9_halves(a, splits, st, job);
-}
-
 int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
   FEDFR_TRY(tn_prepare(p));
   int TI, TJ;

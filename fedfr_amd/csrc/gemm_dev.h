@@ -77,11 +77,6 @@ int launch_wgrad9(const GemmTN& p, int splits, hipStream_t st);
 // wgrad9p.hip: the two same-shape 3x3 / stride-1 weight gradients of a residual block in one launch, 64 x 64 x 9 taps per workgroup
 extern int g_wgrad9p;
 bool wgrad9p_applies(const GemmTN& a, const GemmTN& b);
-int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W, int rounds = 0);   // rounds 0: option "wgrad9p_rounds"
+int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W);
 bool wgrad9p_job_ok(const GemmTN& a, int splits, const W9PJob& job);
 int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job = nullptr);
-// one layer per launch, its batch cut into two halves in the places of the pair's two layers (wgrad9p.hip)
-bool wgrad9h_applies(const GemmTN& a);
-int wgrad9h_pick_splits(const GemmTN& a);
-bool wgrad9h_job_ok(const GemmTN& a, int splits, const W9PJob& job);
-int launch_wgrad9_halves(const GemmTN& a, int splits, hipStream_t st, const W9PJob* job = nullptr);

@@ -377,17 +377,11 @@ static int wgrad_flush(const Ctx& c, WgradPending* pd, hipStream_t st) {
   if (!pd || !pd->job.n) return FEDFR_OK;
   const W9PJob j = pd->job;
   pd->job.n = 0;
-  if (!j.slab[1]) return ew_reduce_slabs_ascending(j.dst[0], j.slab[0], j.nsplit, j.n, st);      // a half-K launch's single slab set
-  if (j.ascending) {
-    FEDFR_TRY(ew_reduce_slabs_ascending(j.dst[0], j.slab[0], j.nsplit, j.n, st));
-    return ew_reduce_slabs_ascending(j.dst[1], j.slab[1], j.nsplit, j.n, st);
-  }
   // two reduction launches on purpose: ONE launch for both layers (ew_reduce_slabs2) measured 16.00 vs 15.85 ms/step same-box in round 3 —
   // the main stream waits for whatever the weight-gradient stream has resident, and two short kernels release the CUs sooner than one long
   FEDFR_TRY(ew_reduce_slabs(j.dst[0], j.slab[0], j.nsplit, j.n, nullptr, 0, st));
   return ew_reduce_slabs(j.dst[1], j.slab[1], j.nsplit, j.n, nullptr, 0, st);
 }
-extern int g_wgrad9p_rounds;
 int g_wgrad_pair_reduce = 1;   // option "wgrad_pair_reduce": one slab-reduction launch for the two 3x3 weight gradients of a block
 // the two 3x3 weight gradients of a residual block; same shape (every block but a stage's first): one paired launch
 #ifdef FEDFR_DEBUG
@@ -413,7 +407,6 @@ static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const 
     W9PJob mine{};
     mine.slab[0] = a.out; mine.slab[1] = b.out; mine.dst[0] = c.grads + cva.w_off; mine.dst[1] = c.grads + cvb.w_off;
     mine.n = (size_t)a.NI * a.NJ; mine.nsplit = sp;
-    mine.ascending = g_wgrad9p_rounds > 1 ? 1 : 0;        // (more slabs than the 8-lane reducer's 32: one fixed order for the carried and the stand-alone sum)
     if (pd) {
       pd->job = mine; pd->set = set;
       return FEDFR_OK;
@@ -434,37 +427,6 @@ static int conv_wgrad2(const Ctx& c, const ConvD& cva, const bf16_t* ina, const 
   }
   FEDFR_TRY(conv_wgrad(c, cva, ina, dya, st));
   return conv_wgrad(c, cvb, inb, dyb, st);
-}
-// Round 5: ONE 3x3 weight gradient per launch, the batch cut into two halves on the paired kernel (wgrad9p.hip, wgrad9h): 256 workgroups that
-// live half as long as the pair's.  The pair's 57 us workgroups, once started beside a BatchNorm pass, kept the NEXT dgrad conv (which cannot
-// share a CU with them) waiting ~30 us per block; a half-K launch (~30 us) is released right behind the dgrad conv that consumed the same dy,
-// runs beside the BatchNorm pass(es) that follow it and is (nearly) gone when the next conv wants the CUs.  Its 2 x splits slabs are one
-// contiguous set over two slab regions; the NEXT launch on the stream sums them (single-tensor job).
-int g_wgrad_split = 1;   // option "wgrad_split": 1 = half-K launch per layer behind its dgrad conv, 2 = the same launches released IN FRONT of the conv, 0 = one paired launch per block (round 4)
-static bool wgrad_half_ok(const Ctx& c, const ConvD& cva, const bf16_t* ina, const bf16_t* dya, const ConvD& cvb, const bf16_t* inb, const bf16_t* dyb) {
-  if (!g_wgrad_split) return false;
-  const GemmTN a = wgrad_problem(c, cva, ina, dya), b = wgrad_problem(c, cvb, inb, dyb);
-  if (!gemm_tn_w9pair_ok(a, b) || !gemm_tn_w9half_ok(a) || !gemm_tn_w9half_ok(b)) return false;
-  return (size_t)2 * gemm_tn_w9half_splits(a) * a.NI * a.NJ <= 2 * c.n->slab_floats;
-}
-static int conv_wgrad_half(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf16_t* dy, hipStream_t st, WgradPending* pd) {
-#ifdef FEDFR_DEBUG
-  if (g_dbg_skip & 1) return FEDFR_OK;
-#endif
-  GemmTN a = wgrad_problem(c, cv, in, dy);
-  const int sp = gemm_tn_w9half_splits(a);
-  const size_t n = (size_t)a.NI * a.NJ;
-  FEDFR_REQUIRE((size_t)2 * sp * n <= 2 * c.n->slab_floats, "conv_wgrad_half: %d slabs of %d x %d exceed two slab regions (%zu floats each)", 2 * sp, a.NI, a.NJ,
-                c.n->slab_floats);
-  const int set = pd->set ^ 1;
-  a.out = c.slab(2 * set);                                // regions 2 set and 2 set + 1 are adjacent: one contiguous slab set
-  const bool carry = pd->job.n && gemm_tn_w9half_job_ok(a, sp, pd->job);
-  if (pd->job.n && !carry) FEDFR_TRY(wgrad_flush(c, pd, st));
-  FEDFR_TRY(gemm_tn_launch_w9half(a, sp, st, carry ? &pd->job : nullptr));
-  W9PJob mine{};
-  mine.slab[0] = a.out; mine.dst[0] = c.grads + cv.w_off; mine.n = n; mine.nsplit = 2 * sp;
-  pd->job = mine; pd->set = set;
-  return FEDFR_OK;
 }
 struct Rows { const float* ptr; int P; };     // where a BatchNorm's partial statistics rows are
 static int bn_coeffs(const Ctx& c, const BnD& b, Rows r, double count, bool training) {
@@ -916,16 +878,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     FEDFR_TRY(bn_bwd(c, k.bn3, nullptr, g, A + k.c2_off, Mo, nullptr, nullptr, 0, dc2, 0, pend));
     pend = Rows{nullptr, 0};
     int f2 = 0, f1 = 0;
-    // round 5 (option wgrad_split): one half-K weight-gradient launch per layer, released behind (1) / in front of (2) the dgrad conv that reads the same dy
-    const bool split = !k.has_ds && wgrad_half_ok(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1);
-    auto release_first = [&]() -> int {                  // the block's first fork: the fused SGD of a finished stage rides behind it
-      fk.order(st, wst);
-      if (sgd_lo >= 0 && sgd_lo < sgd_hi) FEDFR_TRY(wgrad_flush(c, &pend_w, wst));      // the fused SGD reads the finished stage's gradients
-      return sgd_flush();
-    };
-    if (split && g_wgrad_split == 2) { FEDFR_TRY(release_first()); FEDFR_TRY(conv_wgrad_half(c, k.conv2, A + k.a2_off, dc2, wst, &pend_w)); }
     FEDFR_TRY(conv_dgrad(c, k.conv2, dc2, da2, &k.bn2, A + k.c1_off, params + k.alpha_off, &f2));
-    if (split && g_wgrad_split != 2) { FEDFR_TRY(release_first()); FEDFR_TRY(conv_wgrad_half(c, k.conv2, A + k.a2_off, dc2, wst, &pend_w)); }
     // a2 = prelu(bn2(c1))
     FEDFR_TRY(bn_bwd(c, k.bn2, params + k.alpha_off, da2, A + k.c1_off, Mi, nullptr, nullptr, 0, dc1, k.alpha_off, Rows{c.part(), f2}));
     // identity path first (its BN reduction uses the shared partial buffer), then conv1's dgrad whose epilogue may
@@ -933,23 +886,19 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     if (k.has_ds) {
       FEDFR_TRY(bn_bwd(c, k.bnds, nullptr, g, A + k.d_off, Mo, nullptr, nullptr, 0, dd, 0));
     }
-    if (!split) {
-      // ONE fork per block: every event record costs the main stream a ~8 us bubble (kernel trace), so the block's two or three
-      // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
-      FEDFR_TRY(release_first());
-      FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst, &pend_w));
-      if (k.has_ds) {
-        FEDFR_TRY(wgrad_flush(c, &pend_w, wst));
-        FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, dd, wst));
-        FEDFR_TRY(conv_dgrad(c, k.ds, dd, dxd));
-      }
-      wdone[par] = fk.mark(wst);
-      FEDFR_TRY(conv_dgrad(c, k.conv1, dc1, da1, &k.bn1, A + k.x_off, nullptr, &f1));
-    } else {
-      if (g_wgrad_split == 2) { fk.order(st, wst); FEDFR_TRY(conv_wgrad_half(c, k.conv1, A + k.a1_off, dc1, wst, &pend_w)); wdone[par] = fk.mark(wst); }
-      FEDFR_TRY(conv_dgrad(c, k.conv1, dc1, da1, &k.bn1, A + k.x_off, nullptr, &f1));
-      if (g_wgrad_split != 2) { fk.order(st, wst); FEDFR_TRY(conv_wgrad_half(c, k.conv1, A + k.a1_off, dc1, wst, &pend_w)); wdone[par] = fk.mark(wst); }
+    // ONE fork per block: every event record costs the main stream a ~8 us bubble (kernel trace), so the block's two or three
+    // weight-gradient GEMMs are released together once their last operand (dc2, dc1, dd) exists
+    fk.order(st, wst);
+    if (sgd_lo >= 0 && sgd_lo < sgd_hi) FEDFR_TRY(wgrad_flush(c, &pend_w, wst));      // the fused SGD reads the finished stage's gradients
+    FEDFR_TRY(sgd_flush());
+    FEDFR_TRY(conv_wgrad2(c, k.conv2, A + k.a2_off, dc2, k.conv1, A + k.a1_off, dc1, wst, &pend_w));
+    if (k.has_ds) {
+      FEDFR_TRY(wgrad_flush(c, &pend_w, wst));
+      FEDFR_TRY(conv_wgrad(c, k.ds, A + k.x_off, dd, wst));
+      FEDFR_TRY(conv_dgrad(c, k.ds, dd, dxd));
     }
+    wdone[par] = fk.mark(wst);
+    FEDFR_TRY(conv_dgrad(c, k.conv1, dc1, da1, &k.bn1, A + k.x_off, nullptr, &f1));
     // a1 = bn1(x)
     const BlockD* prev = bi > 0 ? &n->blocks[bi - 1] : nullptr;      // its bn3 consumes gin next
     if (k.has_ds && !prev && !n->block_only && g_stem_bnred) {

@@ -18,13 +18,13 @@
 //     at its end; the 16 LDS-DMA instructions of a stage are threaded between the MFMAs of the step that follows the barrier; their
 //     source offsets are scalar arithmetic plus ONE per-lane term (see the plan below); MFMAs are hand-written with the accumulator as a
 //     tied in/out AGPR operand, and every MFMA operand is an aligned pair of 16-row groups (see the K loop).
-// 132 VGPRs + 144 AGPRs at one wave per SIMD (wgrad9: 2 x 144 of 512).  Off by default: see g_wgrad9p.
+// 132 VGPRs + 144 AGPRs at one wave per SIMD (wgrad9: 2 x 144 of 512).  On by default since round 3 (g_wgrad9p below).
 #include "gemm_tn_dev.h"
 #ifndef W9P_ABLATE
 #define W9P_ABLATE 0     // timing experiments only: 1 no in-loop DMA, 2 no in-loop fragment reads, 4 no MFMA, 16 no slab stores, 32 no slab loads by the reduction job
 #endif
 
-// option "wgrad9p".  Off by default: measured on one box, the pair runs in 66-69 us against 89 us for the two single-layer launches with
+// option "wgrad9p".  History (rounds 2-3; it was off at first): measured on one box, the pair runs in 66-69 us against 89 us for the two single-layer launches with
 // their slab reductions (s3 256x256@14, B = 128), the single-stream step drops 18.88 -> 18.11 ms, and two clients sharing the GPU gain
 // 2.7 % (8 275 -> 8 502 img/s) -- but ONE client's dual-stream step gets 0.1-0.3 ms SLOWER (17.6 -> 17.85): conv, dgrad and weight-gradient
 // workgroups never share a CU (registers), so the streams interleave at workgroup granularity, and the main stream now waits for
@@ -49,7 +49,8 @@ __device__ __forceinline__ int w9p_swz(int row) { return (((row >> 1) & 1) << 1)
 // Summation order = the stand-alone kernels' (ew.hip), so the two paths agree bit for bit (template parameter JM):
 //   1 narrow (reduce_slabs_kernel):      a = s_0; a += s_1; ... ascending slabs                       unit j of an output = slabs 4j .. 4j+3
 //   2 wide   (reduce_slabs_wide_kernel, 32 slabs): a_q = (s_q + s_(q+8)) + (s_(q+16) + s_(q+24)), result = ((a_0 + a_1) + a_2) + ...   unit q = a_q
-// Both start an output's accumulator at -0.0f (x + -0.0 == x for every x: "a = first term" without a select).
+// The narrow order starts an output's accumulator at -0.0f (x + -0.0 == x for every x, signed zeros included: "a = first term" without a select); the
+// wide order starts at +0.0f, as reduce_slabs_wide_kernel's lanes do — so both agree with their stand-alone kernels down to the sign of a zero.
 struct W9PJobDev {
   const float* slab[2];
   float* dst[2];
@@ -79,9 +80,7 @@ constexpr int ZG = 2048;                                            // one 16-ro
 constexpr int P_B = ZG + P_ROWS * 128 + ZG, Q_B = Q_ROWS * 128, STAGE_B = P_B + Q_B;
 static_assert(P_B % 1024 == 0 && STAGE_B % 1024 == 0 && (NG - 1) * 2048 < 65536 && 2 * STAGE_B <= 160 * 1024, "stage geometry");
 
-// JM: 0 no slab-reduction job; 1 / 2: narrow / wide order (W9PJobDev).  JU: units of the job per sub-image — 1 (K-step 1), or 2 (K-steps 1 and 3, each
-// with its own four load registers: the half-length workgroups of a split launch carry the same reduction in half as many sub-images)
-template <int JM, int JU = 1>
+template <int JM>   // 0: no slab-reduction job; 1 / 2: narrow / wide order (W9PJobDev)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad9p_kernel(W9P p) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef __attribute__((address_space(3))) unsigned char* lds_uc_t;
@@ -185,51 +184,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned jfirst = jbase - (jlayer ? p.job.n4 : 0u);
   const __amdgpu_buffer_rsrc_t rsJ = make_rsrc(p.job.slab[jlayer], (unsigned)p.job.nsplit * p.job.n4 * 16u);
   unsigned char* const jdst = reinterpret_cast<unsigned char*>(p.job.dst[jlayer]);
-  const f32x4_t jneg0 = {-0.f, -0.f, -0.f, -0.f};
-  f32x4_t jr[JU][4], jacc = jneg0, jt0 = jneg0, jt1 = jneg0;
-#pragma unroll
-  for (int u = 0; u < JU; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) jr[u][r] = jneg0;
-  unsigned jvoff = JM && (unsigned)tid < p.job.per ? (jfirst + (unsigned)tid) * 16u : JOOB, jcv[JU];
+  constexpr float jz = JM == 2 ? 0.f : -0.f;
+  const f32x4_t jneg0 = {jz, jz, jz, jz};
+  f32x4_t jr[4] = {jneg0, jneg0, jneg0, jneg0}, jacc = jneg0, jt0 = jneg0, jt1 = jneg0;
+  unsigned jvoff = JM && (unsigned)tid < p.job.per ? (jfirst + (unsigned)tid) * 16u : JOOB, jcv = JOOB;
   int jj = 0, jo = 0;              // unit within the output / output being requested
   unsigned jsb = 0;                // slab-group byte offset of that unit
-  bool jdone[JU];
-#pragma unroll
-  for (int u = 0; u < JU; ++u) { jcv[u] = JOOB; jdone[u] = false; }
-  // `set` (compile-time): which of the JU register sets the unit travels in; units are requested AND summed in one global order
-  // (set 0 in K-step 1, set 1 in K-step 3 of every sub-image), so the accumulator sees ascending units whatever JU is
-  auto job_load = [&](int set, int r) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
+  bool jdone = false;
+  auto job_load = [&](int r) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
     if constexpr (JM != 0) {
       const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (W9P_ABLATE & 32) ? (int)JOOB : (int)jvoff, (int)(jsb + (unsigned)r * p.job.sr), 0);
-      jr[set][r] = __builtin_bit_cast(f32x4_t, v);
+      jr[r] = __builtin_bit_cast(f32x4_t, v);
     }
   };
-  auto job_advance = [&](int set) {       // behind the four loads of a unit: remember what the unit is for, step to the next one
+  auto job_advance = [&]() {       // behind the four loads of a unit: remember what the unit is for, step to the next one
     if constexpr (JM != 0) {
-      jcv[set] = jvoff;
-      jdone[set] = jj == p.job.upo - 1;
+      jcv = jvoff;
+      jdone = jj == p.job.upo - 1;
       ++jj; jsb += p.job.sb;
-      if (jdone[set]) {
+      if (jdone) {
         jj = 0; jsb = 0; ++jo;
         jvoff = (unsigned)(jo * 256 + tid) < p.job.per ? jvoff + 4096u : JOOB;      // (an exhausted lane stays exhausted: per is not reached again)
       }
     }
   };
-  auto job_add = [&](int set, int r) {      // step r of summing the unit in jr[set]
+  auto job_add = [&](int r) {      // step r of summing the unit in jr
     if constexpr (JM == 1) {
-      jacc += jr[set][r];
+      jacc += jr[r];
     } else if constexpr (JM == 2) {
-      if (r == 0) jt0 = jr[set][0] + jr[set][1];
-      else if (r == 1) jt1 = jr[set][2] + jr[set][3];
+      if (r == 0) jt0 = jr[0] + jr[1];
+      else if (r == 1) jt1 = jr[2] + jr[3];
       else if (r == 2) jt0 = jt0 + jt1;
       else jacc += jt0;
     }
   };
-  auto job_finish = [&](int set) {        // the unit is summed: an output that is complete goes out
+  auto job_finish = [&]() {        // the unit is summed: an output that is complete goes out
     if constexpr (JM != 0) {
-      if (jdone[set]) {
-        if (jcv[set] != JOOB) *reinterpret_cast<float4*>(jdst + jcv[set]) = make_float4(jacc[0], jacc[1], jacc[2], jacc[3]);
+      if (jdone) {
+        if (jcv != JOOB) *reinterpret_cast<float4*>(jdst + jcv) = make_float4(jacc[0], jacc[1], jacc[2], jacc[3]);
         jacc = jneg0;
       }
     }
@@ -361,12 +353,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               }
               if (slot < nr) issue_read(slot);
               if (last && slot >= 2 && slot - 2 < NPW && !(W9P_ABLATE & 1)) issue_piece(slot - 2, it & 1);
-              if (JM != 0 && (kb == 1 || (JU == 2 && kb == 3))) {      // the slab-reduction job: slots K-steps 1 and 3 leave free (20 reads, no DMA)
-                const int set = (JU == 2 && kb == 3) ? 1 : 0;
-                if (slot >= 20 && slot < 24) job_add(set, slot - 20);     // sum the unit this set requested one sub-image ago ...
-                if (slot == 24) job_finish(set);
-                if (slot >= 26 && slot < 30) job_load(set, slot - 26);    // ... and request the next one
-                if (slot == 30) job_advance(set);
+              if (JM != 0 && kb == 1) {                     // the slab-reduction job: slots the second K-step leaves free (20 reads, no DMA)
+                if (slot >= 20 && slot < 24) job_add(slot - 20);          // sum the unit requested one sub-image ago ...
+                if (slot == 24) job_finish();
+                if (slot >= 26 && slot < 30) job_load(slot - 26);         // ... and request the next one
+                if (slot == 30) job_advance();
               }
               __builtin_amdgcn_sched_barrier(0);
               ++slot;
@@ -384,21 +375,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #undef W9P_READ
   w9p_wait_vmcnt<0>();
-  if constexpr (JM != 0) {                                  // the units requested during the last sub-image; then the units a short split had no sub-images for
+  if constexpr (JM != 0) {                                  // the last sub-image's unit; then the units a short split had no sub-images for
+    for (int u = nst - 1; u < p.job.units; ++u) {
+      if (u >= nst) {
 #pragma unroll
-    for (int set = 0; set < JU; ++set) {
+        for (int r = 0; r < 4; ++r) job_load(r);
+        job_advance();
+        w9p_wait_vmcnt<0>();
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) job_add(set, r);
-      job_finish(set);
-    }
-    for (int u = JU * nst; u < p.job.units; ++u) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) job_load(0, r);
-      job_advance(0);
-      w9p_wait_vmcnt<0>();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) job_add(0, r);
-      job_finish(0);
+      for (int r = 0; r < 4; ++r) job_add(r);
+      job_finish();
     }
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are read by VALU moves next (hand-written MFMAs: no automatic hazard nops)
@@ -430,44 +417,35 @@ bool wgrad9p_applies(const GemmTN& a, const GemmTN& b) {
   return g_wgrad9p && wgrad9_applies(a) && wgrad9_applies(b) && a.NI == b.NI && a.NJ == b.NJ && a.Kp == b.Kp && a.C == b.C && a.W == b.W &&
          a.NI % 64 == 0 && a.C % 64 == 0;
 }
-// 2 layers x tiles x splits ~ 256 workgroups (one per CU) x rounds, at least two sub-images per split
-int g_wgrad9p_rounds = 1;   // option "wgrad9p_rounds": 2 = twice the K-splits (512 workgroups of half the length, dispatched in two rounds): a dgrad conv of the
-                            // high-priority stream then waits for half as long a workgroup, at twice the slab traffic
-int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W, int rounds) {
+// 2 layers x tiles x splits ~ 256 workgroups (one per CU), at least two sub-images per split
+int wgrad9p_pick_splits(int Kp, int NI, int NJ, int W) {
   const int stages = (Kp / (W * W)) << (2 * w9p_lg(W));
   const int tiles = (NI / 64) * (NJ / 9 / 64);
-  int splits = 128 * (rounds > 0 ? rounds : g_wgrad9p_rounds) / tiles;
+  int splits = 128 / tiles;
   if (splits < 1) splits = 1;
   if (splits > stages / 2) splits = stages / 2 > 0 ? stages / 2 : 1;
   const int per = ceil_div(stages, splits);
   return ceil_div(stages, per);
 }
 
-// the job's geometry for a carrying launch of `grid` workgroups with `per_split` sub-images each; false = it does not fit (stand-alone reduction).
-// A job with slab[1] == dst[1] == nullptr is a SINGLE tensor (one layer's slabs, written by a half-K launch, wgrad9h below): its n / 4 outputs are
-// spread over the whole grid and always summed in ascending slab order (mode 1).  *ju = units per sub-image the kernel must run (1 or 2).
-static bool w9p_job_geometry(const W9PJob& job, int grid, int per_split, W9PJobDev* d, int* mode = nullptr, int* ju = nullptr) {
-  const bool single = !job.slab[1] && !job.dst[1];
-  if (!job.n || (job.n & 3) || job.nsplit < 1 || !job.slab[0] || !job.dst[0] || (!single && (!job.slab[1] || !job.dst[1])) || grid < 1) return false;
-  const size_t n4 = job.n / 4, total4 = single ? n4 : 2 * n4;
+// the job's geometry for a carrying launch of `grid` workgroups with `per_split` sub-images each; false = it does not fit (stand-alone reduction)
+static bool w9p_job_geometry(const W9PJob& job, int grid, int per_split, W9PJobDev* d, int* mode = nullptr) {
+  if (!job.n || (job.n & 3) || job.nsplit < 1 || !job.slab[0] || !job.slab[1] || !job.dst[0] || !job.dst[1] || grid < 1) return false;
+  const size_t n4 = job.n / 4, total4 = 2 * n4;
   if (total4 % (size_t)grid) return false;
   const size_t per = total4 / grid;
   if (n4 % per || (unsigned long long)job.nsplit * n4 * 16ull >= (1ull << 32)) return false;
-  const bool wide = !single && !job.ascending && job.nsplit >= 16 && n4 <= 65536;       // == reduce_slabs_launch's choice (ew.hip): same summation order either way
+  const bool wide = job.nsplit >= 16 && n4 <= 65536;       // == reduce_slabs_launch's choice (ew.hip): same summation order either way
   if (wide ? job.nsplit != 32 : (job.nsplit % 4) != 0) return false;
   const int nout = (int)((per + 255) / 256);
   const int upo = wide ? 8 : job.nsplit / 4;
-  const long long units = (long long)nout * upo;
-  // one unit per sub-image (K-step 1), or two (K-steps 1 and 3; narrow order only): everything rides under the MFMAs
-  const int need = units <= per_split ? 1 : ((!wide && units <= 2ll * per_split) ? 2 : 0);
-  if (!need) return false;
+  if ((long long)nout * upo > per_split) return false;     // one unit per sub-image: everything rides under the MFMAs
   if (d) {
     const unsigned s1 = (unsigned)n4 * 16u;                // one slab of one layer, in bytes
-    d->slab[0] = job.slab[0]; d->slab[1] = single ? job.slab[0] : job.slab[1]; d->dst[0] = job.dst[0]; d->dst[1] = single ? job.dst[0] : job.dst[1];
-    d->n4 = (unsigned)n4; d->per = (unsigned)per; d->nsplit = job.nsplit; d->upo = upo; d->units = (int)units;
+    d->slab[0] = job.slab[0]; d->slab[1] = job.slab[1]; d->dst[0] = job.dst[0]; d->dst[1] = job.dst[1];
+    d->n4 = (unsigned)n4; d->per = (unsigned)per; d->nsplit = job.nsplit; d->upo = upo; d->units = nout * upo;
     d->sb = wide ? s1 : 4 * s1; d->sr = wide ? 8 * s1 : s1;
     *mode = wide ? 2 : 1;
-    if (ju) *ju = need;
   }
   return true;
 }
@@ -481,38 +459,7 @@ bool wgrad9p_job_ok(const GemmTN& a, int splits, const W9PJob& job) {
   return w9p_job_geometry(job, grid, nstages / splits, nullptr);        // (the shortest split)
 }
 
-// ---- ONE layer per launch, its K range (the batch) cut into two halves that take the places of the pair's two layers (round 5): the same
-// kernel, 256 workgroups that live HALF as long (8 instead of 16 sub-images at B = 128), so that a launch fits the BatchNorm window behind
-// the dgrad conv that produced its operand (net.hip: the paired launch's 57 us workgroups kept the next conv waiting for ~30 us per block).
-// Both halves write ONE contiguous slab set [2 splits][NI][NJ]; the next launch sums it as a single-tensor job (w9p_job_geometry).
-bool wgrad9h_applies(const GemmTN& a) {
-  if (!g_wgrad9p || !wgrad9_applies(a) || a.NI % 64 || a.C % 64) return false;
-  const int images = a.Kp / (a.W * a.W);
-  return images >= 2 && images % 2 == 0 && (a.NI / 64) * (a.C / 64) >= 4;       // (64-channel layers: one tile per layer = 128 slabs per half: they keep the pair)
-}
-int wgrad9h_pick_splits(const GemmTN& a) { return wgrad9p_pick_splits(a.Kp / 2, a.NI, a.NJ, a.W, 1); }      // per half
-bool wgrad9h_job_ok(const GemmTN& a, int splits, const W9PJob& job) {
-  GemmTN h = a;
-  h.Kp = a.Kp / 2;
-  return wgrad9p_job_ok(h, splits, job);
-}
-int launch_wgrad9_pair_impl(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job, double flops);
-int launch_wgrad9_halves(const GemmTN& a, int splits, hipStream_t st, const W9PJob* job) {
-  FEDFR_REQUIRE(wgrad9h_applies(a), "wgrad9_halves: unsupported problem");
-  GemmTN h0 = a, h1 = a;
-  h0.Kp = h1.Kp = a.Kp / 2;
-  h1.P = a.P + (size_t)h0.Kp * a.ldp;
-  h1.Q = a.Q + (size_t)(h0.Kp / (a.W * a.W)) * a.H * a.W * a.C;
-  h1.out = a.out + (size_t)splits * a.NI * a.NJ;
-  h0.p_bytes = h1.p_bytes = a.p_bytes / 2;
-  h0.q_bytes = h1.q_bytes = a.q_bytes / 2;
-  return launch_wgrad9_pair_impl(h0, h1, splits, st, job, 2.0 * a.NI * a.NJ * (double)a.Kp);
-}
-
 int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job) {
-  return launch_wgrad9_pair_impl(a, b, splits, st, job, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp);
-}
-int launch_wgrad9_pair_impl(const GemmTN& a, const GemmTN& b, int splits, hipStream_t st, const W9PJob* job, double flops) {
   FEDFR_REQUIRE(wgrad9p_applies(a, b), "wgrad9_pair: unsupported problem pair");
   W9P p{};
   p.dy[0] = a.P; p.dy[1] = b.P; p.x[0] = a.Q; p.x[1] = b.Q; p.out[0] = a.out; p.out[1] = b.out;
@@ -527,20 +474,18 @@ int launch_wgrad9_pair_impl(const GemmTN& a, const GemmTN& b, int splits, hipStr
   FEDFR_REQUIRE(a.p_bytes == b.p_bytes && a.q_bytes == b.q_bytes, "wgrad9_pair: operand sizes differ");
   FEDFR_REQUIRE(a.p_bytes < (1u << 30) - (1u << 24) && a.q_bytes < (1u << 30) - (1u << 24), "wgrad9_pair: operands must be smaller than 1 GiB");
   const dim3 grid(2 * p.ntiles * splits);
-  int jm = 0, ju = 1;
+  int jm = 0;
   if (job && job->n)
-    FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job, &jm, &ju), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
-  ProfScope prof(16, flops, st);
+    FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job, &jm), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
+  ProfScope prof(16, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
   constexpr size_t lds = 2 * (size_t)STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9p_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  if (jm == 1 && ju == 2) hipLaunchKernelGGL((wgrad9p_kernel<1, 2>), grid, dim3(256), lds, st, p);
-  else if (jm == 1) hipLaunchKernelGGL(wgrad9p_kernel<1>, grid, dim3(256), lds, st, p);
+  if (jm == 1) hipLaunchKernelGGL(wgrad9p_kernel<1>, grid, dim3(256), lds, st, p);
   else if (jm == 2) hipLaunchKernelGGL(wgrad9p_kernel<2>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(wgrad9p_kernel<0>, grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("wgrad9_pair");

@@ -43,8 +43,6 @@ const char* fedfr_last_error_string(void);
  *                       64-channel conv, "conv28_tpw2" [2] two 28x28 tiles per workgroup (1 forward only), "eval_fuse" [1] eval-mode BatchNorm in the conv epilogues
  *   weight gradients    "wgrad9" [1] nine-tap kernel, "wgrad9p" [1] paired 64 x 64 nine-tap kernel, "wgrad9p_bg" [1] a paired launch sums the
  *                       PREVIOUS pair's split-K slabs beside its own work (0: stand-alone reductions), "wgrad9_wgs", "wgrad_pair_reduce" [1],
- *                       "wgrad_split" [1] one half-K launch per 3x3 layer released behind its dgrad conv (2: in front of it, 0: one paired launch per block),
- *                       "wgrad9p_rounds" [1] x K-splits of a paired launch (2: 512 workgroups of half the length),
  *                       "wgrad_depth" [4] generations of weight-gradient operands in flight, "fc_wgrad_aux" [1]
  *   BatchNorm forward   "bn_sliced" [1] channel-sliced passes without finalize launches, "fwd_xmom" [1] bn3 + identity + the next block's bn1 as one
  *                       pass from conv2's raw moments

@@ -758,7 +758,7 @@ def test_roc_vs_reference():
 
 
 def test_paired_weight_gradient_kernel_in_the_network():
-    """option wgrad9p (what Server.train selects for concurrent clients): every block's two same-shape 3x3 weight gradients from the paired
+    """option wgrad9p (default since round 3): every block's two same-shape 3x3 weight gradients from the paired
     64 x 64 nine-tap kernel — same operands, same K order per split, so the network's gradients agree with the single-layer kernel's to fp32
     summation-order level (activations and activation gradients do not depend on the choice at all: bit-identical embeddings)."""
     outs = []
@@ -962,16 +962,6 @@ def test_full_size_step_invariants_r100_b128(monkeypatch, arch):
     # stand-alone reduction kernels' own summation order: with the launches put back (wgrad9p_bg = 0) every gradient bit is the same
     l3, g3, f3 = run(wgrad9p_bg=0)
     assert l3 == l0 and torch.equal(g3, g0) and torch.equal(f3, f0)
-    # (2c) round 5: one half-K weight-gradient launch per 3x3 layer, released behind its dgrad conv (option wgrad_split, default), against the
-    # round-4 selection (one paired launch per block) and against the release in front of the conv: the same sums in another order / the same bits
-    l4, g4, f4 = run(wgrad_split=0)
-    assert abs(l4 - l0) <= 1e-6 * abs(l0) and torch.equal(f4, f0)
-    assert float((g4 - g0).norm()) <= 1e-4 * float(g0.norm()), float((g4 - g0).norm() / g0.norm())
-    assert not torch.equal(g4, g0)                       # (the half-K launches really ran in the default pass)
-    l5, g5, f5 = run(wgrad_split=2)
-    assert l5 == l0 and torch.equal(g5, g0) and torch.equal(f5, f0)
-    l6, g6, f6 = run(wgrad_split=0, wgrad9p_bg=0)
-    assert l6 == l4 and torch.equal(g6, g4)
     # (3)
     nbt = [v for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")]
     assert len(nbt) == {"iresnet100": 154, "iresnet50": 79}[arch] and len({int(v) for v in nbt}) == 1

@@ -322,32 +322,6 @@ def test_conv_wgrad9_pair(B, H, C):
     assert relerr(res[1][0], res[0][0]) < 1e-5 and relerr(res[1][1], res[0][1]) < 1e-5
 
 
-@pytest.mark.parametrize("B,H,C", [(128, 14, 256), (32, 28, 128), (6, 14, 256), (2, 14, 128), (10, 28, 256), (4, 56, 128)])
-def test_conv_wgrad_half_k_launch(B, H, C):
-    """Round 5 (option wgrad_split): ONE 3x3 / stride-1 weight gradient per launch on the paired nine-tap kernel, the batch cut into two halves that
-    take the places of the pair's two layers (csrc/wgrad9p.hip, wgrad9h): == autograd of F.conv2d on the same 16-bit operands, == the previous
-    selection (wgrad_split = 0) up to fp32 summation order; the two halves' slab sets are summed as ONE ascending reduction.  Batch 128 / 32 are
-    the step's own geometries (8 sub-images per workgroup), the small batches the ragged ones (splits capped at half the sub-images)."""
-    x = bf(rnd((B, C, H, H), 5)).float()
-    dy = bf(rnd((B, C, H, H), 6)).float()
-    w = torch.zeros(C, C, 3, 3, requires_grad=True)
-    F.conv2d(x, w, None, 1, 1).backward(dy)
-    ref = w.grad.permute(0, 2, 3, 1)
-    xd, dyd = bf(nhwc(x)).to(dev()), bf(nhwc(dy)).to(dev())
-    nbytes = _C.lib().fedfr_conv2d_wgrad_ws_bytes(B, H, C, C, 3, 1)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev())
-    res = {}
-    for split in (1, 0):
-        dw = torch.full((C, 3, 3, C), float("nan"), device=dev())
-        with _C.option_scope("wgrad_split", split):
-            _C.call("fedfr_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, B, H, C, C, 3, 1, _C.stream())
-            torch.cuda.synchronize()
-        assert relerr(dw, ref) < 2e-4, (split, relerr(dw, ref))
-        res[split] = dw.cpu()
-    assert relerr(res[1], res[0]) < 1e-5
-    assert not torch.equal(res[1], res[0]) or B <= 2          # (it really was another summation order: the half-K launch ran)
-
-
 @pytest.mark.parametrize("M,N,K", [(128, 512, 25088), (32, 512, 1024), (4, 512, 25088), (200, 1000, 512), (128, 64, 192)])
 def test_gemm_nt_plain(M, N, K):
     a, b = bf(rnd((M, K), 1)), bf(rnd((N, K), 2, 0.05))

@@ -92,6 +92,25 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// ---- 16-byte global store of an OUTPUT tile that writes through the L2 (sc0 sc1): the kernel boundary then finds no dirty lines to write back
+// before the dependent launch behind it may start (tools/probe/launch_tail_probe.hip: 12.8 MB stored per launch -> 18.9 vs 18.1 us per
+// dependent launch).  Used by the 3x3 LDS-DMA convs' epilogue (FEDFR_STORE_WT = 1; step -0.04 / -0.08 ms same-box on two boxes); the BatchNorm
+// passes LOSE with it (+0.22 ms: profiles/r05_ab_store_wt_conv_and_bn_v2.txt) and keep plain stores.
+// The s_nop 1: on gfx940+ a VMEM store of more than 64 bits needs TWO wait states before a VALU write of its data registers, and the compiler's
+// hazard pass does not look inside inline asm (without any the two-tile 28x28 dgrad stored garbage; with one wait state a BatchNorm pass did).
+#ifndef FEDFR_STORE_WT
+#define FEDFR_STORE_WT 1
+#endif
+__device__ __forceinline__ void st16_out(void* dst, const uint4& v) {
+#if FEDFR_STORE_WT
+  typedef __attribute__((ext_vector_type(4))) unsigned st16_u4_t;
+  const st16_u4_t vv = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+#else
+  *reinterpret_cast<uint4*>(dst) = v;
+#endif
+}
+
 // ---- wave / block reductions (64-lane wavefront) -----------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

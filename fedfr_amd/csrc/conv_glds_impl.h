@@ -61,6 +61,7 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
+__device__ __forceinline__ void glds_store_out(bf16_t* dst, const uint4& v) { st16_out(dst, v); }
 template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1>   // TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           *reinterpret_cast<uint4*>(p.Cb2 + go) = pack8(y2);
         }
       }
-      *reinterpret_cast<uint4*>(p.Cb + go) = v;
+      glds_store_out(p.Cb + go, v);
     }
   } else {
     // ---- fused BN-backward reduction (ew_bn_bwd_reduce on this tile): thread owns chunk column c (8 channels) of rows rg, rg + RG, ...;
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         const int row = rg + i * RG;
         if (row < PT) {
           const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-          if (!papply) *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+          if (!papply) glds_store_out(p.Cb + (size_t)(m0 + row) * p.ldc + n, dv);
           if (GLDS_FUSED_ABLATE & 2) continue;
           float dy[8], xv[8], dzv[8];
           unpack8(dv, dy);
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
             s1[q] += dz;
             s2[q] += dz * xv[q];
           }
-          if (papply) *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = pack8(dzv);   // ... and the OUTPUT is the masked gradient
+          if (papply) glds_store_out(p.Cb + (size_t)(m0 + row) * p.ldc + n, pack8(dzv));   // ... and the OUTPUT is the masked gradient
         }
       }
     } else if (p.bmom) {                                   // forward: raw moments (sum y, sum y x, sum y y)
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         const int row = rg + i * RG;
         if (row < PT) {
           const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-          *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+          glds_store_out(p.Cb + (size_t)(m0 + row) * p.ldc + n, dv);
           float dy[8], xv[8];
           unpack8(dv, dy);
           unpack8(xr[i], xv);
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         const int row = rg + i * RG;
         if (row < PT) {
           const uint4 dv = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
-          *reinterpret_cast<uint4*>(p.Cb + (size_t)(m0 + row) * p.ldc + n) = dv;
+          glds_store_out(p.Cb + (size_t)(m0 + row) * p.ldc + n, dv);
           if (GLDS_FUSED_ABLATE & 2) continue;
           float dy[8], xv[8];
           unpack8(dv, dy);

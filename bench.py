@@ -556,6 +556,22 @@ def main():
                 ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
                 _C.call("fedfr_profile_read", slot, C.byref(ms), C.byref(n), C.byref(fl))
                 return ms.value, n.value, fl.value
+
+            def read_bytes(slot):
+                b = C.c_double()
+                _C.call("fedfr_profile_read_bytes", slot, C.byref(b))
+                return b.value
+
+            def family(m_, k, f, s_):
+                """one MFMA kernel family of the step, with the roofline that bounds its launches: time at the dense MFMA peak vs time to move its
+                ALGORITHMIC bytes (operands read once, output written once) at the HBM peak"""
+                by = read_bytes(s_)
+                t_mfma, t_hbm = f / (BF16_DENSE_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBPS * 1e9)
+                e = {"kernel": SLOT_NAMES[s_], "ms_per_step": round(m_ / psteps, 3), "launches_per_step": k // psteps, "tflops": round(f / (m_ * 1e-3) / 1e12, 1),
+                     "algorithmic_gb_per_step": round(by / psteps / 1e9, 3), "gbps": round(by / (m_ * 1e-3) / 1e9, 1),
+                     "bound": "hbm" if t_hbm > t_mfma else "mfma"}
+                e["frac_of_bound"] = round((t_hbm if t_hbm > t_mfma else t_mfma) / (m_ * 1e-3), 4)
+                return e
             rows = []
             for slot in range(len(SLOT_NAMES)):
                 ms, n, fl = read(slot)
@@ -591,8 +607,7 @@ def main():
                 if len(rows) > 1:                      # the two 3x3 kernels (forward/dgrad and weight gradient) tie for the largest time share
                     roofline["second"] = entry(*rows[1])
                 roofline["sq_counters"] = sq
-                roofline["all_gemm_kernels"] = [{"kernel": SLOT_NAMES[s_], "ms_per_step": round(m_ / psteps, 3), "launches_per_step": k // psteps,
-                                                 "tflops": round(f / (m_ * 1e-3) / 1e12, 1)} for m_, k, f, s_ in rows]
+                roofline["all_gemm_kernels"] = [family(m_, k, f, s_) for m_, k, f, s_ in rows]
                 # the HBM-bound third of the step: BatchNorm forward / backward streaming passes (algorithmic bytes = tensors read + written once)
                 fam = [hbm_rows[k] for k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply") if hbm_rows[k][1]]
                 if fam:

@@ -31,6 +31,7 @@ SIGNATURES = {
     "fedfr_option_info": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(i32)]),
     "fedfr_profile_enable": (i32, [i32]),
     "fedfr_profile_read": (i32, [i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
+    "fedfr_profile_read_bytes": (i32, [i32, C.POINTER(f64)]),
     "fedfr_net_create": (vp, [C.POINTER(i32), i32, i32, i32]),
     "fedfr_block_create": (vp, [i32, i32, i32, i32, i32]),
     "fedfr_net_create_sphere": (vp, [i32, i32]),

@@ -166,6 +166,10 @@ int fedfr_profile_enable(int on) {
   gemm_profile_enable(on);
   return FEDFR_OK;
 }
+int fedfr_profile_read_bytes(int slot, double* bytes) {
+  FEDFR_REQUIRE(bytes && gemm_profile_read_bytes(slot, bytes) == 0, "profile_read_bytes: bad slot %d", slot);
+  return FEDFR_OK;
+}
 int fedfr_profile_read(int slot, double* total_ms, long long* launches, double* flops) {
   FEDFR_REQUIRE(total_ms && launches && flops, "profile_read: null");
   const int rc = gemm_profile_read(slot, total_ms, launches, flops);

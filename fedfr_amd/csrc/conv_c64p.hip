@@ -338,7 +338,7 @@ int launch_c64p(GemmNT p, hipStream_t st) {
     FEDFR_REQUIRE(p.bx && p.bmean && p.brstd && (BWD == 1 || (p.bgamma && p.bbeta && p.balpha)), "conv3x3_c64p: the fused BatchNorm-backward reduction needs bx / mean / rstd (and gamma / beta / alpha with PReLU)");
     if (p.bwd_fused) *p.bwd_fused = grid;                  // one partial row [3][64] per workgroup
   }
-  ProfScope prof(15, 2.0 * p.M * p.N * (double)p.K, st);           // slot 15: the 64-channel 3x3 layers (56x56, 112x112)
+  ProfScope prof(15, 2.0 * p.M * p.N * (double)p.K, st, gemm_nt_alg_bytes(p, 1));           // slot 15: the 64-channel 3x3 layers (56x56, 112x112)
   hipLaunchKernelGGL((conv3x3_c64p_kernel<W_, R_, STATS, BWD>), dim3(grid), dim3(256), lds, st, p, ntiles, per_wg, stat_rows);
   FEDFR_LAUNCH_CHECK("conv3x3_c64p");
   return FEDFR_OK;

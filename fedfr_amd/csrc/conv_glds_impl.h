@@ -740,7 +740,7 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   attr_once.run([&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15),   /* slot 15: 56x56 and 112x112 */ 2.0 * p.M * p.N * (double)p.K, st);
+  ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15),   /* slot 15: 56x56 and 112x112 */ 2.0 * p.M * p.N * (double)p.K, st, gemm_nt_alg_bytes(p, 1));
   hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;

@@ -104,3 +104,4 @@ void gemm_tn_tiles(int NI, int NJ, int C_or_0, int* TI, int* TJ);
 // optional HIP-event timing of every NT/TN launch (slots: see gemm.hip)
 void gemm_profile_enable(int on);
 int gemm_profile_read(int slot, double* total_ms, long long* launches, double* flops);
+int gemm_profile_read_bytes(int slot, double* bytes);      // algorithmic HBM bytes of the same launches

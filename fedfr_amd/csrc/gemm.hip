@@ -17,7 +17,7 @@
 namespace {
 struct ProfSlot {
   std::vector<hipEvent_t> ev;   // start/stop pairs
-  double flops = 0.0;
+  double flops = 0.0, bytes = 0.0;
   long long launches = 0;
 };
 bool g_prof_on = false;
@@ -25,7 +25,7 @@ ProfSlot g_prof[32];   // 0..17: MFMA GEMM kernels (slot = flops); 20..27: HBM-b
 inline int prof_slot(bool tn, int a, int b) { return (tn ? 4 : 0) + (a == 128 ? 0 : 2) + (b == 128 ? 0 : 1); }
 }  // namespace
 
-ProfScope::ProfScope(int slot, double flops, hipStream_t st) : st_(st) {
+ProfScope::ProfScope(int slot, double flops, hipStream_t st, double bytes) : st_(st) {
   if (!g_prof_on) return;
   ProfSlot* s = &g_prof[slot];
   hipEvent_t a, b;
@@ -33,6 +33,7 @@ ProfScope::ProfScope(int slot, double flops, hipStream_t st) : st_(st) {
   s->ev.push_back(a);
   s->ev.push_back(b);
   s->flops += flops;
+  s->bytes += bytes;
   s->launches += 1;
   (void)hipEventRecord(a, st);
   slot_ = s;
@@ -45,7 +46,7 @@ void gemm_profile_enable(int on) {
   for (auto& s : g_prof) {
     for (auto e : s.ev) (void)hipEventDestroy(e);
     s.ev.clear();
-    s.flops = 0.0;
+    s.flops = s.bytes = 0.0;
     s.launches = 0;
   }
   g_prof_on = on != 0;
@@ -67,6 +68,26 @@ int gemm_profile_read(int slot, double* total_ms, long long* launches, double* f
 }
 
 
+
+int gemm_profile_read_bytes(int slot, double* bytes) {
+  if (slot < 0 || slot >= 32 || !bytes) return -1;
+  *bytes = g_prof[slot].bytes;
+  return 0;
+}
+// algorithmic HBM bytes of an NT / TN launch: every operand read once, the output written once (16-bit activations, fp32 slabs)
+static double nt_alg_bytes(const GemmNT& p, int splits) {
+  const double images = p.mode == 1 ? (double)ceil_div(p.M, p.Ho * p.Wo) : 0.0;
+  const double a = p.mode == 1 ? 2.0 * images * p.H * p.W * p.C : 2.0 * (double)p.M * p.K;
+  (void)splits;                                          // (split-K slabs are overhead, not algorithmic: the output counts once)
+  const double out = p.Cb ? 2.0 * (double)p.M * p.N * (p.par_on == 2 ? 4.0 : 1.0) : 4.0 * (double)p.M * p.N;
+  return a + 2.0 * (double)p.N * p.K + out;
+}
+double gemm_nt_alg_bytes(const GemmNT& p, int splits) { return nt_alg_bytes(p, splits); }
+double gemm_tn_alg_bytes(const GemmTN& p, int splits) {
+  const double q = p.mode == 1 ? 2.0 * (double)ceil_div(p.Kp, p.Ho * p.Wo) * p.H * p.W * p.C : 2.0 * (double)p.Kp * p.NJ;
+  (void)splits;
+  return 2.0 * (double)p.Kp * p.NI + q + 4.0 * (double)p.NI * p.NJ;
+}
 
 // =====================================================================================================
 // NT kernel
@@ -260,7 +281,8 @@ static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   dim3 grid(nbm * p.nbn, splits, p.par_on == 2 ? 4 : 1);
-  ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (p.par_on == 2 ? 64.0 * 9 * p.cpt : p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st);
+  ProfScope prof(prof_slot(false, BM, BN), 2.0 * p.M * p.N * (p.par_on == 2 ? 64.0 * 9 * p.cpt : p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st,
+                 nt_alg_bytes(p, splits));
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_nt");
   return FEDFR_OK;
@@ -615,7 +637,7 @@ static int launch_tn(GemmTN p, int splits, hipStream_t st) {
   });
   p.ntiles = nbi * p.nbj;
   dim3 grid(p.ntiles * splits, 1, 1);
-  ProfScope prof(prof_slot(true, TI, TJ), 2.0 * p.NI * p.NJ * (double)p.Kp, st);
+  ProfScope prof(prof_slot(true, TI, TJ), 2.0 * p.NI * p.NJ * (double)p.Kp, st, gemm_tn_alg_bytes(p, splits));
   hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, USE_TR>), grid, dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_tn");
   return FEDFR_OK;

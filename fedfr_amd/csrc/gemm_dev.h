@@ -41,9 +41,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 struct ProfScope {
   void* slot_ = nullptr;
   hipStream_t st_;
-  ProfScope(int slot, double flops, hipStream_t st);
+  ProfScope(int slot, double flops, hipStream_t st, double bytes = 0.0);   // bytes: ALGORITHMIC HBM bytes of the launch (operands read once, output written once)
   ~ProfScope();
 };
+double gemm_nt_alg_bytes(const GemmNT& p, int splits);      // algorithmic HBM bytes of a launch (gemm.hip)
+double gemm_tn_alg_bytes(const GemmTN& p, int splits);
 extern int g_nt_nbuf, g_tn_target_blocks, g_tn_glds;
 int launch_conv_glds8_w14(GemmNT p, hipStream_t st);       // conv_glds8_w14.hip  same, 8 waves per tile
 int launch_conv_glds8_w28(GemmNT p, hipStream_t st);       // conv_glds8_w28.hip

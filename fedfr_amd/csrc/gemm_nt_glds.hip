@@ -221,7 +221,7 @@ int launch_impl2(GemmNT p, int splits, int slot, hipStream_t st) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_glds_kernel<BM, BN, WM, WN, NS, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   const dim3 grid(nbm * p.nbn, splits, p.par_on == 2 ? 4 : 1);
-  ProfScope prof(slot, 2.0 * p.M * p.N * (p.par_on == 2 ? 64.0 * 9 * p.cpt : p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st);
+  ProfScope prof(slot, 2.0 * p.M * p.N * (p.par_on == 2 ? 64.0 * 9 * p.cpt : p.par_on ? 64.0 * p.ksteps_total : (double)p.K), st, gemm_nt_alg_bytes(p, splits));
   hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BN, WM, WN, NS, CONV>), grid, dim3(64 * WM * WN), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_nt_glds");
   return FEDFR_OK;

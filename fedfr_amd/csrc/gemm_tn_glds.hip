@@ -239,7 +239,7 @@ int launch_tn_glds(GemmTN p, int splits, hipStream_t st) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  ProfScope prof(14, 2.0 * p.NI * p.NJ * (double)p.Kp, st);
+  ProfScope prof(14, 2.0 * p.NI * p.NJ * (double)p.Kp, st, gemm_tn_alg_bytes(p, splits));
   if (g_tn_glds >= 2) hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 4>), dim3(p.ntiles * splits), dim3(512), lds, st, p);
   else hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 2>), dim3(p.ntiles * splits), dim3(256), lds, st, p);
   FEDFR_LAUNCH_CHECK("gemm_tn_glds");

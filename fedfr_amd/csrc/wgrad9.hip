@@ -266,7 +266,7 @@ int launch_wgrad9(const GemmTN& g, int splits, hipStream_t st) {
   FEDFR_REQUIRE(splits >= 1 && ceil_div(p.nstages, p.per_split) == splits, "wgrad9: splits=%d leaves an empty split", splits);
   p.dy_bytes = g.p_bytes; p.x_bytes = g.q_bytes;
   const dim3 grid(p.ntiles * splits);
-  ProfScope prof(16, 2.0 * g.NI * g.NJ * (double)g.Kp, st);
+  ProfScope prof(16, 2.0 * g.NI * g.NJ * (double)g.Kp, st, gemm_tn_alg_bytes(g, 1));      // (the split-K slabs are overhead, not algorithmic)
   constexpr size_t lds14 = w9_lds<14, 14, 4>();
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {

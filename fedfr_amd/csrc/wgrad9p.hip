@@ -477,7 +477,7 @@ int launch_wgrad9_pair(const GemmTN& a, const GemmTN& b, int splits, hipStream_t
   int jm = 0;
   if (job && job->n)
     FEDFR_REQUIRE(w9p_job_geometry(*job, (int)grid.x, p.nstages / splits, &p.job, &jm), "wgrad9_pair: the slab-reduction job does not fit this launch (check gemm_tn_w9pair_job_ok)");
-  ProfScope prof(16, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st);
+  ProfScope prof(16, 2.0 * 2.0 * a.NI * a.NJ * (double)a.Kp, st, gemm_tn_alg_bytes(a, 1) + gemm_tn_alg_bytes(b, 1));      // (the split-K slabs are overhead, not algorithmic)
   constexpr size_t lds = 2 * (size_t)STAGE_B;
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {

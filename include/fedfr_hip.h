@@ -67,6 +67,9 @@ int fedfr_option_info(int index, const char** name, int* value, int* default_val
  * enable(1) resets the counters; read() requires the stream to be synchronised; flops = sum of 2*M*N*K. */
 int fedfr_profile_enable(int on);
 int fedfr_profile_read(int slot, double* total_ms, long long* launches, double* flops);
+/* the ALGORITHMIC HBM bytes of the same launches (slots 0..17: every operand read once, the output written once; split-K slabs and halo re-reads are
+ * not algorithmic): lets a measurement say which roofline bounds a kernel family (bench.py `all_gemm_kernels[].bound`) */
+int fedfr_profile_read_bytes(int slot, double* bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * iresnet plan — replaces IResNet.__init__/_make_layer/forward (backbones/iresnet.py:60-172) and,

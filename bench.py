@@ -565,7 +565,7 @@ def main():
             def family(m_, k, f, s_):
                 """one MFMA kernel family of the step, with the roofline that bounds its launches: time at the dense MFMA peak vs time to move its
                 ALGORITHMIC bytes (operands read once, output written once) at the HBM peak"""
-                by = read_bytes(s_)
+                by = alg_bytes[s_]
                 t_mfma, t_hbm = f / (BF16_DENSE_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBPS * 1e9)
                 e = {"kernel": SLOT_NAMES[s_], "ms_per_step": round(m_ / psteps, 3), "launches_per_step": k // psteps, "tflops": round(f / (m_ * 1e-3) / 1e12, 1),
                      "algorithmic_gb_per_step": round(by / psteps / 1e9, 3), "gbps": round(by / (m_ * 1e-3) / 1e9, 1),
@@ -578,6 +578,7 @@ def main():
                 if n:
                     rows.append((ms, n, fl, slot))
             hbm_rows = {name: read(slot) for slot, name in HBM_SLOTS.items()}
+            alg_bytes = {slot: read_bytes(slot) for _, _, _, slot in rows}      # (before the counters are reset)
             _C.call("fedfr_profile_enable", 0)
             rows.sort(reverse=True)
             traffic = pmc_traffic()

@@ -77,14 +77,15 @@ int gemm_profile_read_bytes(int slot, double* bytes) {
 // algorithmic HBM bytes of an NT / TN launch: every operand read once, the output written once (16-bit activations, fp32 slabs)
 static double nt_alg_bytes(const GemmNT& p, int splits) {
   const double images = p.mode == 1 ? (double)ceil_div(p.M, p.Ho * p.Wo) : 0.0;
-  const double a = p.mode == 1 ? 2.0 * images * p.H * p.W * p.C : 2.0 * (double)p.M * p.K;
+  // (a 1x1 / stride-2 conv touches only the pixels it keeps)
+  const double a = p.mode == 1 ? 2.0 * images * (p.S == 1 && p.up == 1 ? (double)p.Ho * p.Wo : (double)p.H * p.W) * p.C : 2.0 * (double)p.M * p.K;
   (void)splits;                                          // (split-K slabs are overhead, not algorithmic: the output counts once)
   const double out = p.Cb ? 2.0 * (double)p.M * p.N * (p.par_on == 2 ? 4.0 : 1.0) : 4.0 * (double)p.M * p.N;
   return a + 2.0 * (double)p.N * p.K + out;
 }
 double gemm_nt_alg_bytes(const GemmNT& p, int splits) { return nt_alg_bytes(p, splits); }
 double gemm_tn_alg_bytes(const GemmTN& p, int splits) {
-  const double q = p.mode == 1 ? 2.0 * (double)ceil_div(p.Kp, p.Ho * p.Wo) * p.H * p.W * p.C : 2.0 * (double)p.Kp * p.NJ;
+  const double q = p.mode == 1 ? 2.0 * (double)ceil_div(p.Kp, p.Ho * p.Wo) * (p.S == 1 ? (double)p.Ho * p.Wo : (double)p.H * p.W) * p.C : 2.0 * (double)p.Kp * p.NJ;
   (void)splits;
   return 2.0 * (double)p.Kp * p.NI + q + 4.0 * (double)p.NI * p.NJ;
 }

@@ -527,7 +527,6 @@ def main():
             tr.step(imgs[i % nbuf], labs[i % nbuf])
             host_ms.append((time.perf_counter() - th) * 1e3)
         torch.cuda.synchronize()
-    model.check_handoffs()                       # (the stream is idle here: raises if an in-launch hand-off of the timed steps timed out)
 
     # ---- roofline leg: HIP-event timing of every MFMA GEMM launch and of the HBM-bound BatchNorm / SGD kernels, in a separate short
     # pass over the same workload
@@ -696,8 +695,6 @@ def main():
             with torch.cuda.stream(st2):
                 tr2 = client.FusedTrainer(model2, fc2, "CosFace", 30.0, 0.4, lr=1e-3, momentum=0.9, weight_decay=5e-4, aux_slot=1)
             pairs = [(tr, torch.cuda.current_stream()), (tr2, st2)]
-            w9p_prev = _C.get_option("bn_fuse_bwd")
-            _C.call("fedfr_set_option", b"bn_fuse_bwd", 0)      # what Server.train selects when clients share the GPU: no in-launch hand-offs
             csteps = max(5, min(args.steps, 20))
             bar = threading.Barrier(3)
 
@@ -740,9 +737,6 @@ def main():
         except Exception as e:      # an auxiliary leg must never cost the headline number
             leg_errors['concurrent'] = "%s: %s" % (type(e).__name__, e)
             print("bench.py: the concurrent leg failed: %r" % (e,), file=sys.stderr, flush=True)
-        finally:
-            if "w9p_prev" in locals():
-                _C.call("fedfr_set_option", b"bn_fuse_bwd", w9p_prev)
 
     # ---- the second half of BASELINE's metric at N = 1: server-side FedAvg of 1 / 2 / 4 / 8 client states (server.py:25-34) on this GPU
     fedavg = None

@@ -38,7 +38,6 @@ SIGNATURES = {
     "fedfr_net_debug_capture": (i32, [vp, sz]),
     "fedfr_net_set_dropout": (i32, [vp, f32, u64, C.POINTER(i64)]),
     "fedfr_net_set_dropout_step": (i32, [vp, u64]),
-    "fedfr_net_handoff_errors": (i32, [vp, vp, vp, C.POINTER(C.c_uint)]),
     "fedfr_net_destroy": (None, [vp]),
     "fedfr_net_query": (i32, [vp, i32, C.POINTER(i64)]),
     "fedfr_net_tensor_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64),

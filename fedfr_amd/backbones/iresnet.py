@@ -108,13 +108,6 @@ class _Plan:
         _C.call("fedfr_net_query", self.handle, what, C.byref(q))
         return q.value
 
-    def handoff_errors(self) -> int:
-        """Error word of the kernels that hand data between their workgroups inside a launch (fedfr_net_handoff_errors): non-zero = a
-        grid was not co-resident and a step's results are wrong.  Synchronises the current stream."""
-        e = C.c_uint(0)
-        _C.call("fedfr_net_handoff_errors", self.handle, self.ws.data_ptr(), _C.stream(), C.byref(e))
-        return e.value
-
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -324,7 +317,6 @@ class IResNet(nn.Module):
         self._grads_live = False
         self._fwd_generation = 0
         self._bn_frozen = False                 # freeze_BN(test_mode=True): BatchNorms in eval mode inside a training net
-        self._handoff_armed = False             # a pass ran with in-launch hand-offs (option bn_fuse_bwd): check_handoffs() has something to read
         # True: forward / backward run the fp32 VALIDATION path (csrc/net_f32.hip: fp32 activations, exact-fp32 GEMMs, fp64 statistics;
         # ~50x slower) — same parameters, buffers and gradients; what the "1e-3 fp32" tolerance of the parity tests is checked with
         self.validation_fp32 = False
@@ -536,8 +528,6 @@ class IResNet(nn.Module):
     def _pre_forward(self, plan, mode: int):
         """Before every fedfr_net_forward on ``plan``: hand the model's dropout seed / mask index to the C-side plan, so that the mask
         sequence survives plan re-creation and differs between models (the plan's own counter restarts at 0 with every new plan)."""
-        if mode and not self._handoff_armed and _C.get_option("bn_fuse_bwd") != 0:
-            self._handoff_armed = True              # a pass with in-launch hand-offs is about to run: check_handoffs() has something to read
         if mode and self.dropout_p > 0:
             if plan.dropout_seed != self.dropout_seed:
                 off = C.c_longlong()
@@ -703,18 +693,6 @@ class IResNet(nn.Module):
 
     def trainable_count(self) -> int:
         return self._counts[_C.Q_TRAINABLE_COUNT]
-
-    def check_handoffs(self) -> None:
-        """Raise if a kernel with an in-launch hand-off (option bn_fuse_bwd) gave up waiting for
-        the rest of its grid in any pass so far — possible only while several kernel chains share the GPU, which is why ``Server.train``
-        switches those options off for concurrent clients.  Synchronises the stream: call it where the host waits anyway.  With the option
-        off (the default) no plan has ever armed a hand-off: nothing is synchronised or copied."""
-        if not self._handoff_armed:
-            return
-        for plan in self._plans.values():
-            if plan.handoff_errors():
-                raise RuntimeError("fedfr_amd: an in-launch hand-off timed out (a kernel's grid was not co-resident): the results of this "
-                                   "model's last passes are wrong.  Set FEDFR_OPTIONS=bn_fuse_bwd=0 when other work shares the GPU.")
 
 
 def _iresnet(arch, block, layers, pretrained, progress, **kwargs):

@@ -68,7 +68,6 @@ class sphere(IResNet):
         self.dropout_p = 0.0
         self.dropout_seed = 100
         self._dropout_step = 0
-        self._handoff_armed = False
         counts, table = _ir._tensor_table(self.layers_cfg, self.in_hw, 512, sphere_type=self.sphere_type)
         self._counts, self._table = counts, table
         self._flat_state = torch.zeros(self._state_len(counts), dtype=torch.float32)

@@ -864,7 +864,6 @@ class Client(object):
         for l in pending:
             loss_meter.update(l.item(), 1)
         trainer.finish()
-        backbone.check_handoffs()              # once per local epoch set, where the host has just synchronised for the loss anyway
         self.loss_meter = loss_meter
         self.backbone_state_dict = flat_state_dict(backbone)
         self.fc_module.cpu()
@@ -1008,7 +1007,6 @@ class Client(object):
                     drain()
         drain()
         trainer.finish()
-        backbone.check_handoffs()
         self.cos_meter, self.con_meter, self.bce_meter = cos_meter, con_meter, bce_meter
         self.loss_meter = loss_meter
         self.backbone_state_dict = flat_state_dict(backbone)

@@ -28,7 +28,6 @@ extern int g_eval_fuse;
 extern int g_wgrad_depth;
 extern int g_dgrad_parity;
 extern int g_fuse_bnred_next;
-extern int g_bn_fuse_bwd;
 extern int g_event_nofence;
 extern int g_sph_fin_multi;
 extern int g_sph_fuse_prelu_bwd;
@@ -91,7 +90,6 @@ const OptRow kOptions[] = {
     {"wgrad9p", &g_wgrad9p, 0, 0, 1},                      // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
     {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes, 1, 7, 64},
     {"bn_sliced_pre", &g_bn_sliced_pre, 2, 0, 0},          // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)
-    {"bn_fuse_bwd", &g_bn_fuse_bwd, 0, 0, 1},              // reduce + apply pass of a BatchNorm backward in one launch with an in-launch hand-off (bn_sliced.hip)
     {"event_nofence", &g_event_nofence, 0, 0, 1},          // takes effect for events created afterwards (a plan creates its fork / join events on first use)
     {"fuse_bnbwd28", &g_fuse_bnbwd28, 0, 0, 1},
     {"fc_wgrad_aux", &g_fc_wgrad_aux, 0, 0, 1},
@@ -208,20 +206,6 @@ int fedfr_net_set_dropout(fedfr_net_t* n, float p, unsigned long long seed, long
 int fedfr_net_set_dropout_step(fedfr_net_t* n, unsigned long long step) {
   FEDFR_REQUIRE(n && !n->block_only, "net_set_dropout_step: need a network plan");
   n->dropout_step = step;
-  return FEDFR_OK;
-}
-// the error word of the in-launch hand-offs (option bn_fuse_bwd: reduce + apply pass of a BatchNorm backward in one launch): non-zero = a workgroup gave up
-// waiting for the rest of its grid (the grid was not co-resident: several kernel chains shared the GPU) and the step's results are WRONG.
-// Synchronises `stream`; callers ask where they synchronise anyway (end of an epoch, FusedTrainer.finish()).
-int fedfr_net_handoff_errors(const fedfr_net_t* n, const void* ws, void* stream, unsigned* out) {
-  FEDFR_REQUIRE(n && ws && out, "net_handoff_errors: null");
-  *out = 0;
-  if (n->hand_ws != ws) return FEDFR_OK;                  // no pass has used this workspace: nothing to report
-  const unsigned char* src = reinterpret_cast<const unsigned char*>(ws) + n->ws_hand + ew_bn_fused_hand_bytes();
-  if (hipMemcpyAsync(out, src, sizeof(unsigned), hipMemcpyDeviceToHost, ST(stream)) != hipSuccess || hipStreamSynchronize(ST(stream)) != hipSuccess) {
-    fedfr_set_error("net_handoff_errors: device-to-host copy failed");
-    return FEDFR_ERR_HIP;
-  }
   return FEDFR_OK;
 }
 void fedfr_net_destroy(fedfr_net_t* net) {

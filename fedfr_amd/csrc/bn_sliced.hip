@@ -19,11 +19,6 @@
 #include "ew.h"
 #include "gemm_dev.h"   // ProfScope
 
-template <typename K, typename P>
-static inline void launch_maybe_stop(K kernel, dim3 grid, dim3 block, hipStream_t st, P p) {
-  hipLaunchKernelGGL(kernel, grid, block, 0, st, p);
-}
-
 #ifndef BNS_PRIO
 #define BNS_PRIO 3   // wave priority of the backward passes: they share CUs with the weight-gradient kernels of the aux stream
 #endif
@@ -553,333 +548,7 @@ __global__ __launch_bounds__(NTH) void bn_bwd_apply_s_kernel(BnBwdS p) {
   }
 }
 
-// =====================================================================================================
-// backward, passes 1 + 2 in ONE launch (round 3): the partial rows cross workgroups inside the launch
-// =====================================================================================================
-// reduce_s -> apply_s is a kernel boundary, a second fan-in from global memory and a second fetch of dy and x (11.7 + 12.0 us alone on a
-// 14x14x256 tensor, 16 + 15 beside the weight-gradient stream) around a hand-off of G x NV x 32 floats per channel slice.  Here the same
-// workgroups (slice s, pixel group g) keep their whole share of dy and x in registers (NP passes of 64 pixels: 8 NP VGPRs), publish their
-// partial row as 8-byte {epoch, value} GRANULES — one relaxed agent-scope (write-through) 8-byte store each, the tag validates the value, so
-// no flag and no fence (cdna_hip_programming.md Guideline 16, form R2) — and then sweep the G rows of their own slice with relaxed
-// agent-scope loads (they bypass the CU's L1) until every tag carries this launch's epoch.  From there on it is the apply pass: same fp64
-// fan-in in the same order (rows rg, rg + RG, ... per thread, then the row groups), same coefficient expressions, same per-element code,
-// so the results are bit-identical to the two-launch form.
-//   * all C / 32 x G (<= 256) workgroups must be resident together: 256 threads, <= 224 VGPRs (amdgpu_num_vgpr: one such wave per SIMD
-//     still fits beside wgrad9's two 144-register waves), a few KB of LDS; a workgroup that cannot be placed at once waits for a
-//     workgroup of ANOTHER kernel to retire, never for one of this grid, so the launch always completes;
-//   * every spin is bounded: a workgroup that gives up sets *err (results then invalid) instead of hanging the device;
-//   * epochs are unique per launch and the buffer is zeroed once, so a stale granule can never validate; launches that share `hand`
-//     are ordered by their stream.
-#ifndef FUSED_WPE
-#define FUSED_WPE 2      // register budget of the fused kernels as waves per SIMD (2: <= 256 VGPRs; the launcher admits a variant only if it
-                         // actually allocates <= kFusedMaxVgprs: one such wave per SIMD fits beside wgrad9's two 144-register waves)
-#endif
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr unsigned kSpinLimit = 1u << 22;       // x (sweep + s_sleep) ~ seconds
-constexpr int kFusedRowsMax = 32;               // G of the shapes served (14x14x256: 32, 7x7x512: 16)
-
-template <int NV>
-__device__ __forceinline__ void slice_rowsum_publish(float (*v)[8], float* sred /*[4][NV*32]*/, gu64* row, unsigned epoch) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = tid & 3;
-#pragma unroll
-  for (int o = 4; o < 64; o <<= 1)
-#pragma unroll
-    for (int s = 0; s < NV; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[s][j] += __shfl_xor(v[s][j], o, 64);
-  if (lane < 4) {
-#pragma unroll
-    for (int s = 0; s < NV; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sred[wave * (NV * 32) + s * 32 + cl * 8 + j] = v[s][j];
-  }
-  __syncthreads();
-  if (tid < NV * 32) {
-    const float t = (sred[tid] + sred[NV * 32 + tid]) + (sred[2 * NV * 32 + tid] + sred[3 * NV * 32 + tid]);
-    __hip_atomic_store(row + tid, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(t), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// the G rows of a slice -> v (thread (c4, rg): rows rg, rg + RG, ..., four consecutive columns each), exactly what fan_in_issue reads
-template <int NV, int FL>
-__device__ __forceinline__ void handoff_gather(const gu64* rows, int G, unsigned epoch, float4* v, unsigned* err) {
-  constexpr int COLS4 = FanIn<NV>::COLS4, RG = FanIn<NV>::RG, COLS = FanIn<NV>::COLS;
-  const int tid = threadIdx.x;
-  const int c4 = tid % COLS4, rg = min(tid / COLS4, RG - 1);
-  const gu64* src = rows + c4 * 4;
-  unsigned spins = 0;
-  while (true) {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < FL; ++i) {
-      const gu64* r = src + (size_t)min(rg + i * RG, G - 1) * COLS;
-      const unsigned long long x0 = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long x1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long x2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long x3 = __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ok = ok && (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch && (unsigned)(x2 >> 32) == epoch && (unsigned)(x3 >> 32) == epoch;
-      v[i] = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1), __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
-    }
-    if (__all(ok)) break;                               // wave-uniform exit: every lane's granules carry this launch's epoch
-    if (++spins > kSpinLimit) {
-      if ((tid & 63) == 0) atomicOr(err, 1u);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(8);
-  }
-}
-
-template <bool ALPHA, bool NX, bool ADD, int NP>
-__global__ __launch_bounds__(NTH, FUSED_WPE) void bn_bwd_fused_s_kernel(BnBwdS p) {
-  __builtin_amdgcn_s_setprio(BNS_PRIO);
-  constexpr int NV = ALPHA ? 3 : 2, FL = ALPHA ? 4 : 2;   // FL x RG >= kFusedRowsMax (RG = 10 / 16)
-  static_assert(FL * FanIn<NV>::RG >= kFusedRowsMax, "fan-in depth");
-  __shared__ double red[FanIn<NV>::red_doubles];
-  __shared__ double tot[NV * 32];
-  __shared__ float cf[3][SW];
-  __shared__ float sred[4 * 96];
-  const int tid = threadIdx.x;
-  const int NS = p.C >> 5;
-  const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int g = lid / NS, s = lid - g * NS;
-  const int cl = tid & 3, pl = tid >> 2;
-  const int cs = s * SW, c0 = cs + cl * 8;
-  const int m0 = g * p.ppg, m1 = min(p.M, m0 + p.ppg);
-  const int cc = cs + (tid & 31);
-  // ---- every per-channel vector first (in-order vmcnt: a load issued behind the tensor could only be waited for with it)
-  const float ga_ = opt1(p.gamma, p.mean, cc, 1.f), r_ = p.rstd[cc], mu_ = p.mean[cc];
-  float mean[8], rstd[8], G[8], H[8], al[8], nmean[8], nrstd[8];
-  ld8(p.mean + c0, mean);
-  ld8(p.rstd + c0, rstd);
-  if (ALPHA) {
-    ld8(p.sc + c0, G);
-    ld8(p.sh + c0, H);
-    ld8(p.alpha + c0, al);
-  }
-  if (NX) {
-    ld8(p.nmean + c0, nmean);
-    ld8(p.nrstd + c0, nrstd);
-  }
-  // ---- pass 1: the whole share of dy and x, kept
-  uint4 vd[NP], vx[NP];
-#pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    const int m = min(m0 + u * PXP + pl, m1 - 1);
-    const size_t off = (size_t)m * p.C + c0;
-    vd[u] = ld16(p.dy + off);
-    vx[u] = ld16(p.x + off);
-  }
-  float acc[3][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
-#pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    if (m0 + u * PXP + pl < m1) {
-      float dy[8], x[8];
-      unpack8(vd[u], dy);
-      unpack8(vx[u], x);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float dz = dy[j];
-        if (ALPHA) {
-          const float z = x[j] * G[j] + H[j];
-          if (z <= 0.f) {
-            acc[2][j] += dy[j] * z;
-            dz = dy[j] * al[j];
-          }
-        }
-        acc[0][j] += dz;
-        acc[1][j] += dz * (x[j] - mean[j]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);                    // one pixel's temporaries at a time
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[1][j] *= rstd[j];
-  gu64* hand = (gu64*)p.hand + (size_t)s * p.G * (NV * 32);      // this slice's rows [G][NV * 32]
-  slice_rowsum_publish<NV>(acc, sred, hand + (size_t)g * (NV * 32), p.epoch);
-  // (without this the compiler keeps the UNPACKED fp32 copies of pass 1 alive for pass 2: twice the registers, hundreds of spills)
-#pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    asm volatile("" : "+v"(vd[u].x), "+v"(vd[u].y), "+v"(vd[u].z), "+v"(vd[u].w));
-    asm volatile("" : "+v"(vx[u].x), "+v"(vx[u].y), "+v"(vx[u].z), "+v"(vx[u].w));
-  }
-  // ---- the identity-path addend / the next BatchNorm's input of the first passes ride under the hand-off
-  constexpr int NA = (ADD || NX) ? 3 : 0;                // passes of them in flight
-  uint4 va[NP], vn[NP];
-  auto fetch_an = [&](int u) {
-    const int m = min(m0 + u * PXP + pl, m1 - 1);
-    const size_t off = (size_t)m * p.C + c0;
-    if (ADD) va[u] = ld16(p.add + off);
-    if (NX) vn[u] = ld16(p.nx + off);
-  };
-#pragma unroll
-  for (int u = 0; u < NA && u < NP; ++u) fetch_an(u);
-  // ---- hand-off: the G rows of this slice
-  float4 fv[FL];
-  handoff_gather<NV, FL>(hand, p.G, p.epoch, fv, p.err);
-  fan_in_finish<NV, FL>(fv, p.G, tot, red);
-  if (tid < SW) {
-    const int c = cs + tid;
-    const double t1 = tot[tid], t2 = tot[SW + tid];
-    if (g == 0) {
-      if (p.dgamma) p.dgamma[c] = (float)t2;
-      if (p.dbeta) p.dbeta[c] = (float)t1;
-      if (ALPHA && p.dalpha) p.dalpha[c] = (float)tot[(NV - 1) * SW + tid];
-    }
-    const double ga = (double)ga_, r = (double)r_, mu = (double)mu_;
-    const double a = (double)(float)(ga * r), cb = t1 / p.count, cq = t2 / p.count;
-    cf[0][tid] = (float)a;
-    cf[1][tid] = (float)(-a * cq * r);
-    cf[2][tid] = (float)(a * (cq * r * mu - cb));
-  }
-  __syncthreads();
-  float ca[8], cA[8], cB[8];
-  lds8(&cf[0][cl * 8], ca);
-  lds8(&cf[1][cl * 8], cA);
-  lds8(&cf[2][cl * 8], cB);
-  float nacc[2][8];
-  if (NX) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) nacc[0][j] = nacc[1][j] = 0.f;
-  }
-  // ---- pass 2 from registers
-#pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    if ((ADD || NX) && u + NA < NP) fetch_an(u + NA);
-    const int m = m0 + u * PXP + pl;
-    if (m < m1) {
-      float dy[8], x[8], o[8];
-      unpack8(vd[u], dy);
-      unpack8(vx[u], x);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float dz = dy[j];
-        if (ALPHA) {
-          const float z = x[j] * G[j] + H[j];
-          if (z <= 0.f) dz = dy[j] * al[j];
-        }
-        o[j] = ca[j] * dz + (cA[j] * x[j] + cB[j]);
-      }
-      if (ADD) {
-        float a[8];
-        unpack8(va[u], a);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] += a[j];
-      }
-      const uint4 ov = pack8(o);
-      *reinterpret_cast<uint4*>(p.dx + (size_t)m * p.C + c0) = ov;
-      if (NX) {
-        float dn[8], xn[8];
-        unpack8(ov, dn);
-        unpack8(vn[u], xn);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          nacc[0][j] += dn[j];
-          nacc[1][j] += dn[j] * (xn[j] - nmean[j]);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);                    // one pixel's temporaries at a time
-  }
-  if (NX) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) nacc[1][j] *= nrstd[j];
-    float* row = p.npart + (size_t)g * 3 * p.C;
-    __syncthreads();                                      // sred was read by the publish step's last stage; reuse it
-    slice_rowsum<2>(nacc, p.C, cs, sred, row);
-    if (tid < SW) row[2 * (size_t)p.C + cs + tid] = 0.f;
-  }
-}
 }  // namespace
-
-extern int g_bn_sliced;
-int g_bn_fuse_bwd = 0;   // option "bn_fuse_bwd": reduce + apply pass of a BatchNorm backward in one launch where the shape allows (14x14 / 7x7 maps).
-                         // Off: measured same-box (profiles/r03_ab_bn_fuse_bwd_v1.txt) it is worth 3 us per BatchNorm in a single-stream step (18.45 ->
-                         // 18.35 ms) and nothing in the default dual-stream one (16.93 vs 16.95): the in-launch hand-off costs what the kernel
-                         // boundary + second fan-in did, and the windows the weight-gradient stream fills shrink by what the main stream saves
-size_t ew_bn_fused_hand_bytes() { return (size_t)256 * 96 * 8; }     // <= 256 workgroups x <= 96 granules
-bool ew_bn_bwd_fused_ok(int M, int C) {
-  if (!g_bn_fuse_bwd || !g_bn_sliced || C < 64 || C > 1024 || (C % SW) != 0 || M < 256) return false;
-  const int NS = C / SW;
-  const int g = 256 / NS;
-  if (g < 1 || g > kFusedRowsMax) return false;
-  int per = (M + g - 1) / g;
-  per = (per + 7) / 8 * 8;
-  return per <= 13 * PXP;          // the whole share of dy and x in registers: at most 13 passes (104 VGPRs)
-}
-// A variant is used only if its wave fits beside the weight-gradient kernel's on every SIMD (512 - 2 x 144 = 224 registers): a fused
-// workgroup that had to wait for a weight-gradient workgroup to retire would hold up the hand-off of its whole grid.  Read from the code
-// object (hipFuncGetAttributes), once per variant.
-constexpr int kFusedMaxVgprs = 224;
-namespace {
-template <bool A, bool N, bool D, int NP>
-bool fused_fits() {
-  static int regs = -1;
-  if (regs < 0) {
-    hipFuncAttributes at{};
-    regs = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&bn_bwd_fused_s_kernel<A, N, D, NP>)) == hipSuccess ? at.numRegs : 1 << 20;
-  }
-  return regs <= kFusedMaxVgprs;
-}
-template <int NP>
-bool fused_variant_fits(int variant) {
-  switch (variant) {
-    case 0: return fused_fits<false, false, false, NP>();
-    case 1: return fused_fits<false, false, true, NP>();
-    case 2: return fused_fits<false, true, false, NP>();
-    case 3: return fused_fits<false, true, true, NP>();
-    case 4: return fused_fits<true, false, false, NP>();
-    case 5: return fused_fits<true, false, true, NP>();
-    case 6: return fused_fits<true, true, false, NP>();
-    default: return fused_fits<true, true, true, NP>();
-  }
-}
-}  // namespace
-bool ew_bn_bwd_fused_variant_ok(int M, int C, bool alpha, bool nx, bool add) {
-  if (!ew_bn_bwd_fused_ok(M, C)) return false;
-  const int NS = C / SW, g = 256 / NS;
-  int per = (M + g - 1) / g;
-  per = (per + 7) / 8 * 8;
-  const int variant = (alpha ? 4 : 0) | (nx ? 2 : 0) | (add ? 1 : 0);
-  return per <= 7 * PXP ? fused_variant_fits<7>(variant) : fused_variant_fits<13>(variant);
-}
-int ew_bn_bwd_fused_sliced(BnBwdS p, hipStream_t st) {
-  FEDFR_REQUIRE(p.dy && p.x && p.dx && p.mean && p.rstd && p.hand && p.err && p.epoch != 0 && p.M > 0 && p.C > 0 && (p.C % SW) == 0,
-                "bn_bwd_fused_sliced: bad args");
-  FEDFR_REQUIRE(ew_bn_bwd_fused_ok(p.M, p.C), "bn_bwd_fused_sliced: unsupported shape M=%d C=%d", p.M, p.C);
-  FEDFR_REQUIRE(!p.alpha || (p.sc && p.sh), "bn_bwd_fused_sliced: the PReLU mask needs the forward's (scale, shift)");
-  if (p.nx) FEDFR_REQUIRE(p.nmean && p.nrstd && p.npart, "bn_bwd_fused_sliced: next-BN reduction needs mean / rstd / partials");
-  // the reduce pass's geometry (so that the rows, and with them every sum, are the two-launch form's)
-  const int NS = p.C / SW;
-  int g = 256 / NS, per = (p.M + g - 1) / g;
-  per = (per + 7) / 8 * 8;
-  p.ppg = per;
-  p.G = (p.M + per - 1) / per;
-  FEDFR_REQUIRE(p.G <= kFusedRowsMax && (size_t)NS * p.G * 96 * 8 <= ew_bn_fused_hand_bytes(), "bn_bwd_fused_sliced: %d rows", p.G);
-  ProfScope prof(22, (double)p.M * p.C * 2 * (3.0 + (p.add ? 1.0 : 0.0) + (p.nx ? 1.0 : 0.0)), st);
-  const dim3 grid(NS * p.G);
-  const bool small = p.ppg <= 7 * PXP;
-  const int variant = (p.alpha ? 4 : 0) | (p.nx ? 2 : 0) | (p.add ? 1 : 0);
-#define BWD_F(A, N, D)                                                                                   \
-  do {                                                                                                   \
-    if (small) launch_maybe_stop((bn_bwd_fused_s_kernel<A, N, D, 7>), grid, dim3(NTH), st, p);            \
-    else launch_maybe_stop((bn_bwd_fused_s_kernel<A, N, D, 13>), grid, dim3(NTH), st, p);                 \
-  } while (0)
-  switch (variant) {
-    case 0: BWD_F(false, false, false); break;
-    case 1: BWD_F(false, false, true); break;
-    case 2: BWD_F(false, true, false); break;
-    case 3: BWD_F(false, true, true); break;
-    case 4: BWD_F(true, false, false); break;
-    case 5: BWD_F(true, false, true); break;
-    case 6: BWD_F(true, true, false); break;
-    default: BWD_F(true, true, true); break;
-  }
-#undef BWD_F
-  FEDFR_LAUNCH_CHECK("bn_bwd_fused_sliced");
-  return FEDFR_OK;
-}
 
 int g_bn_sliced = 1;   // option "bn_sliced": channel-sliced BatchNorm passes that reduce their partial rows themselves (no finalize launches)
 int g_bn_sliced_pre = 0;   // option "bn_sliced_pre": prefetch profile of the backward apply pass: 0 per-variant default, 1 everything in flight, 2 six passes, 3 three
@@ -986,14 +655,14 @@ int ew_bn_bwd_apply_sliced(BnBwdS p, hipStream_t st) {
 #define BWD_S(A, N, D)                                                                                        \
   do {                                                                                                        \
     if (wide) {                                                                                               \
-      launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 3, 2, 2>), grid, dim3(NTH), st, p);                    \
+      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 3, 2, 2>), grid, dim3(NTH), 0, st, p);                    \
     } else if (prof_id == 1) {                                                                                       \
-      if (small) launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 7, 1>), grid, dim3(NTH), st, p);            \
-      else launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, kMaxPasses, 1>), grid, dim3(NTH), st, p);         \
+      if (small) hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 7, 1>), grid, dim3(NTH), 0, st, p);            \
+      else hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, kMaxPasses, 1>), grid, dim3(NTH), 0, st, p);         \
     } else if (prof_id == 2) {                                                                                \
-      launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 6, 3>), grid, dim3(NTH), st, p);                       \
+      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 6, 3>), grid, dim3(NTH), 0, st, p);                       \
     } else {                                                                                                  \
-      launch_maybe_stop((bn_bwd_apply_s_kernel<A, N, D, 3, 2>), grid, dim3(NTH), st, p);                       \
+      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 3, 2>), grid, dim3(NTH), 0, st, p);                       \
     }                                                                                                         \
   } while (0)
   switch (variant) {

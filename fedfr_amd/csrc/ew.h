@@ -98,18 +98,7 @@ struct BnBwdS {
   const bf16_t* nx; const float *nmean, *nrstd;   // optional: dx reduced as the dy of the BatchNorm that consumes it ...
   float* npart;                                   // ... into ew_bn_sliced_rows(M, C) rows [3][C]; must not alias `part_in`
   int G, ppg;
-  // fused reduce + apply (ew_bn_bwd_fused_sliced): the partial rows cross workgroups INSIDE the launch as 8-byte {epoch, value} granules
-  unsigned long long* hand;                       // >= ew_bn_fused_hand_bytes() bytes, zeroed once before its first use; launches sharing it are stream-ordered
-  unsigned epoch;                                 // unique per launch over the life of `hand`, never 0
-  unsigned* err;                                  // device word, OR-ed with 1 if a workgroup gave up waiting (bounded spin): results invalid
 };
-size_t ew_bn_fused_hand_bytes();
-// fork event attached to the next sliced / fused BatchNorm-backward apply launch of this thread (bn_sliced.hip)
-// reduce pass + apply pass of a BatchNorm backward in ONE launch (same geometry, same arithmetic and summation order as
-// ew_bn_bwd_reduce_sliced followed by ew_bn_bwd_apply_sliced: bit-identical results); the tensors stay in registers across the hand-off
-bool ew_bn_bwd_fused_ok(int M, int C);
-bool ew_bn_bwd_fused_variant_ok(int M, int C, bool alpha, bool nx, bool add);   // ... and this variant's registers let it share a SIMD with the weight-gradient kernel
-int ew_bn_bwd_fused_sliced(BnBwdS p, hipStream_t st);
 int ew_bn_sliced_rows(int M, int C, bool backward = false);
 bool ew_bn_sliced_ok(int M, int C, int P_in, bool backward);
 int ew_bn_apply_sliced(BnApplyS p, hipStream_t st);

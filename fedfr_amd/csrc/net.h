@@ -79,7 +79,7 @@ struct FedfrNet {
   long long act_bf16_count, act_float_off_bytes, act_bytes;
   // workspace layout (byte offsets)
   size_t ws_bytes;
-  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_part2, ws_slab, ws_small, ws_fc, ws_hand, ws_stem = 0;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
+  size_t ws_g[2], ws_t[6], ws_t2[3 * (kWgradDepth - 1)], ws_part, ws_part2, ws_slab, ws_small, ws_fc, ws_stem = 0;   // ws_t2: further copies of t0/t2/t4 (dual-stream backward)
   mutable std::vector<hipEvent_t> events;                                  // fork/join events of the dual-stream backward (host objects)
   size_t g_elems, part_floats, slab_floats;
   int final_hw, final_C, fc_in;
@@ -91,10 +91,6 @@ struct FedfrNet {
   // nn.BatchNorm modules put into eval() inside a training net (IResNet.freeze_BN(test_mode=True), iresnet.py:140-147): set by a forward
   // pass with training = 2 (running statistics normalise, nothing is updated, activations are kept), read by the backward pass
   mutable bool bn_frozen = false;
-  // in-launch hand-off buffer of the fused BatchNorm-backward kernels (bn_sliced.hip): granules + one error word at its end; zeroed when a
-  // workspace is seen for the first time, epochs count launches
-  mutable unsigned hand_epoch = 0;
-  mutable const unsigned char* hand_ws = nullptr;
   int sph_type = 0;                     // 20 / 64: a sphnet plan (net_create_sphere); the iresnet fields above are unused then
   std::vector<SphStageD> sph;
   long long sph_xin_off = 0, sph_flat_off = 0;          // arena: padded NHWC input [B][112][112][64]; (== last activation) NCHW-flat [B][512*49]

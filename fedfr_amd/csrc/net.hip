@@ -173,7 +173,6 @@ static void plan_layout(FedfrNet* n, Builder& b, int in_hw) {
   n->ws_small = wtake((size_t)(3 * 512 + 64 * 2 * 512) * 4 + (size_t)Bq * num_features * 4 + (size_t)Bq * num_features * 2 +
                       (size_t)num_features * n->Bp * 2 + 1024);
   n->ws_fc = wtake((size_t)n->Bp * n->fc_in * 4);
-  n->ws_hand = wtake(ew_bn_fused_hand_bytes() + 256);
   n->ws_stem = wtake((size_t)ew_stem_wgrad_blocks(batch, in_hw, in_hw) * 2048 * 4);     // the stem weight gradient's own partials: it runs on the main stream
                                                                                         // while the weight-gradient stream is still in the slab regions
   n->ws_bytes = w;
@@ -288,17 +287,6 @@ static int conv_fwd_ep(const Ctx& c, const ConvD& cv, const bf16_t* in, bf16_t* 
   p.esc = c.save(bn, 0); p.esh = c.save(bn, 1); p.ealpha = alpha; p.eadd = add;
   if (out2) { p.Cb2 = out2; p.esc2 = c.save(*bn2, 0); p.esh2 = c.save(*bn2, 1); }
   return gemm_nt_launch(p, 1, c.st);
-}
-// first pass on this workspace: no stale hand-off granule may ever carry a live epoch, and the arrival counter starts at zero
-static int hand_init(const FedfrNet* n, unsigned char* ws, hipStream_t st) {
-  if (n->hand_ws == ws) return FEDFR_OK;
-  if (hipMemsetAsync(ws + n->ws_hand, 0, ew_bn_fused_hand_bytes() + 256, st) != hipSuccess) {
-    fedfr_set_error("hand_init: hipMemsetAsync of the hand-off buffer failed");
-    return FEDFR_ERR_HIP;
-  }
-  n->hand_ws = ws;
-  n->hand_epoch = 0;
-  return FEDFR_OK;
 }
 int g_fwd_xmom = 1;       // option "fwd_xmom": bn3 + identity + the next block's bn1 as one pass from conv2's raw moments (14x14 / 28x28 blocks)
 int g_fuse_bnbwd28 = 1;   // option "fuse_bnbwd28": ... and in the two-tiles 28x28 dgrad (with fuse_bnbwd != 0)
@@ -536,7 +524,6 @@ int net_forward(const FedfrNet* n, const float* x, const float* params, float* b
   const int M0 = B * HW * HW;
   bf16_t* A = c.actb;
   if (!tr) FEDFR_TRY(eval_coeffs_all(c));
-  if (tr) FEDFR_TRY(hand_init(n, ws, st));
   Rows prev{c.part(), 0};                  // statistics of the tensor the next BatchNorm normalises
   if (n->block_only) {
     // lone block: x (fp32 NCHW) -> NHWC bf16 block input; an identity "apply" pass leaves the column statistics bn1 needs, exactly
@@ -716,18 +703,6 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
     p.sc = c.save(b, 0); p.sh = c.save(b, 1); p.M = M; p.C = b.C; p.count = count;
     p.dgamma = c.grads + b.g_off; p.dbeta = c.grads + b.b_off; p.dalpha = alpha ? c.grads + alpha_off : nullptr;
     p.add = add; p.dx = dx;
-    if (have.P <= 0 && ew_bn_bwd_fused_variant_ok(M, b.C, alpha != nullptr, nxt, add != nullptr)) {
-      // reduce + apply in one launch: the partial rows cross workgroups inside it (bn_sliced.hip, bn_bwd_fused_s_kernel)
-      if (nxt) {
-        p.nx = next_x; p.nmean = c.save(*next_bn, 2); p.nrstd = c.save(*next_bn, 3); p.npart = c.part2();
-        *next_rows = Rows{p.npart, ew_bn_sliced_rows(M, b.C, true)};
-      }
-      p.hand = reinterpret_cast<unsigned long long*>(c.ws + c.n->ws_hand);
-      p.err = reinterpret_cast<unsigned*>(c.ws + c.n->ws_hand + ew_bn_fused_hand_bytes());
-      p.epoch = ++c.n->hand_epoch;
-      if (p.epoch == 0) p.epoch = ++c.n->hand_epoch;
-      return ew_bn_bwd_fused_sliced(p, c.st);
-    }
     if (have.P > 0) {
       p.part_in = have.ptr; p.P = have.P;
     } else {
@@ -804,7 +779,6 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   Ctx c{n, params, nullptr, shadow, reinterpret_cast<bf16_t*>(act), reinterpret_cast<float*>(act + n->act_float_off_bytes), ws, grads, st};
   const int B = n->B, F = n->F, HW = n->HW;
   bf16_t* A = c.actb;
-  FEDFR_TRY(hand_init(n, ws, st));
   Fork fk{n, st, aux};
   const hipStream_t wst = aux ? aux : st;          // stream of the weight-gradient GEMMs
   if (n->block_only) fk.order(st, wst);             // aux starts after everything already queued on main (forward pass); the full net forks below

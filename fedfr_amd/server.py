@@ -242,36 +242,32 @@ class Server(object):
             # B = 128; 3 regress).  Kernels are deterministic and clients share no state, so the round's result is identical to the sequential
             # round with the same kernel selection (the paired weight-gradient kernel below: otherwise equal up to fp32 summation order).
             import threading
-            from . import _C
-            # Kernel selection is the lone client's (the paired weight-gradient kernel has been the default since round 3), with ONE exception:
-            # kernels whose workgroups wait for each other inside a launch (in-launch hand-offs: option bn_fuse_bwd) rely on their whole grid
-            # being co-resident, which two clients' grids competing for the same CUs cannot promise — a spin could only end by its timeout.
-            # Those switches are forced off while clients share the GPU.  The switch is process-global: the previous value (a user's
-            # FEDFR_OPTIONS setting) is put back when the round's clients are done, also on an error.
+            # Kernel selection is the lone client's (the paired weight-gradient kernel has been the default since round 3).  No kernel of the library
+            # waits for another workgroup of its own launch (round 5 removed the one option that did, bn_fuse_bwd), so grids of several clients may
+            # compete for the CUs freely.
             main = torch.cuda.current_stream(self.device)
             streams = getattr(self, "_client_streams", None)
             if streams is None or len(streams) < par:
                 streams = self._client_streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(par)]
-            with _C.option_scope("bn_fuse_bwd", 0):
-                for w0 in range(0, len(order), par):
-                    errs = []
+            for w0 in range(0, len(order), par):
+                errs = []
 
-                    def target(i, slot):
-                        try:
-                            torch.cuda.set_device(self.device)
-                            streams[slot].wait_stream(main)
-                            with torch.cuda.stream(streams[slot]):
-                                run_client(i, slot)
-                            streams[slot].synchronize()
-                        except BaseException as e:      # noqa: BLE001 — re-raised in the caller's thread
-                            errs.append(e)
-                    ts = [threading.Thread(target=target, args=(i, k), daemon=True) for k, i in enumerate(order[w0: w0 + par])]
-                    for t in ts:
-                        t.start()
-                    for t in ts:
-                        t.join()
-                    if errs:
-                        raise errs[0]
+                def target(i, slot):
+                    try:
+                        torch.cuda.set_device(self.device)
+                        streams[slot].wait_stream(main)
+                        with torch.cuda.stream(streams[slot]):
+                            run_client(i, slot)
+                        streams[slot].synchronize()
+                    except BaseException as e:      # noqa: BLE001 — re-raised in the caller's thread
+                        errs.append(e)
+                ts = [threading.Thread(target=target, args=(i, k), daemon=True) for k, i in enumerate(order[w0: w0 + par])]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+                if errs:
+                    raise errs[0]
         for i in order:
             losses_.append(self.clients[i].get_train_loss())
             models.append(self.clients[i].get_model())

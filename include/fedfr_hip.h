@@ -47,8 +47,8 @@ const char* fedfr_last_error_string(void);
  *   BatchNorm forward   "bn_sliced" [1] channel-sliced passes without finalize launches, "fwd_xmom" [1] bn3 + identity + the next block's bn1 as one
  *                       pass from conv2's raw moments
  *   BatchNorm backward  "fuse_bnbwd" [2] reduction in the dgrad epilogue (1 every fused kernel, 2 the 14x14 layers), "fuse_bnbwd28" [1], "c64p_bnbwd" [1],
- *                       "fuse_bnred_next" [1] an apply pass reduces its output for the next BatchNorm, "stem_bnred" [1], "bn_fuse_bwd" [0] reduce + apply
- *                       in one launch with an in-launch hand-off, "bn_sliced_pre", "bn_sliced_bwd_passes"
+ *                       "fuse_bnred_next" [1] an apply pass reduces its output for the next BatchNorm, "stem_bnred" [1],
+ *                       "bn_sliced_pre", "bn_sliced_bwd_passes"
  *   streams             "event_nofence" [1] fork / join events without a system-scope fence
  *   sphnet              "sph_fin_multi" [1], "sph_pair_wgrad" [1], "sph_fuse_prelu_bwd" [1]
  * Unknown names are an error. */
@@ -98,11 +98,6 @@ int fedfr_net_set_dropout(fedfr_net_t* net, float p, unsigned long long seed, lo
  * workspace release, for every new model — so a host that wants masks that never repeat keeps the count itself (fedfr_amd.IResNet does:
  * one counter per model, handed over before every training forward). */
 int fedfr_net_set_dropout_step(fedfr_net_t* net, unsigned long long step);
-/* Kernels whose workgroups hand data to each other INSIDE a launch (option "bn_fuse_bwd") need their whole grid co-resident; a workgroup that waits too long gives up and sets an
- * error word in the workspace, and that step's results are wrong.  *out = that word (0 = none) — synchronises `stream`; ask where the
- * host synchronises anyway.  It cannot happen while ONE kernel chain owns the GPU; hosts that run several chains on one GPU switch the
- * option off (fedfr_amd.server does). */
-int fedfr_net_handoff_errors(const fedfr_net_t* net, const void* ws, void* stream, unsigned* out);
 /* debug (tests): while buf != NULL, fedfr_net_backward* copies the gradient entering every block (bf16 NHWC, last block first) and then
  * the gradient wrt the first block's input back to back into buf (caller-owned, `elems` bf16 elements); NULL turns it off.  The one
  * exception to "no pointer is retained": clear it before freeing the buffer. */

@@ -319,6 +319,7 @@ class FusedTrainer(_LossScaleGuard):
         self._fuse_sgd = False
         self._sgd_done_from = None
         self._grads_scaled = False          # fp16-storage build: [0, _sgd_done_from) of the gradient buffer still carries the loss scale
+        self._scale_used = 1.0              # ... namely this one (the scale the last backward pass multiplied in)
         self._init_loss_scale(bb.device)
 
     def set_lr(self, lr: float):
@@ -404,7 +405,7 @@ class FusedTrainer(_LossScaleGuard):
             torch.cuda.current_stream().wait_stream(self._shadows_pending)   # dgrad shadows rebuilt on aux after the last SGD step
             self._shadows_pending = None
         aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
-        S = self.loss_scale
+        S = self._scale_used = self.loss_scale      # (the device's scale may be lowered by another trainer's poll before optimizer_step(): remember ours)
         self._grads_scaled = False
         if self.guarded:
             # fp16-storage library: the gradient enters the backbone multiplied by the loss scale S
@@ -453,7 +454,7 @@ class FusedTrainer(_LossScaleGuard):
             ovf = self._overflow.data_ptr()
             if n_rest > 0:
                 _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                        bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / self.loss_scale if scaled else 1.0, ovf, st)
+                        bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / self._scale_used if scaled else 1.0, ovf, st)
             if self.pfc is not None:
                 self.pfc.fused_sgd_update(self.lr, self.mu, self.wd, overflow=self._overflow)      # sampled rows: guarded SGD + scatter back
             else:

@@ -351,8 +351,12 @@ class FusedTrainer(_LossScaleGuard):
                 bb._flat_nbt += 1
             # upstream PartialFC protocol: normalised embeddings in, d(embedding) out
             fn, finv = ops.normalize_rows(feats)
-            x_grad, loss = self.pfc.forward_backward(labels, fn, None)
-            dfeats = ops.normalize_rows_bwd(fn, finv, x_grad.contiguous())
+            if self.pfc.world_size == 1:
+                x_slabs, loss = self.pfc.forward_backward(labels, fn, None, x_grad_slabs=True)      # split-K slabs, added by the pass below
+                dfeats = ops.normalize_rows_bwd_slabs(fn, finv, x_slabs.contiguous())
+            else:
+                x_grad, loss = self.pfc.forward_backward(labels, fn, None)
+                dfeats = ops.normalize_rows_bwd(fn, finv, x_grad.contiguous())
             self._backward(plan, imgs, dfeats, st)
             return loss
         # head: cosine logits -> margin -> softmax CE, gradient wrt cosine written in place

@@ -585,10 +585,11 @@ __global__ __launch_bounds__(256) void softmax_ce_fused_kernel(float* __restrict
 }
 int head_softmax_ce_fused(float* z, const long long* label, int R, int C, int ldz, float s, float m, int arc, float inv_batch, float* prob_t,
                           int nslab, long long slab_stride, hipStream_t st) {
-  FEDFR_REQUIRE(z && label && prob_t && R > 0 && C > 0 && C <= 4096 && ldz >= C && nslab >= 1 && (nslab == 1 || slab_stride >= (long long)R * ldz),
-                "softmax_ce_fused: bad args (rows of at most 4096 classes)");
+  FEDFR_REQUIRE(z && label && prob_t && R > 0 && C > 0 && C <= 16384 && ldz >= C && nslab >= 1 && (nslab == 1 || slab_stride >= (long long)R * ldz),
+                "softmax_ce_fused: bad args (rows of at most 16384 classes)");
   if (C <= 1024) hipLaunchKernelGGL(softmax_ce_fused_kernel<4>, dim3(R), dim3(256), 0, st, z, label, C, ldz, s, m, arc, inv_batch, prob_t, nslab, slab_stride);
-  else hipLaunchKernelGGL(softmax_ce_fused_kernel<16>, dim3(R), dim3(256), 0, st, z, label, C, ldz, s, m, arc, inv_batch, prob_t, nslab, slab_stride);
+  else if (C <= 4096) hipLaunchKernelGGL(softmax_ce_fused_kernel<16>, dim3(R), dim3(256), 0, st, z, label, C, ldz, s, m, arc, inv_batch, prob_t, nslab, slab_stride);
+  else hipLaunchKernelGGL(softmax_ce_fused_kernel<64>, dim3(R), dim3(256), 0, st, z, label, C, ldz, s, m, arc, inv_batch, prob_t, nslab, slab_stride);      // (round 5: the sampled PartialFC head, 8 500 classes)
   FEDFR_LAUNCH_CHECK("softmax_ce_fused");
   return FEDFR_OK;
 }

@@ -264,6 +264,27 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* sh, int& total) 
   return res;
 }
 
+// The digit of the kk-th largest candidate: the highest bin whose count, added to the counts of the bins above it, reaches kk (bin 0 if none
+// does).  Block-parallel (1024 threads, nb = 1024 or 2048 bins, descending bin order through one block scan): a single thread walking up to 2 048
+// LDS words in a dependent chain was ~70 us per pass at n = 85 000 (round 5 trace).  Ends with a barrier; *s_prefix / *s_k are then visible.
+__device__ __forceinline__ void pfc_select_bin(const int* hist, int nb, int kk, unsigned prefix, int shift, int* sh, unsigned* s_prefix, int* s_k) {
+  const int per = nb >> 10;                              // bins per thread (1 or 2), thread t owns bins nb - 1 - per t ... downwards
+  const int top = nb - 1 - per * (int)threadIdx.x;
+  int mine = 0;
+  for (int q = 0; q < per; ++q) mine += hist[top - q];
+  int total;
+  int above = block_excl_scan_1024(mine, sh, total);     // candidates in the bins above this thread's
+  for (int q = 0; q < per; ++q) {
+    const int bin = top - q, h = hist[bin];
+    if (above < kk && (above + h >= kk || bin == 0)) {
+      *s_prefix = prefix | ((unsigned)bin << shift);
+      *s_k = kk - above;
+    }
+    above += h;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(1024) void pfc_topk_kernel(const float* __restrict__ perm, int n, int k, long long* __restrict__ index,
                                                         int* __restrict__ npos_out) {
   __shared__ int hist[2048];
@@ -286,16 +307,7 @@ __global__ __launch_bounds__(1024) void pfc_topk_kernel(const float* __restrict_
       if ((b & mask_hi) == prefix) atomicAdd(&hist[(b >> shifts[pass]) & (nb - 1)], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-      int above = 0, bin = nb - 1;
-      for (; bin > 0; --bin) {
-        if (above + hist[bin] >= kk) break;
-        above += hist[bin];
-      }
-      s_prefix = prefix | ((unsigned)bin << shifts[pass]);
-      s_k = kk - above;
-    }
-    __syncthreads();
+    pfc_select_bin(hist, nb, kk, prefix, shifts[pass], sh, &s_prefix, &s_k);
     prefix = s_prefix;
     kk = s_k;
     mask_hi |= (unsigned)(nb - 1) << shifts[pass];
@@ -324,9 +336,123 @@ __global__ __launch_bounds__(1024) void pfc_topk_kernel(const float* __restrict_
     if (tid == 0) *npos_out = tot;
   }
 }
+// The same selection with WIDE, prefetched loads (round 5).  The kernel above walks the n values four times (three histogram passes + the
+// compaction) with ONE dependent 4-byte global load per thread and iteration: at n = 85 000 that is 4 x 83 L2 round trips = 319 us of the 930 us
+// PartialFC head (profiles/r05_pfc_head_trace_v1.txt).  Here a thread owns NPT CONSECUTIVE values of every chunk of 1024 NPT (fetched as 16-byte
+// loads, the next chunk's in flight while this one is counted), so a pass is n / (1024 NPT) round trips and the ordered compaction needs one
+// pair of block scans per chunk instead of one per 1024 values: same radix select, same index set.  The histogram is kept in NCOPY copies
+// (lane l adds to copy l % NCOPY, rows padded to 2049 words so that the copies of a bin sit in different banks): the values are uniform draws,
+// so half of them share ONE 11-bit digit in the first pass, and 64 lanes adding to one LDS word are served one after the other (the
+// single-copy form of this kernel: 256 us).
+template <int NPT, int NCOPY>
+__global__ __launch_bounds__(1024) void pfc_topk_wide_kernel(const float* __restrict__ perm, int n, int k, long long* __restrict__ index,
+                                                             int* __restrict__ npos_out) {
+  extern __shared__ int hcopies[];                      // [NCOPY][2049]
+  __shared__ int hist[2048];
+  __shared__ int sh[17];
+  int* const myhist = hcopies + (threadIdx.x % NCOPY) * 2049;
+  __shared__ unsigned s_prefix;
+  __shared__ int s_k;
+  static_assert(NPT % 4 == 0, "16-byte loads");
+  const int tid = threadIdx.x;
+  constexpr int CH = 1024 * NPT;
+  const int nch = (n + CH - 1) / CH;
+  auto load = [&](int c, unsigned (&v)[NPT]) {            // values [c CH + tid NPT, + NPT); beyond n: 0 with ok() false
+#pragma unroll
+    for (int j = 0; j < NPT / 4; ++j) {
+      const int i = c * CH + tid * NPT + 4 * j;
+      uint4 q = make_uint4(0u, 0u, 0u, 0u);
+      if (i + 3 < n) q = *reinterpret_cast<const uint4*>(perm + i);
+      else {
+        const unsigned* b = reinterpret_cast<const unsigned*>(perm);
+        if (i < n) q.x = b[i];
+        if (i + 1 < n) q.y = b[i + 1];
+        if (i + 2 < n) q.z = b[i + 2];
+      }
+      v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+  };
+  unsigned prefix = 0, mask_hi = 0;
+  int kk = k;
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  unsigned cur[NPT], nxt[NPT];
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << widths[pass];
+    for (int i = tid; i < NCOPY * 2049; i += 1024) hcopies[i] = 0;
+    load(0, cur);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      if (c + 1 < nch) load(c + 1, nxt);
+      const int nv = n - (c * CH + tid * NPT);
+#pragma unroll
+      for (int j = 0; j < NPT; ++j)
+        if (j < nv && (cur[j] & mask_hi) == prefix) atomicAdd(&myhist[(cur[j] >> shifts[pass]) & (nb - 1)], 1);
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) cur[j] = nxt[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < nb; i += 1024) {              // the copies of a bin, summed
+      int t = 0;
+#pragma unroll
+      for (int q = 0; q < NCOPY; ++q) t += hcopies[q * 2049 + i];
+      hist[i] = t;
+    }
+    __syncthreads();
+    pfc_select_bin(hist, nb, kk, prefix, shifts[pass], sh, &s_prefix, &s_k);
+    prefix = s_prefix;
+    kk = s_k;
+    mask_hi |= (unsigned)(nb - 1) << shifts[pass];
+    __syncthreads();
+  }
+  // prefix == bit pattern T of the k-th largest value; take all > T and the first kk of == T (index order)
+  const unsigned T = prefix;
+  int base = 0, eq_taken = 0, npos = 0;
+  load(0, cur);
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) load(c + 1, nxt);
+    const int i0 = c * CH + tid * NPT, nv = n - i0;
+    int n_gt = 0, n_eq = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      n_gt += (j < nv && cur[j] > T) ? 1 : 0;
+      n_eq += (j < nv && cur[j] == T) ? 1 : 0;
+      npos += (j < nv && cur[j] == 0x40000000u) ? 1 : 0;     // 2.0f marks a positive class
+    }
+    int tot_eq, tot_gt;
+    int eq_before = eq_taken + block_excl_scan_1024(n_eq, sh, tot_eq);
+    const int gt_before = block_excl_scan_1024(n_gt, sh, tot_gt);
+    // selected elements in front of this thread: `base` from earlier chunks (their > T and taken == T), this chunk's predecessors' > T, and of
+    // all == T in front of it the first kk — minus those already counted in `base`
+    int pos = base + gt_before + (min(eq_before, kk) - min(eq_taken, kk));
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const bool gt = j < nv && cur[j] > T, eq = j < nv && cur[j] == T;
+      if (gt || (eq && eq_before < kk)) index[pos++] = i0 + j;
+      eq_before += eq ? 1 : 0;
+    }
+    base += tot_gt + (min(eq_taken + tot_eq, kk) - min(eq_taken, kk));
+    eq_taken += tot_eq;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) cur[j] = nxt[j];
+  }
+  if (npos_out) {
+    int tot;
+    (void)block_excl_scan_1024(npos, sh, tot);
+    if (tid == 0) *npos_out = tot;
+  }
+}
 int optim_pfc_topk(const float* perm, int n, int k, long long* index, int* npos_out, hipStream_t st) {
   FEDFR_REQUIRE(perm && index && n > 0 && k > 0 && k <= n, "pfc_topk: bad args (k=%d n=%d)", k, n);
-  hipLaunchKernelGGL(pfc_topk_kernel, dim3(1), dim3(1024), 0, st, perm, n, k, index, npos_out);
+  if ((reinterpret_cast<size_t>(perm) & 15) == 0 && n >= 8192) {
+    constexpr int NCOPY = 16;
+    constexpr size_t lds = (size_t)NCOPY * 2049 * sizeof(int);
+    static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device
+    attr_once.run([&] {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pfc_topk_wide_kernel<16, NCOPY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    hipLaunchKernelGGL((pfc_topk_wide_kernel<16, NCOPY>), dim3(1), dim3(1024), lds, st, perm, n, k, index, npos_out);
+  } else hipLaunchKernelGGL(pfc_topk_kernel, dim3(1), dim3(1024), 0, st, perm, n, k, index, npos_out);      // (small or unaligned shards: the 4-byte form)
   FEDFR_LAUNCH_CHECK("pfc_topk");
   return FEDFR_OK;
 }

@@ -50,7 +50,7 @@ def normalize_rows_bwd_slabs(xn: torch.Tensor, inv: torch.Tensor, dxn_slabs: tor
 
 
 def softmax_ce_fused(cos_slabs: torch.Tensor, label: torch.Tensor, s: float, m: float, arcface: bool, inv_batch: float):
-    """``softmax_ce_grad`` (no collectives) as ONE launch; ``cos_slabs`` [S, R, C] (C <= 4096) are split-K slabs of the cosine matrix.
+    """``softmax_ce_grad`` (no collectives) as ONE launch; ``cos_slabs`` [S, R, C] (C <= 16384) are split-K slabs of the cosine matrix.
     Returns (prob_target [R], grad = cos_slabs[0], overwritten)."""
     cos_slabs = _chk(cos_slabs, "cosine slabs")
     label = _chk(label, "label", torch.int64)
@@ -147,6 +147,20 @@ def sharded_softmax_ce_grad(cosine: torch.Tensor, label: torch.Tensor, s: float,
             inv_batch, prob_t.data_ptr(), st)
     _C.call("fedfr_nll_mean_ratio", sums2[1].data_ptr(), sums2[0].data_ptr(), R, floor, loss.data_ptr(), st)
     return loss, cosine
+
+
+def sum_slabs(slabs: torch.Tensor) -> torch.Tensor:
+    """Σ_s slabs[s] over the split-K slabs [S, ...] of ``sgemm(..., splits=S)``, ascending s (fedfr_fedavg_multi: ≤ 8 tensors per pass)."""
+    import ctypes as C
+    slabs = _chk(slabs, "slabs")
+    S = slabs.shape[0]
+    out = torch.empty_like(slabs[0])
+    for s0 in range(0, S, 8):
+        k = min(8, S - s0)
+        ptrs = (C.c_void_p * k)(*[slabs[s0 + i].data_ptr() for i in range(k)])
+        wv = (C.c_float * k)(*([1.0] * k))
+        _C.call("fedfr_fedavg_multi", out.data_ptr(), ptrs, wv, k, out.numel(), 1 if s0 else 0, _C.stream())
+    return out
 
 
 def scale(x: torch.Tensor, w: float) -> torch.Tensor:

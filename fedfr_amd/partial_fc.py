@@ -186,8 +186,11 @@ class PartialFC(Module):
         return total_label, norm_weight, winv
 
     @_C.on_device(lambda self: self.device)
-    def forward_backward(self, label, features, optimizer, perm=None):
-        """partial_fc.py:130-176.  Returns (x_grad [B, D], loss_v scalar); ``self.sub_weight.grad`` is set."""
+    def forward_backward(self, label, features, optimizer, perm=None, x_grad_slabs=False):
+        """partial_fc.py:130-176.  Returns (x_grad [B, D], loss_v scalar); ``self.sub_weight.grad`` is set.  ``x_grad_slabs`` (build extension, world
+        size 1): x_grad comes back as the split-K slabs [S, B, D] of its GEMM for a consumer that adds them itself (``ops.normalize_rows_bwd_slabs``).
+        (Moving the loss value and d(sampled class weights) behind the backbone's backward pass onto the weight-gradient stream, as the dense head
+        does, measured neutral in round 5 — 15.51 vs 15.52 ms — and was not kept.)"""
         features = _C.require_gpu_tensor(features.detach().contiguous(), f32, "features")
         W = self.world_size
         total_label, total_features = self._gather_inputs(label, features)                  # G
@@ -198,10 +201,26 @@ class PartialFC(Module):
             loss_v, grad = ops.sharded_softmax_ce_grad(logits, total_label, self._s, self._m, self._arc, inv_batch,
                                                        self.comm.all_reduce, 1e-30)                  # M, S
         else:
-            prob_t, grad = ops.softmax_ce_grad(logits, total_label, self._s, self._m, self._arc, inv_batch)
+            if logits.shape[1] <= 4096:               # margin -> softmax -> gradient with the row in registers: one launch, the same bits as the three
+                # (longer rows: one workgroup per row leaves half the CUs idle at batch 128 — 46 us fused vs 38 for the three at 8 500 classes)
+                prob_t, grad = ops.softmax_ce_fused(logits.unsqueeze(0), total_label, self._s, self._m, self._arc, inv_batch)
+            else:
+                prob_t, grad = ops.softmax_ce_grad(logits, total_label, self._s, self._m, self._arc, inv_batch)
             loss_v = ops.nll_mean(prob_t, 1e-30)
         # logits.backward(grad): d total_features = grad @ norm_weight ; d norm_weight = grad^T @ total_features
-        dfeat = ops.sgemm(grad, norm_weight)
+        # d total_features [B W, D] reduces over the SAMPLED CLASSES (8 500 at 85 000 x 0.1): on 64 x 64 tiles that is 16 workgroups walking 8 500
+        # k-steps each (405 us in the round-5 trace) — split K like the dense head's GEMMs (round 3), here into up to 32 slabs
+        K_ = grad.shape[1]
+        ks = max(1, min(32, K_ // 256))
+        chunk = -(-(-(-K_ // ks)) // 32) * 32
+        ks = -(-K_ // chunk)                              # (no empty last chunk: head_sgemm_splitk refuses one)
+        if ks > 1:
+            dslabs = ops.sgemm(grad, norm_weight, splits=ks)
+            dfeat = dslabs if (x_grad_slabs and W == 1) else ops.sum_slabs(dslabs)
+        else:
+            dfeat = ops.sgemm(grad, norm_weight)
+            if x_grad_slabs and W == 1:
+                dfeat = dfeat.unsqueeze(0)
         dwn = ops.sgemm(grad, total_features, trans_a=True)
         self.sub_weight.grad = ops.normalize_rows_bwd(norm_weight, winv, dwn)
         if W > 1:

@@ -281,7 +281,7 @@ int fedfr_sgemm(const float* A, const float* B, float* C, int M, int N, int K, l
                 long long sbk, long long sbn, int ldc, float alpha, float beta, const float* bias, void* stream);
 /* Round 3, the dense head's latency chain (client.py:69-74 + losses.py:23-29 + client.py:545 at 128 x 1000 x 512): fedfr_sgemm as `splits`
  * split-K slabs C + z * slab_stride (k range z of ceil(K / splits) rounded up to 32; no bias / beta), whose consumers add the slabs in
- * order: fedfr_softmax_ce_fused = fedfr_margin_rowmax + fedfr_exp_rowsum + fedfr_softmax_grad in ONE launch for rows of <= 4096 classes
+ * order: fedfr_softmax_ce_fused = fedfr_margin_rowmax + fedfr_exp_rowsum + fedfr_softmax_grad in ONE launch for rows of <= 16384 classes
  * (bit-identical to the three; cosines summed over nslab slabs, gradient written over slab 0), fedfr_normalize_rows_bwd_slabs =
  * fedfr_normalize_rows_bwd on a dxn given as slabs. */
 int fedfr_sgemm_splitk(const float* A, const float* B, float* C, int M, int N, int K, long long sam, long long sak, long long sbk,

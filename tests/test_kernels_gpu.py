@@ -627,7 +627,8 @@ def test_sgemm_splitk_slabs(M, N, K, tb, splits):
         assert relerr(slabs[z], (a[:, lo:hi].double() @ Bm[lo:hi].double()).float()) < 1e-5, z
 
 
-@pytest.mark.parametrize("R,C,arc,nslab", [(128, 1000, False, 1), (128, 1000, True, 1), (33, 1000, False, 4), (5, 3000, True, 3), (9, 257, False, 2)])
+@pytest.mark.parametrize("R,C,arc,nslab", [(128, 1000, False, 1), (128, 1000, True, 1), (33, 1000, False, 4), (5, 3000, True, 3), (9, 257, False, 2),
+                                           (128, 8500, True, 1), (7, 16384, False, 2)])      # (round 5: rows of up to 16 384 classes — the sampled PartialFC head)
 def test_softmax_ce_fused_equals_three_kernels(R, C, arc, nslab):
     """margin -> softmax -> gradient in one launch: bit-identical to the three-kernel chain on the summed slabs (labels incl. -1)."""
     from fedfr_amd import ops
@@ -758,6 +759,24 @@ def test_pfc_topk_matches_torch(n, k, npos):
     _C.call("fedfr_pfc_topk", permd.data_ptr(), n, k, idx.data_ptr(), cnt.data_ptr(), _C.stream())
     torch.cuda.synchronize()
     assert int(cnt) == npos
+    assert torch.equal(idx.cpu(), ref)
+
+
+@pytest.mark.parametrize("n,k,levels", [(85000, 8500, 50), (40000, 7777, 16), (20001, 20001, 3), (16384, 1, 2), (33000, 32999, 7)])
+def test_pfc_topk_with_ties(n, k, levels):
+    """Heavily tied values (a handful of distinct levels): the selection takes every value above the k-th largest and the FIRST ones in index
+    order of those equal to it — across the chunk boundaries of the wide-load kernel (round 5) exactly as torch's stable ordering does."""
+    g = torch.Generator().manual_seed(n + k)
+    perm = torch.randint(0, levels, (n,), generator=g).float() / levels
+    order = torch.argsort(perm, descending=True, stable=True)                       # ties: ascending index
+    ref = order[:k].sort()[0]
+    d = dev()
+    idx = torch.full((k,), -1, dtype=torch.int64, device=d)
+    cnt = torch.zeros(1, dtype=torch.int32, device=d)
+    permd = perm.to(d)
+    _C.call("fedfr_pfc_topk", permd.data_ptr(), n, k, idx.data_ptr(), cnt.data_ptr(), _C.stream())
+    torch.cuda.synchronize()
+    assert int(cnt) == 0
     assert torch.equal(idx.cpu(), ref)
 
 

@@ -520,6 +520,7 @@ class FusedHeadTrainer(_LossScaleGuard):
         self.mom = torch.empty(self.n_train, dtype=f32, device=bb.device)
         self.head_mom = {}
         self.first = True
+        self.fuse_sgd = os.environ.get("FEDFR_FUSE_SGD", "1") != "0"
         self._init_loss_scale(bb.device)
         self.aux_stream = _make_aux_stream(bb.device, aux_slot)
         self._shadows_pending = None
@@ -555,17 +556,35 @@ class FusedHeadTrainer(_LossScaleGuard):
         guarded = self.guarded
         if guarded:
             dfeats = dfeats * S
-        _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
-                bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st,
-                self.aux_stream.cuda_stream if self.aux_stream is not None else None)
-        # ---- opt.step()  (fp16-storage build: the kernel undoes the scale in place and skips non-finite elements, _LossScaleGuard)
+        aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
         ovf = self._overflow.data_ptr()
-        if guarded:
-            _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                    bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, 1.0 / S, ovf, st)
+        first = 1 if self.first else 0
+        n_rest = self.n_train
+        # ---- backward + opt.step() of the backbone.  Round 5: as in FusedTrainer.step(), the update of every parameter range whose gradient is final
+        # rides on the weight-gradient stream INSIDE the backward pass (fedfr_net_backward2_sgd: the same kernels, the same elementwise arithmetic,
+        # enqueued earlier — bit-identical to backward + one flat update, FEDFR_FUSE_SGD=0); the flat kernel finishes [0, done_from).
+        # (fp16-storage library: the kernels undo the scale in place and skip non-finite elements, _LossScaleGuard)
+        if self.fuse_sgd:
+            import ctypes
+            done = ctypes.c_longlong(0)
+            if guarded:
+                _C.call("fedfr_net_backward2_sgd_scaled", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                        bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                        self.lr, self.mu, self.wd, first, 1.0 / S, ovf, ctypes.byref(done), st, aux)
+            else:
+                _C.call("fedfr_net_backward2_sgd", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                        bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                        self.lr, self.mu, self.wd, first, ctypes.byref(done), st, aux)
+            n_rest = int(done.value)
         else:
+            _C.call("fedfr_net_backward2", plan.handle, imgs.data_ptr(), dfeats.data_ptr(), bb._flat_params.data_ptr(),
+                    bb._shadow.data_ptr(), plan.act.data_ptr(), plan.ws.data_ptr(), bb._flat_grads.data_ptr(), st, aux)
+        if n_rest > 0 and guarded:
+            _C.call("fedfr_sgd_step_scaled", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
+                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, 1.0 / S, ovf, st)
+        elif n_rest > 0:
             _C.call("fedfr_sgd_step", bb._flat_params.data_ptr(), bb._flat_grads.data_ptr(), self.mom.data_ptr(),
-                    bb._shadow.data_ptr(), self.n_train, self.lr, self.mu, self.wd, 1 if self.first else 0, st)
+                    bb._shadow.data_ptr(), n_rest, self.lr, self.mu, self.wd, first, st)
         for hp in self.head_params:
             if hp.grad is None:                                       # torch.optim.SGD skips parameters without a gradient
                 continue

@@ -61,6 +61,17 @@ def softmax_ce_fused(cos_slabs: torch.Tensor, label: torch.Tensor, s: float, m: 
     return prob_t, cos_slabs[0]
 
 
+def _auto_splits(M: int, N: int, K: int) -> int:
+    """split-K degree ``sgemm`` picks by itself: none while the output has >= 128 tiles of 64 x 64 or K is short; else enough slabs of >= 256 k
+    (a multiple of 32) to put ~512 workgroups on the chip, at most 64, none of them empty."""
+    tiles = -(-M // 64) * -(-N // 64)
+    if tiles >= 128 or K < 1024:
+        return 1
+    s = max(1, min(64, K // 256, -(-512 // tiles)))
+    chunk = -(-(-(-K // s)) // 32) * 32
+    return -(-K // chunk)
+
+
 def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
           bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, splits: int = 0) -> torch.Tensor:
     """C = op(A) @ op(B) (+bias) in exact fp32 (v_mfma_f32_16x16x4_f32); A, B row-major contiguous.  ``splits`` > 0: split-K, returns
@@ -80,6 +91,13 @@ def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool
         sbk, sbn = N, 1
     if K != Kb:
         raise RuntimeError("sgemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if splits == 0 and bias is None and out is None:
+        # A long reduction over few 64 x 64 output tiles (d(features) = d(cosine) @ class weights: 128 x 512 over 10 000 ... 85 000 classes is 16
+        # workgroups walking K alone — 4.0 ms at 85 000 in the round-5 trace of config 5): split K into slabs and add them (ascending), as the
+        # dense head's GEMMs have done since round 3.  Same products, another fp32 summation order.
+        auto = _auto_splits(M, N, K)
+        if auto > 1:
+            return sum_slabs(sgemm(a, b, trans_a, trans_b, splits=auto))
     if splits > 0:
         if bias is not None or out is not None:
             raise RuntimeError("sgemm: split-K slabs take neither bias nor out")

@@ -502,6 +502,38 @@ def test_sgd_inside_backward_is_bit_identical(arch, dual, monkeypatch):
     tr.finish()
 
 
+@pytest.mark.parametrize("arch", ["iresnet18", "iresnet50"])
+def test_head_trainer_sgd_inside_backward_is_bit_identical(arch, monkeypatch):
+    """FusedHeadTrainer (the body of train_with_public_data and of the config-5 trainer) folds the backbone's SGD update into the backward pass
+    like FusedTrainer.step() (round 5): parameters, momentum, 16-bit mirrors, head parameters and losses after 3 steps are bit-identical to
+    backward + one flat update (FEDFR_FUSE_SGD=0)."""
+    B, C = 8, 24
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FEDFR_FUSE_SGD", fuse)
+        m, sd, layers = make_model(arch, tag=6.0)
+        fcm = client.FC_module(512, C, "/tmp").to(DEV)
+        fcm.fc.data = R.head_fc(C).to(DEV)
+        margin = losses.CosFace(s=30, m=0.4)
+        tr = client.FusedHeadTrainer(m, list(fcm.parameters()), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        assert tr.fuse_sgd == (fuse == "1")
+
+        def head_loss(feats, labels):
+            return ops.cross_entropy(margin(fcm(feats), labels), labels)
+        ls = []
+        for st in range(3):
+            imgs = R.closed_form_images(B, tag=float(st)).to(DEV)
+            lab = R.closed_form_labels(B, C, tag=st).to(DEV)
+            ls.append(float(tr.step(imgs, lab, head_loss)))
+        tr.finish()
+        torch.cuda.synchronize()
+        res.append((ls, m._flat_params.clone(), tr.mom.clone(), m._shadow[: m.trainable_count()].clone(), fcm.fc.data.clone()))
+    a, b = res
+    assert a[0] == b[0], (a[0], b[0])
+    for i, name in ((1, "parameters"), (2, "momentum"), (3, "16-bit mirror"), (4, "head fc")):
+        assert torch.equal(a[i], b[i]), name
+
+
 @pytest.mark.parametrize("variant", ["full", "seq", "bce_rw"])
 def test_train_with_public_data_vs_reference(variant):
     """Client.train_with_public_data (client.py:287-508) through the fused head trainer: iresnet18, 6 local + 14 public

@@ -491,6 +491,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
       if (mok) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
     }
+  GLDS_STAMP(4);                                        // (staged: conversions, statistics sums and LDS writes of this wave are issued)
   if (TPW > 1 && p.stats) {                             // this tile's partials join the workgroup's row in LDS (a region no DMA touches)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
@@ -527,7 +528,9 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         *reinterpret_cast<float4*>(z + (lane % LPR) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
+  GLDS_STAMP(5);
   __syncthreads();
+  GLDS_STAMP(6);
   constexpr int CPR = BN / 8;
   if constexpr (!FUSED) {
     for (int idx = tid; idx < PT * CPR; idx += NT) {

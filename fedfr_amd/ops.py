@@ -65,7 +65,7 @@ def _auto_splits(M: int, N: int, K: int) -> int:
     """split-K degree ``sgemm`` picks by itself: none while the output has >= 128 tiles of 64 x 64 or K is short; else enough slabs of >= 256 k
     (a multiple of 32) to put ~512 workgroups on the chip, at most 64, none of them empty."""
     tiles = -(-M // 64) * -(-N // 64)
-    if tiles >= 128 or K < 1024:
+    if tiles >= 128 or K < 1024 or (M * N) % 4:           # (sum_slabs adds 16-byte vectors: every slab must start on one)
         return 1
     s = max(1, min(64, K // 256, -(-512 // tiles)))
     chunk = -(-(-(-K // s)) // 32) * 32

@@ -627,6 +627,32 @@ def test_sgemm_splitk_slabs(M, N, K, tb, splits):
         assert relerr(slabs[z], (a[:, lo:hi].double() @ Bm[lo:hi].double()).float()) < 1e-5, z
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(128, 512, 8500, False), (256, 512, 85000, False), (128, 1000, 512, True), (64, 64, 1024, True), (37, 130, 3000, False), (36, 130, 3000, False)])
+def test_sgemm_auto_split_and_sum_slabs(M, N, K, tb):
+    """ops.sgemm with splits=0 owns the output: few tiles over a long reduction are split over K and summed in ascending slab order — equal to
+    sum_slabs() of the explicit slabs bit for bit, and to the fp64 product within the fp32 head tolerance; short / wide products stay unsplit."""
+    from fedfr_amd import ops
+    a, b = rnd((M, K), 11), rnd((N, K) if tb else (K, N), 12)
+    Bm = b.t() if tb else b
+    d = dev()
+    ad, bd = a.to(d), b.to(d)
+    got = ops.sgemm(ad, bd, trans_b=tb)
+    ns = ops._auto_splits(M, N, K)
+    assert got.shape == (M, N)
+    assert relerr(got, (a.double() @ Bm.double()).float()) < 1e-5
+    if ns > 1:
+        slabs = ops.sgemm(ad, bd, trans_b=tb, splits=ns)
+        assert slabs.shape[0] == ns
+        assert torch.equal(got, ops.sum_slabs(slabs))
+        ref = slabs[0].clone()
+        for z in range(1, ns):
+            ref += slabs[z]
+        assert relerr(got, ref) < 1e-6
+    else:
+        assert torch.equal(got, ops.sgemm(ad, bd, trans_b=tb, splits=1).reshape(M, N))
+    assert (ns > 1) == (K >= 1024 and -(-M // 64) * -(-N // 64) < 128 and M * N % 4 == 0)      # (37 x 130: slabs would not start on 16 bytes)
+
+
 @pytest.mark.parametrize("R,C,arc,nslab", [(128, 1000, False, 1), (128, 1000, True, 1), (33, 1000, False, 4), (5, 3000, True, 3), (9, 257, False, 2),
                                            (128, 8500, True, 1), (7, 16384, False, 2)])      # (round 5: rows of up to 16 384 classes — the sampled PartialFC head)
 def test_softmax_ce_fused_equals_three_kernels(R, C, arc, nslab):

@@ -26,6 +26,9 @@
 #ifndef GLDS_FUSED_ABLATE
 #define GLDS_FUSED_ABLATE 0      // timing ablations of the fused BN-backward epilogue (WRONG results): 1 no x loads, 2 no per-element pass, 4 no reduction
 #endif
+#ifndef GLDS_MFMA_STATS
+#define GLDS_MFMA_STATS 1  // forward (plain) launches of the 196-pixel tiles: BatchNorm partial sums of the staged output tile on the matrix cores (below)
+#endif
 #ifdef GLDS_SETPRIO
 #define GLDS_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -62,7 +65,7 @@ __device__ __forceinline__ void glds_wait_vmcnt() {
 }
 
 __device__ __forceinline__ void glds_store_out(bf16_t* dst, const uint4& v) { st16_out(dst, v); }
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1>   // TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1, bool PAPPLY = false>   // PAPPLY (FUSED only): also carries sphnet's PReLU-apply epilogue (p.bmom == 2: the OUTPUT becomes dz — a per-element pass no matrix-core formulation covers); TPW: image tiles a workgroup computes one after the other (2: half as many BatchNorm partial rows — one per workgroup, summed over its tiles and both wave rows — so that the channel-sliced BatchNorm pass can reduce them itself, bn_sliced.hip); BN_: output-channel tile; ONECHUNK: C == 64 (one channel chunk, single image buffer); FUSED: BN-backward reduction in the (dgrad) epilogue; tile = R_ image rows; NPA = LDS-DMA pieces (1 KiB = 8 image rows) per image buffer;
                                              // WN = 2: 4 waves, one per SIMD (112 x 64 wave tiles); WN = 4: 8 waves, two per SIMD (112 x 32)
 __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int stat_rows) {
   constexpr int PT = R_ * W_, BN = BN_, WM = 2, PW = W_ + 2, NW = WM * WN, NT = 64 * NW;
@@ -181,6 +184,14 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   }
 
   f32x4_t acc[TN][TM];
+  // MST (round 5): in-kernel stamps priced the forward epilogue at 4.2 us of a 29 us launch — 1.9 us of it VALU work on the accumulators (round to
+  // 16 bit, back to fp32, mask, sum, square-sum: ~7 operations x 56 values per lane at 4 clocks x 2 waves per SIMD) + 1.1 us of DPP row sums and
+  // 4-byte stores, all with the matrix cores idle.  The statistics are column sums of the STAGED tile Y (196 pixels x 128 channels, 16-bit, in LDS):
+  //   sum_m Y[m][n]   = (ones x Y)[.][n]          sum_m Y[m][n]^2 = diag(Y^T Y)[n]
+  // — wave w takes channels 16 w .. 16 w + 15: per 32-pixel step ONE transposed fragment (2 ds_read_b64_tr_b16) serves as A and B operand of the
+  // Gram MFMA and as B of the ones MFMA; 7 steps = 14 reads + 14 MFMAs per wave for what took ~300 VALU operations per lane.  Products of two
+  // 16-bit values are exact in fp32 and the accumulation is fp32 as before (another summation order).  One partial row per tile (was two).
+  constexpr bool MST = GLDS_MFMA_STATS && !FUSED && PT == 196 && BN == 16 * NW;
   float ssum[TN][4], ssq[TN][4];                        // BatchNorm partials of this wave's columns (one tile)
   float* sStat = reinterpret_cast<float*>(smem + NABUF * A_BYTES + NB * B_BYTES);     // TPW > 1: [2 wave rows][2 statistics][BN], the workgroup's running partial row
 
@@ -209,21 +220,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // FUSED: this thread's share of the BatchNorm input tile x[PT][BN] (same rows / columns as the output tile: chunk column c of rows rg,
-  // rg + RGF, ...) is fetched into registers NOW and rides through the K loop (28 VGPRs at 8 waves; the kernel has one workgroup per CU, so
-  // 256 are there).  The first version fetched it by LDS-DMA after the loop and paid the round trip plus a barrier in the open: the
-  // epilogue cost 13 us on a 28 us kernel, more than the separate reduction pass it replaces.  These loads are older than every LDS-DMA of
-  // the loop, VMEM returns in order, so the loop's counted vmcnt waits are unaffected.
+  // rg + RGF, ...) is fetched into registers right behind the prologue's DMA (below) and rides through the K loop (28 VGPRs at 8 waves; the kernel
+  // has one workgroup per CU, so 256 are there).  The first version fetched it by LDS-DMA after the loop and paid the round trip plus a barrier in
+  // the open: the epilogue cost 13 us on a 28 us kernel, more than the separate reduction pass it replaces.
   constexpr int CPRF = BN / 8, RGF = NT / CPRF, XN = FUSED ? (PT + RGF - 1) / RGF : 1;
   uint4 xr[XN];
-  if constexpr (FUSED && !XLATE) {
-    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
-    const int c_ = tid % CPRF, rg_ = tid / CPRF;
-#pragma unroll
-    for (int i = 0; i < XN; ++i) {
-      const int row = rg_ + i * RGF;
-      xr[i] = (GLDS_FUSED_ABLATE & 1) ? make_uint4(0, 0, 0, 0) : buf_load16(rsX, row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + c_ * 8)) * 2u : OOB);
-    }
-  }
   // prologue: image of chunk 0, weight tiles of taps 0..2; wait for the image and tap 0, fetch tap 0's first fragments
   const bool skip_pro = (GLDS_ABLATE & 8) && TPW > 1 && ti > 0;      // timing ablation: what the second tile's prologue costs (it computes on stale LDS contents)
   if (!skip_pro) {
@@ -232,8 +233,22 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   issue_b(RST ? 3 : 1, 0, 1, true);                      // RST walks the taps dx-major: (dy, dx) = (0,0), (1,0), (2,0), (0,1), ...
   issue_b(RST ? 6 : 2, 0, 2, true);
   }
+  // (round 5: the x loads are issued BEHIND the prologue's DMA — in front of it they delayed the first barrier by 1.1 us per launch, in-kernel stamps:
+  // VMEM returns in order — and the first counted wait leaves them in flight; the loop's waits retire them, long landed, with the DMA issued after them)
+  constexpr int XPRE = (FUSED && !XLATE) ? XN : 0;
+  if constexpr (FUSED && !XLATE) {
+    __builtin_amdgcn_sched_barrier(0);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
+    const int c_ = tid % CPRF, rg_ = tid / CPRF;
+#pragma unroll
+    for (int i = 0; i < XN; ++i) {
+      const int row = rg_ + i * RGF;
+      xr[i] = (GLDS_FUSED_ABLATE & 1) ? make_uint4(0, 0, 0, 0) : buf_load16(rsX, row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + c_ * 8)) * 2u : OOB);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
-  if (!skip_pro) glds_wait_vmcnt<2 * BP>();
+  if (!skip_pro) glds_wait_vmcnt<2 * BP + XPRE>();
   __builtin_amdgcn_s_barrier();
   GLDS_STAMP(1);
   if constexpr (RST) {
@@ -389,7 +404,9 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   // FUSED: the per-channel coefficients of the epilogue's reduction are requested HERE, in front of the drain below, as 16-byte buffer loads:
   // left to hipcc they became 62 dword loads each issued right before its first use (19 exposed waits = 10 of the epilogue's 11 us).
   // fc[a][h]: array a (mean, rstd, gamma, beta, alpha), channels n0 + c * 8 + 4 h .. + 3; fm / fr: mean / rstd of column n0 + tid.
-  float4 fc[FUSED ? 5 : 1][2];
+  constexpr bool MSTF = GLDS_MFMA_STATS && FUSED && PT == 196 && BN == 16 * NW;      // the fused epilogues' column sums on the matrix cores (below)
+  constexpr bool OLDF = FUSED && (PAPPLY || !MSTF);                                   // the per-element reduction pass is compiled in
+  float4 fc[OLDF ? 5 : 1][2];
   float fm = 0.f, fr = 0.f;
   auto load_coefs = [&](int z) {                            // z: zero (opaque in the several-tiles variant, so that nothing here is hoisted in front of the K loop)
     const unsigned cb = (unsigned)p.N * 4u;
@@ -416,7 +433,17 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     }
     if (!XLATE && tid < BN) { fm = p.bmean[n0 + tid + z]; fr = p.brstd[n0 + tid + z]; }     // (XLATE: read once, behind the tile loop)
   };
-  if constexpr (FUSED && !XLATE) load_coefs(0);
+  // MSTF (round 5, after MST above): the fused epilogues' column sums on the matrix cores as well.  The BatchNorm input tile X joins the staged
+  // tile in LDS (same layout, behind it) and per 32-pixel step one transposed fragment of each gives
+  //   sum dy = (ones x DY)[.][n]      sum dy * x = diag(DY^T X)[n]      (forward raw moments: + diag(DY^T DY))
+  // With a PReLU in front (p.balpha: dz = dy * (z <= 0 ? alpha : 1), z = x * sc + sh) the mask is not bilinear — but it is a THRESHOLD on x:
+  // z <= 0  <=>  sgn(sc) x <= T = -sh / |sc|  <=>  t16 - sgn(sc) x >= 0 with t16 = the largest fp16 <= T, and the fp16 difference of two fp16 values
+  // has the exact sign.  One packed FMA + one packed shift + one AND per PAIR of elements build DYPOS = (z > 0 ? dy : 0) on the fragment, and
+  //   sum dz = S(dypos) + alpha (S(dy) - S(dypos)),  sum dz * x likewise,  sum_{z <= 0} dy * z = sc (S(dy x) - S(dypos x)) + sh (S(dy) - S(dypos))
+  // (the bf16 build has no packed arithmetic on its storage type: it compares the two halves of a fragment register as fp32 against T itself — 7
+  // operations per pair instead of 3; sphnet's PReLU-apply form, whose OUTPUT is dz, keeps the per-element pass: PAPPLY instantiations).
+  const bool mstf = MSTF && !(PAPPLY && p.bmom == 2);
+  if constexpr (OLDF && !XLATE) { if (!mstf) load_coefs(0); }
   // drain the (zero-writing) tail DMAs before the staging buffer is reused
   glds_wait_vmcnt<0>();
   if constexpr (XLATE) {
@@ -429,7 +456,18 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       const int row = rg_ + i * RGF;
       xr[i] = buf_load16(rsX, row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + c_ * 8)) * 2u : OOB);
     }
-    load_coefs(z);
+    if constexpr (OLDF) { if (!mstf) load_coefs(z); }
+  }
+  // MSTF: this lane's channel (n0 + 16 wave + (lane & 15)) coefficients, requested now, used behind the MFMA chain
+  float cf[5] = {0.f, 1.f, 1.f, 0.f, 1.f};
+  if constexpr (MSTF) {
+    if (mstf) {
+      int z = 0;
+      if constexpr (TPW > 1) asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+      const int ch = n0 + (((tid + z) >> 6) << 4) + ((tid + z) & 15);
+      if (!p.bmom || p.balpha) { cf[0] = p.bmean[ch]; cf[1] = p.brstd[ch]; }
+      if (p.balpha) { cf[2] = p.bgamma ? p.bgamma[ch] : 1.f; cf[3] = p.bbeta ? p.bbeta[ch] : 0.f; cf[4] = p.balpha[ch]; }
+    }
   }
   __syncthreads();
   constexpr int XOFF = NABUF * A_BYTES;                 // FUSED: the weight ring becomes the reduction scratch of the epilogue
@@ -454,6 +492,10 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         esc_[ni][q] = p.esc[n]; esh_[ni][q] = p.esh[n]; eal_[ni][q] = p.ealpha ? p.ealpha[n] : 1.f;
       }
   }
+  // (two copies of the staging loop behind ONE uniform branch: with the test inside, every one of the 56 values per lane paid a scalar branch
+  // around the eval-mode affine — 62 s_cbranch in a phase that is pure overhead for the matrix cores)
+  auto stage_tile = [&](auto ESC_) {
+  constexpr bool ESC = decltype(ESC_)::value;
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -475,12 +517,12 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float a = acc[ni][mi][q];
-        if (has_esc) {                                       // eval-mode BatchNorm (+PReLU) of the output, on the fp32 accumulator
+        if constexpr (ESC) {                                 // eval-mode BatchNorm (+PReLU) of the output, on the fp32 accumulator
           a = a * esc_[ni][q] + esh_[ni][q];
           if (p.ealpha) a = a > 0.f ? a : eal_[ni][q] * a;
         }
         h[q] = f2bf(a);
-        if constexpr (!FUSED) {                            // (the fused instantiations leave their statistics in the reduction pass below, never these)
+        if constexpr (!FUSED && !MST) {                    // (the fused instantiations leave their statistics in the reduction pass below, never these)
           const float v = mok ? bf2f(h[q]) : 0.f;
           ssum[ni][q] += v;
           ssq[ni][q] += v * v;
@@ -491,8 +533,10 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
       if (mok) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
     }
+  };
+  if (has_esc) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
   GLDS_STAMP(4);                                        // (staged: conversions, statistics sums and LDS writes of this wave are issued)
-  if (TPW > 1 && p.stats) {                             // this tile's partials join the workgroup's row in LDS (a region no DMA touches)
+  if (!MST && TPW > 1 && p.stats) {                     // this tile's partials join the workgroup's row in LDS (a region no DMA touches)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -506,7 +550,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         }
       }
   }
-  if (TPW == 1 && p.stats) {
+  if (!MST && TPW == 1 && p.stats) {
     const int ntile = gridDim.x / p.nbn;
     float* prow_ = p.stats + (size_t)(bt * WM + wm) * 2 * p.N;
 #pragma unroll
@@ -528,11 +572,113 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         *reinterpret_cast<float4*>(z + (lane % LPR) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
+  constexpr int SXOFF = (PT * CST + 1023) & ~1023;
+  static_assert(!MSTF || 2 * SXOFF <= NABUF * A_BYTES + NB * B_BYTES, "staged tile + BatchNorm input tile must fit below the statistics row");
+  if constexpr (MSTF) {
+    if (mstf) {
+      int tz = tid;
+      if constexpr (XLATE) {
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        tz += z;
+      }
+      const int c = tz % CPRF, rg = tz / CPRF;
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        const int row = rg + i * RGF;
+        if ((i + 1) * RGF <= PT || row < PT) *reinterpret_cast<uint4*>(smem + SXOFF + row * CST + c * 16) = xr[i];
+      }
+    }
+  }
   GLDS_STAMP(5);
   __syncthreads();
   GLDS_STAMP(6);
   constexpr int CPR = BN / 8;
+  if constexpr (MST) {
+    // (indices behind an opaque zero when a workgroup loops over tiles: as tile-loop invariants they would be hoisted in front of the K loop and
+    // live through it — the two-tiles instantiation spilled with them)
+    int tidz = tid;
+    if constexpr (TPW > 1) {
+      int z;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+      tidz += z;
+    }
+    const int l15z = tidz & 15, lgz = (tidz >> 4) & 3, wavez = tidz >> 6;
+    if (!(TPW == 1 && (p.eadd || p.Cb2))) {
+      // plain tile: all LDS reads first, then the stores (the store helper is an asm statement the compiler will not move a load across)
+      constexpr int NIT = (PT * CPR + NT - 1) / NT;
+      uint4 v[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int idx = tidz + k * NT;
+        const int row = idx / CPR, c = idx - row * CPR;
+        if ((k + 1) * NT <= PT * CPR || idx < PT * CPR) v[k] = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int idx = tidz + k * NT;
+        const int row = idx / CPR, c = idx - row * CPR;
+        if ((k + 1) * NT <= PT * CPR || idx < PT * CPR) glds_store_out(p.Cb + (size_t)(m0 + row) * p.ldc + n0 + c * 8, v[k]);
+      }
+    }
+    if (p.stats) {
+      typedef __attribute__((address_space(3))) s16x4_t* lds_tr_p;
+      constexpr int KS = (PT + 31) / 32;
+      // lane (g = lane >> 4, li = lane & 15) reads 8 B of row 8 g + (li >> 2) (+ 4 for the second read), columns 4 (li & 3) .. + 3 of this wave's 16;
+      // the transposing read hands lane li column li's values of rows 8 g .. 8 g + 3 — a 16 x 16 x 32 operand fragment of Y^T / Y
+      const unsigned char* tb = sC + (8 * lgz + (l15z >> 2)) * CST + (wavez * 16 + 4 * (l15z & 3)) * 2;
+      f32x4_t gq = {0.f, 0.f, 0.f, 0.f}, gs = {0.f, 0.f, 0.f, 0.f};
+      s16x8_t one8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) one8[j] = FEDFR_FP16 ? (short)0x3c00 : (short)0x3f80;
+      const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, one8);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(tb + ks * 32 * CST));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(tb + ks * 32 * CST + 4 * CST));
+        if ((ks + 1) * 32 > PT) {                            // rows beyond the tile hold stale LDS contents: select zeros (PT % 4 == 0: a group of 4 rows is in or out)
+          const bool lo_ok = ks * 32 + 8 * lgz < PT, hi_ok = ks * 32 + 8 * lgz + 4 < PT;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { lo[j] = lo_ok ? lo[j] : (short)0; hi[j] = hi_ok ? hi[j] : (short)0; }
+        }
+        s16x8_t f8;
+        f8[0] = lo[0]; f8[1] = lo[1]; f8[2] = lo[2]; f8[3] = lo[3];
+        f8[4] = hi[0]; f8[5] = hi[1]; f8[6] = hi[2]; f8[7] = hi[3];
+        const bf16x8_t fr = __builtin_bit_cast(bf16x8_t, f8);
+        gq = MFMA16(fr, fr, gq);                               // Y^T Y: lane holds rows 4 g .. 4 g + 3 of column li
+        gs = MFMA16(ones, fr, gs);                             // every row = the column sums
+      }
+      // the diagonal of the 16 x 16 Gram block lives in the 16 lanes with (li >> 2) == g, register li & 3
+      const int qd = l15z & 3;
+      const float sq = qd == 0 ? gq[0] : qd == 1 ? gq[1] : qd == 2 ? gq[2] : gq[3];
+      if ((l15z >> 2) == lgz) {
+        const int col = wavez * 16 + l15z;
+        if constexpr (TPW == 1) {
+          float* prow_ = p.stats + (size_t)(bt * WM) * 2 * p.N + n0 + col;
+          prow_[0] = gs[0];
+          prow_[p.N] = sq;
+          prow_[2 * (size_t)p.N] = 0.f;                        // the tile's second row slot (the register path left one row per wave row)
+          prow_[3 * (size_t)p.N] = 0.f;
+        } else {
+          float* d = sStat + col;                              // the workgroup's running row: own column, no race, fixed order
+          d[0] = ti == 0 ? gs[0] : d[0] + gs[0];
+          d[BN] = ti == 0 ? sq : d[BN] + sq;
+        }
+      }
+      if constexpr (TPW == 1) {
+        // the BatchNorm finalize sums gemm_nt_stat_rows(M, N) partial rows (128-pixel tiling): zero the ones this tiling leaves
+        const int ntile = gridDim.x / p.nbn;
+        for (int row = ntile * WM + bt * WM + wm; row < stat_rows; row += ntile * WM)
+          if (lane < 2 * (BN / WN / 4)) {
+            constexpr int LPR = BN / WN / 4;
+            float* z = p.stats + (size_t)row * 2 * p.N + (lane / LPR) * p.N + n0 + wn * (BN / WN);
+            *reinterpret_cast<float4*>(z + (lane % LPR) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+      }
+    }
+  }
   if constexpr (!FUSED) {
+    if (!MST || (TPW == 1 && (p.eadd || p.Cb2)))
     for (int idx = tid; idx < PT * CPR; idx += NT) {
       const int row = idx / CPR, c = idx - row * CPR;
       uint4 v = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
@@ -570,8 +716,135 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       }
       glds_store_out(p.Cb + go, v);
     }
-  } else {
-    // ---- fused BN-backward reduction (ew_bn_bwd_reduce on this tile): thread owns chunk column c (8 channels) of rows rg, rg + RG, ...;
+  } else if (mstf) {
+    if constexpr (MSTF) {
+    int tidz = tid;
+    if constexpr (TPW > 1) {
+      int z;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+      tidz += z;
+    }
+    const int l15z = tidz & 15, lgz = (tidz >> 4) & 3, wavez = tidz >> 6;
+    const bool diag = (l15z >> 2) == lgz;
+    const int col = wavez * 16 + l15z;
+    {
+      constexpr int NIT = (PT * CPR + NT - 1) / NT;
+      uint4 v[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int idx = tidz + k * NT;
+        const int row = idx / CPR, c = idx - row * CPR;
+        if ((k + 1) * NT <= PT * CPR || idx < PT * CPR) v[k] = *reinterpret_cast<const uint4*>(sC + row * CST + c * 16);
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int idx = tidz + k * NT;
+        const int row = idx / CPR, c = idx - row * CPR;
+        if ((k + 1) * NT <= PT * CPR || idx < PT * CPR) glds_store_out(p.Cb + (size_t)(m0 + row) * p.ldc + n0 + c * 8, v[k]);
+      }
+    }
+    typedef __attribute__((address_space(3))) s16x4_t* lds_tr_p;
+    constexpr int KS = (PT + 31) / 32;
+    const unsigned char* tb = sC + (8 * lgz + (l15z >> 2)) * CST + (wavez * 16 + 4 * (l15z & 3)) * 2;
+    f32x4_t g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f}, g3 = {0.f, 0.f, 0.f, 0.f}, g4 = {0.f, 0.f, 0.f, 0.f};
+    const bool prelu = p.balpha != nullptr;
+    float Tf = 0.f, nsf = 0.f;                                // bf16 build: the fp32 threshold and -sgn(sc)
+    // PReLU threshold of this lane's channel (see above): z = x * sc + sh, sc = gamma * rstd, sh = beta - mean * sc
+    const float sc_ = cf[2] * cf[1], sh_ = cf[3] - cf[0] * sc_;
+    unsigned nsgn2 = 0, t162 = 0;                             // (-sgn(sc), -sgn(sc)) and (t16, t16) as packed fp16
+    if (prelu) {
+      const float T = -sh_ / fabsf(sc_);
+      unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)T);      // round to nearest ...
+      const float hf = (float)__builtin_bit_cast(_Float16, (unsigned short)hb);
+      if (hf > T) hb = hb == 0u ? 0x8001u : ((hb & 0x8000u) ? hb + 1u : hb - 1u);   // ... then down to the largest fp16 <= T
+      if (sc_ == 0.f) hb = sh_ <= 0.f ? 0x7c00u : 0xfc00u;     // z = sh everywhere: always / never in the PReLU's negative branch
+      t162 = hb | (hb << 16);
+      nsgn2 = sc_ < 0.f ? 0x3c003c00u : 0xbc00bc00u;
+      Tf = sc_ == 0.f ? (sh_ <= 0.f ? __builtin_inff() : -__builtin_inff()) : T;
+      nsf = sc_ < 0.f ? 1.f : -1.f;
+    }
+    s16x8_t one8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one8[j] = FEDFR_FP16 ? (short)0x3c00 : (short)0x3f80;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, one8);
+    const bool mom = p.bmom != 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(tb + ks * 32 * CST));
+      s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(tb + ks * 32 * CST + 4 * CST));
+      s16x4_t xl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(tb + SXOFF + ks * 32 * CST));
+      s16x4_t xh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(tb + SXOFF + ks * 32 * CST + 4 * CST));
+      if ((ks + 1) * 32 > PT) {
+        const bool lo_ok = ks * 32 + 8 * lgz < PT, hi_ok = ks * 32 + 8 * lgz + 4 < PT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lo[j] = lo_ok ? lo[j] : (short)0; hi[j] = hi_ok ? hi[j] : (short)0;
+          xl[j] = lo_ok ? xl[j] : (short)0; xh[j] = hi_ok ? xh[j] : (short)0;
+        }
+      }
+      s16x8_t d8, x8;
+      d8[0] = lo[0]; d8[1] = lo[1]; d8[2] = lo[2]; d8[3] = lo[3]; d8[4] = hi[0]; d8[5] = hi[1]; d8[6] = hi[2]; d8[7] = hi[3];
+      x8[0] = xl[0]; x8[1] = xl[1]; x8[2] = xl[2]; x8[3] = xl[3]; x8[4] = xh[0]; x8[5] = xh[1]; x8[6] = xh[2]; x8[7] = xh[3];
+      const bf16x8_t dfr = __builtin_bit_cast(bf16x8_t, d8), xfr = __builtin_bit_cast(bf16x8_t, x8);
+      g1 = MFMA16(ones, dfr, g1);                            // every row: sum over the pixels of dy (forward: y)
+      g2 = MFMA16(dfr, xfr, g2);                             // diagonal: sum dy * x
+      if (mom) g3 = MFMA16(dfr, dfr, g3);                    // forward raw moments: sum y * y
+      if (prelu) {
+#if FEDFR_FP16
+        typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
+        // e = t16 - sgn x per element (exact sign); sign bit set <=> z > 0
+        const _Float16 ns1 = __builtin_bit_cast(_Float16, (unsigned short)(nsgn2 & 0xffffu)), tt1 = __builtin_bit_cast(_Float16, (unsigned short)(t162 & 0xffffu));
+        const h8_t ns8 = {ns1, ns1, ns1, ns1, ns1, ns1, ns1, ns1}, tt8 = {tt1, tt1, tt1, tt1, tt1, tt1, tt1, tt1};
+        const h8_t e8 = __builtin_elementwise_fma(__builtin_bit_cast(h8_t, x8), ns8, tt8);
+        const s16x8_t m8 = __builtin_bit_cast(s16x8_t, e8) >> 15;
+        const s16x8_t pu = d8 & m8;
+#else
+        // bf16 = the upper half of an fp32: e = T - sgn x on both halves of a register as fp32 (exact sign: an fp32 FMA of a bf16 value rounds once)
+        typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+        const u4_t du = __builtin_bit_cast(u4_t, d8), xu = __builtin_bit_cast(u4_t, x8);
+        u4_t pw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float el = __builtin_fmaf(__uint_as_float(xu[j] << 16), nsf, Tf), eh = __builtin_fmaf(__uint_as_float(xu[j] & 0xffff0000u), nsf, Tf);
+          const unsigned ml = (unsigned)((int)__float_as_uint(el) >> 31), mh = (unsigned)((int)__float_as_uint(eh) >> 31);
+          pw[j] = du[j] & ((ml & 0xffffu) | (mh & 0xffff0000u));
+        }
+        const s16x8_t pu = __builtin_bit_cast(s16x8_t, pw);
+#endif
+        const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pu);
+        g3 = MFMA16(ones, pfr, g3);                          // sum dypos
+        g4 = MFMA16(pfr, xfr, g4);                           // diagonal: sum dypos * x
+      }
+    }
+    const int qd = l15z & 3;
+    float t0 = g1[0];
+    float t1 = qd == 0 ? g2[0] : qd == 1 ? g2[1] : qd == 2 ? g2[2] : g2[3];
+    float t2 = qd == 0 ? g3[0] : qd == 1 ? g3[1] : qd == 2 ? g3[2] : g3[3];
+    if (prelu) {
+      const float sp = g3[0], spx = qd == 0 ? g4[0] : qd == 1 ? g4[1] : qd == 2 ? g4[2] : g4[3];
+      const float sn = t0 - sp, snx = t1 - spx;              // sums over the elements with z <= 0
+      t0 = sp + cf[4] * sn;
+      t1 = spx + cf[4] * snx;
+      t2 = sc_ * snx + sh_ * sn;
+    }
+    const float fm_ = cf[0], fr_ = cf[1];
+    if (diag) {
+      if constexpr (XLATE) {
+        float* d = sStat + col;
+        d[0] = ti == 0 ? t0 : d[0] + t0;
+        d[BN] = ti == 0 ? t1 : d[BN] + t1;
+        d[2 * BN] = ti == 0 ? t2 : d[2 * BN] + t2;
+      } else {
+        float* o = p.bpart + (size_t)bt * 3 * p.N + n0 + col;
+        o[0] = t0;
+        o[p.N] = p.bmom ? t1 : fr_ * (t1 - fm_ * t0);
+        o[2 * (size_t)p.N] = t2;
+      }
+    }
+    }
+  } else if constexpr (OLDF) {
+    // ---- fused BN-backward reduction (ew_bn_bwd_reduce on this tile), per-element form (PAPPLY instantiations: sphnet's PReLU-apply epilogue):
+    // thread owns chunk column c (8 channels) of rows rg, rg + RG, ...;
     // dy from the staged tile, x from the registers loaded before the K loop.  The workgroup owns the CU while it does this, so the pass is
     // kept to the fewest VALU operations: it accumulates sum dz and sum dz * x on the RAW x (one FMA and one add per element without
     // PReLU; with PReLU its input z = x * scale + shift costs one more FMA, a compare and three selects), and the tile's
@@ -708,7 +981,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       const int nrows = gridDim.x / p.nbn;
       for (int i = tid; i < 2 * BN; i += NT) {
         const int stat = i / BN, col = i - stat * BN;
-        p.stats[(size_t)btw * 2 * p.N + (size_t)stat * p.N + n0 + col] = sStat[i] + sStat[2 * BN + i];
+        p.stats[(size_t)btw * 2 * p.N + (size_t)stat * p.N + n0 + col] = MST ? sStat[i] : sStat[i] + sStat[2 * BN + i];
       }
       // rows the finalize kernel's row count (128-pixel tiling) has beyond ours: zeros
       for (int row = nrows + btw; row < stat_rows; row += nrows)
@@ -721,7 +994,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   GLDS_STAMP(3);
 }
 
-template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1>
+template <int W_, int R_, int NPA, int WN, bool FUSED, int BN_ = 128, bool ONECHUNK = false, int TPW = 1, bool PAPPLY = false>
 static int launch_glds(GemmNT p, hipStream_t st) {
   constexpr int PT = R_ * W_;
   FEDFR_REQUIRE(p.N % BN_ == 0 && (ONECHUNK ? p.C == 64 : p.C % 128 == 0) && p.H == W_ && p.W == W_ && p.M % (W_ * W_) == 0 && p.K == 9 * p.C && p.ldc % 8 == 0,
@@ -732,6 +1005,7 @@ static int launch_glds(GemmNT p, hipStream_t st) {
     static_assert(!FUSED || (size_t)(128 * WN / 16) * 3 * 128 * 4 <= 4 * (size_t)128 * 128, "reduction scratch must fit the weight ring");
     FEDFR_REQUIRE(!p.stats, "conv3x3_glds: a fused-epilogue launch leaves reduction rows (bpart), not forward statistics");
     FEDFR_REQUIRE(p.bmom != 2 || p.balpha, "conv3x3_glds: the PReLU-apply epilogue needs the slopes");
+    FEDFR_REQUIRE(p.bmom != 2 || PAPPLY, "conv3x3_glds: the PReLU-apply epilogue lives in the PAPPLY instantiations");
     if (p.bwd_fused) *p.bwd_fused = p.M / PT / TPW;
   }
   p.nbn = p.N / BN_;
@@ -741,10 +1015,10 @@ static int launch_glds(GemmNT p, hipStream_t st) {
   static_assert(lds >= (size_t)PT * (BN_ * 2 + 16) && lds <= 160 * 1024, "LDS budget");
   static PerDeviceOnce attr_once;     // hipFuncSetAttribute is per device (a Server process may drive several)
   attr_once.run([&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW, PAPPLY>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   ProfScope prof(W_ == 14 ? 12 : (W_ == 28 ? 13 : 15),   /* slot 15: 56x56 and 112x112 */ 2.0 * p.M * p.N * (double)p.K, st, gemm_nt_alg_bytes(p, 1));
-  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
+  hipLaunchKernelGGL((conv3x3_glds_kernel<W_, R_, NPA, WN, FUSED, BN_, ONECHUNK, TPW, PAPPLY>), dim3(ntile * p.nbn), dim3(128 * WN), lds, st, p, gemm_nt_stat_rows(p.M, p.N));
   FEDFR_LAUNCH_CHECK("conv3x3_glds");
   return FEDFR_OK;
 }

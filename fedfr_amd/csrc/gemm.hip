@@ -409,6 +409,9 @@ static int gemm_nt_launch_one(GemmNT p, int splits, hipStream_t st) {
       if (p.C == 128 && p.N == 64) return launch_conv_glds_w56_c128_n64(p, st);
     }
     if (p.H == p.W && (p.W == 14 || p.W == 28) && p.N % 128 == 0 && p.C % 128 == 0 && p.M % (p.H * p.W) == 0) {
+      if (p.bpart && p.ldc == p.N && p.bmom == 2)         // sphnet: PReLU-apply epilogue
+        return p.W == 14 ? launch_conv_glds8_fused_w14_papply(p, st)
+                         : (gemm_nt_fused28_two_tiles(p.M) && !p.stats ? launch_conv_glds8_fused_w28s_papply(p, st) : launch_conv_glds8_fused_w28_papply(p, st));
       if (p.bpart && p.ldc == p.N)
         return p.W == 14 ? launch_conv_glds8_fused_w14(p, st)
                          : (gemm_nt_fused28_two_tiles(p.M) && !p.stats ? launch_conv_glds8_fused_w28s(p, st) : launch_conv_glds8_fused_w28(p, st));

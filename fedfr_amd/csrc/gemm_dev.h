@@ -63,6 +63,9 @@ int launch_conv_c64p(GemmNT p, hipStream_t st);
 int launch_conv_glds8_fused_w14(GemmNT p, hipStream_t st); // conv_glds8_fused_w14.hip  + BN-backward reduction epilogue
 int launch_conv_glds8_fused_w28(GemmNT p, hipStream_t st); // conv_glds8_fused_w28.hip
 int launch_conv_glds8_fused_w28s(GemmNT p, hipStream_t st); // conv_glds8_fused_w28s.hip
+int launch_conv_glds8_fused_w14_papply(GemmNT p, hipStream_t st);    // conv_glds8_fused_papply.hip: the three above with sphnet's PReLU-apply epilogue (bmom == 2)
+int launch_conv_glds8_fused_w28_papply(GemmNT p, hipStream_t st);
+int launch_conv_glds8_fused_w28s_papply(GemmNT p, hipStream_t st);
 // gemm_nt_glds.hip: the register-staged NT kernel's shapes with both operands fetched by LDS-DMA into a ring of stages
 extern int g_nt_glds;
 bool gemm_nt_glds_applies(const GemmNT& p, int BM, int splits);

@@ -27,6 +27,9 @@ ProfScope::~ProfScope() {}
 #ifndef PROBE_W
 #define PROBE_W 14
 #endif
+#ifndef PROBE_FUSED
+#define PROBE_FUSED 0      // 1: the dgrad instantiation with the BatchNorm-backward reduction in its epilogue (sums of dy and dy * x; no PReLU), 2: the same with PReLU slopes
+#endif
 
 int main(int argc, char** argv) {
   const int imgs = 128, C = argc > 1 ? atoi(argv[1]) : 256, N = C, W = PROBE_W;
@@ -54,6 +57,18 @@ int main(int argc, char** argv) {
   p.cpt = C / 64; p.Cb = Cb; p.ldc = N; p.stats = stats; p.ksteps_total = K / 64; p.ksteps_per_split = K / 64;
   p.a_bytes = (unsigned)((size_t)M * C * 2); p.b_bytes = (unsigned)((size_t)N * K * 2);
   p.dbg = dbg;
+#if PROBE_FUSED
+  bf16_t* X;
+  float *coef, *bpart;
+  CK(hipMalloc(&X, (size_t)M * N * 2));
+  CK(hipMemcpy(X, ha.data(), (size_t)M * N * 2, hipMemcpyHostToDevice));     // (C == N: the image pattern serves as the BatchNorm input)
+  CK(hipMalloc(&coef, (size_t)5 * N * 4));
+  std::vector<float> hc((size_t)5 * N, 0.5f);
+  CK(hipMemcpy(coef, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&bpart, (size_t)(M / 196) * 3 * N * 4));
+  p.stats = nullptr; p.bx = X; p.bmean = coef; p.brstd = coef + N; p.bgamma = coef + 2 * N; p.bbeta = coef + 3 * N; p.bpart = bpart;
+  p.balpha = PROBE_FUSED == 2 ? coef + 4 * N : nullptr;
+#endif
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0, e1;
@@ -61,9 +76,9 @@ int main(int argc, char** argv) {
   const int reps = 50;
   auto launch = [&]() {
 #if PROBE_W == 14
-    return launch_glds<14, 14, 32, 4, false>(p, st);
+    return launch_glds<14, 14, 32, 4, PROBE_FUSED != 0>(p, st);
 #else
-    return launch_glds<28, 7, 40, 4, false, 128, false, 2>(p, st);
+    return launch_glds<28, 7, 40, 4, PROBE_FUSED != 0, 128, false, 2>(p, st);
 #endif
   };
   for (int i = 0; i < 10; ++i) if (launch()) { printf("launch refused\n"); return 1; }
@@ -74,7 +89,7 @@ int main(int argc, char** argv) {
   CK(hipStreamSynchronize(st));
   float ms = 0.f;
   CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("conv3x3_glds<%d> %d -> %d channels, %d images: %.2f us per launch back to back (HIP events over %d launches)\n", W, C, N, imgs, ms * 1e3f / reps, reps);
+  printf("conv3x3_glds<%d, fused %d, GLDS_MFMA_STATS %d> %d -> %d channels, %d images: %.2f us per launch back to back (HIP events over %d launches)\n", W, PROBE_FUSED, GLDS_MFMA_STATS, C, N, imgs, ms * 1e3f / reps, reps);
   std::vector<unsigned long long> h((size_t)nwg * 16);
   CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
   int used = 0;

@@ -233,22 +233,26 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   issue_b(RST ? 3 : 1, 0, 1, true);                      // RST walks the taps dx-major: (dy, dx) = (0,0), (1,0), (2,0), (0,1), ...
   issue_b(RST ? 6 : 2, 0, 2, true);
   }
-  // (round 5: the x loads are issued BEHIND the prologue's DMA — in front of it they delayed the first barrier by 1.1 us per launch, in-kernel stamps:
-  // VMEM returns in order — and the first counted wait leaves them in flight; the loop's waits retire them, long landed, with the DMA issued after them)
+  // (round 5) Where the x loads go: in front of the prologue's DMA they delayed the first barrier by 1.1 us per launch, right behind it still by
+  // 0.8 us (in-kernel stamps: the eight waves' requests share one queue, 57 KB of x in front of the last wave's weights).  They are issued at the
+  // END of the first tap (x_loads below), when only the loop's 16 KB per tap are in flight, and the counted waits of taps 1 and 2 leave them out.
   constexpr int XPRE = (FUSED && !XLATE) ? XN : 0;
-  if constexpr (FUSED && !XLATE) {
-    __builtin_amdgcn_sched_barrier(0);
-    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
-    const int c_ = tid % CPRF, rg_ = tid / CPRF;
+  static_assert(XPRE == 0 || RST, "the fused instantiations run the padded-raster loop");
+  auto x_loads = [&]() {
+    if constexpr (XPRE > 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.bx, (unsigned)((size_t)p.M * p.N * 2));
+      const int c_ = tid % CPRF, rg_ = tid / CPRF;
 #pragma unroll
-    for (int i = 0; i < XN; ++i) {
-      const int row = rg_ + i * RGF;
-      xr[i] = (GLDS_FUSED_ABLATE & 1) ? make_uint4(0, 0, 0, 0) : buf_load16(rsX, row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + c_ * 8)) * 2u : OOB);
+      for (int i = 0; i < XN; ++i) {
+        const int row = rg_ + i * RGF;
+        xr[i] = (GLDS_FUSED_ABLATE & 1) ? make_uint4(0, 0, 0, 0) : buf_load16(rsX, row < PT ? ((unsigned)(m0 + row) * (unsigned)p.N + (unsigned)(n0 + c_ * 8)) * 2u : OOB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  };
   bf16x8_t f0a[TM], f0b[TN], f1a[TM], f1b[TN];
-  if (!skip_pro) glds_wait_vmcnt<2 * BP + XPRE>();
+  if (!skip_pro) glds_wait_vmcnt<2 * BP>();
   __builtin_amdgcn_s_barrier();
   GLDS_STAMP(1);
   if constexpr (RST) {
@@ -299,7 +303,12 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               // 1 DS read
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (!(GLDS_ABLATE & 17)) { if (!ONECHUNK && (it == 1 || it == 2)) glds_wait_vmcnt<BP + AP>(); else glds_wait_vmcnt<BP>(); }
+          if (!(GLDS_ABLATE & 17)) {
+            if (!ONECHUNK && (it == 1 || it == 2)) {
+              if (XPRE > 0 && h == 0 && cc2 == 0) glds_wait_vmcnt<BP + AP + XPRE>();      // (the x tile, requested at the end of tap 0, stays in flight)
+              else glds_wait_vmcnt<BP + AP>();
+            } else glds_wait_vmcnt<BP>();
+          }
           if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
           // ---- second half: k-step 1 MFMAs; the next tap's new k-step 0 fragments and this tap's DMA issue between them
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
             if (i < BP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // 1 VMEM (LDS-DMA piece)
           }
           __builtin_amdgcn_sched_barrier(0);
+          if (XPRE > 0 && it == 0 && h == 0 && cc2 == 0) x_loads();
           bbuf = nb;
         };
         tap_body(std::integral_constant<int, 0>{}); tap_body(std::integral_constant<int, 1>{}); tap_body(std::integral_constant<int, 2>{});

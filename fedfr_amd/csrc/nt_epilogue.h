@@ -1,5 +1,6 @@
 // Output stage shared by the NT kernels (gemm.hip: register-staged operands; gemm_nt_glds.hip: LDS-DMA operand ring).
 #pragma once
+#include <type_traits>
 #include "gemm_dev.h"
 
 // acc[ni][mi][reg]: n = wn*(BN/WN)+ni*16+lg*4+reg ; m = wm*(BM/WM)+mi*16+l15.  `smem` is reused as the staging tile: every wave must be
@@ -31,25 +32,33 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4_t (&acc)[BN /
   for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
     for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
+  // (two copies of the staging loop behind one uniform branch: dgrad / fc launches carry no statistics, and the conversions back to fp32, adds and
+  // FMAs of the sums are VALU time the matrix cores sit through)
+  auto stage_tile = [&](auto ST_) {
+    constexpr bool ST = decltype(ST_)::value;
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
+    for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-      const int ml = wm * (BM / WM) + mi * 16 + l15;
-      const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
-      bf16_t h[4];
+      for (int mi = 0; mi < TM; ++mi) {
+        const int ml = wm * (BM / WM) + mi * 16 + l15;
+        const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
+        bf16_t h[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        h[q] = f2bf(acc[ni][mi][q]);
-        const float v = bf2f(h[q]);
-        ssum[ni][q] += v;
-        ssq[ni][q] += v * v;
+        for (int q = 0; q < 4; ++q) {
+          h[q] = f2bf(acc[ni][mi][q]);
+          if constexpr (ST) {
+            const float v = bf2f(h[q]);
+            ssum[ni][q] += v;
+            ssq[ni][q] += v * v;
+          }
+        }
+        uint2 pk;
+        pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+        *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
       }
-      uint2 pk;
-      pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-      pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-      *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
-    }
+  };
+  if (p.stats) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
   if (p.stats) {
     float* prow = p.stats + (size_t)(bm * WM + wm) * 2 * p.N;
 #pragma unroll

@@ -479,7 +479,10 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       if (p.balpha) { cf[2] = p.bgamma ? p.bgamma[ch] : 1.f; cf[3] = p.bbeta ? p.bbeta[ch] : 0.f; cf[4] = p.balpha[ch]; }
     }
   }
-  __syncthreads();
+  // every wave is past its last fragment read (LDS only: __syncthreads() would also wait for the x / coefficient loads just issued — vmcnt(7) in the
+  // several-tiles variant, whose x tile was requested a few instructions ago)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   constexpr int XOFF = NABUF * A_BYTES;                 // FUSED: the weight ring becomes the reduction scratch of the epilogue
 
   GLDS_STAMP(2);
@@ -541,7 +544,16 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       uint2 pk;
       pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
       pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-      if (mok) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
+      if constexpr (XLATE) {
+        // inline asm on purpose: the several-tiles fused variant has just requested its x tile, and hipcc — which cannot see that the asm waits of
+        // the K loop retired every LDS-DMA — puts a counted vmcnt wait in front of each LDS store it emits itself: 5 of the 7 x loads, in the open
+        typedef __attribute__((ext_vector_type(2))) unsigned st8_u2_t;
+        const st8_u2_t pv = {pk.x, pk.y};
+        const unsigned sadr = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(sC + ml * CST + nl * 2));
+        if (mok) asm volatile("ds_write_b64 %0, %1" ::"v"(sadr), "v"(pv) : "memory");
+      } else {
+        if (mok) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
+      }
     }
   };
   if (has_esc) stage_tile(std::true_type{}); else stage_tile(std::false_type{});
@@ -601,6 +613,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     }
   }
   GLDS_STAMP(5);
+  if constexpr (XLATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the asm staging writes above)
   __syncthreads();
   GLDS_STAMP(6);
   constexpr int CPR = BN / 8;
@@ -737,6 +750,26 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     const int l15z = tidz & 15, lgz = (tidz >> 4) & 3, wavez = tidz >> 6;
     const bool diag = (l15z >> 2) == lgz;
     const int col = wavez * 16 + l15z;
+    // (the coefficient arithmetic comes BEFORE the copy-out: vmcnt counts loads and stores on gfx9 and they retire out of order with each other,
+    // so a wait for the coefficient loads placed behind the tile's stores is a vmcnt(0) that sits out the write-through stores — ~1 us, asm-checked)
+    const bool prelu = p.balpha != nullptr;
+    float Tf = 0.f, nsf = 0.f;                                // bf16 build: the fp32 threshold and -sgn(sc)
+    // PReLU threshold of this lane's channel (see above): z = x * sc + sh, sc = gamma * rstd, sh = beta - mean * sc
+    const float sc_ = cf[2] * cf[1], sh_ = cf[3] - cf[0] * sc_;
+    unsigned nsgn2 = 0, t162 = 0;                             // (-sgn(sc), -sgn(sc)) and (t16, t16) as packed fp16
+    if (prelu) {
+      const float T = -sh_ / fabsf(sc_);
+      unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)T);      // round to nearest ...
+      const float hf = (float)__builtin_bit_cast(_Float16, (unsigned short)hb);
+      if (hf > T) hb = hb == 0u ? 0x8001u : ((hb & 0x8000u) ? hb + 1u : hb - 1u);   // ... then down to the largest fp16 <= T
+      if (sc_ == 0.f) hb = sh_ <= 0.f ? 0x7c00u : 0xfc00u;     // z = sh everywhere: always / never in the PReLU's negative branch
+      t162 = hb | (hb << 16);
+      nsgn2 = sc_ < 0.f ? 0x3c003c00u : 0xbc00bc00u;
+      Tf = sc_ == 0.f ? (sh_ <= 0.f ? __builtin_inff() : -__builtin_inff()) : T;
+      nsf = sc_ < 0.f ? 1.f : -1.f;
+    }
+    asm volatile("" ::"v"(t162), "v"(nsgn2), "v"(sc_), "v"(sh_), "v"(Tf), "v"(nsf), "v"(cf[0]), "v"(cf[1]), "v"(cf[4]));     // (materialised here)
+    __builtin_amdgcn_sched_barrier(0);
     {
       constexpr int NIT = (PT * CPR + NT - 1) / NT;
       uint4 v[NIT];
@@ -757,22 +790,6 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     constexpr int KS = (PT + 31) / 32;
     const unsigned char* tb = sC + (8 * lgz + (l15z >> 2)) * CST + (wavez * 16 + 4 * (l15z & 3)) * 2;
     f32x4_t g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f}, g3 = {0.f, 0.f, 0.f, 0.f}, g4 = {0.f, 0.f, 0.f, 0.f};
-    const bool prelu = p.balpha != nullptr;
-    float Tf = 0.f, nsf = 0.f;                                // bf16 build: the fp32 threshold and -sgn(sc)
-    // PReLU threshold of this lane's channel (see above): z = x * sc + sh, sc = gamma * rstd, sh = beta - mean * sc
-    const float sc_ = cf[2] * cf[1], sh_ = cf[3] - cf[0] * sc_;
-    unsigned nsgn2 = 0, t162 = 0;                             // (-sgn(sc), -sgn(sc)) and (t16, t16) as packed fp16
-    if (prelu) {
-      const float T = -sh_ / fabsf(sc_);
-      unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)T);      // round to nearest ...
-      const float hf = (float)__builtin_bit_cast(_Float16, (unsigned short)hb);
-      if (hf > T) hb = hb == 0u ? 0x8001u : ((hb & 0x8000u) ? hb + 1u : hb - 1u);   // ... then down to the largest fp16 <= T
-      if (sc_ == 0.f) hb = sh_ <= 0.f ? 0x7c00u : 0xfc00u;     // z = sh everywhere: always / never in the PReLU's negative branch
-      t162 = hb | (hb << 16);
-      nsgn2 = sc_ < 0.f ? 0x3c003c00u : 0xbc00bc00u;
-      Tf = sc_ == 0.f ? (sh_ <= 0.f ? __builtin_inff() : -__builtin_inff()) : T;
-      nsf = sc_ < 0.f ? 1.f : -1.f;
-    }
     s16x8_t one8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) one8[j] = FEDFR_FP16 ? (short)0x3c00 : (short)0x3f80;
@@ -976,6 +993,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
   }
   if (TPW > 1) __syncthreads();                         // the staged output tile has been read: the next tile's image may land on it
   }   // tiles of this workgroup
+  GLDS_STAMP(7);
   if constexpr (XLATE) {
     if (tid < BN) {
       const float t0 = sStat[tid], t1 = sStat[BN + tid], t2 = sStat[2 * BN + tid];

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
   int used = 0;
   while (used < nwg && h[(size_t)used * 16 + 1]) ++used;
   unsigned long long t_first = ~0ull, t_last = 0;
-  std::vector<double> ph[3], ep[4], entry, exit_, mhz;
+  std::vector<double> ph[3], ep[4], entry, exit_, mhz, fin;
   for (int b = 0; b < used; ++b) {
     const unsigned long long* r = &h[(size_t)b * 16];
     t_first = std::min(t_first, r[1]);
@@ -107,6 +107,7 @@ int main(int argc, char** argv) {
     // epilogue split: loop end (2) -> staged (4) -> statistics rows written (5) -> behind the barrier (6) -> tile stored (3)
     const int order[5] = {2, 4, 5, 6, 3};
     for (int i = 0; i < 4; ++i) ep[i].push_back((double)(r[2 * order[i + 1] + 1] - r[2 * order[i] + 1]) * 0.01);
+    fin.push_back((double)(r[7] - r[15]) * 0.01);
     mhz.push_back((double)(r[4] - r[2]) / ((double)(r[5] - r[3]) * 0.01));      // shader-clock ticks per microsecond over the K loop
     entry.push_back((double)(r[1] - t_first) * 0.01);
     exit_.push_back((double)(t_last - r[7]) * 0.01);
@@ -124,6 +125,7 @@ int main(int argc, char** argv) {
   stat("  statistics rows (row sums, stores)", ep[1]);
   stat("  barrier", ep[2]);
   stat("  tile LDS -> global", ep[3]);
+  stat("  (of it: behind the tile loop, final rows)", fin);
   stat("exit before the launch's last exit", exit_);
   stat("s_memtime ticks per us over the K loop", mhz);
   return 0;

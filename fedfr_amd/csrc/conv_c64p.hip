@@ -21,10 +21,14 @@
 // (an LDS-DMA instruction writes 1 KiB linearly), exactly as in conv_glds_impl.h.
 #include <algorithm>
 #include "gemm_dev.h"
+#include "epi_mfma.h"
 
 int g_conv_c64p = 1;   // option "conv_c64p"
+#ifndef C64P_MFMA_STATS
+#define C64P_MFMA_STATS 1   // BatchNorm sums of the epilogue on the matrix cores (epi_mfma.h) instead of ~4-9 VALU operations per output element
+#endif
 #ifndef C64P_ABLATE
-#define C64P_ABLATE 0   // timing experiments only (results are WRONG with any bit set): 1 no per-tile image DMA, 2 no output stores, 4 no MFMA loop
+#define C64P_ABLATE 0   // timing experiments only (results are WRONG with any bit set): 1 no per-tile image DMA, 2 no output stores, 4 no MFMA loop, 8 no statistics arithmetic in the staging, 16 no BatchNorm-backward sums in the copy-out
 #endif
 
 namespace {
@@ -135,10 +139,34 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
 #pragma unroll
     for (int q = 0; q < 4; ++q) ssum[ni][q] = ssq[ni][q] = 0.f;
 
-  // BWD: this thread stores chunk (tid & 7) = channels 8 (tid & 7) .. + 7 of rows tid / 8 + 32 i of EVERY tile: 8 running sums per quantity
+  // MST (round 5): with ONE wave per SIMD nothing covers the epilogue's VALU work — a timing build without the statistics arithmetic runs the
+  // 112x112 layer in 114 instead of 134 us forward, 105 instead of 148 us in the dgrad with the BatchNorm-backward sums.  They are column sums of
+  // the staged tile (and of its products with the BatchNorm input tile): on the matrix cores (epi_mfma.h) wave w takes channels 16 w .. 16 w + 15,
+  // per 32-pixel step one transposed fragment of the staged tile (BWD: and one of the x tile, which the copy-out threads park in the image buffer
+  // this tile has just finished with), accumulators persistent over the tiles of the workgroup.  LDS accesses are inline asm (the next tile's
+  // LDS-DMA is in flight; hipcc would drain it in front of every LDS access it can see), software-pipelined two steps deep.
+  // Measured in the step (profiles/r05_ab_c64p_mfma_stats_v1.txt): forward 39.7 -> 37.6 us (56x56) / 131 -> 126 us (112x112), PReLU dgrad 56.0 -> 46.9 us,
+  // plain dgrad 143 -> 141 us at 112x112 but 42.3 -> 43.2 us at 56x56 (its 4 VALU operations per element cost what the x tile's trip through
+  // LDS + one more barrier cost): that one keeps the register sums.
+  constexpr bool MST = C64P_MFMA_STATS != 0 && (STATS || BWD == 2 || (BWD == 1 && W_ == 112));
+  f32x4_t g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f}, g3 = {0.f, 0.f, 0.f, 0.f}, g4 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned tr_rel = (unsigned)((8 * lg + (l15 >> 2)) * CST + (wave * 16 + 4 * (l15 & 3)) * 2);     // this lane's transposed-read offset inside a [224][CST] tile
+  const unsigned sa_base = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)sA);
+  const bf16x8_t ones = mfma_ones8();
+  PreluThr th = {0u, 0u, 0.f, 0.f};
+  float c_sc = 1.f, c_sh = 0.f, c_al = 1.f;                // BWD == 2: this lane's channel 16 wave + l15
+  if constexpr (MST && BWD == 2) {
+    const int n = wave * 16 + l15;
+    c_sc = p.bgamma[n] * p.brstd[n];
+    c_sh = p.bbeta[n] - p.bmean[n] * c_sc;
+    c_al = p.balpha[n];
+    th = prelu_threshold(c_sc, c_sh);
+  }
+
+  // !MST, BWD: this thread stores chunk (tid & 7) = channels 8 (tid & 7) .. + 7 of rows tid / 8 + 32 i of EVERY tile: 8 running sums per quantity
   float b1[8], b2[8], b3[8], bsc[8], bsh[8], bal[8];
   const __amdgpu_buffer_rsrc_t rsX = make_rsrc(BWD ? (const void*)p.bx : (const void*)p.A, BWD ? (unsigned)((size_t)p.M * 64 * 2) : p.a_bytes);
-  if constexpr (BWD != 0) {
+  if constexpr (BWD != 0 && !MST) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) b1[q] = b2[q] = b3[q] = 0.f;
     if constexpr (BWD == 2) {
@@ -210,7 +238,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           h[q] = f2bf(acc[ni][mi][q]);
-          if constexpr (STATS) {
+          if constexpr (STATS && !MST && !(C64P_ABLATE & 8)) {
             const float v = bf2f(h[q]);
             ssum[ni][q] += v;
             ssq[ni][q] += v * v;
@@ -225,6 +253,16 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own staging writes done ...
     __builtin_amdgcn_s_barrier();                           // ... everybody's (raw barrier: __syncthreads() would drain the DMA as well)
+    if constexpr (MST && BWD != 0) {
+      // the BatchNorm input pieces this thread fetched while the MFMAs ran -> image buffer `cur` (idle until the tile after next is requested; every wave is past
+      // its last fragment read of it: the barrier above), same [row][CST] layout as the staged tile
+      const unsigned xw = sa_base + (unsigned)(cur * A_BYTES) + (unsigned)((tid >> 3) * CST + (tid & 7) * 16);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const u32x4_t xv = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(xw), "v"(xv), "n"(i * 32 * CST) : "memory");
+      }
+    }
     const size_t m0 = (size_t)tile * PT;
     {
       // copy-out, 7 rows per thread: the staging reads are inline asm for the same reason as the writes above (hipcc would wait for
@@ -249,7 +287,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
         *reinterpret_cast<u32x4_t*>(out + 5 * rs) = v5;
         *reinterpret_cast<u32x4_t*>(out + 6 * rs) = v6;
       }
-      if constexpr (BWD != 0) {
+      if constexpr (BWD != 0 && !MST && !(C64P_ABLATE & 16)) {
         // exactly the sums of ew_bn_bwd_reduce on the stored (bf16) dx, on the RAW x: sum dz * xhat = rstd (sum dz x - mean sum dz) is formed
         // once per column at the end (as in the LDS-DMA kernel's fused epilogue, conv_glds_impl.h)
         const u32x4_t vv[7] = {v0, v1, v2, v3, v4, v5, v6};
@@ -275,8 +313,102 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
         }
       }
     }
+    if constexpr (MST && BWD != 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own x pieces are in LDS ...
+      __builtin_amdgcn_s_barrier();                         // ... everybody's
+    }
+    if constexpr (MST && (STATS || BWD != 0)) {
+      // ---- the tile's column sums on the matrix cores: 7 steps of 32 pixels; step j's fragments are requested two steps ahead, the wait that
+      // retires them is tied to their registers ("+v") so that no MFMA is scheduled in front of it
+      constexpr int NRD = BWD != 0 ? 4 : 2;                  // transposed reads per step (staged tile; BWD: + x tile)
+      const unsigned trc = sc_base + tr_rel, trx = sa_base + (unsigned)(cur * A_BYTES) + tr_rel;
+      s16x4_t lo[7], hi[7], xl[7], xh[7];
+      // (macros, not lambdas: clang refuses asm operands that name captured variables)
+#define C64P_ISSUE(j)                                                                                                                          \
+  do {                                                                                                                                         \
+    if constexpr (BWD != 0)                                                                                                                    \
+      asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\tds_read_b64_tr_b16 %2, %5 offset:%6\n\t"      \
+                   "ds_read_b64_tr_b16 %3, %5 offset:%7"                                                                                       \
+                   : "=&v"(lo[j]), "=&v"(hi[j]), "=&v"(xl[j]), "=&v"(xh[j])                                                                    \
+                   : "v"(trc), "v"(trx), "n"((j) * 32 * CST), "n"((j) * 32 * CST + 4 * CST)                                                    \
+                   : "memory");                                                                                                                \
+    else                                                                                                                                       \
+      asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                                                \
+                   : "=&v"(lo[j]), "=&v"(hi[j])                                                                                                \
+                   : "v"(trc), "n"((j) * 32 * CST), "n"((j) * 32 * CST + 4 * CST)                                                              \
+                   : "memory");                                                                                                                \
+  } while (0)
+  // step j's fragments have landed when at most `left` younger reads are outstanding
+#define C64P_RETIRE(j, left)                                                                                                                   \
+  do {                                                                                                                                         \
+    if constexpr (BWD != 0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(lo[j]), "+v"(hi[j]), "+v"(xl[j]), "+v"(xh[j]) : "n"(left) : "memory"); \
+    else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo[j]), "+v"(hi[j]) : "n"(left) : "memory");                                             \
+  } while (0)
+      auto step = [&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        s16x8_t d8;
+        d8[0] = lo[j][0]; d8[1] = lo[j][1]; d8[2] = lo[j][2]; d8[3] = lo[j][3]; d8[4] = hi[j][0]; d8[5] = hi[j][1]; d8[6] = hi[j][2]; d8[7] = hi[j][3];
+        const bf16x8_t dfr = __builtin_bit_cast(bf16x8_t, d8);
+        g1 = MFMA16(ones, dfr, g1);                          // every row: the column sums of the tile
+        if constexpr (STATS) {
+          g2 = MFMA16(dfr, dfr, g2);                         // diagonal: sums of squares
+        } else {
+          s16x8_t x8;
+          x8[0] = xl[j][0]; x8[1] = xl[j][1]; x8[2] = xl[j][2]; x8[3] = xl[j][3]; x8[4] = xh[j][0]; x8[5] = xh[j][1]; x8[6] = xh[j][2]; x8[7] = xh[j][3];
+          const bf16x8_t xfr = __builtin_bit_cast(bf16x8_t, x8);
+          g2 = MFMA16(dfr, xfr, g2);                         // diagonal: sum dy * x
+          if constexpr (BWD == 2) {
+            const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, prelu_pos(d8, x8, th));
+            g3 = MFMA16(ones, pfr, g3);                      // sum of dy over z > 0
+            g4 = MFMA16(pfr, xfr, g4);                       // diagonal: sum of dy * x over z > 0
+          }
+        }
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+      using I6 = std::integral_constant<int, 6>;
+      C64P_ISSUE(0); C64P_ISSUE(1); C64P_ISSUE(2);
+      C64P_RETIRE(0, 2 * NRD); step(I0{}); C64P_ISSUE(3);
+      C64P_RETIRE(1, 2 * NRD); step(I1{}); C64P_ISSUE(4);
+      C64P_RETIRE(2, 2 * NRD); step(I2{}); C64P_ISSUE(5);
+      C64P_RETIRE(3, 2 * NRD); step(I3{}); C64P_ISSUE(6);
+      C64P_RETIRE(4, 2 * NRD); step(I4{});
+      C64P_RETIRE(5, NRD); step(I5{});
+      C64P_RETIRE(6, 0); step(I6{});
+#undef C64P_ISSUE
+#undef C64P_RETIRE
+    }
   }
-  if constexpr (BWD != 0) {
+  if constexpr (MST && BWD != 0) {
+    // one partial row [3][64] per workgroup, straight from the 16 diagonal lanes of every wave
+    if ((l15 >> 2) == lg) {
+      const int n = wave * 16 + l15;
+      float t0 = g1[0], t1 = mfma_diag(g2, l15), t2 = 0.f;
+      if constexpr (BWD == 2) {
+        const float sp = g3[0], spx = mfma_diag(g4, l15);
+        const float sn = t0 - sp, snx = t1 - spx;            // sums over the elements with z <= 0
+        t0 = sp + c_al * sn;
+        t1 = spx + c_al * snx;
+        t2 = c_sc * snx + c_sh * sn;
+      }
+      float* o = p.bpart + (size_t)blockIdx.x * 3 * 64 + n;
+      o[0] = t0;
+      o[64] = p.brstd[n] * (t1 - p.bmean[n] * t0);
+      o[128] = t2;
+    }
+  }
+  if constexpr (MST && STATS) {
+    // rows 2 b (the sums) and 2 b + 1 (zeros: the register path left one row per wave row)
+    if ((l15 >> 2) == lg) {
+      const int n = wave * 16 + l15;
+      float* prow_ = p.stats + (size_t)((int)blockIdx.x * 2) * 128;
+      prow_[n] = g1[0];
+      prow_[64 + n] = mfma_diag(g2, l15);
+      prow_[128 + n] = 0.f;
+      prow_[192 + n] = 0.f;
+    }
+  }
+  if constexpr (BWD != 0 && !MST) {
     // one partial row per workgroup: the 32 row groups meet in LDS (the image buffers are idle: the last tile's MFMA loop is behind the
     // staging barrier of its epilogue, no DMA is in flight)
     __syncthreads();
@@ -303,7 +435,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(GemmNT p, int ntiles,
       o[128] = t2;
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS && !MST) {
     float* prow_ = p.stats + (size_t)((int)blockIdx.x * 2 + wm) * 128;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
@@ -355,7 +487,7 @@ int conv_c64p_grid(int M) {                 // workgroups of a launch over M out
 bool conv_c64p_applies(const GemmNT& p) {
   return g_conv_c64p && p.mode == 1 && p.S == 3 && p.C == 64 && p.N == 64 && p.K == 576 && p.stride == 1 && p.pad == 1 && p.up == 1 && p.H == p.W &&
          (p.W == 112 || p.W == 56) && p.Ho == p.H && p.Wo == p.W && p.M % (p.W * p.W) == 0 && p.Cb && p.ldc == 64 && !p.Cf && !(p.bpart && p.stats) &&
-         !p.esc && !p.eadd && !p.Cb2 && !p.par_on;
+         !p.esc && !p.eadd && !p.Cb2 && !p.par_on && !p.bmom;
 }
 int launch_conv_c64p(GemmNT p, hipStream_t st) {
   FEDFR_REQUIRE(conv_c64p_applies(p), "conv3x3_c64p: unsupported shape");

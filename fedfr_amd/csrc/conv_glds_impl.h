@@ -3,6 +3,7 @@
 #include <type_traits>
 #include <algorithm>
 #include "gemm_dev.h"
+#include "epi_mfma.h"
 
 // In-kernel phase stamps for tools/stamp (compiled out of the product)
 #ifdef FEDFR_HALO2_STAMPS
@@ -753,22 +754,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
     // (the coefficient arithmetic comes BEFORE the copy-out: vmcnt counts loads and stores on gfx9 and they retire out of order with each other,
     // so a wait for the coefficient loads placed behind the tile's stores is a vmcnt(0) that sits out the write-through stores — ~1 us, asm-checked)
     const bool prelu = p.balpha != nullptr;
-    float Tf = 0.f, nsf = 0.f;                                // bf16 build: the fp32 threshold and -sgn(sc)
-    // PReLU threshold of this lane's channel (see above): z = x * sc + sh, sc = gamma * rstd, sh = beta - mean * sc
+    // PReLU threshold of this lane's channel (epi_mfma.h): z = x * sc + sh, sc = gamma * rstd, sh = beta - mean * sc
     const float sc_ = cf[2] * cf[1], sh_ = cf[3] - cf[0] * sc_;
-    unsigned nsgn2 = 0, t162 = 0;                             // (-sgn(sc), -sgn(sc)) and (t16, t16) as packed fp16
-    if (prelu) {
-      const float T = -sh_ / fabsf(sc_);
-      unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)T);      // round to nearest ...
-      const float hf = (float)__builtin_bit_cast(_Float16, (unsigned short)hb);
-      if (hf > T) hb = hb == 0u ? 0x8001u : ((hb & 0x8000u) ? hb + 1u : hb - 1u);   // ... then down to the largest fp16 <= T
-      if (sc_ == 0.f) hb = sh_ <= 0.f ? 0x7c00u : 0xfc00u;     // z = sh everywhere: always / never in the PReLU's negative branch
-      t162 = hb | (hb << 16);
-      nsgn2 = sc_ < 0.f ? 0x3c003c00u : 0xbc00bc00u;
-      Tf = sc_ == 0.f ? (sh_ <= 0.f ? __builtin_inff() : -__builtin_inff()) : T;
-      nsf = sc_ < 0.f ? 1.f : -1.f;
-    }
-    asm volatile("" ::"v"(t162), "v"(nsgn2), "v"(sc_), "v"(sh_), "v"(Tf), "v"(nsf), "v"(cf[0]), "v"(cf[1]), "v"(cf[4]));     // (materialised here)
+    PreluThr th = {0u, 0u, 0.f, 0.f};
+    if (prelu) th = prelu_threshold(sc_, sh_);
+    asm volatile("" ::"v"(th.t162), "v"(th.nsgn2), "v"(sc_), "v"(sh_), "v"(th.Tf), "v"(th.nsf), "v"(cf[0]), "v"(cf[1]), "v"(cf[4]));     // (materialised here)
     __builtin_amdgcn_sched_barrier(0);
     {
       constexpr int NIT = (PT * CPR + NT - 1) / NT;
@@ -817,27 +807,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       g2 = MFMA16(dfr, xfr, g2);                             // diagonal: sum dy * x
       if (mom) g3 = MFMA16(dfr, dfr, g3);                    // forward raw moments: sum y * y
       if (prelu) {
-#if FEDFR_FP16
-        typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
-        // e = t16 - sgn x per element (exact sign); sign bit set <=> z > 0
-        const _Float16 ns1 = __builtin_bit_cast(_Float16, (unsigned short)(nsgn2 & 0xffffu)), tt1 = __builtin_bit_cast(_Float16, (unsigned short)(t162 & 0xffffu));
-        const h8_t ns8 = {ns1, ns1, ns1, ns1, ns1, ns1, ns1, ns1}, tt8 = {tt1, tt1, tt1, tt1, tt1, tt1, tt1, tt1};
-        const h8_t e8 = __builtin_elementwise_fma(__builtin_bit_cast(h8_t, x8), ns8, tt8);
-        const s16x8_t m8 = __builtin_bit_cast(s16x8_t, e8) >> 15;
-        const s16x8_t pu = d8 & m8;
-#else
-        // bf16 = the upper half of an fp32: e = T - sgn x on both halves of a register as fp32 (exact sign: an fp32 FMA of a bf16 value rounds once)
-        typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
-        const u4_t du = __builtin_bit_cast(u4_t, d8), xu = __builtin_bit_cast(u4_t, x8);
-        u4_t pw;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float el = __builtin_fmaf(__uint_as_float(xu[j] << 16), nsf, Tf), eh = __builtin_fmaf(__uint_as_float(xu[j] & 0xffff0000u), nsf, Tf);
-          const unsigned ml = (unsigned)((int)__float_as_uint(el) >> 31), mh = (unsigned)((int)__float_as_uint(eh) >> 31);
-          pw[j] = du[j] & ((ml & 0xffffu) | (mh & 0xffff0000u));
-        }
-        const s16x8_t pu = __builtin_bit_cast(s16x8_t, pw);
-#endif
+        const s16x8_t pu = prelu_pos(d8, x8, th);
         const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pu);
         g3 = MFMA16(ones, pfr, g3);                          // sum dypos
         g4 = MFMA16(pfr, xfr, g4);                           // diagonal: sum dypos * x

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(NTH) void bn_apply_s_kernel(BnApplyS p) {
   opt8(p.alpha, p.part, c0, al, 1.f);
   float4 fv[kFwdFL];
   fan_in_issue<2, kFwdFL>(p.part, p.P, p.C, 2, cs, fv);
+  const double ic = 1.0 / p.count;                      // (ew.h: bn_rsqrt; formed here, under the loads)
+  asm volatile("" ::"v"(ic));
   uint4 a1[NP], a2[X2 ? NP : 1];
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
@@ -173,10 +175,10 @@ __global__ __launch_bounds__(NTH) void bn_apply_s_kernel(BnApplyS p) {
   fan_in_finish<2, kFwdFL>(fv, p.P, tot, red);
   if (tid < SW) {
     const int c = cs + tid;
-    const double mean = tot[tid] / p.count;
-    double var = tot[SW + tid] / p.count - mean * mean;
+    const double mean = tot[tid] * ic;
+    double var = tot[SW + tid] * ic - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)p.eps);
+    const double rstd = bn_rsqrt(var + (double)p.eps);
     const float sc = (float)((double)ga * rstd), sh = (float)((double)be - mean * (double)ga * rstd);
     cf[0][tid] = sc;
     cf[1][tid] = sh;
@@ -254,6 +256,10 @@ __global__ __launch_bounds__(NTH) void bn_apply2_s_kernel(BnApply2S p) {
   float4 fv[FL];
   fan_in_issue<3, FL>(p.part, p.P, p.C, 3, cs, fv);
   uint4 a1[NP], a2[NP];
+  const double ic = 1.0 / p.count;                      // (ew.h: bn_rsqrt) the count's reciprocal and the identity path's variance: formed under the loads
+  double vx = 1.0 / ((double)xr * (double)xr) - (double)p.eps;
+  if (vx < 0.0) vx = 0.0;
+  asm volatile("" ::"v"(ic), "v"(vx));
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     const int m = min(m0 + u * PXP + pl, m1 - 1);
@@ -264,20 +270,18 @@ __global__ __launch_bounds__(NTH) void bn_apply2_s_kernel(BnApply2S p) {
   fan_in_finish<3, FL>(fv, p.P, tot, red);
   if (tid < SW) {
     const int c = cs + tid;
-    const double mean = tot[tid] / p.count;
-    double var = tot[2 * SW + tid] / p.count - mean * mean;
+    const double mean = tot[tid] * ic;
+    double var = tot[2 * SW + tid] * ic - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)p.eps);
+    const double rstd = bn_rsqrt(var + (double)p.eps);
     const float sc = (float)((double)ga * rstd), sh = (float)((double)be - mean * (double)ga * rstd);
     // statistics of out = sc x1 + sh + x2 (with the fp32 coefficients the elements are computed with)
     const double mx = (double)xm;
-    double vx = 1.0 / ((double)xr * (double)xr) - (double)p.eps;
-    if (vx < 0.0) vx = 0.0;
-    const double cov = tot[SW + tid] / p.count - mean * mx;
+    const double cov = tot[SW + tid] * ic - mean * mx;
     const double omean = (double)sc * mean + (double)sh + mx;
     double ovar = (double)sc * (double)sc * var + vx + 2.0 * (double)sc * cov;
     if (ovar < 0.0) ovar = 0.0;
-    const double orstd = 1.0 / sqrt(ovar + (double)p.eps);
+    const double orstd = bn_rsqrt(ovar + (double)p.eps);
     const float nsc = (float)((double)nga * orstd), nsh = (float)((double)nbe - omean * (double)nga * orstd);
     cf[0][tid] = sc; cf[1][tid] = sh; cf[2][tid] = nsc; cf[3][tid] = nsh;
     if (g == 0) {
@@ -449,6 +453,8 @@ __global__ __launch_bounds__(NTH) void bn_bwd_apply_s_kernel(BnBwdS p) {
 #pragma unroll
   for (int u = 0; u < NPRE; ++u) pre[u] = fetch(m0 + u * PXP + pl);
 
+  const double ic = 1.0 / p.count;                      // (ew.h: bn_rsqrt; formed under the loads)
+  asm volatile("" ::"v"(ic));
   fan_in_finish<NV, FL>(fv, p.P, tot, red);
   if (tid < SW) {
     const int c = cs + tid;
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(NTH) void bn_bwd_apply_s_kernel(BnBwdS p) {
       if (ALPHA && p.dalpha) p.dalpha[c] = (float)tot[(NV - 1) * SW + tid];
     }
     const double ga = (double)ga_, r = (double)r_, mu = (double)mu_;
-    const double a = (double)(float)(ga * r), cb = t1 / p.count, cq = t2 / p.count;
+    const double a = (double)(float)(ga * r), cb = t1 * ic, cq = t2 * ic;
     cf[0][tid] = (float)a;
     cf[1][tid] = (float)(-a * cq * r);
     cf[2][tid] = (float)(a * (cq * r * mu - cb));

@@ -4,6 +4,17 @@
 #pragma once
 #include "common.h"
 
+// 1 / sqrt(v) in fp64 (v > 0): the hardware estimate + two Newton steps.  `1.0 / sqrt(v)` is a square-root and a divide sequence — ~70 dependent
+// fp64 operations — on the critical path of EVERY BatchNorm pass (each workgroup derives its coefficients itself, bn_sliced.hip), and so were the
+// divisions by the pixel count: the passes multiply by its reciprocal, formed while their loads are in flight.  Every path (sliced passes, finalize
+// kernels) uses the same expressions, so fused and unfused passes still agree bit for bit.
+__device__ __forceinline__ double bn_rsqrt(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  y = y * (1.5 - 0.5 * v * y * y);
+  y = y * (1.5 - 0.5 * v * y * y);
+  return y;
+}
+
 // ---- forward BN -------------------------------------------------------------------------------------
 // partials: [P][2][C] (sum, sumsq).  tmp must hold 64*2*C floats when P > 1024 (two-stage reduce).
 int ew_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,

@@ -120,10 +120,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const double ts = rg_reduce(s0 + s1, rs, rg, cl);
   const double tq = rg_reduce(q0 + q1, rq, rg, cl);
   if (rg == 0 && blockIdx.x * 32 + cl < C) {
-    const double mean = ts / count;
-    double var = tq / count - mean * mean;
+    const double ic = 1.0 / count;
+    const double mean = ts * ic;
+    double var = tq * ic - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double rstd = bn_rsqrt(var + (double)eps);
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = (float)((double)g * rstd);
     scale[c] = sc;
@@ -201,10 +202,11 @@ __global__ __launch_bounds__(256) void bn_finalize8_kernel(const float* __restri
   fin8_accumulate<2>(part, P, C, c0, 2, tot);
   if (threadIdx.x < 8) {
     const int c = c0 + threadIdx.x;
-    const double mean = tot[0][threadIdx.x] / count;
-    double var = tot[1][threadIdx.x] / count - mean * mean;
+    const double ic = 1.0 / count;
+    const double mean = tot[0][threadIdx.x] * ic;
+    double var = tot[1][threadIdx.x] * ic - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double rstd = bn_rsqrt(var + (double)eps);
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     scale[c] = (float)((double)g * rstd);
     shift[c] = (float)((double)b - mean * (double)g * rstd);
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize8_kernel(const float* __re
     if (dbeta) dbeta[c] = (float)t1;
     if (dalpha) dalpha[c] = (float)tot[2][threadIdx.x];
     const double g = gamma ? (double)gamma[c] : 1.0, r = rstd ? (double)rstd[c] : 1.0, mu = mean ? (double)mean[c] : 0.0;
-    const double a = (double)(float)(g * r), cb = t1 / count, cc = t2 / count;
+    const double a = (double)(float)(g * r), cb = t1 * (1.0 / count), cc = t2 * (1.0 / count);
     coef[c] = (float)a;
     coef[C + c] = (float)(-a * cc * r);
     coef[2 * C + c] = (float)(a * (cc * r * mu - cb));

@@ -50,8 +50,9 @@ PMC_KEYS = {"conv3x3_glds_kernel<14,14>": ("conv3x3_glds_kernel<14, 14",), W9P: 
 # translation units (fedfr_amd/csrc) a replayed counter belongs to: a summary under profiles/ carries the git blob hashes of the sources it was
 # collected on (tools/source_stamp.py); a difference to the working tree marks the field stale
 _COMMON_TU = ["common.h", "gemm_dev.h"]
-KERNEL_TUS = {"conv14": ["conv_glds_impl.h", "conv_glds8_w14.hip", "conv_glds8_fused_w14.hip", "nt_epilogue.h"] + _COMMON_TU,
-              "conv28": ["conv_glds_impl.h", "conv_glds8_w28.hip", "conv_glds8_fused_w28.hip", "nt_epilogue.h"] + _COMMON_TU,
+KERNEL_TUS = {"conv14": ["conv_glds_impl.h", "epi_mfma.h", "conv_glds8_w14.hip", "conv_glds8_fused_w14.hip", "nt_epilogue.h"] + _COMMON_TU,
+              "conv28": ["conv_glds_impl.h", "epi_mfma.h", "conv_glds8_w28.hip", "conv_glds8_w28s.hip", "conv_glds8_fused_w28.hip", "conv_glds8_fused_w28s.hip",
+                         "nt_epilogue.h"] + _COMMON_TU,
               "w9p": ["wgrad9p.hip", "gemm_tn_dev.h"] + _COMMON_TU,
               "tn_glds": ["gemm_tn_glds.hip", "gemm_tn_dev.h"] + _COMMON_TU}
 

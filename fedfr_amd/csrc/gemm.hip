@@ -679,8 +679,12 @@ int gemm_tn_launch_w9pair(GemmTN a, GemmTN b, int splits, hipStream_t st, const 
   return launch_wgrad9_pair(a, b, splits, st, job);
 }
 
+#ifndef TN_ABLATE
+#define TN_ABLATE 0     // timing experiments only (WRONG results): 1 = no weight gradient of the 64 -> 64 stride-2 3x3 layer (112 -> 56)
+#endif
 int gemm_tn_launch(GemmTN p, int splits, hipStream_t st) {
   FEDFR_TRY(tn_prepare(p));
+  if ((TN_ABLATE & 1) && p.mode == 1 && p.stride == 2 && p.C == 64 && p.S == 3) return FEDFR_OK;
   int TI, TJ;
   if (p.mode == 1) {
     if (wgrad9_applies(p)) return launch_wgrad9(p, splits, st);

@@ -20,6 +20,9 @@
 //     tied in/out AGPR operand, and every MFMA operand is an aligned pair of 16-row groups (see the K loop).
 // 132 VGPRs + 144 AGPRs at one wave per SIMD (wgrad9: 2 x 144 of 512).  On by default since round 3 (g_wgrad9p below).
 #include "gemm_tn_dev.h"
+#ifndef W9P_PRIO
+#define W9P_PRIO 0       // wave priority of the pair's waves (the BatchNorm-backward passes that share its CUs run at BNS_PRIO, bn_sliced.hip)
+#endif
 #ifndef W9P_ABLATE
 #define W9P_ABLATE 0     // timing experiments only: 1 no in-loop DMA, 2 no in-loop fragment reads, 4 no MFMA, 16 no slab stores, 32 no slab loads by the reduction job
 #endif
@@ -86,6 +89,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   typedef __attribute__((address_space(3))) unsigned char* lds_uc_t;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
+#if W9P_PRIO
+  __builtin_amdgcn_s_setprio(W9P_PRIO);
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cih = wave >> 1, coh = wave & 1;               // 32-channel halves of the 64 x 64 block

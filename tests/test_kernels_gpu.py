@@ -126,7 +126,8 @@ def test_conv_dgrad(B, H, Cin, Cout, k, s):
 
 @pytest.mark.parametrize("B,H,Cin,Cout,prelu", [(131, 14, 256, 256, True), (65, 28, 128, 128, False), (2, 14, 64, 64, True),
                                                 (5, 112, 64, 64, False), (5, 112, 64, 64, True), (19, 56, 64, 64, False), (19, 56, 64, 64, True),
-                                                (3, 56, 64, 64, True), (64, 28, 128, 128, True), (33, 28, 256, 128, False)])
+                                                (3, 56, 64, 64, True), (64, 28, 128, 128, True), (33, 28, 256, 128, False),
+                                                (131, 14, 256, 256, "signs"), (64, 28, 128, 128, "signs"), (19, 56, 64, 64, "signs")])
 def test_conv_dgrad_fused_bn_bwd_reduction(B, H, Cin, Cout, prelu):
     """dgrad epilogue also reduces (sum dz, sum dz*xhat, sum dx*min(z,0)) of the BN that precedes the conv.  The 64 -> 64 layers of the
     56x56 / 112x112 maps run on the persistent kernel (conv_c64p.hip): one partial row per workgroup, 1 or 2 tiles each here."""
@@ -140,6 +141,17 @@ def test_conv_dgrad_fused_bn_bwd_reduction(B, H, Cin, Cout, prelu):
     bnx = bf(rnd((B * H * H, Cin), 9) * 1.5 + 0.2).to(d)
     mean, rstd = (rnd((Cin,), 10) * 0.2).to(d), (rnd((Cin,), 11) * 0.2 + 1.0).to(d)
     gamma, beta, alpha = (rnd((Cin,), 12) * 0.2 + 1).to(d), (rnd((Cin,), 13) * 0.3).to(d), (rnd((Cin,), 14) * 0.1 + 0.25).to(d)
+    if prelu == "signs":
+        # (round 5: the matrix-core epilogues take the PReLU mask from a per-channel THRESHOLD on x — z <= 0 <=> sgn(sc) x <= -sh / |sc| — so the
+        # sign of gamma, gamma == 0 (z = beta everywhere: always / never masked), beta == 0 and x sitting exactly ON a representable threshold
+        # are cases of their own)
+        gamma = gamma.clone(); beta = beta.clone()
+        gamma[::3] *= -1.0
+        gamma[5::16] = 0.0
+        beta[7::16] = 0.0
+        beta[5::32] = -0.25
+        gamma[9::16] = 1.0; beta[9::16] = -0.5; mean[9::16] = 0.0; rstd[9::16] = 1.0       # threshold x = 0.5 exactly ...
+        bnx[::7, 9::16] = 0.5                                                                 # ... and x on it: z == 0 counts as masked
     dx = torch.empty(B, H, H, Cin, dtype=S16(), device=d)
     part = torch.full((((B * H * H + 127) // 128), 3, Cin), float("nan"), device=d)
     rows = C.c_int(0)

@@ -14,6 +14,9 @@
 //   * Beyond the last K-step the pipeline keeps issuing (out-of-range) pieces, so the vmcnt immediates are the same in every iteration.
 #include "nt_epilogue.h"
 
+#ifndef NT_GLDS_NS
+#define NT_GLDS_NS 4     // ring stages of the 8-wave 128 x 128 tile (5 = all 160 KB of LDS)
+#endif
 namespace {
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmNT p_) {
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int AP = (BM / 8) / NW, BP = (BN / 8) / NW, PER = AP + BP;     // LDS-DMA pieces (8 rows) per wave and K-step
   constexpr int NRD = TM + TN, NM = TM * TN;
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && NS >= 3 && NS <= 4 && AP >= 1 && BP >= 1, "tile geometry");
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && NS >= 3 && NS <= 5 && AP >= 1 && BP >= 1, "tile geometry");
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -254,6 +257,6 @@ int launch_nt_glds(const GemmNT& p, int BM, int splits, int slot, hipStream_t st
   // 64-row tiling puts them, as long as both tilings agree on the row count
   const int v = g_nt_glds & 7;
   const bool up = v >= 3 && BM == 64 && (!p.stats || ceil_div(p.M, 64) == 2 * ceil_div(p.M, 128));
-  if (BM == 128 || up) return (v & 1) == 0 ? launch_impl<128, 128, 2, 4, 4>(p, splits, slot, st) : launch_impl<128, 128, 2, 2, 4>(p, splits, slot, st);
+  if (BM == 128 || up) return (v & 1) == 0 ? launch_impl<128, 128, 2, 4, NT_GLDS_NS>(p, splits, slot, st) : launch_impl<128, 128, 2, 2, 4>(p, splits, slot, st);
   return launch_impl<64, 128, 1, 4, 3>(p, splits, slot, st);       // 72 KB: two workgroups per CU
 }

@@ -526,6 +526,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         mok = x_ < W_;
         ml = mok ? y_ * W_ + x_ : 0;
       }
+      // (padded-raster kernels: the filler columns' lanes write to a dump row behind the tile instead of sitting out a predicated store — 14
+      // s_and_saveexec / taken-branch pairs per lane in a phase that is pure overhead for the matrix cores; nothing reads row PT: the copy-out stops
+      // in front of it, the transposed statistics reads select zeros beyond the tile, the x tile of the fused variants starts 1 KB-aligned behind it)
+      constexpr bool DUMP = RST && (PT + 1) * (BN * 2 + 16) <= ((PT * (BN * 2 + 16) + 1023) & ~1023);
+      if constexpr (DUMP) ml = mok ? ml : PT;
       const int nl = wn * (BN / WN) + ni * 16 + lg * 4;
       bf16_t h[4];
 #pragma unroll
@@ -551,9 +556,9 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
         typedef __attribute__((ext_vector_type(2))) unsigned st8_u2_t;
         const st8_u2_t pv = {pk.x, pk.y};
         const unsigned sadr = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(sC + ml * CST + nl * 2));
-        if (mok) asm volatile("ds_write_b64 %0, %1" ::"v"(sadr), "v"(pv) : "memory");
+        if (DUMP || mok) asm volatile("ds_write_b64 %0, %1" ::"v"(sadr), "v"(pv) : "memory");
       } else {
-        if (mok) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
+        if (DUMP || mok) *reinterpret_cast<uint2*>(sC + ml * CST + nl * 2) = pk;
       }
     }
   };

@@ -1624,7 +1624,9 @@ def test_every_switch_alternative_matches_the_default(name):
         got = _switch_step("iresnet18", B, C, **{name: val})
         dl, dg, df = abs(got[0] - ref[0]) / abs(ref[0]), float((got[1] - ref[1]).norm()) / gn, float((got[2] - ref[2]).norm() / ref[2].norm())
         print("switch %s = %d: loss %.2e, backbone gradients %.2e, head gradient %.2e" % (name, val, dl, dg, df))
-        assert np.isfinite(got[0]) and dl < 1e-3 and df < 2e-3, (name, val, dl, df)
+        # (the bf16 build's storage noise is 8x the product's: a switch that moves one fp32 bit of a BatchNorm coefficient flips bf16 roundings through
+        # the net — sliced vs row-slab passes differ by 4.6e-3 in the head gradient there, 2e-5 in the loss)
+        assert np.isfinite(got[0]) and dl < T16(1e-3, 4e-3) and df < T16(2e-3, 1.2e-2), (name, val, dl, df)
         # kernels that round at other points (fused epilogues, derived statistics) move a 16-bit network by its storage noise; pure reorderings stay at 1e-4
         loose = name in ("fwd_xmom", "fuse_bnbwd", "fuse_bnbwd28", "c64p_bnbwd", "conv_c64p", "bn_sliced", "fuse_bnred_next", "stem_bnred", "nt_glds", "conv28_tpw2")
         assert dg < (2e-2 if loose else 1e-3), (name, val, dg)

@@ -382,6 +382,91 @@ def parity_leg(dev):
     return out
 
 
+ROUND_LOCAL_STEPS = 8     # local steps per client in the `fedavg_round` leg (the reference: local_epoch x len(loader), client.py:537)
+
+
+def round_leg(args, dev, imgs, labs, B, NC):
+    """The second half of BASELINE's metric on ONE GPU: a whole FedAvg round of 1 / 2 / 4 / 8 clients through the reference-shaped objects
+    (fedfr_amd.server.Server.train == reference server.py:265-338): every client receives the global model, trains ROUND_LOCAL_STEPS local steps of
+    the headline workload (Client.train == client.py:511-571, loss.item() every step as the reference does), then FedPavg over the client states
+    (server.py:25-34) + load_state_dict into the global model.  Clients run one after another, the way the reference runs them (server.py:283), and
+    with args.parallel_clients = 2 (two clients of the round concurrently on this GPU).  -> dict for the JSON line"""
+    from fedfr_amd import client, server
+    from fedfr_amd.config import config as cfg
+    S = ROUND_LOCAL_STEPS
+    nbuf = len(imgs)
+
+    class Args:
+        network, loss, local_epoch, output_dir, BCE_local, aggr_alg, parallel_clients = args.arch, "CosFace", 1, "/tmp", False, "FedAvg", 1
+
+    class DS:
+        ID_base = 0
+
+    class Loader(list):
+        dataset = DS()
+
+    class Data:
+        train_class_sizes = [NC] * 8
+        train_dataset_sizes = [1000.0 + r for r in range(8)]
+        train_loaders = [Loader([(imgs[(s_ + c) % nbuf], labs[(s_ + c) % nbuf]) for s_ in range(S)]) for c in range(8)]      # resident in HBM
+    lr0 = cfg.lr
+    cfg.lr = 1e-3
+    try:
+        clients = [client.Client(c, Args, Data, device=dev) for c in range(8)]
+        srv = server.Server(clients, Data, Args, device=dev)
+        out = {"unit": "ms", "local_steps_per_client": S, "batch": B,
+               "what": "Server.train(): per client load_state_dict(global) + %d local train steps (loss.item() per step) + state snapshot, then FedPavg + "
+                       "load_state_dict; all on one MI355X" % S, "sequential": {}, "parallel_clients_2": {}}
+        for par, key in ((1, "sequential"), (2, "parallel_clients_2")):
+            Args.parallel_clients = par
+            srv.current_client_list = list(range(min(par, 2)))
+            srv.train()                                    # warm-up: arenas of the resident backbone(s), streams
+            torch.cuda.synchronize()
+            for n in (1, 2, 4, 8):
+                srv.current_client_list = list(range(n))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                srv.train()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) * 1e3
+                # the aggregation share, timed on its own over the same client states
+                models = [clients[i].get_model() for i in range(n)]
+                sizes = [clients[i].get_data_size() for i in range(n)]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                srv.federated_model.load_state_dict(server.FedPavg(models, sizes))
+                torch.cuda.synchronize()
+                agg = (time.perf_counter() - t1) * 1e3
+                out[key][str(n)] = {"round_ms": round(dt, 2), "aggregation_ms": round(agg, 3), "ms_per_client_step": round((dt - agg) / (n * S), 3)}
+        return out
+    finally:
+        cfg.lr = lr0
+
+
+def rccl_world1_round_leg(args):
+    """The same round through fedavg_all_reduce over RCCL at world size 1 (the N > 1 code path: local steps, then ONE in-place all-reduce of the
+    flat model state), in a FRESH child process started after this process's legs (`FEDFR_FORCE_DIST=1 bench.py --secondary`): never a re-exec of a
+    process that has touched the GPU."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--secondary", "--gpus", "1", "--steps", str(ROUND_LOCAL_STEPS), "--warmup", "3",
+           "--arch", args.arch, "--batch", str(args.batch), "--classes", str(args.classes), "--head", "dense"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update({"FEDFR_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_ADDR": "127.0.0.1"})
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    line = next((t for t in reversed(r.stdout.splitlines()) if t.startswith("{") and '"metric"' in t), None)
+    if r.returncode != 0 or line is None:
+        return {"error": "child exited %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+    d = json.loads(line)
+    return {"round_ms": d.get("fedavg_round_ms"), "exchange_ms": d.get("fedavg_exchange_ms"), "local_steps": d["steps"], "rccl_ranks": d.get("rccl_ranks"),
+            "collective_backend": d.get("collective_backend"),
+            "measured_by": "fresh child process `FEDFR_FORCE_DIST=1 bench.py --secondary --steps %d` (RCCL communicator of ONE rank: the collective's "
+                           "launch + in-place pass over 261 MB, no xGMI traffic)" % ROUND_LOCAL_STEPS}
+
+
 def main():
     select_library(sys.argv[1:])
     rc = self_launch(sys.argv[1:])
@@ -772,6 +857,24 @@ def main():
             leg_errors['fedavg'] = "%s: %s" % (type(e).__name__, e)
             print("bench.py: the fedavg leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
+    # ---- ... and the ROUND itself at N = 1: 1 / 2 / 4 / 8 clients trained one after another on this GPU (the reference's way, server.py:283) and
+    # two at a time, + FedPavg + load_state_dict; then the same round through fedavg_all_reduce over RCCL at world 1 (fresh child process)
+    fedavg_round = None
+    if rank == 0 and world == 1 and not args.no_profile and not use_dist and args.head == "dense":
+        try:
+            tr.finish()
+            torch.cuda.synchronize()
+            fedavg_round = round_leg(args, dev, imgs, labs, B, NC)
+        except Exception as e:      # an auxiliary leg must never cost the headline number
+            leg_errors['fedavg_round'] = "%s: %s" % (type(e).__name__, e)
+            print("bench.py: the fedavg_round leg failed: %r" % (e,), file=sys.stderr, flush=True)
+        if fedavg_round is not None and not args.no_bf16_build:      # (child processes: after this process's own GPU legs)
+            try:
+                torch.cuda.synchronize()
+                fedavg_round["rccl_world1"] = rccl_world1_round_leg(args)
+            except Exception as e:      # noqa: BLE001
+                fedavg_round["rccl_world1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     parity = None
     if rank == 0 and (secondary or not args.no_profile) and not collective_step:
         try:
@@ -837,6 +940,12 @@ def main():
             "concurrent_clients": concurrent,
             "fedavg": fedavg,
         }
+        if fedavg_round is not None:
+            # BASELINE's "FedAvg round time 1/2/4/8 clients" measured on ONE GPU (clients one after another, as the reference runs them)
+            out["fedavg_round_ms"] = {k: v["round_ms"] for k, v in fedavg_round["sequential"].items()}
+            out["fedavg_round"] = fedavg_round
+            if cpu and isinstance(cpu.get("fedpavg_s"), dict):
+                fedavg_round["cpu_oracle_fedpavg_s"] = cpu["fedpavg_s"]       # the aggregation alone on the host cores (cpu_baseline), beside it
         if rccl_ranks is not None:
             out["rccl_ranks"] = rccl_ranks
             out["collective_backend"] = "rccl" if backend == "nccl" else backend
@@ -845,6 +954,16 @@ def main():
         if use_dist:
             out["fedavg_round_ms"] = round(dt * 1e3, 3)
             out["fedavg_exchange_ms"] = round((dt - t_local) * 1e3, 3)
+        # the line's LAST key: the numbers a reader of a truncated log tail needs (everything above has the detail)
+        out["summary"] = {"ms_per_step": out["ms_per_step"], "images_per_sec": out["value"], "dtype": out["dtype"], "step_mfma_frac": out["step_mfma_frac"],
+                          "roofline_frac": roofline and roofline.get("frac"), "roofline_kernel_us": roofline and roofline.get("avg_launch_us"),
+                          "parity_vs_reference": parity and {k: parity[k] for k in ("embeddings_eval", "embeddings_train", "cosine_logits_train")},
+                          "fedavg_round_ms": out.get("fedavg_round_ms"),
+                          "fedavg_round_ms_parallel_clients_2": fedavg_round and {k: v["round_ms"] for k, v in fedavg_round["parallel_clients_2"].items()},
+                          "fedavg_round_rccl_world1": fedavg_round and fedavg_round.get("rccl_world1") and
+                          {k: fedavg_round["rccl_world1"].get(k) for k in ("round_ms", "exchange_ms", "local_steps", "error") if k in fedavg_round["rccl_world1"]},
+                          "cpu_baseline_images_per_sec": cpu and cpu.get("value"), "cpu_cores": cpu and cpu.get("cores"),
+                          "options_non_default": out["options_non_default"], "leg_errors": sorted(leg_errors) or None}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

@@ -654,8 +654,8 @@ class ShardedHeadTrainer(FusedHeadTrainer):
     """
 
     def __init__(self, backbone, pfc, bce_module=None, id_base: int = 0, lr: float = 0.1, momentum: float = 0.9,
-                 weight_decay: float = 5e-4, bce_weight: float = 10.0):
-        super().__init__(backbone, list(bce_module.parameters()) if bce_module is not None else [], lr, momentum, weight_decay)
+                 weight_decay: float = 5e-4, bce_weight: float = 10.0, aux_slot: int = 0):
+        super().__init__(backbone, list(bce_module.parameters()) if bce_module is not None else [], lr, momentum, weight_decay, aux_slot=aux_slot)
         self.pfc, self.bce_module, self.id_base, self.bce_weight = pfc, bce_module, int(id_base), float(bce_weight)
         self.bce_loss = losses.BCE_loss() if bce_module is not None else None
         if bce_module is not None:

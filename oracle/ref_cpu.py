@@ -291,12 +291,13 @@ def _bn(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, training: boo
 
 
 def ibasic_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: int,
-                 training: bool, bn_frozen: bool = False) -> torch.Tensor:
-    """iresnet.py:46-57: BN→conv3x3(s1)→BN→PReLU→conv3x3(stride)→BN, (+1x1 conv+BN shortcut), add."""
+                 training: bool, bn_frozen: bool = False, prelu_hook=None) -> torch.Tensor:
+    """iresnet.py:46-57: BN→conv3x3(s1)→BN→PReLU→conv3x3(stride)→BN, (+1x1 conv+BN shortcut), add.
+    ``prelu_hook(name, z, weight)`` (tests only) stands in for F.prelu — e.g. a PReLU whose BACKWARD uses an injected sign pattern."""
     out = _bn(sd, p + ".bn1", x, training, bn_frozen)
     out = F.conv2d(out, sd[p + ".conv1.weight"], None, 1, 1)
     out = _bn(sd, p + ".bn2", out, training, bn_frozen)
-    out = F.prelu(out, sd[p + ".prelu.weight"])
+    out = prelu_hook(p + ".prelu", out, sd[p + ".prelu.weight"]) if prelu_hook else F.prelu(out, sd[p + ".prelu.weight"])
     out = F.conv2d(out, sd[p + ".conv2.weight"], None, stride, 1)
     out = _bn(sd, p + ".bn3", out, training, bn_frozen)
     if (p + ".downsample.0.weight") in sd:
@@ -309,7 +310,7 @@ def ibasic_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, stride: i
 
 def iresnet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, layers: Sequence[int],
                     training: bool = True, return_taps: bool = False, dropout_p: float = 0.0,
-                    dropout_mask: Optional[torch.Tensor] = None, bn_frozen: bool = False):
+                    dropout_mask: Optional[torch.Tensor] = None, bn_frozen: bool = False, prelu_hook=None):
     """iresnet.py:158-172 with fp16=False (CPU path).  ``bn_frozen``: after IResNet.freeze_BN(test_mode=True) (iresnet.py:140-147) — every
     BatchNorm in eval mode while the net trains (dropout stays on).  ``dropout_p`` > 0 with an injected keep-``dropout_mask`` [B, 25088] (0/1): the
     nn.Dropout(p, inplace=True) of iresnet.py:169 with that mask (torch's RNG stream is not part of the contract; FL configs use p = 0,
@@ -317,11 +318,11 @@ def iresnet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, layers: Sequen
     taps = {}
     h = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
     h = _bn(sd, "bn1", h, training, bn_frozen)
-    h = F.prelu(h, sd["prelu.weight"])
+    h = prelu_hook("prelu", h, sd["prelu.weight"]) if prelu_hook else F.prelu(h, sd["prelu.weight"])
     taps["stem"] = h
     for si, nblk in enumerate(layers):
         for bi in range(nblk):
-            h = ibasic_block(sd, "layer%d.%d" % (si + 1, bi), h, 2 if bi == 0 else 1, training, bn_frozen)
+            h = ibasic_block(sd, "layer%d.%d" % (si + 1, bi), h, 2 if bi == 0 else 1, training, bn_frozen, prelu_hook)
         taps["layer%d" % (si + 1)] = h
     h = _bn(sd, "bn2", h, training, bn_frozen)
     h = torch.flatten(h, 1)
@@ -711,14 +712,15 @@ def public_fixture_state(g, variant: str):
 
 def train_step_grads(sd: Dict[str, torch.Tensor], fc: torch.Tensor, imgs: torch.Tensor,
                      labels: torch.Tensor, layers: Sequence[int], loss_name: str = "CosFace",
-                     s: float = 30.0, m: float = 0.4):
-    """One fwd+bwd; returns (feats, cosine, loss, {key: grad}, fc_grad).  BN buffers in sd are updated."""
+                     s: float = 30.0, m: float = 0.4, prelu_hook=None):
+    """One fwd+bwd; returns (feats, cosine, loss, {key: grad}, fc_grad).  BN buffers in sd are updated.
+    ``prelu_hook``: see ibasic_block (tests inject the HIP path's PReLU sign pattern into this backward pass)."""
     keys = trainable_keys(sd)
     ps = [sd[k].requires_grad_(True) for k in keys]
     fc.requires_grad_(True)
     for p in ps + [fc]:
         p.grad = None
-    feats = iresnet_forward(sd, imgs, layers, training=True)
+    feats = iresnet_forward(sd, imgs, layers, training=True, prelu_hook=prelu_hook)
     cosine = fc_module_forward(feats, fc)
     logits = MARGINS[loss_name](cosine.clone(), labels, s, m)
     loss = F.cross_entropy(logits, labels)

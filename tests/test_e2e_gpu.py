@@ -9,7 +9,9 @@ DIRECTION of gradients that passed a PReLU.  Rounding the PReLU's input moves el
 derivative from 1 to the slope, so a flipped fraction f of the elements changes the gradient by ~ (1 - slope) sqrt(f) in relative L2 —
 sqrt(1e-3) = 3e-2 for fp16's 2^-11, sqrt(8e-3) = 9e-2 for bf16's 2^-8, 8e-4 for the fp32 validation path (measured: 2.7-3.5e-2, 8.5e-2-1.2e-1,
 2.5-8e-4).  The same kernels with slope 1 (no kink) are inside 1e-2 on every gradient (test_gradients_without_the_prelu_kink_meet_the_spec,
-tests/test_block_gpu.py `*_lin`).  T16(fp16_bound, bf16_bound) picks the bound of the loaded library; the bf16 bounds (what 7 mantissa bits
+tests/test_block_gpu.py `*_lin`), and on the REAL networks with their real slopes the law is checked element by element
+(test_prelu_kink_law_and_mask_injected_gradients: flipped inputs counted per PReLU, every parameter's error <= 1.5 x the prediction; with the HIP
+path's sign pattern injected into the fp32 oracle's backward pass every gradient norm and direction is inside 1e-2).  T16(fp16_bound, bf16_bound) picks the bound of the loaded library; the bf16 bounds (what 7 mantissa bits
 allow, measured in round 4) are used by the child-process subset that loads libfedfr_hip_bf16.so."""
 import os
 
@@ -31,7 +33,10 @@ DEV = torch.device("cuda:0")
 SPEC = 1e-2                 # north_star: embeddings, logits, grads within 1e-2 of the reference for 16-bit storage
 # stated exceptions on fp16 storage (see the module docstring): per-parameter gradient direction behind a PReLU kink
 # (median / worst tensor over a network), worst single parameter tensor's gradient NORM (a bn3 scale: a sum of kink-affected products)
-KINK_DIR_MEDIAN, KINK_DIR_MAX, KINK_NORM_MAX = 5e-2, 1.2e-1, 3e-2
+# = measured x 1.25 (iresnet100 b6: median 3.87e-2, max 6.24e-2, worst norm 1.63e-2).  The LAW behind them is an assertion of its own:
+# test_prelu_kink_law_and_mask_injected_gradients counts the flipped PReLU inputs and bounds every parameter's error by the prediction, and shows
+# every gradient inside 1e-2 (measured 6.8e-3) of the fp32 oracle once both sides differentiate with the same sign pattern
+KINK_DIR_MEDIAN, KINK_DIR_MAX, KINK_NORM_MAX = 4.9e-2, 8e-2, 2.1e-2
 
 
 def T16(fp16_bound, bf16_bound):
@@ -438,6 +443,115 @@ def test_gradients_without_the_prelu_kink_meet_the_spec(arch, batch):
     assert rel(fcm.fc.grad, fcg_ref) < T16(SPEC, 3.3e-2)
 
 
+class _MaskedPReLU(torch.autograd.Function):
+    """F.prelu in the forward direction; the BACKWARD pass uses an injected sign pattern (`pos` = where the HIP path's PReLU input was
+    positive) instead of the sign of its own input: d/dz = 1 where pos, the slope elsewhere; d/dslope = sum of dy z over the rest."""
+
+    @staticmethod
+    def forward(ctx, z, w, pos):
+        ctx.save_for_backward(z, w, pos)
+        return F.prelu(z, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, w, pos = ctx.saved_tensors
+        wv = w.view(1, -1, 1, 1)
+        dz = torch.where(pos, dy, dy * wv)
+        dw = torch.where(pos, torch.zeros_like(dy), dy * z).sum(dim=(0, 2, 3))
+        return dz, dw, None
+
+
+@pytest.mark.parametrize("arch,batch", [("iresnet50", 8), ("iresnet100", 6)])
+def test_prelu_kink_law_and_mask_injected_gradients(arch, batch):
+    """Closes the one parity exception with a CHECK on the real network with its real slopes:
+    (b) the fp32 oracle's backward pass run with the HIP path's PReLU sign pattern (read back from the saved activations, injected through
+        oracle.ref_cpu's prelu_hook — the way the dropout test injects the HIP mask): every parameter gradient of the HIP step, norm AND direction,
+        is inside north_star's 1e-2 of it — what is left of the kink class once both sides differentiate the same piecewise-linear function;
+    (a) the law itself: per PReLU the fraction f of inputs whose sign differs between the HIP activations and the fp32 oracle is counted, and
+        the observed direction error of a parameter against the plain fp32 oracle (= the reference, tests/test_oracle_golden.py) is at most
+        1.5 x sqrt(sum over the PReLUs its gradient passed of (1 - slope)^2 f) plus its mask-injected error (triangle inequality)."""
+    C = 32
+    m, sd, layers = make_model(arch)
+    m.train()
+    fcm = client.FC_module(512, C, "/tmp").to(DEV)
+    fc0 = R.head_fc(C)
+    fcm.fc.data = fc0.clone().to(DEV)
+    x, lab = R.closed_form_images(batch), R.closed_form_labels(batch, C)
+    cosine = client.Sequential_model(m, fcm)(x.to(DEV))
+    loss = ops.cross_entropy(losses.CosFace(s=30, m=0.4)(cosine, lab.to(DEV)), lab.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    # the HIP path's sign pattern: a = prelu(z) has the sign of z (every closed-form slope is positive)
+    assert all(float(v.min()) > 0 for k, v in sd.items() if k.endswith("prelu.weight"))
+    plan = m._plan(batch)
+    hip_pos = {}
+
+    def nchw(a, C_):
+        hw = int(round((a.shape[0] // batch) ** 0.5))
+        return (a.view(batch, hw, hw, C_) > 0).permute(0, 3, 1, 2).contiguous()
+    hip_pos["prelu"] = nchw(_hip_act(plan, -1, 1), 64)
+    order = ["prelu"]
+    bi_g = 0
+    for si, nblk in enumerate(layers):
+        for bi in range(nblk):
+            a2 = _hip_act(plan, bi_g, 3)
+            name = "layer%d.%d.prelu" % (si + 1, bi)
+            hip_pos[name] = nchw(a2, a2.shape[1])
+            order.append(name)
+            bi_g += 1
+    flips, slope = {}, {}
+
+    def hook(name, z, w):
+        own = z.detach() > 0
+        flips[name] = float((own != hip_pos[name]).float().mean())
+        slope[name] = float(w.detach().mean())
+        return _MaskedPReLU.apply(z, w, hip_pos[name])
+    sd_a = {k: v.clone() for k, v in sd.items()}
+    _, c_ref, l_ref, g_ref, fcg_ref = R.train_step_grads(sd_a, fc0.clone(), x, lab, layers)                       # the reference's own derivative
+    sd_b = {k: v.clone() for k, v in sd.items()}
+    _, c_m, l_m, g_m, fcg_m = R.train_step_grads(sd_b, fc0.clone(), x, lab, layers, prelu_hook=hook)            # ... with the HIP sign pattern
+    assert torch.equal(c_ref, c_m)                                                                                # (forward values are untouched)
+    gmax = max(float(v.norm()) for v in g_ref.values())
+    names = [k for k in R.trainable_keys(sd) if float(g_ref[k].norm()) > 1e-3 * gmax]
+    sums = [k for k in names if k.endswith(("bn1.bias", "bn2.bias"))]       # nearly cancelling column sums: listed apart, as everywhere
+    rest = [k for k in names if k not in sums]
+    # (b) HIP vs the mask-injected oracle
+    nerr = np.array([abs(float(params[k].grad.norm()) - float(g_m[k].norm())) / float(g_m[k].norm()) for k in rest])
+    derr = {k: rel(params[k].grad, g_m[k]) for k in rest}
+    dv = np.array(list(derr.values()))
+    wk = max(derr, key=derr.get)
+    print("MEASURED %s mask-injected oracle: grad norms median %.3e max %.3e; directions median %.3e max %.3e (%s); head grad %.3e; flipped "
+          "fraction per PReLU median %.3e max %.3e" % (arch, np.median(nerr), nerr.max(), np.median(dv), dv.max(), wk, rel(fcm.fc.grad, fcg_m),
+                                                      np.median(list(flips.values())), max(flips.values())))
+    # (a) the law: prediction per parameter from the flips of the PReLUs its gradient passed through
+    idx = {n: i for i, n in enumerate(order)}
+
+    def first_prelu(k):
+        """index (forward order) of the first PReLU the gradient of parameter k has passed on its way back from the loss"""
+        if not k.startswith("layer"):
+            return 0 if k in ("conv1.weight", "bn1.weight", "bn1.bias", "prelu.weight") else len(order)      # stem: all of them; tail: none
+        blk = ".".join(k.split(".")[:2])
+        own = idx[blk + ".prelu"]
+        behind = k.split(".")[2] in ("bn1", "conv1", "bn2", "prelu")
+        return own if behind else own + 1
+    obs = {k: rel(params[k].grad, g_ref[k]) for k in rest}
+    kink = {k: rel(g_m[k], g_ref[k]) for k in rest}                         # the kink's share alone (CPU, both sides fp32)
+    worst = (0.0, None)
+    for k in rest:
+        pred = float(np.sqrt(sum(((1.0 - slope[n]) ** 2) * flips[n] for n in order[first_prelu(k):])))
+        bound = 1.5 * pred + 1.05 * derr[k] + 1e-4
+        worst = max(worst, (obs[k] / bound, k))
+        assert obs[k] <= bound, (k, obs[k], pred, derr[k])
+        assert kink[k] <= 1.5 * pred + 1e-4, (k, kink[k], pred)
+    ov, kv = np.array(list(obs.values())), np.array(list(kink.values()))
+    print("MEASURED %s kink law: observed directions vs fp32 oracle median %.3e max %.3e; kink share (oracle vs mask-injected oracle) median %.3e "
+          "max %.3e; worst observed / bound %.2f (%s)" % (arch, np.median(ov), ov.max(), np.median(kv), kv.max(), worst[0], worst[1]))
+    assert np.median(nerr) < T16(SPEC, 2e-2) and nerr.max() < T16(SPEC, 6e-2), (np.median(nerr), nerr.max())
+    assert np.median(dv) < T16(SPEC, 5e-2) and dv.max() < T16(SPEC, 0.15), (np.median(dv), dv.max(), wk)
+    assert rel(fcm.fc.grad, fcg_m) < T16(SPEC, 3.3e-2)
+
+
 def test_fused_client_loop_vs_reference():
     """FusedTrainer == the reference hot loop (client.py:537-550): iresnet18, 3 SGD steps (lr 0.01, momentum 0.9,
     wd 5e-4), closed-form data.  Losses track the fp32 reference to < 0.5 % (measured 0.07 %)."""
@@ -454,7 +568,7 @@ def test_fused_client_loop_vs_reference():
     np.testing.assert_allclose(np.array(ls), g["losses"], rtol=5e-3)
     out = m.state_dict()
     for k in ("bn1.running_mean", "bn1.running_var", "layer4.1.bn3.running_var", "features.running_mean"):
-        assert rel(out[k], g["sd_" + k]) < 3e-2, (k, rel(out[k], g["sd_" + k]))
+        assert rel(out[k], g["sd_" + k]) < T16(SPEC, 3e-2), (k, rel(out[k], g["sd_" + k]))      # measured 5.2e-3 on fp16
     assert int(out["bn1.num_batches_tracked"]) == int(g["sd_bn1.num_batches_tracked"])
     for k in ("conv1.weight", "layer2.0.downsample.0.weight", "bn1.weight", "prelu.weight", "features.bias"):
         assert rel(out[k], g["sd_" + k]) < 1e-2, (k, rel(out[k], g["sd_" + k]))
@@ -688,7 +802,7 @@ def test_sweeps_and_hard_negative_mining_vs_reference():
 # 5.4e-2 / 8.5e-2 max: the PReLU-kink class (every sphnet unit is conv -> PReLU)
 # bf16 subset, round 4 x 1.25: sphere20 6.3e-3, 4.1e-3 / 5.8e-2, 0.106 / 0.160; sphere64 5.5e-3, 5.8e-3 / 3.3e-2, 0.075 / 0.273
 SPH_TOL_BF16 = {20: (2e-2, 1e-2, 0.12, 0.15, 0.4), 64: (7e-3, 7.5e-3, 4.2e-2, 0.095, 0.345)}
-SPH_TOL_FP16 = (SPEC, SPEC, KINK_NORM_MAX, KINK_DIR_MEDIAN, KINK_DIR_MAX)
+SPH_TOL_FP16 = (SPEC, SPEC, 2.5e-2, 4.3e-2, 1.07e-1)      # kink class: measured (2.0e-2, 3.4e-2, 8.5e-2) x 1.25
 
 
 @pytest.mark.parametrize("type_", [20, 64])

@@ -294,6 +294,119 @@ def test_config5_scale_properties():
     assert all(np.isfinite(v) and 5.0 < v < 40.0 for v in res[0][0])             # ~ ln(8 * 1062) + s * m for random weights
 
 
+# ---- BASELINE configs 4 and 5 at their FULL size (iresnet100, batch 128 per client) on one GPU ---------------------------------------
+_R100_SD = {}
+
+
+def _r100_state(rank):
+    """iresnet100 closed-form state, generated ONCE (8 s of hashing on the CPU) and made client-specific by a rank-dependent scale of the stem
+    and bn weights (different local models, so 'one averaged model' means something)."""
+    if "sd" not in _R100_SD:
+        _R100_SD["sd"] = R.closed_form_state_dict(R.IRESNET_LAYERS["iresnet100"])
+    sd = {k: v.clone() for k, v in _R100_SD["sd"].items()}
+    sd["conv1.weight"] = sd["conv1.weight"] * (1.0 + 0.05 * rank)
+    for k in sd:
+        if k.endswith("bn2.weight") or k.endswith("bn1.bias"):
+            sd[k] = sd[k] + 0.01 * rank
+    return sd
+
+
+def test_config4_full_size():
+    """BASELINE config 4 at full size: 4 clients (thread-ranks) x iresnet100 + CosFace over a dense 1000-class head, batch 128, ONE local
+    train step each (client.py:537-550), then the round's exchange (server.fedavg_all_reduce, ONE all-reduce of the 261 MB flat state,
+    replacing server.py:25-34): every rank ends with the same model and it is FedPavg of the four local models BIT FOR BIT (the in-process
+    communicator sums in ascending rank order, like the reference loop)."""
+    W, B, C = 4, 128, 1000
+    sizes = [300.0, 100.0, 250.0, 50.0]
+    imgs = [R.closed_form_images(B, tag=float(r)).to(DEV) for r in range(W)]
+    labs = [R.closed_form_labels(B, C, tag=r).to(DEV) for r in range(W)]
+    for r in range(W):
+        _r100_state(r)            # (the shared base state, built outside the threads)
+
+    def run(c):
+        rank = c.rank
+        bb = backbones.iresnet100(False, dropout=0, fp16=True)
+        bb.load_state_dict(_r100_state(rank))
+        bb = bb.to(DEV)
+        fc = R.head_fc(C).to(DEV)
+        tr = client.FusedTrainer(bb, fc, "CosFace", 30.0, 0.4, lr=0.01, aux_slot=rank)
+        loss = float(tr.step(imgs[rank], labs[rank]))
+        tr.finish()
+        torch.cuda.synchronize()
+        local = client.flat_state_dict(bb, clone=True)
+        calls = []
+        real = c.all_reduce
+        c.all_reduce = lambda t, op="sum": (calls.append(t.numel()), real(t, op))[1]
+        server.fedavg_all_reduce(bb, sizes[rank], sum(sizes), c)
+        torch.cuda.synchronize()
+        assert calls == [bb._flat_state.numel()]                     # ONE collective: the whole state, in place
+        return loss, local, bb._flat_state.clone(), {k: bb.state_dict()[k].clone() for k in ("bn1.num_batches_tracked", "layer3.9.bn2.num_batches_tracked")}
+    out = ThreadComm.run(W, run, device=DEV)
+    assert all(np.isfinite(o[0]) and 5.0 < o[0] < 40.0 for o in out), [o[0] for o in out]
+    assert len({o[0] for o in out}) == W                              # four different clients
+    expect = server.FedPavg([o[1] for o in out], sizes)
+    for r in range(W):
+        assert torch.equal(out[r][2], out[0][2]), r                   # one averaged model on every rank
+    m = backbones.iresnet100(False, dropout=0, fp16=True).to(DEV)
+    m.load_state_dict(expect)
+    n_float = m._flat_params.numel() + m._flat_bufs.numel()
+    assert torch.equal(out[0][2][:n_float], m._flat_state[:n_float])   # == FedPavg of the four local models, bit for bit
+    for k, v in out[0][3].items():
+        assert int(v) == int(float(expect[k])), k                     # counters: float average truncated to int64 (F9)
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 at full size on one GPU: 8 clients (thread-ranks) x iresnet100, batch 128 each (global batch 1024), ONE CosFace PartialFC
+    over 85 000 identities class-sharded 10 625 per rank (sample_rate 0.1 -> 1 062 sampled rows per shard, partial_fc.py:118-176) + a private BCE
+    head per client; 2 steps, then the FedAvg exchange (server.py:25-34).  Size-independent properties: one global softmax (the same loss on every
+    rank), sorted sampled index sets that contain the shard's positives, only sampled rows touched, one averaged model == FedPavg of the local
+    models, everything finite.  ~10 GB of arenas per client: 80 GB of the 288."""
+    W, B, C = 8, 128, 85000
+    n_ids = C // W
+    sizes = [100.0 + r for r in range(W)]
+    for r in range(W):
+        _r100_state(r)
+    imgs = [[R.closed_form_images(B, tag=float(r + st)).to(DEV) for st in range(2)] for r in range(W)]
+
+    def run(c):
+        rank = c.rank
+        bb = backbones.iresnet100(False, dropout=0, fp16=True)
+        bb.load_state_dict(_r100_state(rank))
+        bb = bb.to(DEV)
+        pfc = PartialFC(rank=rank, local_rank=0, world_size=W, batch_size=B, resume=False, margin_softmax=losses.CosFace(s=30, m=0.4),
+                        num_classes=C, sample_rate=0.1, embedding_size=512, prefix="/tmp", comm=c)
+        assert (pfc.num_local, pfc.num_sample) == (10625, 1062)
+        w0 = pfc.weight.clone()
+        bm = client.BCE_module(512, 256, 1).to(DEV)
+        tr = client.ShardedHeadTrainer(bb, pfc, bm, id_base=rank * n_ids, lr=0.01, aux_slot=rank)       # (own weight-gradient stream per client)
+        lab = (R.closed_form_labels(B, 256, tag=rank) + rank * n_ids).to(DEV)
+        outs = [tr.step(imgs[rank][st], lab) for st in range(2)]
+        torch.cuda.synchronize()
+        idx = pfc.index
+        assert idx.numel() == 1062 and bool((idx[1:] > idx[:-1]).all())
+        mine = lab[(lab >= pfc.class_start) & (lab < pfc.class_start + pfc.num_local)] - pfc.class_start
+        assert bool(torch.isin(mine, idx).all())
+        changed = (pfc.weight != w0).any(dim=1)
+        assert 1062 <= int(changed.sum()) <= 2 * 1062
+        assert bool(torch.isfinite(bb._flat_params).all()) and bool(torch.isfinite(pfc.weight).all())
+        local = client.flat_state_dict(bb, clone=True)
+        tr.end_round(sizes[rank], sum(sizes))
+        torch.cuda.synchronize()
+        return [(float(o[0]), float(o[1]), float(o[2])) for o in outs], local, bb._flat_state.clone()
+    res = ThreadComm.run(W, run, device=DEV)
+    for r in range(1, W):
+        assert [o[1] for o in res[r][0]] == [o[1] for o in res[0][0]]           # one global softmax: the same sharded-head loss on every rank
+        assert torch.equal(res[r][2], res[0][2])                                # one averaged model after the exchange
+    assert all(np.isfinite(v) for o in res for t in o[0] for v in t)
+    assert all(5.0 < o[1] < 40.0 for o in res[0][0]), res[0][0]                  # ~ ln(8 * 1062) + s * m for random class weights
+    assert len({res[r][0][0][2] for r in range(W)}) == W                        # the private BCE losses differ per client
+    expect = server.FedPavg([res[r][1] for r in range(W)], sizes)
+    m = backbones.iresnet100(False, dropout=0, fp16=True).to(DEV)
+    m.load_state_dict(expect)
+    n_float = m._flat_params.numel() + m._flat_bufs.numel()
+    assert torch.equal(res[0][2][:n_float], m._flat_state[:n_float])             # == FedPavg of the eight local models, bit for bit
+
+
 def test_config3_full_size_properties():
     """BASELINE config 3 once at full size: iresnet100 + ArcFace + PartialFC sample_rate 0.1 over 85 000 identities, B = 128."""
     C, B = 85000, 128

@@ -5,10 +5,10 @@ and therefore the same ``state_dict`` keys, same ``forward(x[B,3
 What differs is underneath:
 
 * every parameter / buffer is a *view* into one flat fp32 tensor (conv weights are stored KRSC, i.e.
-  they are channels_last OIHW tensors), so SGD, FedAvg and the bf16 weight shadows are single flat
+  they are channels_last OIHW tensors), so SGD, FedAvg and the 16-bit weight shadows are single flat
   kernels / collectives;
 * forward and backward are one call each into libfedfr_hip.so (``fedfr_net_forward`` /
-  ``fedfr_net_backward``): NHWC bf16 activations, MFMA implicit-GEMM convolutions, fused BN
+  ``fedfr_net_backward``): NHWC 16-bit activations (fp16 storage in the product library), MFMA implicit-GEMM convolutions, fused BN
   statistics, fp32 master weights.  There is no PyTorch fallback: without the library (or on a CPU
   tensor) ``forward`` raises.
 """
@@ -291,7 +291,7 @@ class IResNet(nn.Module):
             raise ValueError("BasicBlock only supports groups=1 and base_width=64")       # iresnet.py:33-34
         if replace_stride_with_dilation is not None and any(replace_stride_with_dilation):
             raise NotImplementedError("Dilation > 1 not supported in BasicBlock")          # iresnet.py:35-36
-        self.fp16 = fp16          # accepted for signature parity; this backend always stores bf16 / accumulates fp32
+        self.fp16 = fp16          # accepted for signature parity; this backend always stores 16-bit (fp16 in the product library, bf16 in libfedfr_hip_bf16.so) / accumulates fp32
         self.layers_cfg = tuple(int(v) for v in layers)
         self.num_features = num_features
         self.in_hw = 112

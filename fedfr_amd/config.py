@@ -11,7 +11,7 @@ config = _AttrDict()
 config.dataset = "ms1m_split"
 config.embedding_size = 512
 config.sample_rate = 1
-config.fp16 = True            # reference: fp16 autocast; this backend: bf16 storage / fp32 accumulate
+config.fp16 = True            # reference: fp16 autocast; this backend: fp16 storage (libfedfr_hip.so; bf16 in libfedfr_hip_bf16.so) / fp32 accumulate
 config.momentum = 0.9
 config.weight_decay = 5e-4
 config.lr = 0.05

@@ -40,7 +40,15 @@ template <int N_>
 __device__ __forceinline__ void w9p_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
-__device__ __forceinline__ int w9p_swz(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }   // == tn_swz<128>
+// LDS rows are 128 B (8 chunks of 16 B); a lane quad of a transposed read takes 32 B (a chunk PAIR) of one row, a 32-lane group (the unit the
+// LDS serves a ds_read_b64_tr_b16 in: 2 x 32 lanes, 64 banks of 4 B) eight consecutive rows.  Rows of equal parity share their 32-bank half, so the
+// four of them need four different chunk pairs: the pair index is XOR-ed with row bits 1-2.  (Rounds 2-5 used row bits 1 and 3 — tn_swz<128>, laid
+// out for 16-lane service groups: rows u and u + 4 then met in the same banks, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 exactly,
+// profiles/r06_pmc_sq_step_v1.txt.)
+#ifndef W9P_SWZ_OLD
+#define W9P_SWZ_OLD 0
+#endif
+__device__ __forceinline__ int w9p_swz(int row) { return W9P_SWZ_OLD ? ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 3) << 1); }
 
 // The split-K slabs of the PREVIOUS paired launch on this stream, summed by this launch's workgroups beside their own work (round 4).  A
 // stand-alone reduction is bandwidth-bound at 5-7 us per layer plus its launch boundary: 13 of the 66 us a pair cost.  Here a workgroup owns
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int MARK_LANE = (int)0x80000000u, MARK_ROW = 0x40000000;
   const int Wi = p.W;
   const int prow = lane >> 3, odd = wave & 1, whalf = wave >> 1;
-  const int lchunk = ((lane & 7) ^ ((((prow >> 1) & 1) << 1) | (odd << 2))) * 16;     // swz(row): row bit 1 = prow bit 1, row bit 3 = piece parity
+  const int lchunk = ((lane & 7) ^ (W9P_SWZ_OLD ? ((((prow >> 1) & 1) << 1) | (odd << 2)) : (((prow >> 1) & 3) << 1))) * 16;     // swz(row): row bits 1-2 = prow bits 1-2 (a piece is 8 aligned rows)
   const int vlaneP = (prow * p.cout * 2 + lchunk) | ((odd && prow >= 6) ? MARK_LANE : 0);
   const int laneQ = prow * p.cin * 2 + lchunk;
   const bool q_edge_lane = odd ? prow == 7 : prow == 0;    // this wave's pieces hold raster column 15 (odd half) or 0 (even half) in that lane row

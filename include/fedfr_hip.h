@@ -9,7 +9,7 @@
  *   - all pointers are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr()); the library
  *     allocates no device memory and retains no pointer after return.
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it.
- *   - activations are NHWC bf16 (raw uint16 bits); conv weights are KRSC ([Cout][kh][kw][Cin]) which is
+ *   - activations are NHWC in the 16-bit storage type (IEEE fp16 in libfedfr_hip.so, bf16 in libfedfr_hip_bf16.so: fedfr_storage_dtype(); raw uint16 bits); conv weights are KRSC ([Cout][kh][kw][Cin]) which is
  *     exactly a torch channels_last OIHW tensor; parameters / grads / optimizer state are fp32.
  */
 #ifndef FEDFR_HIP_H
@@ -98,8 +98,8 @@ int fedfr_net_set_dropout(fedfr_net_t* net, float p, unsigned long long seed, lo
  * workspace release, for every new model — so a host that wants masks that never repeat keeps the count itself (fedfr_amd.IResNet does:
  * one counter per model, handed over before every training forward). */
 int fedfr_net_set_dropout_step(fedfr_net_t* net, unsigned long long step);
-/* debug (tests): while buf != NULL, fedfr_net_backward* copies the gradient entering every block (bf16 NHWC, last block first) and then
- * the gradient wrt the first block's input back to back into buf (caller-owned, `elems` bf16 elements); NULL turns it off.  The one
+/* debug (tests): while buf != NULL, fedfr_net_backward* copies the gradient entering every block (16-bit storage type, NHWC, last block first) and then
+ * the gradient wrt the first block's input back to back into buf (caller-owned, `elems` 16-bit elements); NULL turns it off.  The one
  * exception to "no pointer is retained": clear it before freeing the buffer. */
 int fedfr_net_debug_capture(uint16_t* buf, size_t elems);
 enum {
@@ -107,7 +107,7 @@ enum {
   FEDFR_Q_TRAINABLE_COUNT = 1,
   FEDFR_Q_BUFFER_COUNT = 2,     /* fp32 BN running stats */
   FEDFR_Q_NBT_COUNT = 3,        /* int64 num_batches_tracked scalars */
-  FEDFR_Q_SHADOW_COUNT = 4,     /* bf16 elements */
+  FEDFR_Q_SHADOW_COUNT = 4,     /* 16-bit elements */
   FEDFR_Q_ACT_BYTES = 5,
   FEDFR_Q_WS_BYTES = 6,
   FEDFR_Q_NUM_TENSORS = 7,
@@ -118,13 +118,13 @@ int fedfr_net_query(const fedfr_net_t* net, int what, long long* out);
  * 5 fc.bias 6 running_mean 7 running_var 8 num_batches_tracked; region: 0 params 1 bufs 2 nbt. */
 int fedfr_net_tensor_info(const fedfr_net_t* net, int i, char* name, int name_cap, int* kind, int* region,
                           long long* offset, int* ndim, int* shape4);
-/* debug/inspection: where a saved activation lives inside `act` (bf16 element offset, [rows][channels] NHWC view).
+/* debug/inspection: where a saved activation lives inside `act` (16-bit element offset, [rows][channels] NHWC view).
  * block < 0: which = 0 stem conv output, 1 stem activation, 2 flattened bn2 output [B][fc_in] (NCHW order);
  * block >= 0: which = 0 block input, 1 bn1 out, 2 conv1 out, 3 prelu(bn2) out, 4 conv2 out, 5 downsample conv out
  * (offset -1 if the block has none), 6 block output, 7 gradient wrt the block input (fedfr_block_create plans only, after a backward).  An eval-mode forward (training = 0) applies the BatchNorms in the conv epilogues
  * where the kernel has one and then does not store the raw conv outputs (2, 4); fedfr_set_option("eval_fuse", 0) restores them. */
 int fedfr_net_act_info(const fedfr_net_t* net, int block, int which, long long* offset, int* rows, int* channels);
-/* refresh the bf16 weight shadows from fp32 params (after load_state_dict / an external optimizer step);
+/* refresh the 16-bit weight shadows (storage type: fp16 / bf16 per build) from fp32 params (after load_state_dict / an external optimizer step);
  * fwd_shadow_too = 0 when fedfr_sgd_step already wrote the mirror region. */
 int fedfr_net_prepare_weights(const fedfr_net_t* net, const float* params, uint16_t* shadow, int fwd_shadow_too,
                               void* stream);
@@ -144,7 +144,7 @@ int fedfr_net_backward(const fedfr_net_t* net, const float* x, const float* dfea
 int fedfr_net_backward2(const fedfr_net_t* net, const float* x, const float* dfeats, const float* params,
                         const uint16_t* shadow, void* act, void* ws, float* grads, void* stream, void* aux_stream);
 /* fedfr_net_backward2 with `torch.optim.SGD(...).step()` (client.py:396,550; fedfr_sgd_step semantics: coupled weight decay, momentum
- * buffer, bf16 mirror refreshed) folded in: parameter ranges whose gradients are final — the bn2 / fc / features tail, then each stage
+ * buffer, 16-bit mirror refreshed) folded in: parameter ranges whose gradients are final — the bn2 / fc / features tail, then each stage
  * of residual blocks as the pass leaves it — are updated on aux_stream while `stream` walks the earlier stages.  When the call's work
  * completes, parameters [*done_from, trainable_count) are updated; the caller runs fedfr_sgd_step on [0, *done_from) (stem + stage 1).
  * params / shadow are the buffers the pass reads (now written too); results are bit-identical to backward + one flat fedfr_sgd_step. */
@@ -159,7 +159,7 @@ int fedfr_net_backward2_sgd_scaled(const fedfr_net_t* net, const float* x, const
 
 /* fp32 VALIDATION path of the same plan (csrc/net_f32.hip): IResNet.forward / autograd backward (iresnet.py:46-57,158-172) with fp32
  * activations and exact-fp32 arithmetic (im2col + the fp32-MFMA GEMM, two-pass BatchNorm in fp64) — what the "1e-3 fp32" tolerance is
- * checked with, and the yardstick that separates the product path's bf16 storage noise from kernel error.  Slow by design (one launch per
+ * checked with, and the yardstick that separates the product path's 16-bit storage noise from kernel error.  Slow by design (one launch per
  * operation, ~40 TFLOP/s); whole-network plans, dropout 0, training 0 / 1.  arena (fedfr_net_f32_arena_floats floats) keeps the
  * activations between forward and backward, ws (fedfr_net_f32_ws_floats floats) is scratch; params / bufs / grads are the plan's
  * ordinary fp32 buffers (grads assigned; running statistics updated by a training forward). */
@@ -172,8 +172,8 @@ int fedfr_net_f32_backward(const fedfr_net_t* net, const float* dfeats, const fl
 
 /* ------------------------------------------------------------------------------------------------
  * single convolutions — replace nn.Conv2d fwd / dgrad / wgrad at the call sites iresnet.py:38,41,76,121
- * (implicit GEMM on v_mfma_f32_16x16x32_bf16).  w: bf16 KRSC; wd: bf16 dgrad shadow [Cin][kh'][kw'][Cout].
- * stats (optional): [fedfr_conv2d_stat_rows][2][Cout] fp32 partial (sum, sumsq) of the bf16 output.
+ * (implicit GEMM on v_mfma_f32_16x16x32_f16 / _bf16 per build).  w: 16-bit KRSC; wd: 16-bit dgrad shadow [Cin][kh'][kw'][Cout].
+ * stats (optional): [fedfr_conv2d_stat_rows][2][Cout] fp32 partial (sum, sumsq) of the 16-bit output.
  * ------------------------------------------------------------------------------------------------ */
 int fedfr_conv2d_stat_rows(int batch, int hout, int cout);
 int fedfr_conv2d_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* stats, int batch, int hin, int cin,
@@ -199,7 +199,7 @@ int fedfr_conv2d_wgrad(const uint16_t* x, const uint16_t* dy, float* dw, void* w
 int fedfr_conv2d_wgrad_pair(const uint16_t* xa, const uint16_t* dya, float* dwa, const uint16_t* xb, const uint16_t* dyb,
                             float* dwb, void* ws, size_t ws_bytes, int batch, int hin, int cin, int cout, int ksize,
                             int stride, void* stream);
-int fedfr_weight_shadows(const float* w_krsc, uint16_t* w_bf16, uint16_t* wd_bf16, int cout, int ksize, int cin,
+int fedfr_weight_shadows(const float* w_krsc, uint16_t* w_h16, uint16_t* wd_h16, int cout, int ksize, int cin,
                          void* stream);
 /* plain GEMMs on the same kernels: C[m][n] = sum_k A[m][k] B[n][k] (fp32 out) and C[i][j] = sum_p P[p][i] Q[p][j] */
 int fedfr_gemm_nt(const uint16_t* A, const uint16_t* B, float* C, void* ws, size_t ws_bytes, int M, int N, int K,
@@ -213,7 +213,7 @@ int fedfr_stem_wgrad(const float* x, const uint16_t* dy, float* dw, void* ws, in
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (train) + PReLU + residual — replace nn.BatchNorm2d / nn.PReLU / `out += identity`
- * (iresnet.py:37-56).  Tensors are [M][C] bf16 views of NHWC activations.
+ * (iresnet.py:37-56).  Tensors are [M][C] views (16-bit storage type) of NHWC activations.
  * ------------------------------------------------------------------------------------------------ */
 int fedfr_bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
@@ -249,7 +249,7 @@ int fedfr_bn_apply_sliced(const float* partials, int P, double count, const floa
                           float* stats, void* stream);
 /* Round 3, the forward moment pass (option "fwd_xmom"; reference: the bn3 + identity of IBasicBlock.forward, backbones/iresnet.py:69-78, and the
  * bn1 of the NEXT block, :62).  fedfr_conv2d_fwd_moments: 3x3 / stride-1 conv whose epilogue leaves, per workgroup, rows [3][cout] of the raw
- * moments (sum y, sum y * other, sum y * y) of its bf16 output against a same-shape tensor `other`; *rows = number of rows written (0: this
+ * moments (sum y, sum y * other, sum y * y) of its 16-bit output against a same-shape tensor `other`; *rows = number of rows written (0: this
  * shape is not served by a kernel with that epilogue, nothing was written to `partials`, y is still computed).  `partials` must hold
  * batch * hin * hin / 196 rows.  fedfr_bn_apply2_sliced: y = bn(x1) + x2 and y2 = bn_next(y), both BatchNorms in training mode, from those
  * rows and the saved statistics (x2_mean, x2_rstd) of x2: the statistics of y are derived — mean = scale * mean(x1) + shift + mean(x2),
@@ -323,7 +323,7 @@ int fedfr_class_accumulate(const float* feats, const long long* label, int B, in
  * dalpha = sum dy * z over z <= 0, dx = dz (+ add).  partials: [fedfr_bn_bwd_rows][3][C], coef: [3][C] scratch. */
 int fedfr_bias_prelu_bwd(const uint16_t* dy, const uint16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
                          float* coef, float* dbias, float* dalpha, const uint16_t* add, uint16_t* dx, void* stream);
-/* fp32 NCHW [B][C][HW] -> bf16 NHWC [B][HW][Cpad] with zero channels C..Cpad-1 (3-channel input of sphnet's first conv) */
+/* fp32 NCHW [B][C][HW] -> 16-bit NHWC [B][HW][Cpad] with zero channels C..Cpad-1 (3-channel input of sphnet's first conv) */
 int fedfr_pad_input_nhwc(const float* src_nchw, uint16_t* dst_nhwc, int B, int C, int HW, int Cpad, void* stream);
 /* input pipeline (dataset.py:81-92): uint8 [B][H][W][3] + optional per-image flip flags -> fp32 [B][3][H][W] = (x/255 - 0.5)/0.5 */
 int fedfr_preprocess_u8(const unsigned char* src_hwc, const unsigned char* flip, float* dst_nchw, int B, int H, int W, void* stream);
@@ -342,14 +342,14 @@ int fedfr_sum_scale(const float* x, int n, float scale, float* out, void* stream
  * optimiser / aggregation / PartialFC sampling — replace torch.optim.SGD.step (client.py:396,550),
  * FedPavg / FedAvg_on_FC (server.py:25-46), PartialFC.sample / update (partial_fc.py:89-116).
  * ------------------------------------------------------------------------------------------------ */
-int fedfr_sgd_step(float* params, const float* grads, float* momentum_buf, uint16_t* bf16_shadow, size_t n, float lr,
+int fedfr_sgd_step(float* params, const float* grads, float* momentum_buf, uint16_t* h16_shadow, size_t n, float lr,
                    float momentum, float weight_decay, int first_step, void* stream);
 /* fedfr_sgd_step on a gradient buffer that holds gradient / grad_scale (the GradScaler of client.py:394-396 with a static scale: the
  * fp16-storage build's backward pass runs on loss-scaled gradients): the kernel multiplies by grad_scale before the update and stores the
  * unscaled gradient back, so `grads` reads like p.grad afterwards.  grad_scale a power of two => bit-identical to unscale + fedfr_sgd_step.
  * Overflow guard (GradScaler.step's skip, without its host synchronisation): an element whose gradient is not finite keeps its parameter,
  * momentum and mirror value, and the device word *overflow (optional) is set to 1; the caller reads and clears it when it next synchronises. */
-int fedfr_sgd_step_scaled(float* params, float* grads, float* momentum_buf, uint16_t* bf16_shadow, size_t n, float lr, float momentum,
+int fedfr_sgd_step_scaled(float* params, float* grads, float* momentum_buf, uint16_t* h16_shadow, size_t n, float lr, float momentum,
                           float weight_decay, int first_step, float grad_scale, unsigned* overflow, void* stream);
 int fedfr_fedavg_axpy(float* dst, const float* src, float w, size_t n, int accumulate, void* stream);
 /* dst = (accumulate ? dst : 0) + sum_i ws[i] * srcs[i] over k <= 8 client states (HOST arrays of k device pointers / k weights) in one pass,

@@ -32,7 +32,8 @@ for f in glob.glob(out + "/**/p1_kernel_trace.csv", recursive=True):
         dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("# tools/pmc_sq_step.sh %s %s : SQ counters per kernel over a 3-step single-stream run of bench.py (per-dispatch averages)" % (os.environ["TAG"], os.environ["RX"]))
 print("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_BUSY_CYCLES per SQ (summed over SEs/XCDs);")
-print("# MfmaBusy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES; durations under --pmc are inflated: quote durations from --stats runs")
+print("# mfma_busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (4 x SQ_WAVE_CYCLES / SQ_WAVES): the share of a wave's lifetime during which its SIMD's matrix")
+print("# pipe is busy (bench.py's definition); waves_per_simd = SQ_WAVES / 1024; durations under --pmc are inflated: quote durations from --stats runs")
 rows = []
 for k, d in agg.items():
     n = max(cnt[(k, "SQ_WAVE_CYCLES")], 1)
@@ -45,8 +46,8 @@ for tot_us, k, d, n in sorted(rows, reverse=True):
     print("   share of wave cycles: wait_any %.3f  wait_inst_any %.3f  active_any %.3f (valu %.3f lds %.3f vmem %.3f sca %.3f)  lds_issue_wait %.3f" % (
         per("SQ_WAIT_ANY") / wc, per("SQ_WAIT_INST_ANY") / wc, per("SQ_ACTIVE_INST_ANY") / wc, per("SQ_ACTIVE_INST_VALU") / wc,
         per("SQ_ACTIVE_INST_LDS") / wc, per("SQ_ACTIVE_INST_VMEM") / wc, per("SQ_ACTIVE_INST_SCA") / wc, per("SQ_WAIT_INST_LDS") / wc))
-    print("   MfmaBusy %.3f   insts/dispatch: valu %.0f mfma %.0f lds %.0f vmem_rd %.0f vmem_wr %.0f salu %.0f smem %.0f   lds bank conflict / idx active %.3f (%.0f / %.0f)" % (
-        per("SQ_VALU_MFMA_BUSY_CYCLES") / busy, per("SQ_INSTS_VALU"), per("SQ_INSTS_MFMA"), per("SQ_INSTS_LDS"), per("SQ_INSTS_VMEM_RD"),
+    print("   mfma_busy %.3f  waves_per_simd %.2f   insts/dispatch: valu %.0f mfma %.0f lds %.0f vmem_rd %.0f vmem_wr %.0f salu %.0f smem %.0f   lds bank conflict / idx active %.3f (%.0f / %.0f)" % (
+        (per("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0) / max(4.0 * per("SQ_WAVE_CYCLES") / max(per("SQ_WAVES"), 1.0), 1.0), per("SQ_WAVES") / 1024.0, per("SQ_INSTS_VALU"), per("SQ_INSTS_MFMA"), per("SQ_INSTS_LDS"), per("SQ_INSTS_VMEM_RD"),
         per("SQ_INSTS_VMEM_WR"), per("SQ_INSTS_SALU"), per("SQ_INSTS_SMEM"), per("SQ_LDS_BANK_CONFLICT") / max(per("SQ_LDS_IDX_ACTIVE"), 1.0),
         per("SQ_LDS_BANK_CONFLICT"), per("SQ_LDS_IDX_ACTIVE")))
 PY

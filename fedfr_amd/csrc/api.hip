@@ -12,23 +12,18 @@
 
 static thread_local char g_err[512] = "";
 extern int g_tn_use_tr;
-extern int g_nt_nbuf;
-extern int g_tn_target_blocks;
 extern int g_fuse_bnbwd;
 extern int g_tn_glds;
 extern int g_nt_glds;
 extern int g_wgrad_pair_reduce;
 extern int g_wgrad9;
 extern int g_conv_c64p;
-extern int g_bn_sliced, g_bn_sliced_pre, g_bn_sliced_bwd_passes;
+extern int g_bn_sliced;
 extern int g_wgrad9p, g_wgrad9p_bg;
-extern int g_wgrad9_wgs;
 extern int g_conv28_tpw2;
 extern int g_eval_fuse;
-extern int g_wgrad_depth;
 extern int g_dgrad_parity;
 extern int g_fuse_bnred_next;
-extern int g_event_nofence;
 extern int g_sph_fin_multi;
 extern int g_sph_fuse_prelu_bwd;
 extern int g_sph_pair_wgrad;
@@ -38,7 +33,6 @@ extern int g_dbg_skip;
 extern int g_c64p_bnbwd;
 extern int g_stem_bnred;
 extern int g_fwd_xmom;
-extern int g_fc_wgrad_aux;
 extern int g_fuse_bnbwd28;
 
 void fedfr_set_error(const char* fmt, ...) {
@@ -72,34 +66,26 @@ namespace {
 struct OptRow { const char* name; int* var; int kind; int lo, hi; };
 const OptRow kOptions[] = {
     {"tn_use_tr", &g_tn_use_tr, 0, 0, 1},                  // 0: scalar-LDS fallback fragments of the register-staged TN kernel (validation)
-    {"tn_target_blocks", &g_tn_target_blocks, 1, 1, 1 << 20},
     {"fuse_bnred_next", &g_fuse_bnred_next, 0, 0, 1},
     {"dgrad_parity", &g_dgrad_parity, 1, 0, 2},
     {"wgrad_pair_reduce", &g_wgrad_pair_reduce, 0, 0, 1},
     {"nt_glds", &g_nt_glds, 1, 0, 15},                    // 0 register-staged NT kernel, 1..4 LDS-DMA operand ring where it pays, + 8 everywhere it can (gemm_nt_glds.hip)
     {"tn_glds", &g_tn_glds, 2, 0, 0},                      // 0 register-staged kernel, 1 LDS-DMA with 4 waves, 2 LDS-DMA with 8 waves
-    {"wgrad_depth", &g_wgrad_depth, 1, 2, kWgradDepth},
     {"eval_fuse", &g_eval_fuse, 0, 0, 1},                  // eval-mode forward: BatchNorm (+PReLU, +identity, +next bn1) in the conv epilogues
     {"wgrad9", &g_wgrad9, 0, 0, 1},                        // nine-tap weight-gradient kernel for 3x3 / stride-1 layers
     {"fuse_bnbwd", &g_fuse_bnbwd, 1, 0, 2},
     {"conv_c64p", &g_conv_c64p, 0, 0, 1},                  // persistent register-resident-weights kernel for the 64 -> 64 channel 3x3 layers (112x112 / 56x56)
     {"bn_sliced", &g_bn_sliced, 0, 0, 1},                  // channel-sliced BatchNorm passes without finalize launches (bn_sliced.hip)
-    {"wgrad9_wgs", &g_wgrad9_wgs, 1, 64, 1024},           // workgroups a wgrad9 launch aims for (more = shorter workgroups, more split-K slabs)
     {"conv28_tpw2", &g_conv28_tpw2, 1, 0, 2},              // 28x28 convs with two image tiles per workgroup (1: forward, 2: dgrad too)
     {"wgrad9p_bg", &g_wgrad9p_bg, 0, 0, 1},                // a paired launch sums the PREVIOUS pair's split-K slabs beside its own work (0: stand-alone reduce_slabs launches)
     {"wgrad9p", &g_wgrad9p, 0, 0, 1},                      // paired 64 x 64 nine-tap weight-gradient kernel for the two 3x3 / stride-1 layers of a residual block
-    {"bn_sliced_bwd_passes", &g_bn_sliced_bwd_passes, 1, 7, 64},
-    {"bn_sliced_pre", &g_bn_sliced_pre, 2, 0, 0},          // prefetch profile of the sliced BatchNorm-backward apply pass (0 = per-variant default)
-    {"event_nofence", &g_event_nofence, 0, 0, 1},          // takes effect for events created afterwards (a plan creates its fork / join events on first use)
     {"fuse_bnbwd28", &g_fuse_bnbwd28, 0, 0, 1},
-    {"fc_wgrad_aux", &g_fc_wgrad_aux, 0, 0, 1},
     {"fwd_xmom", &g_fwd_xmom, 0, 0, 1},
     {"stem_bnred", &g_stem_bnred, 0, 0, 1},
     {"sph_fuse_prelu_bwd", &g_sph_fuse_prelu_bwd, 0, 0, 1},
     {"sph_fin_multi", &g_sph_fin_multi, 0, 0, 1},
     {"sph_pair_wgrad", &g_sph_pair_wgrad, 0, 0, 1},
     {"c64p_bnbwd", &g_c64p_bnbwd, 0, 0, 1},
-    {"nt_nbuf", &g_nt_nbuf, 1, 1, 2},
 #ifdef FEDFR_DEBUG
     {"dbg_skip", &g_dbg_skip, 2, 0, 0},                    // WRONG results: 1 = no weight-gradient launches of the residual blocks' 3x3 convs (timing bound)
 #endif

@@ -557,11 +557,12 @@ __global__ __launch_bounds__(NTH) void bn_bwd_apply_s_kernel(BnBwdS p) {
 }  // namespace
 
 int g_bn_sliced = 1;   // option "bn_sliced": channel-sliced BatchNorm passes that reduce their partial rows themselves (no finalize launches)
-int g_bn_sliced_pre = 0;   // option "bn_sliced_pre": prefetch profile of the backward apply pass: 0 per-variant default, 1 everything in flight, 2 six passes, 3 three
+// (round 6: the alternative prefetch profiles of the backward apply pass — everything in flight / six passes, option "bn_sliced_pre" 1 / 2 — lost every
+// sweep of rounds 3-5 (+0.6 / +0.8 ms: such a wave does not fit beside a weight-gradient wave) and were removed with their 32 instantiations)
 
 // geometry: C / 32 slices x G pixel groups, ~256 workgroups, at most 13 passes of 64 pixels per workgroup (more groups on larger maps)
 constexpr int kMaxPasses = 13;
-int g_bn_sliced_bwd_passes = 26;   // option "bn_sliced_bwd_passes": most passes a workgroup of the BACKWARD kernels makes (they stream in chunks, any count works): 26 keeps a
+static const int g_bn_sliced_bwd_passes = 26;   // most passes a workgroup of the BACKWARD kernels makes (they stream in chunks, any count works): 26 keeps a
                                    // 28x28 map at 256 workgroups instead of 484 that are dispatched in two rounds between the weight-gradient workgroups (17.20 -> 17.11 ms/step)
 static void sliced_geometry(int M, int C, int* G, int* ppg, bool backward = false) {
   const int NS = C / SW;
@@ -651,25 +652,14 @@ int ew_bn_bwd_apply_sliced(BnBwdS p, hipStream_t st) {
                 "bn_bwd_apply_sliced: output rows alias the input rows");
   ProfScope prof(22, (double)p.M * p.C * 2 * (3.0 + (p.add ? 1.0 : 0.0) + (p.nx ? 1.0 : 0.0)), st);
   const dim3 grid((p.C / SW) * p.G);
-  const bool small = p.ppg <= 7 * PXP;
   const int variant = (p.alpha ? 4 : 0) | (p.nx ? 2 : 0) | (p.add ? 1 : 0);
-  // default profile: see the kernel comment (registers beside wgrad9)
-  static const int kProfile[8] = {3, 3, 3, 3, 3, 3, 3, 3};   // same-box A/B in the dual-stream step: 17.37-17.44 ms with 3, 17.48 with 1, 17.50-17.58 with 2 (row-slab kernels: 17.77-17.85)
-  const int prof_id = g_bn_sliced_pre >= 1 && g_bn_sliced_pre <= 3 ? g_bn_sliced_pre : kProfile[variant];
+  // ONE prefetch profile (three passes in flight, chunks of two): see the kernel comment (registers beside the weight-gradient waves)
   const bool wide = p.P > (p.alpha ? kBwdFL3 * FanIn<3>::RG : kBwdFL2 * FanIn<2>::RG);
   FEDFR_REQUIRE(p.P <= 2 * (p.alpha ? kBwdFL3 * FanIn<3>::RG : kBwdFL2 * FanIn<2>::RG), "bn_bwd_apply_sliced: %d partial rows", p.P);
 #define BWD_S(A, N, D)                                                                                        \
   do {                                                                                                        \
-    if (wide) {                                                                                               \
-      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 3, 2, 2>), grid, dim3(NTH), 0, st, p);                    \
-    } else if (prof_id == 1) {                                                                                       \
-      if (small) hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 7, 1>), grid, dim3(NTH), 0, st, p);            \
-      else hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, kMaxPasses, 1>), grid, dim3(NTH), 0, st, p);         \
-    } else if (prof_id == 2) {                                                                                \
-      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 6, 3>), grid, dim3(NTH), 0, st, p);                       \
-    } else {                                                                                                  \
-      hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 3, 2>), grid, dim3(NTH), 0, st, p);                       \
-    }                                                                                                         \
+    if (wide) hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 3, 2, 2>), grid, dim3(NTH), 0, st, p);            \
+    else hipLaunchKernelGGL((bn_bwd_apply_s_kernel<A, N, D, 3, 2>), grid, dim3(NTH), 0, st, p);                    \
   } while (0)
   switch (variant) {
     case 0: BWD_S(false, false, false); break;

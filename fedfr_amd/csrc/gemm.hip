@@ -255,14 +255,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p_) {
   nt_epilogue<BM, BN, WM, WN, 256>(p, acc, smem, bm, m0, n0, split, wm, wn, tid, lane);   // all waves are past the last barrier of the K loop
 }
 
-int g_nt_nbuf = 2;   // option "nt_nbuf": LDS stages of the NT kernel (1 -> 4 blocks/CU, 2 -> one barrier per K-step)
+// (the single-stage variant of the NT kernel, option "nt_nbuf" = 1, lost every sweep of rounds 2-5 and was removed in round 6: two LDS stages, one
+// barrier per K-step)
 
 template <int BM, int BN, int WM, int WN, int NBUF>
 static int launch_nt_impl(const GemmNT& p0, int splits, hipStream_t st);
 
 template <int BM, int BN, int WM, int WN>
 static int launch_nt(const GemmNT& p0, int splits, hipStream_t st) {
-  if (g_nt_nbuf == 1) return launch_nt_impl<BM, BN, WM, WN, 1>(p0, splits, st);
   return launch_nt_impl<BM, BN, WM, WN, 2>(p0, splits, st);
 }
 
@@ -592,7 +592,7 @@ void gemm_tn_tiles(int NI, int NJ, int C, int* TI, int* TJ) {
   *TJ = (NJ <= 64) ? 64 : 128;
 }
 
-int g_tn_target_blocks = 416;   // option "tn_target_blocks"
+static const int g_tn_target_blocks = 416;   // workgroups a register-staged weight-gradient GEMM aims for (256 / 832 measured neutral in rounds 4-5: no switch)
 int g_tn_glds = 2;              // option "tn_glds": LDS-DMA wgrad kernel for 128-multiple conv shapes: 2 = 8 waves (two per SIMD: one wave's VALU / DMA issue hides
                                 // behind the other's MFMAs, +20 % over 1 = 4 waves), 0 = register-staged kernel
 
@@ -615,14 +615,14 @@ int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
 
 // slab count to size a workspace for: the largest any kernel choice (options can be toggled after a plan was created) would use
 int gemm_tn_max_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
-  const int w9 = g_wgrad9, gl = g_tn_glds, ww = g_wgrad9_wgs;
+  const int w9 = g_wgrad9, gl = g_tn_glds;
   int m = 1;
   for (int a = 0; a < 2; ++a)
     for (int b = 0; b < 3; ++b) {
-      g_wgrad9 = a; g_tn_glds = b; g_wgrad9_wgs = std::max(ww, 512);
+      g_wgrad9 = a; g_tn_glds = b;
       m = std::max(m, gemm_tn_pick_splits(Kp, NI, NJ, C, Wo, stride));
     }
-  g_wgrad9 = w9; g_tn_glds = gl; g_wgrad9_wgs = ww;
+  g_wgrad9 = w9; g_tn_glds = gl;
   return m;
 }
 

@@ -46,7 +46,7 @@ struct ProfScope {
 };
 double gemm_nt_alg_bytes(const GemmNT& p, int splits);      // algorithmic HBM bytes of a launch (gemm.hip)
 double gemm_tn_alg_bytes(const GemmTN& p, int splits);
-extern int g_nt_nbuf, g_tn_target_blocks, g_tn_glds;
+extern int g_tn_glds;
 int launch_conv_glds8_w14(GemmNT p, hipStream_t st);       // conv_glds8_w14.hip  same, 8 waves per tile
 int launch_conv_glds8_w28(GemmNT p, hipStream_t st);       // conv_glds8_w28.hip
 int launch_conv_glds8_w28_stats(GemmNT p, hipStream_t st); // conv_glds8_w28s.hip  two image tiles per workgroup, one BatchNorm partial row each
@@ -74,7 +74,7 @@ int launch_tn_glds(GemmTN p, int splits, hipStream_t st);   // gemm_tn_glds.hip 
 bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode);
 int gemm_tn_glds_pick_splits(int Kp, int NI, int NJ);
 // wgrad9.hip: 3x3 stride-1 weight gradient, all nine taps per workgroup, operands staged once
-extern int g_wgrad9, g_wgrad9_wgs;
+extern int g_wgrad9;
 bool wgrad9_applies(const GemmTN& p);
 bool wgrad9_applies_shape(int Kp, int NI, int NJ, int C, int W, int stride);
 int wgrad9_pick_splits(int Kp, int NI, int NJ, int W);

@@ -347,9 +347,9 @@ static int conv_wgrad(const Ctx& c, const ConvD& cv, const bf16_t* in, const bf1
     p.out = dst;
     return gemm_tn_launch(p, 1, st);
   }
-  // the slab workspace was sized at plan creation (gemm_tn_max_splits); an option raised afterwards (tn_target_blocks) must not overrun it
+  // the slab workspace was sized at plan creation (gemm_tn_max_splits over every kernel choice)
   FEDFR_REQUIRE((size_t)splits * p.NI * p.NJ <= c.n->slab_floats, "conv_wgrad: %d split-K slabs of %d x %d exceed the plan's slab workspace "
-                "(%zu floats): create the plan after changing tn_target_blocks", splits, p.NI, p.NJ, c.n->slab_floats);
+                "(%zu floats)", splits, p.NI, p.NJ, c.n->slab_floats);
   p.out = c.slab();
   FEDFR_TRY(gemm_tn_launch(p, splits, st));
   return ew_reduce_slabs(dst, c.slab(), splits, (size_t)p.NI * p.NJ, nullptr, 0, st);
@@ -683,7 +683,7 @@ static int dbg_capture(const bf16_t* src, size_t elems, size_t* off, hipStream_t
   *off += elems;
   return FEDFR_OK;
 }
-int g_wgrad_depth = kWgradDepth;   // option "wgrad_depth" (2..kWgradDepth): generations of weight-gradient operands in flight
+static const int g_wgrad_depth = kWgradDepth;   // generations of weight-gradient operands in flight (fewer: the main stream waits for the weight-gradient stream)
 int g_fuse_bnred_next = 1;   // option "fuse_bnred_next": a BN-backward apply pass also reduces its output for the BN that consumes it
 // BatchNorm (+PReLU) backward: dx = a dz + A x + B (+ addend).  `have`: partial rows that already exist (left by the pass that produced
 // dy); else a reduce pass runs first.  With next_bn, dx is also reduced as the dy of that BatchNorm's backward -> *next_rows.
@@ -734,8 +734,8 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
 }
 
 int g_stem_bnred = 1;     // option "stem_bnred": the stem's BatchNorm-backward reduction rides in the first block's bn1 apply pass
-int g_fc_wgrad_aux = 1;   // option "fc_wgrad_aux": fc's weight gradient runs on the weight-gradient stream
-int g_event_nofence = 1;   // option "event_nofence": fork / join events created with hipEventDisableSystemFence
+// (fc's weight gradient runs on the weight-gradient stream, and fork / join events are created with hipEventDisableSystemFence — a system-scope
+// release per event costs the main stream ~5 us: options "fc_wgrad_aux" / "event_nofence" of rounds 3-5, removed in round 6 after losing every sweep)
 // fork/join helpers for the dual-stream backward (events are created once per plan)
 namespace {
 struct Fork {
@@ -746,7 +746,7 @@ struct Fork {
   hipEvent_t ev() {
     if (next == n->events.size()) {
       hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (g_event_nofence ? hipEventDisableSystemFence : hipEventReleaseToDevice)) != hipSuccess) { ok = false; return nullptr; }
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { ok = false; return nullptr; }
       n->events.push_back(e);
     }
     return n->events[next++];
@@ -803,7 +803,7 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
     GemmTN p{};
     p.P = c.dyb(); p.Q = A + n->t_off; p.Kp = B; p.NI = F; p.NJ = n->fc_in; p.mode = 0; p.ldp = F; p.ldq = n->fc_in;
     p.out = grads + n->fc_w_off; p.use_tr = g_tn_use_tr;
-    FEDFR_TRY(gemm_tn_launch(p, 1, g_fc_wgrad_aux ? wst : st));
+    FEDFR_TRY(gemm_tn_launch(p, 1, wst));
   }
   {  // dX [Bp][fc_in] = dY W   (reduction over F: P = dY^T [F][Bp], Q = W [F][fc_in])
     GemmTN p{};

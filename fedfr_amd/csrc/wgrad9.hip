@@ -244,7 +244,7 @@ static int w9_stages(int Kp, int W) {
   return images << (2 * w9_lg(W));
 }
 // one workgroup per CU: as many K-splits (whole stages) as it takes to put ~256 workgroups on the chip, at least two stages each
-int g_wgrad9_wgs = 256;   // option "wgrad9_wgs": workgroups a launch aims for (256 = one per CU; 512 = half as long each, twice the slabs)
+static const int g_wgrad9_wgs = 256;   // workgroups a launch aims for: one per CU (512 = half as long each, twice the slabs: lost in rounds 3-5, no switch)
 int wgrad9_pick_splits(int Kp, int NI, int NJ, int W) {
   const int stages = w9_stages(Kp, W);
   const int tiles = (NI / 32) * (NJ / 9 / 64);

@@ -36,20 +36,20 @@ const char* fedfr_last_error_string(void);
 /* Kernel-choice switches for same-box A/B measurements and validation fallbacks (no reference counterpart; every setting stays inside the
  * tests' tolerances; FEDFR_OPTIONS="name=value,..." in the environment applies them when the library is loaded; fedfr_option_info lists
  * them with their defaults).  Round 4 removed the switches whose alternative lost twice (the register-staged halo conv kernels, the
- * BatchNorm-on-load conv, the two-blocks-per-CU weight-gradient pair, sphnet's activation epilogue, the fork / join placement and row-slab sweeps).  [default]:
- *   GEMM kernels        "nt_glds" [4] LDS-DMA operand ring of the NT GEMM (0 register-staged everywhere, +8 every shape it serves), "nt_nbuf",
+ * BatchNorm-on-load conv, the two-blocks-per-CU weight-gradient pair, sphnet's activation epilogue, the fork / join placement and row-slab sweeps);
+ * round 6 the numeric tuning parameters and the switches whose alternative lost every same-box sweep of rounds 2-5 and validates nothing (nt_nbuf,
+ * tn_target_blocks, wgrad9_wgs, wgrad_depth, fc_wgrad_aux, bn_sliced_pre, bn_sliced_bwd_passes, event_nofence): what is left selects a kernel
+ * family or a fusion that the tests compare against its alternative.  [default]:
+ *   GEMM kernels        "nt_glds" [4] LDS-DMA operand ring of the NT GEMM (0 register-staged everywhere, +8 every shape it serves),
  *                       "tn_glds" [2] LDS-DMA weight-gradient GEMM (0 register-staged, 1 four waves), "tn_use_tr" [1] (0 scalar LDS fragments),
- *                       "tn_target_blocks", "dgrad_parity" [2] stride-2 dgrad by output-parity class (2: one launch), "conv_c64p" [1] persistent
+ *                       "dgrad_parity" [2] stride-2 dgrad by output-parity class (2: one launch), "conv_c64p" [1] persistent
  *                       64-channel conv, "conv28_tpw2" [2] two 28x28 tiles per workgroup (1 forward only), "eval_fuse" [1] eval-mode BatchNorm in the conv epilogues
  *   weight gradients    "wgrad9" [1] nine-tap kernel, "wgrad9p" [1] paired 64 x 64 nine-tap kernel, "wgrad9p_bg" [1] a paired launch sums the
- *                       PREVIOUS pair's split-K slabs beside its own work (0: stand-alone reductions), "wgrad9_wgs", "wgrad_pair_reduce" [1],
- *                       "wgrad_depth" [4] generations of weight-gradient operands in flight, "fc_wgrad_aux" [1]
+ *                       PREVIOUS pair's split-K slabs beside its own work (0: stand-alone reductions), "wgrad_pair_reduce" [1]
  *   BatchNorm forward   "bn_sliced" [1] channel-sliced passes without finalize launches, "fwd_xmom" [1] bn3 + identity + the next block's bn1 as one
  *                       pass from conv2's raw moments
  *   BatchNorm backward  "fuse_bnbwd" [2] reduction in the dgrad epilogue (1 every fused kernel, 2 the 14x14 layers), "fuse_bnbwd28" [1], "c64p_bnbwd" [1],
- *                       "fuse_bnred_next" [1] an apply pass reduces its output for the next BatchNorm, "stem_bnred" [1],
- *                       "bn_sliced_pre", "bn_sliced_bwd_passes"
- *   streams             "event_nofence" [1] fork / join events without a system-scope fence
+ *                       "fuse_bnred_next" [1] an apply pass reduces its output for the next BatchNorm, "stem_bnred" [1]
  *   sphnet              "sph_fin_multi" [1], "sph_pair_wgrad" [1], "sph_fuse_prelu_bwd" [1]
  * Unknown names are an error. */
 int fedfr_set_option(const char* name, int value);

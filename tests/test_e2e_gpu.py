@@ -1678,10 +1678,12 @@ def test_bf16_build_reference_parity_subset():
 # ("each is a code path the parity suite must keep alive").  Switches with tests of their own elsewhere are listed too: this is
 # the ONE place that walks the whole option table (test_abi checks that the header documents it).
 SWITCH_ALTERNATIVES = {
-    "tn_use_tr": [0], "tn_target_blocks": [256], "fuse_bnred_next": [0], "dgrad_parity": [1, 0], "wgrad_pair_reduce": [0], "nt_glds": [0, 12],
-    "tn_glds": [0, 1], "wgrad_depth": [2], "wgrad9": [0], "fuse_bnbwd": [0, 1], "conv_c64p": [0], "bn_sliced": [0], "wgrad9_wgs": [512],
-    "conv28_tpw2": [0, 1], "wgrad9p_bg": [0], "wgrad9p": [0], "bn_sliced_bwd_passes": [13], "bn_sliced_pre": [1, 2], "event_nofence": [0],
-    "fuse_bnbwd28": [0], "fc_wgrad_aux": [0], "fwd_xmom": [0], "stem_bnred": [0], "c64p_bnbwd": [0], "nt_nbuf": [1],
+    "tn_use_tr": [0], "fuse_bnred_next": [0], "dgrad_parity": [1, 0], "wgrad_pair_reduce": [0], "nt_glds": [0, 12],
+    "tn_glds": [0, 1], "wgrad9": [0], "fuse_bnbwd": [0, 1], "conv_c64p": [0], "bn_sliced": [0],
+    "conv28_tpw2": [0, 1], "wgrad9p_bg": [0], "wgrad9p": [0],
+    "fuse_bnbwd28": [0], "fwd_xmom": [0], "stem_bnred": [0], "c64p_bnbwd": [0],
+    # (round 6 removed eight tuning switches whose alternative lost every sweep and validated nothing: tn_target_blocks, wgrad_depth, wgrad9_wgs,
+    # bn_sliced_bwd_passes, bn_sliced_pre, event_nofence, fc_wgrad_aux, nt_nbuf)
     # not exercised by an iresnet training step: eval_fuse (eval-mode forward: test_eval_forward_fused_epilogues_match_separate_passes), sph_*
     # (sphnet: test_sphnet_options below)
     "eval_fuse": [], "sph_fuse_prelu_bwd": [], "sph_fin_multi": [], "sph_pair_wgrad": [],
@@ -1744,7 +1746,7 @@ def test_every_switch_alternative_matches_the_default(name):
         # kernels that round at other points (fused epilogues, derived statistics) move a 16-bit network by its storage noise; pure reorderings stay at 1e-4
         loose = name in ("fwd_xmom", "fuse_bnbwd", "fuse_bnbwd28", "c64p_bnbwd", "conv_c64p", "bn_sliced", "fuse_bnred_next", "stem_bnred", "nt_glds", "conv28_tpw2")
         assert dg < (2e-2 if loose else 1e-3), (name, val, dg)
-        if name in ("event_nofence", "wgrad_depth", "fc_wgrad_aux", "wgrad9p_bg"):
+        if name in ("wgrad9p_bg",):
             assert got[0] == ref[0] and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), name
 
 

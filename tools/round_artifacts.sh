@@ -13,6 +13,7 @@ cp gpurun_out/profile_round/${TAG}_pmc_hbm_traffic_256x256_14.txt gpurun_out/${T
 bash tools/trace_step.sh $TAG > /dev/null 2>&1; echo "trace done"
 bash tools/pmc_step_traffic.sh $TAG > gpurun_out/${TAG}_pmc_hbm_traffic_whole_step.txt 2>&1; echo "step traffic done"
 bash tools/pmc_sq_all.sh > /dev/null 2>&1; echo "sq counters done"
+bash tools/pmc_sq_step.sh $TAG > /dev/null 2>&1; echo "whole-step sq counters done"
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_r100_b128.json 2> gpurun_out/${TAG}_bench.err; echo "bench done"
 python3 bench.py --lib bf16 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_r100_b128_bf16_storage.json 2>> gpurun_out/${TAG}_bench.err
 python3 bench.py --arch iresnet50 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > gpurun_out/${TAG}_bench_r50_b128_config2.json 2>> gpurun_out/${TAG}_bench.err

@@ -692,6 +692,11 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
                   const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, Rows have = Rows{nullptr, 0}, const BnD* next_bn = nullptr,
                   const bf16_t* next_x = nullptr, Rows* next_rows = nullptr, const float* next_alpha = nullptr) {
   // (next_alpha: the consuming BatchNorm has a PReLU behind it — the stem's; served by the row-slab apply pass without own PReLU / addend)
+#ifdef FEDFR_DBG_SKIP14
+  // timing experiment only (WRONG results; tools/build_ablate.sh net.hip FEDFR_DBG_SKIP14 1): the bn1 / bn3 backward passes of the 14x14 stage are free —
+  // the upper bound of anything that takes them out of the dispatcher's hands
+  if (FEDFR_DBG_SKIP14 && !alpha && !c.n->block_only && M == c.n->B * 196 && b.C == 256) return FEDFR_OK;
+#endif
   const bool nxt = next_bn && next_x && next_rows && g_fuse_bnred_next && next_bn->C == b.C &&
                    (!next_alpha || (!alpha && !add && !ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C, true), true)));
   // frozen BatchNorm (eval mode inside a training net): mean / rstd were constants, so dx = gamma rstd dz — the same passes with an infinite

@@ -399,3 +399,47 @@ def test_block_bf16_storage_floor(name):
         assert max(behind.values()) < 1e-2, behind
     else:
         assert 1e-2 < max(behind.values()) < 8e-2, behind
+
+
+def test_prelu_hook_is_transparent_and_injects_a_sign_pattern():
+    """oracle.ref_cpu's ``prelu_hook`` (round 6; what tests/test_e2e_gpu.py::test_prelu_kink_law_and_mask_injected_gradients injects the HIP path's
+    PReLU sign pattern through): a hook that differentiates with the layer's OWN sign pattern reproduces the plain oracle's gradients; a hook with a
+    pattern that differs in a fraction f of the elements moves the gradients behind that PReLU by about (1 - slope) sqrt(f) and leaves the forward
+    values and everything in front of the first flipped layer untouched."""
+    class _Masked(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, z, w, pos):
+            ctx.save_for_backward(z, w, pos)
+            return F.prelu(z, w)
+
+        @staticmethod
+        def backward(ctx, dy):
+            z, w, pos = ctx.saved_tensors
+            return torch.where(pos, dy, dy * w.view(1, -1, 1, 1)), torch.where(pos, torch.zeros_like(dy), dy * z).sum(dim=(0, 2, 3)), None
+    layers = R.IRESNET_LAYERS["iresnet18"]
+    sd = R.closed_form_state_dict(layers)
+    fc0, x, lab = R.head_fc(16), R.closed_form_images(2), R.closed_form_labels(2, 16)
+    run = lambda hook: R.train_step_grads({k: v.clone() for k, v in sd.items()}, fc0.clone(), x, lab, layers, prelu_hook=hook)   # noqa: E731
+    _, c0, l0, g0, _ = run(None)
+    _, c1, l1, g1, _ = run(lambda name, z, w: _Masked.apply(z, w, z.detach() > 0))
+    assert torch.equal(c0, c1) and l0 == l1
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm()) <= 1e-5 * float(g0[k].norm()) + 1e-12, k
+    gen = torch.Generator().manual_seed(3)
+    flips = {}
+
+    def flipped(name, z, w):
+        pos = z.detach() > 0
+        if name == "layer3.1.prelu":                       # flip 1 % of this ONE layer's pattern
+            f = torch.rand(pos.shape, generator=gen) < 0.01
+            pos = pos ^ f
+            flips[name] = (float(f.float().mean()), float(w.detach().mean()))
+        return _Masked.apply(z, w, pos)
+    _, c2, l2, g2, _ = run(flipped)
+    assert torch.equal(c0, c2) and l0 == l2                # forward values do not depend on the injected pattern
+    f, slope = flips["layer3.1.prelu"]
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    assert rel(g2["layer4.0.conv1.weight"], g0["layer4.0.conv1.weight"]) < 1e-6          # in front of the flipped layer (backward order): untouched
+    e = rel(g2["layer3.1.conv1.weight"], g0["layer3.1.conv1.weight"])                    # right behind it
+    pred = (1.0 - slope) * f ** 0.5
+    assert 0.2 * pred < e < 2.0 * pred, (e, pred)

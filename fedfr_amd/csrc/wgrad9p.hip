@@ -23,6 +23,11 @@
 #ifndef W9P_PRIO
 #define W9P_PRIO 0       // wave priority of the pair's waves (the BatchNorm-backward passes that share its CUs run at BNS_PRIO, bn_sliced.hip)
 #endif
+#ifndef W9P_SPREAD
+#define W9P_SPREAD 3     // a stage's LDS-DMA pieces are issued over SIX K-steps, three per step (round 6; 1 / 2: over four steps, back to back / eight MFMAs apart);
+                         // 0: all sixteen in the last K-step of the sub-image before (rounds 3-5).  Same-box: 15.14 -> 15.04 ms per step, 69.5 -> 66.6 us per pair
+                         // (profiles/r06_ab_w9p_dma_spread_v1.txt)
+#endif
 #ifndef W9P_ABLATE
 #define W9P_ABLATE 0     // timing experiments only: 1 no in-loop DMA, 2 no in-loop fragment reads, 4 no MFMA, 16 no slab stores, 32 no slab loads by the reduction job
 #endif
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int rowstepP = 2 * Wi * p.cout * 2, rowstepQ = 2 * Wi * p.cin * 2;            // two raster rows (one round)
   const int waveP = (whalf * Wi + odd * 8) * p.cout * 2, waveQ = (whalf * Wi + odd * 8) * p.cin * 2;
   int st_baseP = 0, st_baseQ = 0, st_top = 0, st_bot = 0, vlaneQ = laneQ;    // of the stage being issued
-  auto stage_setup = [&](int s, bool live) {
+  auto stage_setup = [&](int s, bool live) __attribute__((always_inline)) {
     const int per_img = 1 << (2 * p.lg);
     const int img = s >> (2 * p.lg), sub = s & (per_img - 1);
     const int y0 = (sub >> p.lg) * W_, x0 = (sub & ((1 << p.lg) - 1)) * W_;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool edge = odd ? x0 + W_ == Wi : x0 == 0;        // scalar: this wave's border column lies outside the image
     vlaneQ = (edge && q_edge_lane) ? (laneQ | MARK_LANE) : laneQ;
   };
-  auto issue_piece = [&](int j, int buf) {                  // j: compile-time
+  auto issue_piece = [&](int j, int buf) __attribute__((always_inline)) {                  // j: compile-time
     if (j < P_PIECES / 4) {
       const int vo = st_baseP + j * rowstepP + vlaneP;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)(smem + buf * STAGE_B + ZG + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // with the row: one address per (tx, block)), every other shift is a multiple of 16 rows = an immediate.
   const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
   const unsigned lds0 = (unsigned)(size_t)(lds_uc_t)smem;
-  auto frag_off = [&](int u, int colblk) {
+  auto frag_off = [&](int u, int colblk) __attribute__((always_inline)) {
     const int col = colblk + 4 * pp;
     return (unsigned)(u * 128 + (((col >> 3) ^ w9p_swz(u)) << 4) + ((col >> 2) & 1) * 8);
   };
@@ -205,13 +210,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int jj = 0, jo = 0;              // unit within the output / output being requested
   unsigned jsb = 0;                // slab-group byte offset of that unit
   bool jdone = false;
-  auto job_load = [&](int r) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
+  auto job_load = [&](int r) __attribute__((always_inline)) {     // load r of the unit being requested (soffset: a wave-uniform slab offset; out-of-range voffset reads as zeros)
     if constexpr (JM != 0) {
       const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsJ, (W9P_ABLATE & 32) ? (int)JOOB : (int)jvoff, (int)(jsb + (unsigned)r * p.job.sr), 0);
       jr[r] = __builtin_bit_cast(f32x4_t, v);
     }
   };
-  auto job_advance = [&]() {       // behind the four loads of a unit: remember what the unit is for, step to the next one
+  auto job_advance = [&]() __attribute__((always_inline)) {       // behind the four loads of a unit: remember what the unit is for, step to the next one
     if constexpr (JM != 0) {
       jcv = jvoff;
       jdone = jj == p.job.upo - 1;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   };
-  auto job_add = [&](int r) {      // step r of summing the unit in jr
+  auto job_add = [&](int r) __attribute__((always_inline)) {      // step r of summing the unit in jr
     if constexpr (JM == 1) {
       jacc += jr[r];
     } else if constexpr (JM == 2) {
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       else jacc += jt0;
     }
   };
-  auto job_finish = [&]() {        // the unit is summed: an output that is complete goes out
+  auto job_finish = [&]() __attribute__((always_inline)) {        // the unit is summed: an output that is complete goes out
     if constexpr (JM != 0) {
       if (jdone) {
         if (jcv != JOOB) *reinterpret_cast<float4*>(jdst + jcv) = make_float4(jacc[0], jacc[1], jacc[2], jacc[3]);
@@ -263,14 +268,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 #define W9P_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
   u32x2_t Ef[2][2 * KS], Of[2][KS + 1][2], Qg[3][2][NG];
-  auto frag = [](const u32x2_t& lo, const u32x2_t& hi) {
+  auto frag = [](const u32x2_t& lo, const u32x2_t& hi) __attribute__((always_inline)) {
     const u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
   // dy group j (-1 .. 2 KS) sits at byte (j + 1) * 2048 from aP; read r of the fragments a K-step needs first:
   //   E_k halves (4: co block, half), O_k halves (4), Q pairs k and k + 1 (24: tx, ci block, 4 groups)
-  auto read_E = [&](const unsigned* base, int k, int r) { const int b = r >> 1, h = r & 1; W9P_READ(Ef[b][2 * k + h], base[b], (2 * k + h + 1) * 2048); };
-  auto read_O = [&](const unsigned* base, int k, int r) { const int b = r >> 1, h = r & 1; W9P_READ(Of[b][k][h], base[b], (2 * k + h) * 2048); };
+  auto read_E = [&](const unsigned* base, int k, int r) __attribute__((always_inline)) { const int b = r >> 1, h = r & 1; W9P_READ(Ef[b][2 * k + h], base[b], (2 * k + h + 1) * 2048); };
+  auto read_O = [&](const unsigned* base, int k, int r) __attribute__((always_inline)) { const int b = r >> 1, h = r & 1; W9P_READ(Of[b][k][h], base[b], (2 * k + h) * 2048); };
 
   // prologue: sub-images s0 and s0 + 1 in flight, the first one landed, its first K-step's fragments fetched
   stage_setup(s0, true);
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // Q pair 1 is fetched at the top of step 0 (12 reads in front of the regular ones, waited for before the bottom-row taps): 24
       // fewer registers live across the loop edge, where the allocator otherwise parks fragments in AGPRs and shuffles them back
       const int nr = last ? 20 : (kb == KS - 2 ? 24 : (kb == 0 ? 32 : 20));
-      auto issue_read = [&](int r0) {
+      auto issue_read = [&](int r0) __attribute__((always_inline)) {
         if (W9P_ABLATE & 2) return;
         int r = r0;
         if (kb == 0) {
@@ -366,7 +371,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
               }
               if (slot < nr) issue_read(slot);
+#if W9P_SPREAD
+              // Round 6: the 16 LDS-DMA pieces of a stage go out a few per K-step over several steps — the last step of sub-image it (behind its barrier: the
+              // buffer is free) and the first steps of sub-image it + 1 — instead of all in the last step, where 16 VMEM issues between 48 MFMAs beside 20
+              // fragment reads stall the wave (a piece costs ~60 cycles among bare MFMAs, 100-185 inside a phase that already carries eight:
+              // MI355X_MICROARCH.md).  The stage is first read a whole sub-image later; the vmcnt(0) at the top of the NEXT last step still covers every
+              // piece.  stage_setup's state (set in the last step) persists until the next last step.
+              {
+                constexpr int PPS = NPW / 4;
+                static_assert(NPW % 4 == 0, "pieces per wave and stage split over four K-steps");
+                // (slot windows that do not depend on kb, so that few call sites survive in the rolled K-step body: the full-unroll budget.  Steps 0-2 use
+                // slots 32 .. 35, behind step 0's 32 fragment reads and step 1's job.  Sub-image 0 re-issues stage 1, already in flight from the prologue: the
+                // same bytes to the same place.)
+#if W9P_SPREAD == 1
+                if (last && slot >= 2 && slot - 2 < PPS && !(W9P_ABLATE & 1)) issue_piece(slot - 2, it & 1);
+                if (!last && kb < 3 && slot >= 32 && slot - 32 < PPS && !(W9P_ABLATE & 1)) issue_piece(PPS * (kb + 1) + slot - 32, (it & 1) ^ 1);
+#elif W9P_SPREAD == 2      // the same four steps, the pieces eight MFMAs apart (slots 4, 12, 20, 28)
+                if (last && (slot & 7) == 4 && slot < 32 && !(W9P_ABLATE & 1)) issue_piece(slot >> 3, it & 1);
+                if (!last && kb < 3 && (slot & 7) == 4 && slot < 32 && !(W9P_ABLATE & 1)) issue_piece(PPS * (kb + 1) + (slot >> 3), (it & 1) ^ 1);
+#else                      // six steps (the last one and steps 0-4 of the next sub-image): 3 + 3 + 3 + 3 + 2 + 2 pieces at slots 33 .. 35
+                if (last && slot >= 33 && slot < 36 && !(W9P_ABLATE & 1)) issue_piece(slot - 33, it & 1);
+                if (!last && kb < 5 && slot >= 33 && slot < 36 && 3 * (kb + 1) + slot - 33 < NPW && !(W9P_ABLATE & 1)) issue_piece(3 * (kb + 1) + slot - 33, (it & 1) ^ 1);
+#endif
+              }
+#else
               if (last && slot >= 2 && slot - 2 < NPW && !(W9P_ABLATE & 1)) issue_piece(slot - 2, it & 1);
+#endif
               if (JM != 0 && kb == 1) {                     // the slab-reduction job: slots the second K-step leaves free (20 reads, no DMA)
                 if (slot >= 20 && slot < 24) job_add(slot - 20);          // sum the unit requested one sub-image ago ...
                 if (slot == 24) job_finish();

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../fedfr_amd/csrc"
 make > /dev/null
 obj=${src%.hip}.o
 flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -ffp-contract=on"
-case $src in conv_c64p.hip|wgrad9p.hip) ;; *) flags="$flags -mllvm -amdgpu-mfma-vgpr-form=1" ;; esac
+case $src in conv_c64p.hip) ;; wgrad9p.hip) flags="$flags -mllvm -pragma-unroll-threshold=200000" ;; *) flags="$flags -mllvm -amdgpu-mfma-vgpr-form=1" ;; esac
 for ab in "$@"; do
   mkdir -p build_ab$ab && cp build/*.o build_ab$ab/
   hipcc $flags -D$macro=$ab -c $src -o build_ab$ab/$obj

@@ -21,6 +21,9 @@
 #ifndef GLDS_RASTER
 #define GLDS_RASTER 1      // padded-raster M index with fragment reuse across vertical taps (14x14 / 28x28 instantiations)
 #endif
+#ifndef GLDS_ASPREAD
+#define GLDS_ASPREAD 1     // padded-raster kernels: the next channel chunk's image is requested one LDS-DMA piece per tap over the first taps (0: all pieces at tap 0, rounds 1-5)
+#endif
 #ifndef GLDS_ABLATE
 #define GLDS_ABLATE 0      // timing ablations (WRONG results): 1 no in-loop LDS-DMA, 2 no per-tap barrier, 4 no fragment reads, 8 no prologue DMA / wait for the second tile of a workgroup, 16 no in-loop vmcnt waits (DMA still issued; RST path)
 #endif
@@ -136,6 +139,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
       const unsigned vo = (live && a_src[j] != OOB) ? a_src[j] + coff : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + abuf * A_BYTES + (j * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
     }
+  };
+  auto issue_a1 = [&](int j, int cc, int abuf, bool live) {      // piece j of this wave only (GLDS_ASPREAD: one piece per tap)
+    const unsigned coff = (unsigned)cc * 128u;
+    const unsigned vo = (live && a_src[j] != OOB) ? a_src[j] + coff : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + abuf * A_BYTES + (j * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
   };
   auto issue_b = [&](int tap, int cc, int bbuf, bool live) {
     const unsigned koff = (unsigned)(tap * p.C + cc * 64) * 2u;
@@ -305,10 +313,19 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           }
           __builtin_amdgcn_sched_barrier(0);
           if (!(GLDS_ABLATE & 17)) {
+#if GLDS_ASPREAD
+            // The next chunk's image goes out ONE piece per tap (taps 0 .. AP - 1, behind the tap's weight pieces) instead of AP pieces at tap 0.  This
+            // tap waits for the weight slice of tap it + 1, issued at tap it - 2; younger than it: the image piece of tap it - 2, then tap it - 1's
+            // weight slice and image piece (and, in the first chunk of a fused launch, the x tile requested at the END of tap 0).
+            constexpr int NA = ONECHUNK ? 0 : ((it >= 2 && it - 2 < AP) ? 1 : 0) + ((it >= 1 && it - 1 < AP) ? 1 : 0);
+            if (XPRE > 0 && (it == 1 || it == 2) && h == 0 && cc2 == 0) glds_wait_vmcnt<BP + NA + XPRE>();
+            else glds_wait_vmcnt<BP + NA>();
+#else
             if (!ONECHUNK && (it == 1 || it == 2)) {
               if (XPRE > 0 && h == 0 && cc2 == 0) glds_wait_vmcnt<BP + AP + XPRE>();      // (the x tile, requested at the end of tap 0, stays in flight)
               else glds_wait_vmcnt<BP + AP>();
             } else glds_wait_vmcnt<BP>();
+#endif
           }
           if (!(GLDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
@@ -323,7 +340,11 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
             constexpr int i3 = it + 3, j3 = i3 >= 9 ? i3 - 9 : i3;
             const int cc3 = i3 >= 9 ? cc + 1 : cc;
             issue_b((j3 % 3) * 3 + j3 / 3, cc3, (bbuf + 3) & (NB - 1), cc3 < cpt);
+#if GLDS_ASPREAD
+            if constexpr (!ONECHUNK && it < AP) issue_a1(it, cc + 1, h ^ 1, more_c);
+#else
             if (!ONECHUNK && it == 0) issue_a(cc + 1, h ^ 1, more_c);
+#endif
           }
           GLDS_PRIO(1);
 #pragma unroll
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(128 * WN) void conv3x3_glds_kernel(GemmNT p, int st
           for (int i = 0; i < NE; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, MP2, 0);
             if (i < NR2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (i < BP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // 1 VMEM (LDS-DMA piece)
+            if (i < BP + ((GLDS_ASPREAD && !ONECHUNK && it < AP) ? 1 : 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM (LDS-DMA piece); placing them evenly over the half's MFMAs instead measured equal (profiles/r06_ab_conv_dma_spread_v1.txt)
           }
           __builtin_amdgcn_sched_barrier(0);
           if (XPRE > 0 && it == 0 && h == 0 && cc2 == 0) x_loads();

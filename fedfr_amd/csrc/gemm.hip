@@ -596,9 +596,10 @@ static const int g_tn_target_blocks = 416;   // workgroups a register-staged wei
 int g_tn_glds = 2;              // option "tn_glds": LDS-DMA wgrad kernel for 128-multiple conv shapes: 2 = 8 waves (two per SIMD: one wave's VALU / DMA issue hides
                                 // behind the other's MFMAs, +20 % over 1 = 4 waves), 0 = register-staged kernel
 
-int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
-  if (Wo > 0 && wgrad9_applies_shape(Kp, NI, NJ, C, Wo, stride)) return wgrad9_pick_splits(Kp, NI, NJ, Wo);
-  if (C > 0 && gemm_tn_glds_applies(NI, NJ, C, 1)) return gemm_tn_glds_pick_splits(Kp, NI, NJ);
+// K-split count of a weight-gradient problem given WHICH kernel family serves it (use_w9: the nine-tap kernel, use_glds: the LDS-DMA ring GEMM)
+static int tn_pick_splits_for(int Kp, int NI, int NJ, int C, int Wo, bool use_w9, bool use_glds) {
+  if (use_w9) return wgrad9_pick_splits(Kp, NI, NJ, Wo);
+  if (use_glds) return gemm_tn_glds_pick_splits(Kp, NI, NJ);
   int TI, TJ;
   gemm_tn_tiles(NI, NJ, C, &TI, &TJ);
   const int tiles = ceil_div(NI, TI) * ceil_div(NJ, TJ);
@@ -612,17 +613,18 @@ int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
   const int per = ceil_div(ksteps, splits);
   return ceil_div(ksteps, per);
 }
+int gemm_tn_pick_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
+  return tn_pick_splits_for(Kp, NI, NJ, C, Wo, Wo > 0 && wgrad9_applies_shape(Kp, NI, NJ, C, Wo, stride), C > 0 && gemm_tn_glds_applies(NI, NJ, C, 1));
+}
 
-// slab count to size a workspace for: the largest any kernel choice (options can be toggled after a plan was created) would use
+// slab count to size a workspace for: the largest any kernel choice (options can be toggled after a plan was created) would use.  Round 6: computed
+// from the shape predicates alone — the earlier version toggled the process-global switches in a loop and restored them, which a second host thread
+// (Server.train with parallel_clients, thread-ranks) could observe mid-flight: "wgrad9_pair: unsupported problem pair" out of a concurrent backward pass
 int gemm_tn_max_splits(int Kp, int NI, int NJ, int C, int Wo, int stride) {
-  const int w9 = g_wgrad9, gl = g_tn_glds;
-  int m = 1;
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 3; ++b) {
-      g_wgrad9 = a; g_tn_glds = b;
-      m = std::max(m, gemm_tn_pick_splits(Kp, NI, NJ, C, Wo, stride));
-    }
-  g_wgrad9 = w9; g_tn_glds = gl;
+  const bool w9 = Wo > 0 && wgrad9_shape_ok(Kp, NI, NJ, C, Wo, stride), gl = C > 0 && gemm_tn_glds_shape_ok(NI, NJ, C, 1);
+  int m = tn_pick_splits_for(Kp, NI, NJ, C, Wo, false, false);
+  if (gl) m = std::max(m, tn_pick_splits_for(Kp, NI, NJ, C, Wo, false, true));
+  if (w9) m = std::max(m, tn_pick_splits_for(Kp, NI, NJ, C, Wo, true, false));
   return m;
 }
 

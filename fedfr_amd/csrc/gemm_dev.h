@@ -72,11 +72,13 @@ bool gemm_nt_glds_applies(const GemmNT& p, int BM, int splits);
 int launch_nt_glds(const GemmNT& p, int BM, int splits, int slot, hipStream_t st);
 int launch_tn_glds(GemmTN p, int splits, hipStream_t st);   // gemm_tn_glds.hip  wgrad GEMM, LDS-DMA operand ring
 bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode);
+bool gemm_tn_glds_shape_ok(int NI, int NJ, int C, int mode);
 int gemm_tn_glds_pick_splits(int Kp, int NI, int NJ);
 // wgrad9.hip: 3x3 stride-1 weight gradient, all nine taps per workgroup, operands staged once
 extern int g_wgrad9;
 bool wgrad9_applies(const GemmTN& p);
 bool wgrad9_applies_shape(int Kp, int NI, int NJ, int C, int W, int stride);
+bool wgrad9_shape_ok(int Kp, int NI, int NJ, int C, int W, int stride);
 int wgrad9_pick_splits(int Kp, int NI, int NJ, int W);
 int launch_wgrad9(const GemmTN& p, int splits, hipStream_t st);
 // wgrad9p.hip: the two same-shape 3x3 / stride-1 weight gradients of a residual block in one launch, 64 x 64 x 9 taps per workgroup

@@ -208,9 +208,8 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_glds_kernel(GemmTN p) {
 }
 }  // namespace
 
-bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode) {
-  return g_tn_glds > 0 && mode == 1 && NI % 128 == 0 && NJ % 128 == 0 && C % 128 == 0;
-}
+bool gemm_tn_glds_shape_ok(int NI, int NJ, int C, int mode) { return mode == 1 && NI % 128 == 0 && NJ % 128 == 0 && C % 128 == 0; }
+bool gemm_tn_glds_applies(int NI, int NJ, int C, int mode) { return g_tn_glds > 0 && gemm_tn_glds_shape_ok(NI, NJ, C, mode); }
 
 // one block per CU (128 KiB of LDS): choose the K-split count that minimises rounds x (K-steps per split + fixed overhead)
 int gemm_tn_glds_pick_splits(int Kp, int NI, int NJ) {

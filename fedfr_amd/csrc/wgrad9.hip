@@ -232,8 +232,12 @@ static int w9_lg(int W) {
     if (W == (14 << lg)) return lg;
   return -1;
 }
+// (the shape alone: what gemm_tn_max_splits sizes workspaces with, whatever the switches say at that moment)
+bool wgrad9_shape_ok(int Kp, int NI, int NJ, int C, int W, int stride) {
+  return stride == 1 && w9_lg(W) >= 0 && C > 0 && C % 64 == 0 && NI % 32 == 0 && NJ == 9 * C && Kp % (W * W) == 0;
+}
 bool wgrad9_applies_shape(int Kp, int NI, int NJ, int C, int W, int stride) {
-  return g_wgrad9 && g_tn_use_tr && stride == 1 && w9_lg(W) >= 0 && C > 0 && C % 64 == 0 && NI % 32 == 0 && NJ == 9 * C && Kp % (W * W) == 0;
+  return g_wgrad9 && g_tn_use_tr && wgrad9_shape_ok(Kp, NI, NJ, C, W, stride);
 }
 bool wgrad9_applies(const GemmTN& p) {
   return p.mode == 1 && p.use_tr && p.S == 3 && p.pad == 1 && p.H == p.W && p.Ho == p.H && p.Wo == p.W && p.ldp == p.NI &&

@@ -31,7 +31,7 @@ extern int g_sph_pair_wgrad;
 extern int g_dbg_skip;
 #endif
 extern int g_c64p_bnbwd;
-extern int g_stem_bnred;
+extern int g_stem_bnred, g_stem_fuse_wgrad;
 extern int g_fwd_xmom;
 extern int g_fuse_bnbwd28;
 
@@ -82,6 +82,7 @@ const OptRow kOptions[] = {
     {"fuse_bnbwd28", &g_fuse_bnbwd28, 0, 0, 1},
     {"fwd_xmom", &g_fwd_xmom, 0, 0, 1},
     {"stem_bnred", &g_stem_bnred, 0, 0, 1},
+    {"stem_fuse_wgrad", &g_stem_fuse_wgrad, 0, 0, 1},      // the stem's BatchNorm + PReLU backward applied inside its weight-gradient kernel (no apply pass, no d(conv output) tensor)
     {"sph_fuse_prelu_bwd", &g_sph_fuse_prelu_bwd, 0, 0, 1},
     {"sph_fin_multi", &g_sph_fin_multi, 0, 0, 1},
     {"sph_pair_wgrad", &g_sph_pair_wgrad, 0, 0, 1},

@@ -146,7 +146,10 @@ int ew_stem_stat_rows(int B, int H, int W);
 int ew_stem_fwd(const float* x, const float* w, bf16_t* y, float* stats, int B, int H, int W, hipStream_t st);
 // dw (KRSC fp32 [64][3][3][3]) = sum over pixels; tmp holds stem_wgrad_blocks*64*32 floats
 int ew_stem_wgrad_blocks(int B, int H, int W);
-int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st);
+// x0 != nullptr: dy is the gradient wrt the stem's activation and the kernel applies the BatchNorm + PReLU backward (coef [3][64] of
+// bn_bwd_finalize, the forward's scale / shift, the slopes) to the tile on its way in, bit-identical to bn_bwd_apply + the plain form
+int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st, const bf16_t* x0 = nullptr,
+                  const float* coef = nullptr, const float* sc = nullptr, const float* sh = nullptr, const float* alpha = nullptr);
 int ew_preprocess_u8(const unsigned char* src, const unsigned char* flip, float* dst, int B, int H, int W, hipStream_t st);
 int ew_bias_prelu_bwd(const bf16_t* dy, const bf16_t* x, const float* bias, const float* alpha, int M, int C, float* partials,
                       float* coef, float* dbias, float* dalpha, const bf16_t* add, bf16_t* dx, hipStream_t st);

@@ -1412,7 +1412,17 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
 #endif
 constexpr int SW_PX = STEM_WGRAD_PX;          // pixels per stage (256 threads: SW_PX pixels x 256 / SW_PX slices of the 32 im2col columns)
 constexpr int SW_CPITCH = 2 * SW_PX + 16;     // colT row pitch in bytes: +16 B keeps the 16 k-rows of a b128 fragment read on distinct banks
-__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+// FUSE (round 6): dy is the gradient wrt the stem's ACTIVATION and the BatchNorm + PReLU backward is applied to the tile on its way into LDS — the same
+// expression, in the same order, rounded to the same 16 bits as bn_bwd_apply_kernel<true, 0, false> would have stored it (dz = z <= 0 ? dy alpha : dy with
+// z = G x0 + H, o = a dz + (A x0 + B)): the 205 MB tensor d(conv output) that only this kernel ever read is neither written nor read back.
+struct StemFuse {
+  const bf16_t* x0;       // the stem conv's raw output [px][64]
+  const float* coef;      // [3][64] from bn_bwd_finalize8_kernel
+  const float *sc, *sh;   // the forward's (scale, shift): the PReLU mask is the forward's
+  const float* alpha;
+};
+template <bool FUSE>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, StemFuse fz,
                                                               float* __restrict__ tmp, int B, int H, int W, int px_per_block) {
   __shared__ __attribute__((aligned(16))) unsigned char sdy[SW_PX * 128];          // [px][64 co] bf16, chunk-swizzled (tn_swz<128>)
   __shared__ __attribute__((aligned(16))) unsigned char scol[2][32 * SW_CPITCH];   // hi / lo: [k 0..31][px] bf16
@@ -1439,8 +1449,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
   }
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((size_t)B * 3 * H * W * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy) + (size_t)mbeg * 64, 0, (int)((size_t)(mend - mbeg) * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(FUSE ? fz.x0 : dy) + (size_t)mbeg * 64, 0, (int)((size_t)(mend - mbeg) * 128), 0x00020000);
+  float ca[8], cA[8], cB[8], G[8], Hs[8], al[8];      // FUSE: this thread's 16-byte chunk is the same eight channels in every stage (256 % 8 == 0)
+  if (FUSE) {
+    const int c0 = (tid & 7) * 8;
+    load8f(fz.coef, c0, ca, 1.f);
+    load8f(fz.coef + 64, c0, cA, 0.f);
+    load8f(fz.coef + 128, c0, cB, 0.f);
+    load8f(fz.sc, c0, G, 1.f);
+    load8f(fz.sh, c0, Hs, 0.f);
+    load8f(fz.alpha, c0, al, 1.f);
+  }
   for (int mc = mbeg; mc < mend; mc += SW_PX) {
-    uint4 dv[SW_PX / 32];
+    uint4 dv[SW_PX / 32], xv[SW_PX / 32];
     unsigned raw[KSL];
     // dy tile: SW_PX px x 8 chunks of 16 B (rows at or beyond mend lie beyond this workgroup's descriptor: zeros)
 #pragma unroll
@@ -1449,6 +1470,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
       const int px = idx >> 3, c = idx & 7;
       const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsD, (mc - mbeg + px) * 128 + c * 16, 0, 0);
       dv[i] = make_uint4(v[0], v[1], v[2], v[3]);
+      if (FUSE) {
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rsX0, (mc - mbeg + px) * 128 + c * 16, 0, 0);
+        xv[i] = make_uint4(q[0], q[1], q[2], q[3]);
+      }
     }
     {   // im2col of this thread's pixel
       const int m = mc + pxl;
@@ -1467,6 +1492,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
     for (int i = 0; i < SW_PX / 32; ++i) {
       const int idx = tid + 256 * i;
       const int px = idx >> 3, c = idx & 7;
+      if (FUSE) {
+        float d[8], x0[8], o[8];
+        unpack8(dv[i], d);
+        unpack8(xv[i], x0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float dz = d[j];
+          const float z = x0[j] * G[j] + Hs[j];
+          if (z <= 0.f) dz = d[j] * al[j];
+          o[j] = ca[j] * dz + (cA[j] * x0[j] + cB[j]);
+        }
+        dv[i] = mc + px < mend ? pack8(o) : make_uint4(0, 0, 0, 0);      // rows beyond this workgroup's range read as zeros, and B is not zero
+      }
       *reinterpret_cast<uint4*>(sdy + px * 128 + ((c ^ tn_swz<128>(px)) << 4)) = dv[i];
     }
     // transposed: colT[k][px], k = (tap, ci), rows 27..31 zero
@@ -1513,12 +1551,16 @@ int ew_stem_wgrad_blocks(int B, int H, int W) {
   const int M = B * H * W;
   return ceil_div(M, stem_px_per_block(M));
 }
-int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st) {
+int ew_stem_wgrad(const float* x, const bf16_t* dy, float* dw, float* tmp, int B, int H, int W, hipStream_t st, const bf16_t* x0, const float* coef,
+                  const float* sc, const float* sh, const float* alpha) {
   FEDFR_REQUIRE(x && dy && dw && tmp && B > 0 && H > 0 && W > 0, "stem_wgrad: bad args");
+  FEDFR_REQUIRE(!x0 || (STEM_WGRAD_MFMA && coef && sc && sh && alpha), "stem_wgrad: the fused BatchNorm + PReLU backward needs coefficients, (scale, shift) and slopes");
   const int M = B * H * W;
   const int ppb = stem_px_per_block(M);
   const int nblk = ceil_div(M, ppb);
-  if (STEM_WGRAD_MFMA) hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nblk), dim3(256), 0, st, x, dy, tmp, B, H, W, ppb);
+  const StemFuse fz{x0, coef, sc, sh, alpha};
+  if (x0) hipLaunchKernelGGL(stem_wgrad_mfma_kernel<true>, dim3(nblk), dim3(256), 0, st, x, dy, fz, tmp, B, H, W, ppb);
+  else if (STEM_WGRAD_MFMA) hipLaunchKernelGGL(stem_wgrad_mfma_kernel<false>, dim3(nblk), dim3(256), 0, st, x, dy, fz, tmp, B, H, W, ppb);
   else hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dy, tmp, B, H, W, ppb);
   FEDFR_LAUNCH_CHECK("stem_wgrad");
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, tmp, nblk, dw);

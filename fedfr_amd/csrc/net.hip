@@ -690,7 +690,8 @@ int g_fuse_bnred_next = 1;   // option "fuse_bnred_next": a BN-backward apply pa
 // Channel-sliced passes without a finalize launch where the shape allows (bn_sliced.hip), else reduce / finalize / apply of ew.hip.
 static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* dy, const bf16_t* x, int M, const bf16_t* add,
                   const bf16_t* add_up, int H, bf16_t* dx, long long alpha_off, Rows have = Rows{nullptr, 0}, const BnD* next_bn = nullptr,
-                  const bf16_t* next_x = nullptr, Rows* next_rows = nullptr, const float* next_alpha = nullptr) {
+                  const bf16_t* next_x = nullptr, Rows* next_rows = nullptr, const float* next_alpha = nullptr, bool coef_only = false) {
+  // (coef_only: reduce if needed + finalize, no apply pass — the consumer applies c.coef() itself: the stem's weight gradient; row-slab form only)
   // (next_alpha: the consuming BatchNorm has a PReLU behind it — the stem's; served by the row-slab apply pass without own PReLU / addend)
 #ifdef FEDFR_DBG_SKIP14
   // timing experiment only (WRONG results; tools/build_ablate.sh net.hip FEDFR_DBG_SKIP14 1): the bn1 / bn3 backward passes of the 14x14 stage are free —
@@ -702,7 +703,7 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   // frozen BatchNorm (eval mode inside a training net): mean / rstd were constants, so dx = gamma rstd dz — the same passes with an infinite
   // count (the two mean terms vanish); dgamma / dbeta / dalpha are the same sums
   const double count = c.n->bn_frozen ? HUGE_VAL : (double)M;
-  if (!add_up && ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C, true), true)) {
+  if (!coef_only && !add_up && ew_bn_sliced_ok(M, b.C, have.P > 0 ? have.P : ew_bn_sliced_rows(M, b.C, true), true)) {
     BnBwdS p{};
     p.dy = dy; p.x = x; p.mean = c.save(b, 2); p.rstd = c.save(b, 3); p.gamma = c.gamma(b); p.alpha = alpha;
     p.sc = c.save(b, 0); p.sh = c.save(b, 1); p.M = M; p.C = b.C; p.count = count;
@@ -735,9 +736,11 @@ static int bn_bwd(const Ctx& c, const BnD& b, const float* alpha, const bf16_t* 
   if (have.P <= 0) FEDFR_TRY(ew_bn_bwd_reduce(p, c.st));      // else: the producing pass already wrote the partials
   FEDFR_TRY(ew_bn_bwd_finalize(have.P > 0 ? have.ptr : c.part(), have.P > 0 ? have.P : ew_bn_bwd_grid(M, b.C), b.C, count, c.gamma(b), c.save(b, 2),
                                c.save(b, 3), c.grads + b.g_off, c.grads + b.b_off, alpha ? c.grads + alpha_off : nullptr, c.coef(), c.st));
+  if (coef_only) return FEDFR_OK;
   return ew_bn_bwd_apply(p, c.st);
 }
 
+int g_stem_fuse_wgrad = 1;   // option "stem_fuse_wgrad": the stem's BatchNorm + PReLU backward is applied by its weight-gradient kernel on load (no d(conv output) tensor)
 int g_stem_bnred = 1;     // option "stem_bnred": the stem's BatchNorm-backward reduction rides in the first block's bn1 apply pass
 // (fc's weight gradient runs on the weight-gradient stream, and fork / join events are created with hipEventDisableSystemFence — a system-scope
 // release per event costs the main stream ~5 us: options "fc_wgrad_aux" / "event_nofence" of rounds 3-5, removed in round 6 after losing every sweep)
@@ -909,7 +912,13 @@ int net_backward(const FedfrNet* n, const float* x, const float* dfeats, const f
   } else {
   // ---- stem: a0 = prelu(bn1(conv1(x))) ----
   bf16_t* dz0 = c.t(1);
-  FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, dz0, n->stem_alpha_off, pend));
+  const bool fuse = g_stem_fuse_wgrad != 0;
+  FEDFR_TRY(bn_bwd(c, n->stem_bn, params + n->stem_alpha_off, c.g(cur), A + n->c0_off, M0, nullptr, nullptr, 0, dz0, n->stem_alpha_off, pend, nullptr, nullptr,
+                   nullptr, nullptr, fuse));
+  if (fuse)     // the only reader of d(conv output) is the weight gradient: it applies the backward to its operand tile (two 205 MB streams fewer at batch 128)
+    FEDFR_TRY(ew_stem_wgrad(x, c.g(cur), grads + n->stem.w_off, reinterpret_cast<float*>(ws + n->ws_stem), B, HW, HW, st, A + n->c0_off, c.coef(),
+                            c.save(n->stem_bn, 0), c.save(n->stem_bn, 1), params + n->stem_alpha_off));
+  else
   FEDFR_TRY(ew_stem_wgrad(x, dz0, grads + n->stem.w_off, reinterpret_cast<float*>(ws + n->ws_stem), B, HW, HW, st));
   fk.order(wst, st);
   }

@@ -49,7 +49,8 @@ const char* fedfr_last_error_string(void);
  *   BatchNorm forward   "bn_sliced" [1] channel-sliced passes without finalize launches, "fwd_xmom" [1] bn3 + identity + the next block's bn1 as one
  *                       pass from conv2's raw moments
  *   BatchNorm backward  "fuse_bnbwd" [2] reduction in the dgrad epilogue (1 every fused kernel, 2 the 14x14 layers), "fuse_bnbwd28" [1], "c64p_bnbwd" [1],
- *                       "fuse_bnred_next" [1] an apply pass reduces its output for the next BatchNorm, "stem_bnred" [1]
+ *                       "fuse_bnred_next" [1] an apply pass reduces its output for the next BatchNorm, "stem_bnred" [1],
+ *                       "stem_fuse_wgrad" [1] the stem's BatchNorm + PReLU backward applied inside its weight-gradient kernel (no apply pass)
  *   sphnet              "sph_fin_multi" [1], "sph_pair_wgrad" [1], "sph_fuse_prelu_bwd" [1]
  * Unknown names are an error.  The switches are process-wide and NOT synchronised: set them before other host threads call into the library.  The library
  * itself never writes one (round 6: plan creation used to toggle two of them for a moment, which raced with other threads' launches). */

@@ -1681,7 +1681,7 @@ SWITCH_ALTERNATIVES = {
     "tn_use_tr": [0], "fuse_bnred_next": [0], "dgrad_parity": [1, 0], "wgrad_pair_reduce": [0], "nt_glds": [0, 12],
     "tn_glds": [0, 1], "wgrad9": [0], "fuse_bnbwd": [0, 1], "conv_c64p": [0], "bn_sliced": [0],
     "conv28_tpw2": [0, 1], "wgrad9p_bg": [0], "wgrad9p": [0],
-    "fuse_bnbwd28": [0], "fwd_xmom": [0], "stem_bnred": [0], "c64p_bnbwd": [0],
+    "fuse_bnbwd28": [0], "fwd_xmom": [0], "stem_bnred": [0], "stem_fuse_wgrad": [0], "c64p_bnbwd": [0],
     # (round 6 removed eight tuning switches whose alternative lost every sweep and validated nothing: tn_target_blocks, wgrad_depth, wgrad9_wgs,
     # bn_sliced_bwd_passes, bn_sliced_pre, event_nofence, fc_wgrad_aux, nt_nbuf)
     # not exercised by an iresnet training step: eval_fuse (eval-mode forward: test_eval_forward_fused_epilogues_match_separate_passes), sph_*

@@ -576,14 +576,15 @@ def test_fused_client_loop_vs_reference():
     assert rel(fc, g["head_fc"]) < 5e-2
 
 
-@pytest.mark.parametrize("arch,dual", [("iresnet18", True), ("iresnet50", True), ("iresnet18", False)])
-def test_sgd_inside_backward_is_bit_identical(arch, dual, monkeypatch):
+@pytest.mark.parametrize("arch,dual,B", [("iresnet18", True, 8), ("iresnet50", True, 8), ("iresnet18", False, 8), ("iresnet50", True, 128)])
+def test_sgd_inside_backward_is_bit_identical(arch, dual, B, monkeypatch):
     """step() folds torch.optim.SGD's update into the backward pass (fedfr_net_backward2_sgd: the bn2 / fc / features tail and every finished
     stage are updated on the weight-gradient stream while the main stream is still in the earlier stages).  Same kernels, same element-wise
     arithmetic, only enqueued earlier: parameters, momentum buffers, bf16 mirrors and losses after 3 steps are bit-identical to
-    backward + one flat fedfr_sgd_step (FEDFR_FUSE_SGD=0), with one stream and with two."""
+    backward + one flat fedfr_sgd_step (FEDFR_FUSE_SGD=0), with one stream and with two; at batch 128 too (round 6: the size at which the paired
+    weight-gradient launches carry each other's slab reductions)."""
     monkeypatch.setenv("FEDFR_DUAL_STREAM", "1" if dual else "0")
-    B, C = 8, 40
+    C = 40
     res = []
     for fuse in ("1", "0"):
         monkeypatch.setenv("FEDFR_FUSE_SGD", fuse)

@@ -45,6 +45,9 @@ __device__ __forceinline__ int ew_block_id() {
 #endif
 
 static inline int rows_per_pass(int C) { return EW_THREADS / (C >> 3); }
+#ifndef EW_APPLY_BLOCKS
+#define EW_APPLY_BLOCKS 1024
+#endif
 static int slab_rows(int M, int C, int max_blocks) {
   const int rpp = rows_per_pass(C);
   long long rows = (long long)rpp * 8;
@@ -385,12 +388,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int sla
   }
 }
 
-int ew_bn_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 1024)); }
+int ew_bn_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, EW_APPLY_BLOCKS)); }
 
 int ew_bn_apply(const BnApply& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_apply"));
   FEDFR_REQUIRE(p.x1 && p.y, "bn_apply: null tensor");
-  const int slab = slab_rows(p.M, p.C, 1024);
+  const int slab = slab_rows(p.M, p.C, EW_APPLY_BLOCKS);
   const int grid = ceil_div(p.M, slab);
   const size_t lds = p.stats ? (size_t)rows_per_pass(p.C) * 2 * p.C * sizeof(float) : 0;
   ProfScope prof(20, (double)p.M * p.C * 2 * (p.x2 ? 3 : 2), st);
@@ -542,7 +545,10 @@ __global__ __launch_bounds__(EW_THREADS, ALPHA ? 4 : 5) void bn_bwd_reduce_kerne
 
 // workgroups a row-slab bn_bwd_reduce / bn_bwd_apply launch aims for (= partial rows it leaves).  Round 3 swept both and the loads' cache policy
 // (profiles/r03_ab_ew_rowslab_options_v1.txt): nothing moved the step, the sweep's switches are gone
-constexpr int kEwReduceBlocks = 512, kEwBwdApplyBlocks = 2048;
+// Round 6: the apply pass aims for 768 workgroups (2048 in rounds 3-5) = ONE dispatch round of its three-per-CU variants on 256 CUs, and a third of
+// the partial rows for the finalize launch behind it: -0.03 ... -0.04 ms per step same-box on two boxes (profiles/r06_ab_bwd_apply_blocks_v1.txt; 512 and
+// 1024, and 256 / 1024 for the reduce pass: equal)
+constexpr int kEwReduceBlocks = 512, kEwBwdApplyBlocks = 768;
 int ew_bn_bwd_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, kEwReduceBlocks)); }
 
 int ew_bn_bwd_reduce(const BnBwd& p, hipStream_t st) {
@@ -1309,7 +1315,10 @@ int ew_stem_fwd(const float* x, const float* w, bf16_t* y, float* stats, int B, 
   const int M = B * H * W;
   FEDFR_REQUIRE((size_t)B * 3 * H * W * 4 < (1ull << 31), "stem_fwd: input larger than 2 GiB (32-bit buffer offsets)");
   const int ntiles = ceil_div(M, 256);
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(256), 0, st, x, w, y, stats, B, H, W, ntiles);
+#ifndef STEM_FWD_BLOCKS
+#define STEM_FWD_BLOCKS 2048
+#endif
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(ntiles < STEM_FWD_BLOCKS ? ntiles : STEM_FWD_BLOCKS), dim3(256), 0, st, x, w, y, stats, B, H, W, ntiles);
   FEDFR_LAUNCH_CHECK("stem_fwd");
   return FEDFR_OK;
 }
@@ -1540,8 +1549,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
     for (int r = 0; r < 4; ++r) o[(wave * 16 + (lane >> 4) * 4 + r) * 32 + kb * 16 + (lane & 15)] = acc[kb][r];
 }
 
+#ifndef STEM_WGRAD_BLOCKS
+#define STEM_WGRAD_BLOCKS 1024
+#endif
 static int stem_px_per_block(int M) {
-  int ppb = ceil_div(M, 1024);
+  int ppb = ceil_div(M, STEM_WGRAD_BLOCKS);
   const int q = STEM_WGRAD_MFMA ? SW_PX : 64;           // whole stages
   ppb = (ppb + q - 1) / q * q;
   if (ppb < q) ppb = q;

@@ -45,9 +45,6 @@ __device__ __forceinline__ int ew_block_id() {
 #endif
 
 static inline int rows_per_pass(int C) { return EW_THREADS / (C >> 3); }
-#ifndef EW_APPLY_BLOCKS
-#define EW_APPLY_BLOCKS 1024
-#endif
 static int slab_rows(int M, int C, int max_blocks) {
   const int rpp = rows_per_pass(C);
   long long rows = (long long)rpp * 8;
@@ -388,12 +385,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(BnApply p, int sla
   }
 }
 
-int ew_bn_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, EW_APPLY_BLOCKS)); }
+int ew_bn_apply_grid(int M, int C) { return ceil_div(M, slab_rows(M, C, 1024)); }
 
 int ew_bn_apply(const BnApply& p, hipStream_t st) {
   FEDFR_TRY(check_mc(p.M, p.C, "bn_apply"));
   FEDFR_REQUIRE(p.x1 && p.y, "bn_apply: null tensor");
-  const int slab = slab_rows(p.M, p.C, EW_APPLY_BLOCKS);
+  const int slab = slab_rows(p.M, p.C, 1024);
   const int grid = ceil_div(p.M, slab);
   const size_t lds = p.stats ? (size_t)rows_per_pass(p.C) * 2 * p.C * sizeof(float) : 0;
   ProfScope prof(20, (double)p.M * p.C * 2 * (p.x2 ? 3 : 2), st);
@@ -1315,10 +1312,7 @@ int ew_stem_fwd(const float* x, const float* w, bf16_t* y, float* stats, int B, 
   const int M = B * H * W;
   FEDFR_REQUIRE((size_t)B * 3 * H * W * 4 < (1ull << 31), "stem_fwd: input larger than 2 GiB (32-bit buffer offsets)");
   const int ntiles = ceil_div(M, 256);
-#ifndef STEM_FWD_BLOCKS
-#define STEM_FWD_BLOCKS 2048
-#endif
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(ntiles < STEM_FWD_BLOCKS ? ntiles : STEM_FWD_BLOCKS), dim3(256), 0, st, x, w, y, stats, B, H, W, ntiles);
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(ntiles < 2048 ? ntiles : 2048), dim3(256), 0, st, x, w, y, stats, B, H, W, ntiles);
   FEDFR_LAUNCH_CHECK("stem_fwd");
   return FEDFR_OK;
 }
@@ -1549,11 +1543,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
     for (int r = 0; r < 4; ++r) o[(wave * 16 + (lane >> 4) * 4 + r) * 32 + kb * 16 + (lane & 15)] = acc[kb][r];
 }
 
-#ifndef STEM_WGRAD_BLOCKS
-#define STEM_WGRAD_BLOCKS 1024
-#endif
 static int stem_px_per_block(int M) {
-  int ppb = ceil_div(M, STEM_WGRAD_BLOCKS);
+  int ppb = ceil_div(M, 1024);
   const int q = STEM_WGRAD_MFMA ? SW_PX : 64;           // whole stages
   ppb = (ppb + q - 1) / q * q;
   if (ppb < q) ppb = q;

@@ -79,10 +79,7 @@ int optim_sgd(float* p, float* g, float* buf, bf16_t* shadow, size_t n, float lr
   FEDFR_REQUIRE(p && g && buf && n > 0, "sgd: bad args");
   FEDFR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd: buffers must be 16-byte aligned");
   const size_t work = n / 4 + 1;
-#ifndef SGD_BLOCKS
-#define SGD_BLOCKS 4096
-#endif
-  const int grid = (int)((work + 255) / 256 > SGD_BLOCKS ? SGD_BLOCKS : (work + 255) / 256);
+  const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
   const bool unscale = gscale != 1.f || overflow != nullptr;
   ProfScope prof(26, (double)n * (first ? 16.0 : 20.0) + (shadow ? 2.0 * n : 0.0) + (unscale ? 4.0 * n : 0.0), st);      // p, g (, buf) read; p, buf (, bf16 mirror, unscaled g) written
   if (unscale)
